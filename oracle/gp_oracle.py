@@ -1,0 +1,386 @@
+"""CPU oracle for the GP-posterior + acquisition hot path.  TEST INFRASTRUCTURE ONLY.
+
+This module is a numpy/scipy fp64 *restatement* of the algorithm that
+secondmind-labs/trieste (reference @ 2024-10-16) runs for the path
+
+    GaussianProcessRegression.update / predict / predict_joint
+      -> expected_improvement / batch_monte_carlo_expected_improvement
+      -> decoupled Thompson trajectories
+      -> candidate sweep + arg-max.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import it; the product (``trieste_amd``) never does and has no CPU fallback.
+
+Pinning status (see DESIGN.md "Oracle"):
+  * The arithmetic of this path lives in third-party packages that are NOT vendored in
+    /root/reference and NOT installable here: gpflow==2.9.2, gpflux==0.4.4,
+    tensorflow==2.16.1, tensorflow-probability==0.24.0
+    (reference tests/latest/constraints.txt:27,28,70,72).  Their published formulas are
+    restated below, anchored on the reference's own call sites (cited per function).
+  * The reference holds NO numeric golden vectors for this path (its tests are
+    self-consistency identities and Monte-Carlo bounds).  The oracle is therefore pinned
+    against (i) 50-digit mpmath golden vectors committed under tests/golden/ (generated
+    by oracle/make_goldens.py) and (ii) every identity the reference's tests assert
+    (tests/test_oracle_identities.py).  Bit-level parity with GPflow itself is UNPINNED
+    and cannot be established in this container.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import numpy as np
+from scipy.linalg import cholesky as _cholesky
+from scipy.linalg import solve_triangular as _solve_triangular
+from scipy.special import ndtr as _ndtr
+
+JITTER = 1e-6  # reference trieste/utils/misc.py:180-183 (DEFAULTS.JITTER)
+VAR_FLOOR = 1e-12  # reference trieste/models/gpflow/interface.py:123
+
+KERNEL_KINDS = ("rbf", "matern12", "matern32", "matern52")
+
+
+# --------------------------------------------------------------------------------------
+# A.1 kernels (gpflow.kernels.Stationary / SquaredExponential / Matern{12,32,52}; chosen by
+# reference trieste/models/gpflow/builders.py:383-408).  Call sites: models.py:212-215,
+# sampler.py:677,690,843.
+# --------------------------------------------------------------------------------------
+def scaled_square_dist(X: np.ndarray, X2: np.ndarray, lengthscales: np.ndarray) -> np.ndarray:
+    """gpflow ``Stationary.scaled_squared_euclid_dist``: inputs are divided by the
+    lengthscales and r^2 = |a|^2 + |b|^2 - 2 a.b (gpflow.utilities.ops.square_distance)."""
+    A = X / lengthscales
+    B = X2 / lengthscales
+    As = np.sum(A * A, axis=-1)[..., :, None]
+    Bs = np.sum(B * B, axis=-1)[..., None, :]
+    return As + Bs - 2.0 * np.matmul(A, np.swapaxes(B, -1, -2))
+
+
+def kernel_from_r2(kind: str, variance: float, r2: np.ndarray) -> np.ndarray:
+    """K(r^2).  SquaredExponential: variance*exp(-r2/2).  Matern: r = sqrt(max(r2, 1e-36))
+    (gpflow ``IsotropicStationary.K_r2`` -> ``K_r``)."""
+    if kind == "rbf":
+        return variance * np.exp(-0.5 * r2)
+    r = np.sqrt(np.maximum(r2, 1e-36))
+    if kind == "matern12":
+        return variance * np.exp(-r)
+    if kind == "matern32":
+        s3 = math.sqrt(3.0)
+        return variance * (1.0 + s3 * r) * np.exp(-s3 * r)
+    if kind == "matern52":
+        s5 = math.sqrt(5.0)
+        return variance * (1.0 + s5 * r + 5.0 / 3.0 * np.square(r)) * np.exp(-s5 * r)
+    raise ValueError(f"unknown kernel kind {kind!r}")
+
+
+def kernel_matrix(kind, variance, lengthscales, X, X2=None) -> np.ndarray:
+    X = np.asarray(X, dtype=np.float64)
+    X2 = X if X2 is None else np.asarray(X2, dtype=np.float64)
+    ls = np.broadcast_to(np.asarray(lengthscales, dtype=np.float64), (X.shape[-1],))
+    return kernel_from_r2(kind, variance, scaled_square_dist(X, X2, ls))
+
+
+# --------------------------------------------------------------------------------------
+# A.2 update  (reference models/gpflow/models.py:171-186 -> interface.py:108-112 ->
+# gpflow GPRPosterior._precompute: Kmm + sigma^2 I, cholesky (no jitter), err = Y - m(X))
+# --------------------------------------------------------------------------------------
+@dataclass
+class GPRState:
+    kind: str
+    variance: float
+    lengthscales: np.ndarray  # [d]
+    noise: float
+    mean_const: float
+    X: np.ndarray  # [N, d]
+    Y: np.ndarray  # [N]
+    L: np.ndarray  # [N, N] lower Cholesky factor of K + noise*I
+    err: np.ndarray  # [N]  Y - mean_const
+
+    @property
+    def N(self) -> int:
+        return self.X.shape[0]
+
+    @property
+    def d(self) -> int:
+        return self.X.shape[1]
+
+
+def gpr_update(kind, variance, lengthscales, noise, mean_const, X, Y) -> GPRState:
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    Y = np.asarray(Y, dtype=np.float64).reshape(-1)
+    if X.ndim != 2 or X.shape[0] != Y.shape[0]:
+        raise ValueError("X must be [N, d] and Y [N] / [N, 1]")
+    ls = np.array(np.broadcast_to(np.asarray(lengthscales, dtype=np.float64), (X.shape[1],)))
+    K = kernel_matrix(kind, variance, ls, X)
+    K[np.diag_indices_from(K)] += noise
+    L = _cholesky(K, lower=True)  # raises LinAlgError if not PD (TF: InvalidArgumentError)
+    return GPRState(kind, float(variance), ls, float(noise), float(mean_const), X, Y, L,
+                    Y - mean_const)
+
+
+# --------------------------------------------------------------------------------------
+# A.3 predict  (reference interface.py:119-124 + gpflow base_conditional_with_lm:
+#   A = L^-1 Kmn;  fvar = Knn - sum(A^2);  A <- L^-T A;  fmean = A^T err (+ mean fn);
+#   var clipped to [1e-12, max])
+# --------------------------------------------------------------------------------------
+def predict(state: GPRState, Xq: np.ndarray, clip: bool = True) -> Tuple[np.ndarray, np.ndarray]:
+    Xq = np.asarray(Xq, dtype=np.float64)
+    lead = Xq.shape[:-1]
+    Xf = Xq.reshape(-1, Xq.shape[-1])
+    if Xf.shape[0] == 0:
+        return np.zeros(lead), np.zeros(lead)
+    Kmn = kernel_matrix(state.kind, state.variance, state.lengthscales, state.X, Xf)
+    A = _solve_triangular(state.L, Kmn, lower=True)
+    var = state.variance - np.sum(A * A, axis=0)
+    A2 = _solve_triangular(state.L.T, A, lower=False)
+    mean = A2.T @ state.err + state.mean_const
+    if clip:
+        var = np.clip(var, VAR_FLOOR, np.finfo(np.float64).max)
+    return mean.reshape(lead), var.reshape(lead)
+
+
+def predict_y(state: GPRState, Xq):
+    """reference models.py:167-169: Gaussian likelihood adds the noise variance."""
+    m, v = predict(state, Xq)
+    return m, v + state.noise
+
+
+def predict_joint(state: GPRState, Xq: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """reference interface.py:126-133.  Xq [..., q, d] -> mean [..., q], cov [..., q, q]
+    (the reference's trailing/latent singleton axes are dropped); diag clipped at 1e-12."""
+    Xq = np.asarray(Xq, dtype=np.float64)
+    lead, q, d = Xq.shape[:-2], Xq.shape[-2], Xq.shape[-1]
+    Xg = Xq.reshape(-1, q, d)
+    G = Xg.shape[0]
+    means = np.empty((G, q))
+    covs = np.empty((G, q, q))
+    for g in range(G):
+        Kmn = kernel_matrix(state.kind, state.variance, state.lengthscales, state.X, Xg[g])
+        Knn = kernel_matrix(state.kind, state.variance, state.lengthscales, Xg[g])
+        A = _solve_triangular(state.L, Kmn, lower=True)
+        cov = Knn - A.T @ A
+        A2 = _solve_triangular(state.L.T, A, lower=False)
+        means[g] = A2.T @ state.err + state.mean_const
+        dg = np.clip(np.diag(cov), VAR_FLOOR, np.finfo(np.float64).max)
+        cov[np.diag_indices(q)] = dg
+        covs[g] = cov
+    return means.reshape(lead + (q,)), covs.reshape(lead + (q, q))
+
+
+def covariance_between_points(state: GPRState, X1: np.ndarray, X2: np.ndarray) -> np.ndarray:
+    """reference models/gpflow/models.py:188-254:  K12 - (L^-1 Kx1)^T (L^-1 Kx2)."""
+    Kx1 = kernel_matrix(state.kind, state.variance, state.lengthscales, state.X, X1)
+    Kx2 = kernel_matrix(state.kind, state.variance, state.lengthscales, state.X, X2)
+    K12 = kernel_matrix(state.kind, state.variance, state.lengthscales, X1, X2)
+    A1 = _solve_triangular(state.L, Kx1, lower=True)
+    A2 = _solve_triangular(state.L, Kx2, lower=True)
+    return K12 - A1.T @ A2
+
+
+# --------------------------------------------------------------------------------------
+# A.4 eta and the acquisition tails (reference acquisition/function/function.py)
+# --------------------------------------------------------------------------------------
+def eta_min_mean(state: GPRState, Xtrain: Optional[np.ndarray] = None) -> float:
+    """function.py:145-149: eta = min over the dataset's query points of the posterior MEAN."""
+    m, _ = predict(state, state.X if Xtrain is None else Xtrain)
+    return float(np.min(m))
+
+
+def normal_cdf(z):
+    return _ndtr(z)
+
+
+def normal_pdf(z):
+    return np.exp(-0.5 * np.square(z)) / math.sqrt(2.0 * math.pi)
+
+
+def expected_improvement(mean, var, eta):
+    """function.py:220-223: normal = Normal(mean, sqrt(var));
+    (eta-mean)*normal.cdf(eta) + var*normal.prob(eta)."""
+    mean = np.asarray(mean, dtype=np.float64)
+    var = np.asarray(var, dtype=np.float64)
+    sd = np.sqrt(var)
+    z = (eta - mean) / sd
+    return (eta - mean) * normal_cdf(z) + var * (normal_pdf(z) / sd)
+
+
+def probability_of_improvement(mean, var, threshold):
+    """function.py:509-510: Normal(mean, sqrt(var)).cdf(threshold)."""
+    return normal_cdf((threshold - np.asarray(mean)) / np.sqrt(var))
+
+
+def negative_lower_confidence_bound(mean, var, beta=1.96):
+    """function.py:389-418: -(mean - beta*sqrt(var))."""
+    return -(np.asarray(mean) - beta * np.sqrt(var))
+
+
+def ei_values(state: GPRState, Xq: np.ndarray, eta: float) -> np.ndarray:
+    m, v = predict(state, Xq)
+    return expected_improvement(m, v, eta)
+
+
+# --------------------------------------------------------------------------------------
+# A.5 batch Monte-Carlo EI (sampler.py:208-287 + function.py:1181-1186); eps passed in.
+# --------------------------------------------------------------------------------------
+def batch_reparam_samples(state: GPRState, Xq: np.ndarray, eps: np.ndarray,
+                          jitter: float = JITTER) -> np.ndarray:
+    """Xq [G, q, d], eps [q, S] -> samples [G, S, q]:  mean + (chol(cov + jitter I) @ eps)^T."""
+    mean, cov = predict_joint(state, Xq)
+    G, q = mean.shape
+    out = np.empty((G, eps.shape[1], q))
+    for g in range(G):
+        Lq = _cholesky(cov[g] + jitter * np.eye(q), lower=True)
+        out[g] = mean[g][None, :] + (Lq @ eps).T
+    return out
+
+
+def batch_mc_ei(state: GPRState, Xq: np.ndarray, eps: np.ndarray, eta: float,
+                jitter: float = JITTER) -> np.ndarray:
+    """qEI [G] = mean_S max(eta - min_q samples, 0)."""
+    s = batch_reparam_samples(state, Xq, eps, jitter)  # [G, S, q]
+    return np.mean(np.maximum(eta - np.min(s, axis=-1), 0.0), axis=-1)
+
+
+# --------------------------------------------------------------------------------------
+# A.6 decoupled trajectories (sampler.py:661-738, 801-806, 841-855, 901-936;
+# gpflux RandomFourierFeaturesCosine, gpflux.math.compute_A_inv_b); draws passed in.
+# --------------------------------------------------------------------------------------
+def rff_features(state: GPRState, Xq: np.ndarray, W: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """phi(x) = sqrt(2 variance / F) * cos((x / ls) W^T + b), W [F, d], b [F] -> [M, F]."""
+    F = W.shape[0]
+    return math.sqrt(2.0 * state.variance / F) * np.cos((Xq / state.lengthscales) @ W.T + b)
+
+
+def decoupled_weights(state: GPRState, W, b, w, xi) -> np.ndarray:
+    """sampler.py:702-736 (exact-GP branch 679-690): u = (Y - c) + sqrt(noise)*xi;
+    v = (K + noise I)^-1 (u - Phi_Z w).  w [F, B], xi [N, B] -> v [N, B]."""
+    w = np.asarray(w, dtype=np.float64).reshape(W.shape[0], -1)
+    xi = np.asarray(xi, dtype=np.float64).reshape(state.N, -1)
+    u = state.err[:, None] + math.sqrt(state.noise) * xi
+    phiZ = rff_features(state, state.X, W, b)
+    diff = u - phiZ @ w
+    # compute_A_inv_b does its own Cholesky of Kmm (= K + noise I, identical to state.L)
+    t = _solve_triangular(state.L, diff, lower=True)
+    return _solve_triangular(state.L.T, t, lower=False)
+
+
+def trajectory_eval(state: GPRState, W, b, w, v, Xq: np.ndarray) -> np.ndarray:
+    """sampler.py:923-936: f(x)_b = phi(x).w_b + k(x, X).v_b + c.   Xq [M, d] (shared by all
+    B trajectories) or [M, B, d] -> [M, B]."""
+    w = np.asarray(w, dtype=np.float64).reshape(W.shape[0], -1)
+    v = np.asarray(v, dtype=np.float64).reshape(state.N, -1)
+    B = w.shape[1]
+    Xq = np.asarray(Xq, dtype=np.float64)
+    if Xq.ndim == 2:
+        phi = rff_features(state, Xq, W, b)
+        Kx = kernel_matrix(state.kind, state.variance, state.lengthscales, Xq, state.X)
+        return phi @ w + Kx @ v + state.mean_const
+    out = np.empty((Xq.shape[0], B))
+    for bb in range(B):
+        phi = rff_features(state, Xq[:, bb, :], W, b)
+        Kx = kernel_matrix(state.kind, state.variance, state.lengthscales, Xq[:, bb, :], state.X)
+        out[:, bb] = phi @ w[:, bb] + Kx @ v[:, bb] + state.mean_const
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# A.7 sweep semantics (acquisition/optimizer.py:124-170, 247-341; sampler.py:88-123,223-273)
+# --------------------------------------------------------------------------------------
+def argmax_first(values: np.ndarray, axis: int = 0):
+    """tf.math.argmax: first index wins ties (numpy argmax has the same rule)."""
+    return np.argmax(values, axis=axis)
+
+
+def argmin_first(values: np.ndarray, axis: int = 0):
+    return np.argmin(values, axis=axis)
+
+
+def top_k(values: np.ndarray, k: int):
+    """tf.math.top_k on a 1-D array: descending values, ties by lower index first."""
+    order = np.lexsort((np.arange(values.shape[0]), -values))[:k]
+    return values[order], order
+
+
+def ei_argmax(state: GPRState, Xq: np.ndarray, eta: float):
+    vals = ei_values(state, Xq, eta)
+    i = int(argmax_first(vals))
+    return float(vals[i]), i
+
+
+def ei_sweep_reference_shape(state: GPRState, Xq: np.ndarray, eta: float, chunk: int = 10000):
+    """The reference's algorithmic shape for a large sweep: per chunk materialise K*,
+    two triangular solves, column norms, EI; running arg-max (acquisition/utils.py:31-109 +
+    optimizer.py:124-150).  Used as bench.py's cpu_baseline ("port")."""
+    best, best_i = -np.inf, -1
+    for s in range(0, Xq.shape[0], chunk):
+        vals = ei_values(state, Xq[s:s + chunk], eta)
+        i = int(np.argmax(vals))
+        if vals[i] > best:
+            best, best_i = float(vals[i]), s + i
+    return best, best_i
+
+
+# --------------------------------------------------------------------------------------
+# A.8 objectives on [0,1]^d (reference trieste/objectives/single_objectives.py)
+# --------------------------------------------------------------------------------------
+def _branin_internals(x, scale, translate):  # :83-96
+    x0 = x[..., 0] * 15.0 - 5.0
+    x1 = x[..., 1] * 15.0
+    b = 5.1 / (4 * math.pi ** 2)
+    c = 5 / math.pi
+    r, s, t = 6, 10, 1 / (8 * math.pi)
+    return scale * ((x1 - b * x0 ** 2 + c * x0 - r) ** 2 + s * (1 - t) * np.cos(x0) + translate)
+
+
+def branin(x):  # :99-107
+    return _branin_internals(np.asarray(x, dtype=np.float64), 1.0, 10.0)
+
+
+def scaled_branin(x):  # :110-119
+    return _branin_internals(np.asarray(x, dtype=np.float64), 1 / 51.95, -44.81)
+
+
+BRANIN_MINIMIZERS = (np.array([[-math.pi, 12.275], [math.pi, 2.275], [9.42478, 2.475]])
+                     + np.array([5.0, 0.0])) / 15.0  # :122-131
+BRANIN_MINIMUM = 0.397887
+SCALED_BRANIN_MINIMUM = -1.047393
+
+_H6_a = np.array([1.0, 1.2, 3.0, 3.2])
+_H6_A = np.array([[10.0, 3.0, 17.0, 3.5, 1.7, 8.0], [0.05, 10.0, 17.0, 0.1, 8.0, 14.0],
+                  [3.0, 3.5, 1.7, 10.0, 17.0, 8.0], [17.0, 8.0, 0.05, 10.0, 0.1, 14.0]])
+_H6_P = np.array([[0.1312, 0.1696, 0.5569, 0.0124, 0.8283, 0.5886],
+                  [0.2329, 0.4135, 0.8307, 0.3736, 0.1004, 0.9991],
+                  [0.2348, 0.1451, 0.3522, 0.2883, 0.3047, 0.6650],
+                  [0.4047, 0.8828, 0.8732, 0.5743, 0.1091, 0.0381]])
+HARTMANN6_MINIMIZER = np.array([[0.20169, 0.150011, 0.476874, 0.275332, 0.311652, 0.6573]])
+HARTMANN6_MINIMUM = -3.32237
+
+
+def hartmann_6(x):  # :476-501
+    x = np.asarray(x, dtype=np.float64)
+    inner = -np.sum(_H6_A * (x[..., None, :] - _H6_P) ** 2, axis=-1)
+    return -np.sum(_H6_a * np.exp(inner), axis=-1)
+
+
+def ackley(x):  # :434-459 with 1/5 -> 1/d ("Ackley-8", "Ackley-16")
+    x = (np.asarray(x, dtype=np.float64) - 0.5) * (32.768 * 2.0)
+    d = x.shape[-1]
+    e1 = -0.2 * np.sqrt(np.sum(x ** 2, -1) / d)
+    e2 = np.sum(np.cos(2.0 * math.pi * x), -1) / d
+    return -20.0 * np.exp(e1) - np.exp(e2) + 20.0 + math.e
+
+
+# --------------------------------------------------------------------------------------
+# Synthetic configurations shared by tests and bench.py
+# --------------------------------------------------------------------------------------
+def synthetic_problem(objective, d: int, N: int, seed: int = 1234):
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(size=(N, d))
+    Yraw = objective(X)
+    Y = (Yraw - Yraw.mean()) / Yraw.std()
+    return X, Y
+
+
+def default_lengthscales(d: int) -> np.ndarray:
+    """builders.py:41, 413-423 on the unit cube: 0.2 * (upper-lower) * sqrt(d)."""
+    return np.full(d, 0.2 * math.sqrt(d))

@@ -1,0 +1,225 @@
+"""Generate 50-digit mpmath golden vectors for the GP hot path -> tests/golden/gp_goldens.json.
+
+TEST INFRASTRUCTURE.  Run from the repo root:  python oracle/make_goldens.py
+
+Why mpmath and not the reference: trieste's arithmetic for this path lives in GPflow /
+GPflux / TensorFlow(-Probability), none of which is installed (or installable) here, and the
+reference's own tests hold no numeric golden vectors.  The goldens are
+therefore computed from the published formulas (with the reference call
+sites cited in oracle/gp_oracle.py) in 50-digit arithmetic, rounded once to float64.
+
+Every quantity is computed independently of oracle/gp_oracle.py (own Cholesky, own
+substitutions, mpmath ncdf/npdf), so the goldens pin the numpy oracle as well as the HIP engine.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import mpmath as mp
+import numpy as np
+
+mp.mp.dps = 50
+
+
+def mpf(x):
+    return mp.mpf(float(x))  # inputs are float64 values, taken exactly
+
+
+def kern(kind, variance, ls, a, b):
+    r2 = mp.mpf(0)
+    for k in range(len(a)):
+        t = (mpf(a[k]) - mpf(b[k])) / mpf(ls[k])
+        r2 += t * t
+    v = mpf(variance)
+    if kind == "rbf":
+        return v * mp.exp(-r2 / 2)
+    r = mp.sqrt(r2)
+    if kind == "matern12":
+        return v * mp.exp(-r)
+    if kind == "matern32":
+        s = mp.sqrt(3)
+        return v * (1 + s * r) * mp.exp(-s * r)
+    if kind == "matern52":
+        s = mp.sqrt(5)
+        return v * (1 + s * r + mp.mpf(5) / 3 * r2) * mp.exp(-s * r)
+    raise ValueError(kind)
+
+
+def chol(A):
+    n = A.rows
+    L = mp.zeros(n, n)
+    for j in range(n):
+        s = A[j, j] - sum(L[j, k] ** 2 for k in range(j))
+        L[j, j] = mp.sqrt(s)
+        for i in range(j + 1, n):
+            L[i, j] = (A[i, j] - sum(L[i, k] * L[j, k] for k in range(j))) / L[j, j]
+    return L
+
+
+def fsub(L, b):  # L y = b
+    n = L.rows
+    y = [mp.mpf(0)] * n
+    for i in range(n):
+        y[i] = (b[i] - sum(L[i, k] * y[k] for k in range(i))) / L[i, i]
+    return y
+
+
+def bsub(L, y):  # L^T x = y
+    n = L.rows
+    x = [mp.mpf(0)] * n
+    for i in reversed(range(n)):
+        x[i] = (y[i] - sum(L[k, i] * x[k] for k in range(i + 1, n))) / L[i, i]
+    return x
+
+
+def f64(x):
+    return float(x)
+
+
+def make_case(name, kind, d, N, variance, ls, noise, mean_const, seed, M=6, q=3, S=4, F=5, B=2):
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(size=(N, d))
+    Y = rng.normal(size=N)
+    # candidates: random, one exactly AT a training input, one a hair away, one far outside
+    Xq = rng.uniform(size=(M, d))
+    Xq[0] = X[0]
+    if N > 1:
+        Xq[1] = X[1] + 1e-7
+    Xq[-1] = 5.0 + rng.uniform(size=d)  # far field: EI underflows, var -> variance
+    ls = [float(v) for v in np.broadcast_to(np.asarray(ls, dtype=float), (d,))]
+
+    K = mp.zeros(N, N)
+    for i in range(N):
+        for j in range(N):
+            K[i, j] = kern(kind, variance, ls, X[i], X[j])
+        K[i, i] += mpf(noise)
+    L = chol(K)
+    err = [mpf(Y[i]) - mpf(mean_const) for i in range(N)]
+    alpha = bsub(L, fsub(L, err))
+
+    def post(xs):
+        """mean list, full covariance matrix at the list of points xs."""
+        n = len(xs)
+        A = []
+        means = []
+        for x in xs:
+            ks = [kern(kind, variance, ls, X[i], x) for i in range(N)]
+            A.append(fsub(L, ks))
+            means.append(sum(ks[i] * alpha[i] for i in range(N)) + mpf(mean_const))
+        cov = mp.zeros(n, n)
+        for a in range(n):
+            for b_ in range(n):
+                cov[a, b_] = kern(kind, variance, ls, xs[a], xs[b_]) - sum(
+                    A[a][i] * A[b_][i] for i in range(N))
+        return means, cov
+
+    # predict at candidates
+    mean, var_raw = [], []
+    for x in Xq:
+        m, c = post([x])
+        mean.append(m[0])
+        var_raw.append(c[0, 0])
+    var = [max(v, mp.mpf("1e-12")) for v in var_raw]
+    # eta = min posterior mean at the training inputs
+    tm = [post([x])[0][0] for x in X]
+    eta = min(tm)
+    ei, pi_, lcb = [], [], []
+    for m, v in zip(mean, var):
+        sd = mp.sqrt(v)
+        z = (eta - m) / sd
+        ei.append((eta - m) * mp.ncdf(z) + sd * mp.npdf(z))
+        pi_.append(mp.ncdf(z))
+        lcb.append(-(m - mp.mpf("1.96") * sd))
+
+    # joint posterior for G=2 groups of q points, + qEI given eps
+    G = 2
+    Xg = rng.uniform(size=(G, q, d))
+    if N > 1:
+        Xg[0, 0] = 0.5 * (X[0] + X[1])
+    eps = rng.normal(size=(q, S))
+    jm, jc, qei = [], [], []
+    jitter = mp.mpf("1e-6")
+    for g in range(G):
+        m, c = post([Xg[g, a] for a in range(q)])
+        for a in range(q):
+            c[a, a] = max(c[a, a], mp.mpf("1e-12"))
+        jm.append([f64(v) for v in m])
+        jc.append([[f64(c[a, b_]) for b_ in range(q)] for a in range(q)])
+        cj = c.copy()
+        for a in range(q):
+            cj[a, a] += jitter
+        Lq = chol(cj)
+        acc = mp.mpf(0)
+        for s in range(S):
+            smp = [m[a] + sum(Lq[a, k] * mpf(eps[k, s]) for k in range(a + 1)) for a in range(q)]
+            acc += max(eta - min(smp), mp.mpf(0))
+        qei.append(f64(acc / S))
+
+    # decoupled trajectory given (W, b, w, xi)
+    Wf = rng.normal(size=(F, d))
+    bf = rng.uniform(0, 2 * np.pi, size=F)
+    w = rng.normal(size=(F, B))
+    xi = rng.normal(size=(N, B))
+
+    def phi(x):
+        c = mp.sqrt(2 * mpf(variance) / F)
+        return [c * mp.cos(sum(mpf(x[k]) / mpf(ls[k]) * mpf(Wf[f, k]) for k in range(d)) + mpf(bf[f]))
+                for f in range(F)]
+
+    phiZ = [phi(X[i]) for i in range(N)]
+    vmat = []
+    for bb in range(B):
+        diff = [err[i] + mp.sqrt(mpf(noise)) * mpf(xi[i, bb])
+                - sum(phiZ[i][f] * mpf(w[f, bb]) for f in range(F)) for i in range(N)]
+        vmat.append(bsub(L, fsub(L, diff)))
+    traj = []
+    for x in Xq:
+        ph = phi(x)
+        ks = [kern(kind, variance, ls, X[i], x) for i in range(N)]
+        traj.append([f64(sum(ph[f] * mpf(w[f, bb]) for f in range(F))
+                         + sum(ks[i] * vmat[bb][i] for i in range(N)) + mpf(mean_const))
+                     for bb in range(B)])
+
+    return {
+        "name": name, "kind": kind, "d": d, "N": N, "variance": variance, "lengthscales": ls,
+        "noise": noise, "mean_const": mean_const,
+        "X": X.tolist(), "Y": Y.tolist(), "Xq": Xq.tolist(),
+        "L": [[f64(L[i, j]) for j in range(N)] for i in range(N)],
+        "alpha": [f64(a) for a in alpha],
+        "mean": [f64(m) for m in mean], "var_raw": [f64(v) for v in var_raw],
+        "var": [f64(v) for v in var], "eta": f64(eta),
+        "ei": [f64(v) for v in ei], "pi": [f64(v) for v in pi_], "nlcb": [f64(v) for v in lcb],
+        "Xg": Xg.tolist(), "eps": eps.tolist(), "joint_mean": jm, "joint_cov": jc, "qei": qei,
+        "jitter": 1e-6,
+        "rff_W": Wf.tolist(), "rff_b": bf.tolist(), "traj_w": w.tolist(), "traj_xi": xi.tolist(),
+        "traj_v": [[f64(vmat[bb][i]) for bb in range(B)] for i in range(N)],
+        "traj": traj,
+    }
+
+
+def main(out_path):
+    cases = []
+    sid = 100
+    for kind in ("rbf", "matern52"):
+        for (N, d) in ((1, 1), (2, 2), (5, 2), (8, 6), (8, 1), (5, 6)):
+            for noise in (1e-7, 1e-3, 1e-1):
+                sid += 1
+                ls = [0.2 * np.sqrt(d) * (1.0 + 0.3 * k) for k in range(d)]  # ARD
+                variance = 1.0 if noise != 1e-3 else 2.5
+                cases.append(make_case(f"{kind}_N{N}_d{d}_s{noise:g}", kind, d, N, variance, ls,
+                                       noise, 0.3 if noise == 1e-1 else 0.0, sid))
+    for kind in ("matern12", "matern32"):
+        sid += 1
+        cases.append(make_case(f"{kind}_N5_d2", kind, 2, 5, 1.3, [0.3, 0.5], 1e-4, -0.2, sid))
+    # tie case: two identical candidates (first index must win) is exercised in tests directly.
+    with open(out_path, "w") as f:
+        json.dump({"generator": "oracle/make_goldens.py", "mp_dps": mp.mp.dps, "cases": cases}, f)
+    print(f"wrote {len(cases)} cases to {out_path} ({os.path.getsize(out_path)} bytes)")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else os.path.join(
+        os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+        "gp_goldens.json"))

@@ -1,0 +1,58 @@
+"""The numpy oracle vs the 50-digit mpmath golden vectors (runs on CPU, no GPU needed)."""
+import numpy as np
+import pytest
+
+from oracle import gp_oracle as O
+from tests.util import assert_close, cancellation_floor, load_goldens
+
+CASES = load_goldens()
+
+
+def _state(c):
+    return O.gpr_update(c["kind"], c["variance"], np.array(c["lengthscales"]), c["noise"],
+                        c["mean_const"], np.array(c["X"]), np.array(c["Y"]))
+
+
+@pytest.mark.parametrize("c", CASES, ids=[c["name"] for c in CASES])
+def test_oracle_matches_mpmath(c):
+    st = _state(c)
+    N, var0, noise = c["N"], c["variance"], c["noise"]
+    floor = cancellation_floor(N, var0, noise)
+    assert_close(st.L, np.array(c["L"]), atol=floor, what="L")
+    Xq = np.array(c["Xq"])
+    mean, var = O.predict(st, Xq)
+    _, var_raw = O.predict(st, Xq, clip=False)
+    assert_close(mean, c["mean"], atol=floor * 10, what="mean")
+    assert_close(var_raw, c["var_raw"], atol=floor, what="var_raw")
+    assert_close(var, c["var"], atol=floor, what="var")
+    eta = O.eta_min_mean(st)
+    assert_close(eta, c["eta"], atol=floor * 10, what="eta")
+    # acquisition tails from the GOLDEN mean/var (isolates the tail arithmetic) ...
+    gm, gv = np.array(c["mean"]), np.array(c["var"])
+    assert_close(O.expected_improvement(gm, gv, c["eta"]), c["ei"], atol=1e-300, what="ei(golden mv)")
+    assert_close(O.probability_of_improvement(gm, gv, c["eta"]), c["pi"], atol=1e-300, what="pi")
+    assert_close(O.negative_lower_confidence_bound(gm, gv), c["nlcb"], what="nlcb")
+    # joint
+    jm, jc = O.predict_joint(st, np.array(c["Xg"]))
+    assert_close(jm, c["joint_mean"], atol=floor * 10, what="joint mean")
+    assert_close(jc, c["joint_cov"], atol=floor, what="joint cov")
+    # trajectory
+    W, b = np.array(c["rff_W"]), np.array(c["rff_b"])
+    w, xi = np.array(c["traj_w"]), np.array(c["traj_xi"])
+    v = O.decoupled_weights(st, W, b, w, xi)
+    scale = max(1.0, np.max(np.abs(np.array(c["traj_v"]))))
+    assert_close(v, c["traj_v"], atol=floor * scale / min(noise, 1.0) , what="traj v")
+    tv = O.trajectory_eval(st, W, b, w, np.array(c["traj_v"]), Xq)
+    assert_close(tv, c["traj"], atol=1e-9 * scale, what="trajectory")
+
+
+@pytest.mark.parametrize("c", [c for c in CASES if c["noise"] >= 1e-3],
+                         ids=[c["name"] for c in CASES if c["noise"] >= 1e-3])
+def test_oracle_ei_and_qei_end_to_end(c):
+    """Well-conditioned cases: full pipeline (own posterior -> EI / qEI) within 1e-5 relative."""
+    st = _state(c)
+    floor = cancellation_floor(c["N"], c["variance"], c["noise"])
+    ei = O.ei_values(st, np.array(c["Xq"]), c["eta"])
+    assert_close(ei, c["ei"], atol=floor, what="ei")
+    qei = O.batch_mc_ei(st, np.array(c["Xg"]), np.array(c["eps"]), c["eta"], c["jitter"])
+    assert_close(qei, c["qei"], atol=floor * 10, what="qei")
