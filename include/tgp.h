@@ -1,0 +1,168 @@
+/*
+ * tgp.h -- C-ABI of the MI355X-native GP-posterior + batch-acquisition engine (libtgp.so).
+ *
+ * The reference (secondmind-labs/trieste @ 2024-10-16) has NO C/FFI boundary: its plug-in API is a
+ * set of duck-typed Python protocols (trieste/models/interfaces.py:38-327,
+ * trieste/acquisition/interface.py:27-157, trieste/acquisition/optimizer.py:73-87).  This header
+ * is the boundary one level below those protocols: each entry point states the reference
+ * interface whose arithmetic it replaces.  The Python host layer (trieste_amd/) binds it with
+ * ctypes and re-exposes the reference's protocol names.  See INTEGRATION.md for the stub a
+ * trieste maintainer would add.
+ *
+ * Conventions
+ *   - every function returns an int status (TGP_OK == 0); tgp_last_error() gives the message;
+ *     nothing aborts: a non-positive-definite K + s2*I returns TGP_ERR_NOT_PD so the host can
+ *     raise and the BO loop can record Err (reference bayesian_optimizer.py:855-875,
+ *     models/gpflow/models.py:312-315).
+ *   - all arrays are float64, row-major, densely packed.
+ *   - `where` says where the CALLER's buffers live: TGP_HOST (pageable/pinned host memory; the
+ *     library stages them through its own device scratch) or TGP_DEVICE (device pointers on the
+ *     handle's GPU, e.g. torch tensors' data_ptr()).  Scalars/small outputs documented as "host"
+ *     are always host pointers.
+ *   - the handle owns all internal device memory; the caller owns every buffer it passes.
+ *   - one host thread per handle; calls are synchronous on return (work is queued on the
+ *     handle's HIP stream -- tgp_set_stream -- and the stream is synchronised before returning).
+ *   - no torch types, no C++ types: plain pointers and sizes only.
+ */
+#ifndef TGP_H
+#define TGP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tgp_handle_s* tgp_handle;
+typedef struct tgp_traj_s* tgp_traj;
+
+enum tgp_status {
+  TGP_OK = 0,
+  TGP_ERR_SHAPE = 1,   /* bad sizes / dimension mismatch  (reference: ValueError)             */
+  TGP_ERR_NOT_PD = 2,  /* Cholesky pivot <= 0 or NaN      (reference: InvalidArgumentError)   */
+  TGP_ERR_ALLOC = 3,   /* hipMalloc failed                (reference: MemoryError hint :864)  */
+  TGP_ERR_HIP = 4,     /* any other HIP runtime error                                         */
+  TGP_ERR_STATE = 5,   /* call order: e.g. predict before set_data                            */
+  TGP_ERR_ARG = 6      /* invalid argument value (negative jitter, unknown kernel, ...)       */
+};
+
+/* gpflow.kernels.{SquaredExponential, Matern12, Matern32, Matern52} (chosen by
+ * trieste/models/gpflow/builders.py:383-408). */
+enum tgp_kernel { TGP_RBF = 0, TGP_MATERN12 = 1, TGP_MATERN32 = 2, TGP_MATERN52 = 3 };
+
+enum tgp_where { TGP_HOST = 0, TGP_DEVICE = 1 };
+
+/* acquisition tails on (mean, var): trieste/acquisition/function/function.py */
+enum tgp_acq {
+  TGP_ACQ_EI = 0,   /* expected_improvement.__call__            function.py:215-223; param = eta   */
+  TGP_ACQ_PI = 1,   /* probability_below_threshold / PoF         function.py:509-510; param = thr  */
+  TGP_ACQ_NLCB = 2  /* negative_lower_confidence_bound           function.py:415-416; param = beta */
+};
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+/* One handle == one GPR model resident on one GPU (reference: GaussianProcessRegression.__init__,
+ * models/gpflow/models.py:88-134).  d = input dimension (1..32). */
+int tgp_create(int device_id, int d, int kernel_kind, tgp_handle* out);
+int tgp_destroy(tgp_handle h);
+const char* tgp_last_error(tgp_handle h); /* h may be NULL: message of the last failed create */
+const char* tgp_version(void);
+/* Use the caller's HIP stream (e.g. torch.cuda.current_stream().cuda_stream); NULL = default. */
+int tgp_set_stream(tgp_handle h, void* hip_stream);
+
+/* ---- model state ------------------------------------------------------------------------ */
+/* Hyper-parameters of kernel + Gaussian likelihood + Constant mean (builders.py:399-443).
+ * lengthscales: host [d] (ARD).  Invalidates the factorisation until the next tgp_set_data. */
+int tgp_set_hyper(tgp_handle h, double variance, const double* lengthscales, double noise_variance,
+                  double mean_const);
+
+/* == GaussianProcessRegression.update_encoded (models.py:171-186) + update_posterior_cache
+ * (interface.py:108-112): assign X [N,d], Y [N]; K = k(X,X) + noise*I; L = chol(K) (no jitter);
+ * err = Y - c.  Additionally caches W = L^-1 and alpha = K^-1 err.  TGP_ERR_NOT_PD on failure. */
+int tgp_set_data(tgp_handle h, const double* X, const double* Y, int64_t N, int where);
+
+int tgp_get_sizes(tgp_handle h, int64_t* N, int* d);
+/* Read back the cache (tests / checkpoint-free restore checks): any pointer may be NULL.
+ * L [N,N] lower (upper = 0), Winv [N,N] = L^-1, alpha [N].  `where` applies to all three. */
+int tgp_get_factor(tgp_handle h, double* L, double* Winv, double* alpha, int where);
+
+/* ---- posterior -------------------------------------------------------------------------- */
+/* == GPflowPredictor.predict_encoded (interface.py:119-124): mean [M], var [M] = clip(k** -
+ * |L^-1 k*|^2, 1e-12, max).  Either output may be NULL. */
+int tgp_predict(tgp_handle h, const double* Xq, int64_t M, double* mean, double* var, int where);
+
+/* Posterior mean only (no N^2 term), used for eta.  mean [M]. */
+int tgp_predict_mean(tgp_handle h, const double* Xq, int64_t M, double* mean, int where);
+
+/* == GPflowPredictor.predict_joint_encoded (interface.py:126-133): Xq [G,q,d] ->
+ * mean [G,q], cov [G,q,q] = K** - A^T A with the DIAGONAL clipped to >= 1e-12.  q <= 64. */
+int tgp_predict_joint(tgp_handle h, const double* Xq, int64_t G, int q, double* mean, double* cov,
+                      int where);
+
+/* == ExpectedImprovement.prepare/update (function.py:145-149): eta = min_i mean(X_i) over the
+ * model's own training inputs.  eta: host scalar. */
+int tgp_eta(tgp_handle h, double* eta);
+
+/* ---- acquisition sweep ------------------------------------------------------------------- */
+/* acquisition values out [M] (== expected_improvement.__call__ etc. on x [M,1,d]). */
+int tgp_acq_values(tgp_handle h, int acq_kind, double param, const double* Xq, int64_t M,
+                   double* out, int where);
+
+/* Fused predict + acquisition + arg-max (== _get_max_discrete_points, optimizer.py:124-150, over
+ * `optimize_discrete` / `generate_random_search_optimizer` candidates).  First index wins ties
+ * (tf.math.argmax).  Outputs are HOST: best_val, best_idx (= index_base + local index), best_x [d]
+ * (may be NULL).  Values are never written to HBM. */
+int tgp_acq_argmax(tgp_handle h, int acq_kind, double param, const double* Xq, int64_t M,
+                   int64_t index_base, double* best_val, int64_t* best_idx, double* best_x,
+                   int where);
+
+/* Streaming top-k (== generate_initial_points, optimizer.py:247-341, one batch): k <= 1024.
+ * Descending by value, ties by lower index.  Host outputs vals [k], idx [k]. */
+int tgp_acq_topk(tgp_handle h, int acq_kind, double param, const double* Xq, int64_t M,
+                 int64_t index_base, int k, double* vals, int64_t* idx, int where);
+
+/* == Box.sample (space.py:843-867) on the device: out [M,d] DEVICE pointer, uniform in
+ * [lower, upper) per dimension; element (row first+i, col c) depends only on (seed, first+i, c)
+ * (Philox4x32-10), so shards of one logical sample are consistent across GPUs.
+ * TF's own Philox stream is not reproducible outside TF: parity tests pass candidates in. */
+int tgp_sample_box(tgp_handle h, uint64_t seed, int64_t first, int64_t M, const double* lower,
+                   const double* upper, double* out_device);
+
+/* ---- batch Monte-Carlo EI ---------------------------------------------------------------- */
+/* == batch_monte_carlo_expected_improvement.__call__ (function.py:1181-1186) with
+ * BatchReparametrizationSampler.sample (sampler.py:208-287): Xq [G,q,d], eps [q,S] (the
+ * sampler's fixed draws, host or device like Xq), out [G] = mean_S max(eta - min_q(mean +
+ * chol(cov + jitter*I) eps), 0).  q <= 64. */
+int tgp_qei(tgp_handle h, const double* Xq, int64_t G, int q, const double* eps, int S, double eta,
+            double jitter, double* out, int where);
+
+/* ---- decoupled Thompson trajectories ------------------------------------------------------ */
+/* == DecoupledTrajectorySampler._prepare_weight_sampler + weight_sampler(B)
+ * (sampler.py:661-738) given the draws: rff_W [F,d], rff_b [F] (the RFF basis, gpflux
+ * RandomFourierFeaturesCosine), w [F,B] (prior weights), xi [N,B] (noise draws).
+ * v = (K + noise I)^-1 ((Y - c) + sqrt(noise) xi - Phi_Z w) is computed from the CACHED factor
+ * (the reference re-factorises per trajectory, sampler.py:730).  All inputs HOST. */
+int tgp_traj_create(tgp_handle h, const double* rff_W, const double* rff_b, int F, const double* w,
+                    const double* xi, int B, tgp_traj* out);
+int tgp_traj_destroy(tgp_traj t);
+/* canonical weights v [N,B] (host), for tests. */
+int tgp_traj_get_v(tgp_traj t, double* v);
+/* == feature_decomposition_trajectory.__call__ (sampler.py:901-936): Xq [M,d] shared by all B
+ * trajectories (per_traj_inputs = 0) or [M,B,d] (= 1); out [M,B]. */
+int tgp_traj_eval(tgp_traj t, const double* Xq, int64_t M, int per_traj_inputs, double* out,
+                  int where);
+/* == ThompsonSamplerFromTrajectory.sample (acquisition/sampler.py:262-271) for B trajectories:
+ * arg-min over Xq [M,d]; host outputs best_val [B], best_idx [B] (first index wins ties). */
+int tgp_traj_argmin(tgp_traj t, const double* Xq, int64_t M, int64_t index_base, double* best_val,
+                    int64_t* best_idx, int where);
+
+/* ---- measurement ------------------------------------------------------------------------- */
+/* Duration (ms, HIP events on the handle's stream) and launch count of the dominant kernel of
+ * the most recent sweep-type call (predict / acq_values / acq_argmax / qei / traj_*). */
+int tgp_last_kernel_ms(tgp_handle h, double* ms, int* launches);
+/* Sweep tile configuration knob for experiments: variant id (0 = default). */
+int tgp_set_variant(tgp_handle h, int variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TGP_H */

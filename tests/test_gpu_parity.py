@@ -1,0 +1,301 @@
+"""GPU parity tests: the HIP engine (through the C-ABI) vs the mpmath goldens and the numpy oracle.
+
+Tolerances: 1e-5 relative (BASELINE.json north_star) plus the cancellation floor for
+variance-derived quantities defined in tests/util.py.
+"""
+import numpy as np
+import pytest
+
+from oracle import gp_oracle as O
+from tests.util import assert_close, cancellation_floor, load_goldens
+
+pytestmark = pytest.mark.gpu
+
+CASES = load_goldens()
+
+
+def _engine(kind, d, variance, ls, noise, c, X, Y):
+    from trieste_amd.engine import GPEngine
+
+    eng = GPEngine(d, kind)
+    eng.set_hyper(variance, ls, noise, c)
+    eng.set_data(X, Y)
+    return eng
+
+
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("c", CASES, ids=[c["name"] for c in CASES])
+def test_engine_matches_mpmath_goldens(c):
+    N, var0, noise = c["N"], c["variance"], c["noise"]
+    floor = cancellation_floor(N, var0, noise)
+    X, Y = np.array(c["X"]), np.array(c["Y"])
+    eng = _engine(c["kind"], c["d"], var0, c["lengthscales"], noise, c["mean_const"], X, Y)
+    L, W, alpha = eng.get_factor()
+    assert_close(L, np.array(c["L"]), atol=floor, what="L")
+    assert_close(W @ np.array(c["L"]), np.eye(N), rtol=0, atol=1e-9 * (1 + var0 / noise), what="W L = I")
+    ascale = max(1.0, np.abs(np.array(c["alpha"])).max())
+    assert_close(alpha, c["alpha"], atol=floor * ascale / min(noise, 1.0), what="alpha")
+    Xq = np.array(c["Xq"])
+    mean, var = eng.predict(Xq)
+    assert_close(mean, c["mean"], atol=floor * 10, what="mean")
+    assert_close(var, c["var"], atol=floor, what="var")
+    assert_close(eng.predict_mean(Xq), c["mean"], atol=floor * 10, what="predict_mean")
+    assert_close(eng.eta(), c["eta"], atol=floor * 10, what="eta")
+    if noise >= 1e-3:  # well conditioned: acquisition values end to end
+        assert_close(eng.acq_values("ei", c["eta"], Xq), c["ei"], atol=floor, what="ei")
+        assert_close(eng.acq_values("pi", c["eta"], Xq), c["pi"], atol=max(floor, 1e-300) * 1e3, what="pi")
+        assert_close(eng.acq_values("nlcb", 1.96, Xq), c["nlcb"], atol=floor * 10, what="nlcb")
+        assert_close(eng.qei(np.array(c["Xg"]), np.array(c["eps"]), c["eta"], c["jitter"]), c["qei"],
+                     atol=floor * 10, what="qei")
+    jm, jc = eng.predict_joint(np.array(c["Xg"]))
+    assert_close(jm, c["joint_mean"], atol=floor * 10, what="joint mean")
+    assert_close(jc, c["joint_cov"], atol=floor, what="joint cov")
+    traj = eng.trajectory(np.array(c["rff_W"]), np.array(c["rff_b"]), np.array(c["traj_w"]),
+                          np.array(c["traj_xi"]))
+    scale = max(1.0, np.max(np.abs(np.array(c["traj_v"]))))
+    assert_close(traj.v(), c["traj_v"], atol=floor * scale / min(noise, 1.0), what="traj v")
+    if noise >= 1e-3:
+        assert_close(traj(Xq), c["traj"], atol=1e-7 * scale, what="trajectory")
+
+
+# ----------------------------------------------------------------------------------------------
+CONFIGS = [
+    # (name, objective, d, kind, N, noise)
+    ("branin_m52_N50", O.branin, 2, "matern52", 50, 1e-3),
+    ("hartmann_rbf_N300", O.hartmann_6, 6, "rbf", 300, 1e-2),
+    ("ackley8_m52_N1000", O.ackley, 8, "matern52", 1000, 1e-2),
+    ("ackley8_m52_N1000_lownoise", O.ackley, 8, "matern52", 1000, 1e-5),
+    ("ackley16_m32_N257", O.ackley, 16, "matern32", 257, 1e-3),
+    ("ackley3_m12_N130", O.ackley, 3, "matern12", 130, 1e-3),
+]
+
+
+def _problem(obj, d, kind, N, noise, M=1500, seed=5678):
+    X, Y = O.synthetic_problem(obj, d, N)
+    ls = O.default_lengthscales(d)
+    c = float(np.mean(Y))
+    st = O.gpr_update(kind, 1.0, ls, noise, c, X, Y)
+    rng = np.random.default_rng(seed)
+    Xq = rng.uniform(size=(M, d))
+    Xq[:5] = X[:5]                 # exactly at training inputs (variance cancellation)
+    Xq[5] = Xq[6]                  # duplicated candidate (ties -> first index)
+    Xq[-3:] = 4.0 + rng.uniform(size=(3, d))  # far field: var -> variance, EI underflow
+    return X, Y, ls, c, st, Xq
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=[c[0] for c in CONFIGS])
+def test_sweep_matches_oracle(cfg):
+    _, obj, d, kind, N, noise = cfg
+    X, Y, ls, c, st, Xq = _problem(obj, d, kind, N, noise)
+    floor = cancellation_floor(N, 1.0, noise)
+    eng = _engine(kind, d, 1.0, ls, noise, c, X, Y)
+    mean, var = eng.predict(Xq)
+    om, ov = O.predict(st, Xq)
+    assert_close(mean, om, atol=floor * 100, what="mean")
+    assert_close(var, ov, atol=floor, what="var")
+    eta = eng.eta()
+    assert_close(eta, O.eta_min_mean(st), atol=floor * 100, what="eta")
+    ei = eng.acq_values("ei", eta, Xq)
+    oei = O.expected_improvement(om, ov, eta)
+    assert_close(ei, oei, atol=floor * 10, what="ei")
+    # fused arg-max == arg-max of the engine's own values (first index on ties), and its value
+    # agrees with the oracle's maximum
+    val, idx, x = eng.acq_argmax("ei", eta, Xq)
+    assert idx == int(np.argmax(ei)) and val == ei[idx]
+    assert_close(val, np.max(oei), atol=floor * 10, what="max ei")
+    np.testing.assert_array_equal(x, Xq[idx])
+    # top-k == stable descending sort of the engine's values
+    k = 17
+    tv, ti = eng.acq_topk("ei", eta, Xq, k)
+    ov_, oi_ = O.top_k(ei, k)
+    np.testing.assert_array_equal(ti, oi_)
+    np.testing.assert_array_equal(tv, ov_)
+
+
+def test_ties_pick_first_index_and_sharding_is_consistent():
+    _, obj, d, kind, N, noise = CONFIGS[2]
+    X, Y, ls, c, st, Xq = _problem(obj, d, kind, N, noise, M=1000)
+    Xq = np.concatenate([Xq, Xq[::-1]], axis=0)  # every candidate appears twice
+    eng = _engine(kind, d, 1.0, ls, noise, c, X, Y)
+    eta = eng.eta()
+    val, idx, _ = eng.acq_argmax("ei", eta, Xq)
+    ei = eng.acq_values("ei", eta, Xq)
+    assert idx == int(np.argmax(ei))
+    twin = len(Xq) - 1 - idx
+    assert ei[twin] == ei[idx] and idx < twin
+    # contiguous shards with index_base reproduce the global winner (the multi-GPU contract)
+    best = (-np.inf, -1)
+    for lo, hi in ((0, 700), (700, 1300), (1300, 2000)):
+        v, i, _ = eng.acq_argmax("ei", eta, Xq[lo:hi], index_base=lo)
+        if v > best[0] or (v == best[0] and i < best[1]):
+            best = (v, i)
+    assert best == (val, idx)
+
+
+def test_device_resident_inputs_match_host_inputs():
+    import torch
+
+    _, obj, d, kind, N, noise = CONFIGS[1]
+    X, Y, ls, c, st, Xq = _problem(obj, d, kind, N, noise, M=777)
+    eng = _engine(kind, d, 1.0, ls, noise, c, X, Y)
+    m0, v0 = eng.predict(Xq)
+    Xd = torch.from_numpy(Xq).cuda()
+    eng.use_torch_stream()
+    m1, v1 = eng.predict(Xd)
+    assert m1.is_cuda and v1.is_cuda
+    np.testing.assert_array_equal(m1.cpu().numpy(), m0)
+    np.testing.assert_array_equal(v1.cpu().numpy(), v0)
+    eta = eng.eta()
+    a = eng.acq_argmax("ei", eta, Xq)
+    b = eng.acq_argmax("ei", eta, Xd)
+    assert a[0] == b[0] and a[1] == b[1]
+    np.testing.assert_array_equal(a[2], b[2])
+    ms, n = eng.last_kernel_ms()
+    assert ms > 0 and n == 1
+
+
+def test_edge_cases_and_errors():
+    from trieste_amd._lib import NotPositiveDefiniteError
+    from trieste_amd.engine import GPEngine
+
+    eng = GPEngine(2, "matern52")
+    with pytest.raises(RuntimeError):
+        eng.set_data(np.zeros((3, 2)), np.zeros(3))  # hyper-parameters not set
+    eng.set_hyper(1.0, [0.3, 0.4], 1e-2, 0.1)
+    with pytest.raises(RuntimeError):
+        eng.predict(np.zeros((1, 2)))  # no data yet
+    with pytest.raises(ValueError):
+        eng.set_data(np.zeros((3, 3)), np.zeros(3))  # wrong dimension (reference: ValueError)
+    with pytest.raises(ValueError):
+        eng.set_data(np.zeros((3, 2)), np.zeros(4))
+    # N = 1
+    eng.set_data(np.array([[0.2, 0.7]]), np.array([1.5]))
+    st = O.gpr_update("matern52", 1.0, np.array([0.3, 0.4]), 1e-2, 0.1, np.array([[0.2, 0.7]]), np.array([1.5]))
+    Xq = np.random.default_rng(1).uniform(size=(131, 2))
+    m, v = eng.predict(Xq)
+    om, ov = O.predict(st, Xq)
+    assert_close(m, om, atol=1e-12, what="N=1 mean")
+    assert_close(v, ov, atol=1e-12, what="N=1 var")
+    # empty query
+    m, v = eng.predict(np.zeros((0, 2)))
+    assert m.shape == (0,) and v.shape == (0,)
+    with pytest.raises(ValueError):
+        eng.acq_argmax("ei", 0.0, np.zeros((0, 2)))
+    # single query point
+    m, v = eng.predict(Xq[:1])
+    assert_close(m, om[:1], atol=1e-12)
+    # not positive definite: duplicated inputs with (numerically) no noise
+    eng.set_hyper(1.0, [0.3, 0.4], 1e-30, 0.0)
+    with pytest.raises(NotPositiveDefiniteError):
+        eng.set_data(np.array([[0.5, 0.5], [0.5, 0.5], [0.1, 0.2]]), np.array([1.0, 1.0, 0.0]))
+    with pytest.raises(RuntimeError):
+        eng.predict(Xq)  # failed update leaves the model unusable until the next good update
+    # update with new data of a different size (reference models.py:146-165: dynamic shapes)
+    eng.set_hyper(1.0, [0.3, 0.4], 1e-2, 0.0)
+    X2 = np.random.default_rng(2).uniform(size=(200, 2))
+    Y2 = O.branin(X2)
+    Y2 = (Y2 - Y2.mean()) / Y2.std()
+    eng.set_data(X2, Y2)
+    st2 = O.gpr_update("matern52", 1.0, np.array([0.3, 0.4]), 1e-2, 0.0, X2, Y2)
+    m, v = eng.predict(Xq)
+    om, ov = O.predict(st2, Xq)
+    assert_close(m, om, atol=1e-9)
+    assert_close(v, ov, atol=1e-10)
+
+
+def test_joint_and_qei_match_oracle():
+    _, obj, d, kind, N, noise = CONFIGS[1]
+    X, Y, ls, c, st, _ = _problem(obj, d, kind, N, noise)
+    floor = cancellation_floor(N, 1.0, noise)
+    eng = _engine(kind, d, 1.0, ls, noise, c, X, Y)
+    rng = np.random.default_rng(7)
+    for q, G, S in ((1, 9, 8), (3, 50, 16), (5, 11, 32), (50, 7, 64), (64, 3, 8), (17, 6, 8)):
+        Xg = rng.uniform(size=(G, q, d))
+        Xg[0, 0] = X[0]
+        jm, jc = eng.predict_joint(Xg)
+        om, oc = O.predict_joint(st, Xg)
+        assert_close(jm, om, atol=floor * 100, what=f"joint mean q={q}")
+        assert_close(jc, oc, atol=floor, what=f"joint cov q={q}")
+        eps = rng.normal(size=(q, S))
+        eta = O.eta_min_mean(st)
+        got = eng.qei(Xg, eps, eta, 1e-6)
+        want = O.batch_mc_ei(st, Xg, eps, eta, 1e-6)
+        assert_close(got, want, atol=floor * 100, what=f"qei q={q}")
+    # q = 1 qEI with many draws is close to analytic EI (reference test_function.py:1359-1371)
+
+
+def test_trajectories_match_oracle_and_argmin():
+    _, obj, d, kind, N, noise = CONFIGS[2]
+    X, Y, ls, c, st, Xq = _problem(obj, d, kind, N, noise, M=900)
+    eng = _engine(kind, d, 1.0, ls, noise, c, X, Y)
+    rng = np.random.default_rng(11)
+    F, B = 96, 3
+    W = rng.standard_t(5, size=(F, d))
+    b = rng.uniform(0, 2 * np.pi, size=F)
+    w = rng.normal(size=(F, B))
+    xi = rng.normal(size=(N, B))
+    traj = eng.trajectory(W, b, w, xi)
+    ov = O.decoupled_weights(st, W, b, w, xi)
+    vs = np.abs(ov).max()
+    assert_close(traj.v(), ov, rtol=1e-5, atol=1e-7 * vs, what="v")
+    got = traj(Xq)
+    want = O.trajectory_eval(st, W, b, w, traj.v(), Xq)
+    assert_close(got, want, rtol=1e-5, atol=1e-8 * max(1.0, vs), what="traj eval")
+    vals, idx = traj.argmin(Xq)
+    np.testing.assert_array_equal(idx, np.argmin(got, axis=0))
+    np.testing.assert_array_equal(vals, got[idx, np.arange(B)])
+    # per-trajectory inputs [M, B, d]
+    Xb = rng.uniform(size=(50, B, d))
+    got_b = traj(Xb)
+    want_b = O.trajectory_eval(st, W, b, w, traj.v(), Xb)
+    assert_close(got_b, want_b, rtol=1e-5, atol=1e-8 * max(1.0, vs), what="traj eval per-traj inputs")
+
+
+def test_sample_box_is_uniform_and_shard_consistent():
+    from trieste_amd.engine import GPEngine
+
+    eng = GPEngine(3, "rbf")
+    lo, up = np.array([0.0, -1.0, 2.0]), np.array([1.0, 1.0, 5.0])
+    a = eng.sample_box(42, 0, 10000, lo, up).cpu().numpy()
+    assert a.shape == (10000, 3)
+    assert np.all(a >= lo) and np.all(a < up)
+    assert_close(a.mean(0), (lo + up) / 2, rtol=0, atol=0.05)
+    b = eng.sample_box(42, 6000, 4000, lo, up).cpu().numpy()
+    np.testing.assert_array_equal(a[6000:], b)
+    c = eng.sample_box(43, 0, 100, lo, up).cpu().numpy()
+    assert not np.array_equal(a[:100], c)
+
+
+# ---- full-size, size-independent properties (no oracle at this size) --------------------------
+def test_headline_size_properties():
+    """N = 4096, d = 8, Matern-5/2 (BASELINE headline): identities that hold at any size."""
+    d, N, noise = 8, 4096, 1e-2
+    X, Y = O.synthetic_problem(O.ackley, d, N)
+    ls = O.default_lengthscales(d)
+    c = float(np.mean(Y))
+    eng = _engine("matern52", d, 1.0, ls, noise, c, X, Y)
+    L, W, alpha = eng.get_factor()
+    # (1) W is the inverse of L, and L L^T reproduces K + noise I on a random probe
+    rng = np.random.default_rng(3)
+    z = rng.normal(size=N)
+    assert_close(W @ (L @ z), z, rtol=0, atol=1e-8, what="W L z = z")
+    K = O.kernel_matrix("matern52", 1.0, ls, X)
+    K[np.diag_indices(N)] += noise
+    assert_close(L @ (L.T @ z), K @ z, rtol=1e-9, atol=1e-9, what="L L^T z = K z")
+    # (2) at the training inputs: mean = Y - noise * alpha (exact identity), var = noise-ish small
+    m, v = eng.predict(X[:512])
+    assert_close(m, Y[:512] - noise * alpha[:512], rtol=1e-7, atol=1e-8, what="mean at train")
+    assert np.all(v > 0) and np.all(v < noise * 1.0001)
+    # (3) a small oracle slice: 300 candidates against the (slow) CPU restatement
+    st = O.gpr_update("matern52", 1.0, ls, noise, c, X, Y)
+    Xq = rng.uniform(size=(300, d))
+    om, ov = O.predict(st, Xq)
+    gm, gv = eng.predict(Xq)
+    floor = cancellation_floor(N, 1.0, noise)
+    assert_close(gm, om, atol=floor * 100, what="mean vs oracle")
+    assert_close(gv, ov, atol=floor, what="var vs oracle")
+    # (4) far field: var -> variance, mean -> c, EI underflows to exactly 0 (tf semantics)
+    far = 10.0 + rng.uniform(size=(4, d))
+    fm, fv = eng.predict(far)
+    assert_close(fm, np.full(4, c), rtol=0, atol=1e-12)
+    assert_close(fv, np.ones(4), rtol=0, atol=1e-12)

@@ -1,0 +1,103 @@
+"""ctypes binding of libtgp.so (the C-ABI in include/tgp.h).
+
+There is NO CPU fallback: if the HIP library is missing or no GPU is visible, creating an
+engine raises.  (The numpy oracle under oracle/ is test infrastructure and is never imported
+from this package.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtgp.so")
+
+TGP_OK, TGP_ERR_SHAPE, TGP_ERR_NOT_PD, TGP_ERR_ALLOC, TGP_ERR_HIP, TGP_ERR_STATE, TGP_ERR_ARG = range(7)
+HOST, DEVICE = 0, 1
+KERNELS = {"rbf": 0, "squared_exponential": 0, "matern12": 1, "matern32": 2, "matern52": 3}
+ACQ = {"ei": 0, "pi": 1, "nlcb": 2}
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int64)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); every symbol declared in include/tgp.h
+SIGNATURES = {
+    "tgp_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "tgp_destroy": (C.c_int, [_vp]),
+    "tgp_last_error": (C.c_char_p, [_vp]),
+    "tgp_version": (C.c_char_p, []),
+    "tgp_set_stream": (C.c_int, [_vp, _vp]),
+    "tgp_set_hyper": (C.c_int, [_vp, C.c_double, _vp, C.c_double, C.c_double]),
+    "tgp_set_data": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int]),
+    "tgp_get_sizes": (C.c_int, [_vp, _ip, C.POINTER(C.c_int)]),
+    "tgp_get_factor": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int]),
+    "tgp_predict": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, C.c_int]),
+    "tgp_predict_mean": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int]),
+    "tgp_predict_joint": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, C.c_int]),
+    "tgp_eta": (C.c_int, [_vp, _dp]),
+    "tgp_acq_values": (C.c_int, [_vp, C.c_int, C.c_double, _vp, C.c_int64, _vp, C.c_int]),
+    "tgp_acq_argmax": (C.c_int, [_vp, C.c_int, C.c_double, _vp, C.c_int64, C.c_int64, _dp, _ip, _vp,
+                                 C.c_int]),
+    "tgp_acq_topk": (C.c_int, [_vp, C.c_int, C.c_double, _vp, C.c_int64, C.c_int64, C.c_int, _vp, _vp,
+                               C.c_int]),
+    "tgp_sample_box": (C.c_int, [_vp, C.c_uint64, C.c_int64, C.c_int64, _vp, _vp, _vp]),
+    "tgp_qei": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, C.c_int, C.c_double, C.c_double, _vp,
+                          C.c_int]),
+    "tgp_traj_create": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, C.POINTER(_vp)]),
+    "tgp_traj_destroy": (C.c_int, [_vp]),
+    "tgp_traj_get_v": (C.c_int, [_vp, _vp]),
+    "tgp_traj_eval": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, C.c_int]),
+    "tgp_traj_argmin": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, _vp, _vp, C.c_int]),
+    "tgp_last_kernel_ms": (C.c_int, [_vp, _dp, C.POINTER(C.c_int)]),
+    "tgp_set_variant": (C.c_int, [_vp, C.c_int]),
+}
+
+_lib = None
+
+
+class TgpError(RuntimeError):
+    """Any non-OK status from libtgp that has no closer Python analogue."""
+
+
+class NotPositiveDefiniteError(TgpError, ArithmeticError):
+    """Cholesky of K + noise*I (or of a q x q joint covariance) failed.  The reference surfaces
+    this as tf.errors.InvalidArgumentError (trieste/models/gpflow/models.py:312-315)."""
+
+
+def load():
+    """Load libtgp.so (once).  Raises ImportError with build instructions if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build the HIP engine first (python -c 'import __graft_entry__ as g; "
+            "g.build()' or make -C trieste_amd/csrc).  trieste_amd has no CPU fallback.")
+    # torch ships its own libamdhip64.so.7; importing it first makes libtgp bind to the SAME HIP
+    # runtime instance so device pointers / streams can be shared with torch tensors.
+    import torch  # noqa: F401
+
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here == header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(lib, handle, rc):
+    if rc == TGP_OK:
+        return
+    msg = lib.tgp_last_error(handle)
+    msg = msg.decode() if msg else ""
+    if rc in (TGP_ERR_SHAPE, TGP_ERR_ARG):
+        raise ValueError(msg)
+    if rc == TGP_ERR_NOT_PD:
+        raise NotPositiveDefiniteError(msg)
+    if rc == TGP_ERR_ALLOC:
+        raise MemoryError(msg)
+    if rc == TGP_ERR_STATE:
+        raise RuntimeError(msg)
+    raise TgpError(f"libtgp status {rc}: {msg}")

@@ -1,0 +1,791 @@
+// Host side of the C-ABI declared in include/tgp.h: handle state, device memory, the recursive
+// Cholesky / triangular-inverse driver of `update`, staging of caller buffers and launch glue.
+#include "../../include/tgp.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "tgp_internal.hpp"
+
+namespace tgp {
+hipError_t launch_sweep_kind0(hipStream_t, const SweepArgs&, bool, int64_t);
+hipError_t launch_sweep_kind1(hipStream_t, const SweepArgs&, bool, int64_t);
+hipError_t launch_sweep_kind2(hipStream_t, const SweepArgs&, bool, int64_t);
+hipError_t launch_sweep_kind3(hipStream_t, const SweepArgs&, bool, int64_t);
+}  // namespace tgp
+
+using namespace tgp;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {  // grow-only device buffer
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipSuccess) cap = bytes;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <class T>
+  T* as() const { return (T*)p; }
+};
+
+}  // namespace
+
+struct tgp_handle_s {
+  int device = 0, d = 0, dp = 0, kind = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // hyper-parameters
+  bool have_hyper = false, have_data = false;
+  double variance = 1.0, noise = 1.0, mean_const = 0.0;
+  std::vector<double> ls;  // [d]
+  int64_t N = 0, Npad = 0;
+  int variant = 0;
+  // model state on device
+  DevBuf d_ls, d_X, d_Y, d_Xs, d_A, d_L, d_W, d_alpha, d_err, d_tmp1, d_tmp2, d_info;
+  // scratch
+  DevBuf s_in, s_in2, s_out1, s_out2, s_out3, s_blkv, s_blki, s_small;
+  // timing of the dominant kernel
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double last_ms = 0.0;
+  int last_launches = 0;
+};
+
+struct tgp_traj_s {
+  tgp_handle h = nullptr;
+  int F = 0, B = 0;
+  DevBuf d_W, d_b, d_ws, d_v;
+};
+
+namespace {
+
+int fail(tgp_handle h, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (h) h->err = buf;
+  else g_create_error = buf;
+  return code;
+}
+
+#define HIPCHK(h, expr)                                                                      \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return fail(h, e_ == hipErrorOutOfMemory ? TGP_ERR_ALLOC : TGP_ERR_HIP, "%s: %s", #expr, \
+                  hipGetErrorString(e_));                                                    \
+  } while (0)
+
+ModelDev model_dev(tgp_handle h) {
+  ModelDev m;
+  m.kind = h->kind;
+  m.d = h->d;
+  m.dp = h->dp;
+  m.N = h->N;
+  m.Npad = h->Npad;
+  m.variance = h->variance;
+  m.noise = h->noise;
+  m.mean_const = h->mean_const;
+  m.ls = h->d_ls.as<double>();
+  m.Xs = h->d_Xs.as<double>();
+  m.Wt = h->d_A.as<double>();  // A is recycled as Wt after the factorisation
+  m.alpha = h->d_alpha.as<double>();
+  return m;
+}
+
+// Bring a caller array onto the device (no-op for TGP_DEVICE).
+int stage_in(tgp_handle h, DevBuf& buf, const double* src, size_t count, int where,
+             const double** out) {
+  if (where == TGP_DEVICE) {
+    *out = src;
+    return TGP_OK;
+  }
+  HIPCHK(h, buf.reserve(count * sizeof(double)));
+  HIPCHK(h, hipMemcpyAsync(buf.p, src, count * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  *out = buf.as<double>();
+  return TGP_OK;
+}
+
+// Where a kernel should write an output of `count` doubles destined for dst.
+int stage_out_prepare(tgp_handle h, DevBuf& buf, double* dst, size_t count, int where, double** dev) {
+  if (!dst) {
+    *dev = nullptr;
+    return TGP_OK;
+  }
+  if (where == TGP_DEVICE) {
+    *dev = dst;
+    return TGP_OK;
+  }
+  HIPCHK(h, buf.reserve(count * sizeof(double)));
+  *dev = buf.as<double>();
+  return TGP_OK;
+}
+
+int stage_out_finish(tgp_handle h, const double* dev, double* dst, size_t count, int where) {
+  if (!dst || where == TGP_DEVICE) return TGP_OK;
+  HIPCHK(h, hipMemcpyAsync(dst, dev, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  return TGP_OK;
+}
+
+int sync(tgp_handle h) {
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return TGP_OK;
+}
+
+int set_device(tgp_handle h) {
+  HIPCHK(h, hipSetDevice(h->device));
+  return TGP_OK;
+}
+
+hipError_t launch_sweep_timed(tgp_handle h, const SweepArgs& a, bool joint) {
+  const int64_t grid = sweep_grid(a, joint);
+  if (grid <= 0) return hipSuccess;
+  (void)hipEventRecord(h->ev0, h->stream);
+  hipError_t e;
+  switch (h->kind) {
+    case TGP_RBF: e = launch_sweep_kind0(h->stream, a, joint, grid); break;
+    case TGP_MATERN12: e = launch_sweep_kind1(h->stream, a, joint, grid); break;
+    case TGP_MATERN32: e = launch_sweep_kind2(h->stream, a, joint, grid); break;
+    default: e = launch_sweep_kind3(h->stream, a, joint, grid); break;
+  }
+  (void)hipEventRecord(h->ev1, h->stream);
+  h->last_launches = 1;
+  h->last_ms = -1.0;  // resolved lazily in tgp_last_kernel_ms
+  return e;
+}
+
+// ---- recursive Cholesky + inverse:  A (SPD, lower used) -> L, W = L^-1, all ld = Npad ----------
+//   chol_inv(lo, hi):  leaf (64):  L_dd, W_dd from A_dd
+//     else  chol_inv(lo, mid);  L21 = A21 W11^T;  A22 -= L21 L21^T;  chol_inv(mid, hi);
+//           T = L21 W11 (into the dead A21);  W21 = -W22 T.
+void chol_inv(tgp_handle h, int64_t lo, int64_t hi) {
+  const int64_t ld = h->Npad;
+  double* A = h->d_A.as<double>();
+  double* L = h->d_L.as<double>();
+  double* W = h->d_W.as<double>();
+  const int64_t n = hi - lo;
+  if (n <= LEAF) {
+    launch_leaf(h->stream, A, L, W, ld, lo, h->d_info.as<int>());
+    return;
+  }
+  const int64_t nblk = n / LEAF;
+  const int64_t mid = lo + (nblk / 2) * LEAF;
+  const int s1 = (int)(mid - lo), s2 = (int)(hi - mid);
+  chol_inv(h, lo, mid);
+  double* A21 = A + mid * ld + lo;
+  double* L21 = L + mid * ld + lo;
+  double* W11 = W + lo * ld + lo;
+  double* A22 = A + mid * ld + mid;
+  launch_gemm(h->stream, true, s2, s1, s1, 1.0, A21, ld, W11, ld, 0.0, L21, ld, false);
+  launch_gemm(h->stream, true, s2, s2, s1, -1.0, L21, ld, L21, ld, 1.0, A22, ld, true);
+  chol_inv(h, mid, hi);
+  double* W22 = W + mid * ld + mid;
+  double* W21 = W + mid * ld + lo;
+  launch_gemm(h->stream, false, s2, s1, s1, 1.0, L21, ld, W11, ld, 0.0, A21, ld, false);
+  launch_gemm(h->stream, false, s2, s1, s2, -1.0, W22, ld, A21, ld, 0.0, W21, ld, false);
+}
+
+}  // namespace
+
+namespace tgp {
+int64_t sweep_grid(const SweepArgs& a, bool joint) {
+  if (!joint) return (a.M + SW_BN - 1) / SW_BN;
+  const int gp = 64 / a.q;
+  return (a.G + 2 * gp - 1) / (2 * gp);
+}
+}  // namespace tgp
+
+extern "C" {
+
+const char* tgp_version(void) { return "tgp 0.1 (gfx950)"; }
+
+const char* tgp_last_error(tgp_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int tgp_create(int device_id, int d, int kernel_kind, tgp_handle* out) {
+  if (!out) return fail(nullptr, TGP_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  if (d < 1 || d > MAX_D) return fail(nullptr, TGP_ERR_SHAPE, "d must be in 1..%d, got %d", MAX_D, d);
+  if (kernel_kind < 0 || kernel_kind > 3)
+    return fail(nullptr, TGP_ERR_ARG, "unknown kernel kind %d", kernel_kind);
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0)
+    return fail(nullptr, TGP_ERR_HIP, "no HIP device available (%s): this engine has no CPU fallback",
+                e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  if (device_id < 0 || device_id >= ndev)
+    return fail(nullptr, TGP_ERR_ARG, "device %d out of range (have %d)", device_id, ndev);
+  tgp_handle h = new (std::nothrow) tgp_handle_s();
+  if (!h) return fail(nullptr, TGP_ERR_ALLOC, "host allocation failed");
+  h->device = device_id;
+  h->d = d;
+  h->dp = dpad_of(d);
+  h->kind = kernel_kind;
+  if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipEventCreate(&h->ev0)) != hipSuccess ||
+      (e = hipEventCreate(&h->ev1)) != hipSuccess) {
+    delete h;
+    return fail(nullptr, TGP_ERR_HIP, "device init failed: %s", hipGetErrorString(e));
+  }
+  *out = h;
+  return TGP_OK;
+}
+
+int tgp_destroy(tgp_handle h) {
+  if (!h) return TGP_OK;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  for (DevBuf* b : {&h->d_ls, &h->d_X, &h->d_Y, &h->d_Xs, &h->d_A, &h->d_L, &h->d_W, &h->d_alpha,
+                    &h->d_err, &h->d_tmp1, &h->d_tmp2, &h->d_info, &h->s_in, &h->s_in2, &h->s_out1,
+                    &h->s_out2, &h->s_out3, &h->s_blkv, &h->s_blki, &h->s_small})
+    b->release();
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  delete h;
+  return TGP_OK;
+}
+
+int tgp_set_stream(tgp_handle h, void* hip_stream) {
+  if (!h) return TGP_ERR_ARG;
+  h->stream = (hipStream_t)hip_stream;
+  return TGP_OK;
+}
+
+int tgp_set_variant(tgp_handle h, int variant) {
+  if (!h) return TGP_ERR_ARG;
+  h->variant = variant;
+  return TGP_OK;
+}
+
+int tgp_set_hyper(tgp_handle h, double variance, const double* lengthscales, double noise_variance,
+                  double mean_const) {
+  if (!h) return TGP_ERR_ARG;
+  if (!lengthscales) return fail(h, TGP_ERR_ARG, "lengthscales is NULL");
+  if (!(variance > 0.0) || !(noise_variance > 0.0) || !std::isfinite(mean_const))
+    return fail(h, TGP_ERR_ARG, "variance and noise_variance must be positive, mean finite");
+  for (int c = 0; c < h->d; ++c)
+    if (!(lengthscales[c] > 0.0)) return fail(h, TGP_ERR_ARG, "lengthscale %d must be positive", c);
+  if (int rc = set_device(h)) return rc;
+  h->variance = variance;
+  h->noise = noise_variance;
+  h->mean_const = mean_const;
+  h->ls.assign(lengthscales, lengthscales + h->d);
+  std::vector<double> lsp(h->dp, 1.0);
+  for (int c = 0; c < h->d; ++c) lsp[c] = lengthscales[c];
+  HIPCHK(h, h->d_ls.reserve(h->dp * sizeof(double)));
+  HIPCHK(h, hipMemcpy(h->d_ls.p, lsp.data(), h->dp * sizeof(double), hipMemcpyHostToDevice));
+  h->have_hyper = true;
+  h->have_data = false;  // factorisation is stale
+  return TGP_OK;
+}
+
+int tgp_set_data(tgp_handle h, const double* X, const double* Y, int64_t N, int where) {
+  if (!h) return TGP_ERR_ARG;
+  if (!h->have_hyper) return fail(h, TGP_ERR_STATE, "tgp_set_hyper must be called before tgp_set_data");
+  if (!X || !Y) return fail(h, TGP_ERR_ARG, "X / Y is NULL");
+  if (N < 1) return fail(h, TGP_ERR_SHAPE, "N must be >= 1, got %lld", (long long)N);
+  if (int rc = set_device(h)) return rc;
+  h->have_data = false;
+  const int64_t Npad = ((N + NPAD_MULT - 1) / NPAD_MULT) * NPAD_MULT;
+  const size_t nn = (size_t)Npad * Npad * sizeof(double);
+  const int d = h->d, dp = h->dp;
+  HIPCHK(h, h->d_X.reserve((size_t)N * d * sizeof(double)));
+  HIPCHK(h, h->d_Y.reserve((size_t)N * sizeof(double)));
+  HIPCHK(h, h->d_Xs.reserve((size_t)Npad * dp * sizeof(double)));
+  HIPCHK(h, h->d_A.reserve(nn));
+  HIPCHK(h, h->d_L.reserve(nn));
+  HIPCHK(h, h->d_W.reserve(nn));
+  HIPCHK(h, h->d_alpha.reserve(Npad * sizeof(double)));
+  HIPCHK(h, h->d_err.reserve(Npad * sizeof(double)));
+  HIPCHK(h, h->d_tmp1.reserve(Npad * sizeof(double)));
+  HIPCHK(h, h->d_tmp2.reserve(Npad * sizeof(double)));
+  HIPCHK(h, h->d_info.reserve(sizeof(int)));
+  const hipMemcpyKind kindcp = where == TGP_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  HIPCHK(h, hipMemcpyAsync(h->d_X.p, X, (size_t)N * d * sizeof(double), kindcp, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->d_Y.p, Y, (size_t)N * sizeof(double), kindcp, h->stream));
+  HIPCHK(h, hipMemsetAsync(h->d_info.p, 0, sizeof(int), h->stream));
+  h->N = N;
+  h->Npad = Npad;
+  hipStream_t s = h->stream;
+  double* A = h->d_A.as<double>();
+  double* L = h->d_L.as<double>();
+  double* W = h->d_W.as<double>();
+  launch_scale_inputs(s, h->d_X.as<double>(), h->d_ls.as<double>(), h->d_Xs.as<double>(), N, Npad, d, dp);
+  launch_assemble_K(s, h->d_Xs.as<double>(), A, N, Npad, dp, h->kind, h->variance, h->noise);
+  HIPCHK(h, hipMemsetAsync(L, 0, nn, s));
+  HIPCHK(h, hipMemsetAsync(W, 0, nn, s));
+  chol_inv(h, 0, Npad);
+  // err = Y - c (zero padded)  -- gpflow GPRPosterior._precompute: err = Y - mean_function(X)
+  launch_center(s, h->d_Y.as<double>(), h->mean_const, h->d_err.as<double>(), N, Npad);
+  // Wt (into A, dead now) = masked transpose of W; alpha = Wt (W err)
+  launch_transpose_mask(s, W, A, N, Npad);
+  launch_trmv(s, W, Npad, Npad, h->d_err.as<double>(), h->d_tmp2.as<double>(), true);
+  launch_trmv(s, A, Npad, Npad, h->d_tmp2.as<double>(), h->d_alpha.as<double>(), false);
+  // the padding rows of W carry the identity: alpha/tmp there are err_pad = 0 -> stay 0.
+  int info = 0;
+  HIPCHK(h, hipMemcpyAsync(&info, h->d_info.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  HIPCHK(h, hipGetLastError());
+  if (info != 0)
+    return fail(h, TGP_ERR_NOT_PD, "Cholesky failed: K + noise*I is not positive definite (pivot %d)",
+                info - 1);
+  h->have_data = true;
+  return TGP_OK;
+}
+
+int tgp_get_sizes(tgp_handle h, int64_t* N, int* d) {
+  if (!h) return TGP_ERR_ARG;
+  if (N) *N = h->have_data ? h->N : 0;
+  if (d) *d = h->d;
+  return TGP_OK;
+}
+
+int tgp_get_factor(tgp_handle h, double* L, double* Winv, double* alpha, int where) {
+  if (!h) return TGP_ERR_ARG;
+  if (!h->have_data) return fail(h, TGP_ERR_STATE, "no factorisation: call tgp_set_data first");
+  if (int rc = set_device(h)) return rc;
+  const hipMemcpyKind k = where == TGP_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  const size_t rowb = (size_t)h->N * sizeof(double);
+  if (L) HIPCHK(h, hipMemcpy2DAsync(L, rowb, h->d_L.p, (size_t)h->Npad * sizeof(double), rowb, h->N, k, h->stream));
+  if (Winv) HIPCHK(h, hipMemcpy2DAsync(Winv, rowb, h->d_W.p, (size_t)h->Npad * sizeof(double), rowb, h->N, k, h->stream));
+  if (alpha) HIPCHK(h, hipMemcpyAsync(alpha, h->d_alpha.p, rowb, k, h->stream));
+  return sync(h);
+}
+
+static int sweep_common(tgp_handle h, const double* Xq, int64_t M, double* mean, double* var, double* acq,
+                        int acq_kind, double param, int where, bool want_best, int64_t index_base,
+                        double* best_val, int64_t* best_idx, double* best_x) {
+  if (!h) return TGP_ERR_ARG;
+  if (!h->have_data) return fail(h, TGP_ERR_STATE, "model has no data: call tgp_set_data first");
+  if (M < 0) return fail(h, TGP_ERR_SHAPE, "M must be >= 0");
+  if (M > 0 && !Xq) return fail(h, TGP_ERR_ARG, "Xq is NULL");
+  if (int rc = set_device(h)) return rc;
+  h->last_launches = 0;
+  h->last_ms = 0.0;
+  if (M == 0) {
+    if (want_best) return fail(h, TGP_ERR_SHAPE, "arg-max over an empty candidate set");
+    return TGP_OK;
+  }
+  const double* dXq;
+  if (int rc = stage_in(h, h->s_in, Xq, (size_t)M * h->d, where, &dXq)) return rc;
+  SweepArgs a{};
+  a.m = model_dev(h);
+  a.Xq = dXq;
+  a.M = M;
+  if (int rc = stage_out_prepare(h, h->s_out1, mean, M, where, &a.mean_out)) return rc;
+  if (int rc = stage_out_prepare(h, h->s_out2, var, M, where, &a.var_out)) return rc;
+  if (int rc = stage_out_prepare(h, h->s_out3, acq, M, where, &a.acq_out)) return rc;
+  a.acq_kind = acq_kind;
+  a.acq_param = param;
+  a.index_base = index_base;
+  const int64_t grid = sweep_grid(a, false);
+  if (want_best) {
+    HIPCHK(h, h->s_blkv.reserve(grid * sizeof(double)));
+    HIPCHK(h, h->s_blki.reserve(grid * sizeof(int64_t)));
+    HIPCHK(h, h->s_small.reserve(64));
+    a.blk_val = h->s_blkv.as<double>();
+    a.blk_idx = h->s_blki.as<int64_t>();
+  }
+  HIPCHK(h, launch_sweep_timed(h, a, false));
+  if (want_best) {
+    double* fv = h->s_small.as<double>();
+    int64_t* fi = (int64_t*)(fv + 1);
+    launch_argmax_final(h->stream, a.blk_val, a.blk_idx, grid, fv, fi);
+    double hv;
+    int64_t hi;
+    HIPCHK(h, hipMemcpyAsync(&hv, fv, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(&hi, fi, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    if (int rc = sync(h)) return rc;
+    if (best_val) *best_val = hv;
+    if (best_idx) *best_idx = hi;
+    if (best_x) {
+      const int64_t local = hi - index_base;
+      if (local < 0 || local >= M) return fail(h, TGP_ERR_HIP, "arg-max produced no valid index (all NaN?)");
+      if (where == TGP_DEVICE)
+        HIPCHK(h, hipMemcpy(best_x, dXq + local * h->d, h->d * sizeof(double), hipMemcpyDeviceToHost));
+      else
+        memcpy(best_x, Xq + local * h->d, h->d * sizeof(double));
+    }
+  }
+  if (int rc = stage_out_finish(h, a.mean_out, mean, M, where)) return rc;
+  if (int rc = stage_out_finish(h, a.var_out, var, M, where)) return rc;
+  if (int rc = stage_out_finish(h, a.acq_out, acq, M, where)) return rc;
+  if (int rc = sync(h)) return rc;
+  HIPCHK(h, hipGetLastError());
+  return TGP_OK;
+}
+
+int tgp_predict(tgp_handle h, const double* Xq, int64_t M, double* mean, double* var, int where) {
+  return sweep_common(h, Xq, M, mean, var, nullptr, -1, 0.0, where, false, 0, nullptr, nullptr, nullptr);
+}
+
+int tgp_predict_mean(tgp_handle h, const double* Xq, int64_t M, double* mean, int where) {
+  if (!h) return TGP_ERR_ARG;
+  if (!h->have_data) return fail(h, TGP_ERR_STATE, "model has no data: call tgp_set_data first");
+  if (M < 0 || (M > 0 && (!Xq || !mean))) return fail(h, TGP_ERR_ARG, "bad arguments");
+  if (M == 0) return TGP_OK;
+  if (int rc = set_device(h)) return rc;
+  const double* dXq;
+  double* dmean;
+  if (int rc = stage_in(h, h->s_in, Xq, (size_t)M * h->d, where, &dXq)) return rc;
+  if (int rc = stage_out_prepare(h, h->s_out1, mean, M, where, &dmean)) return rc;
+  launch_predict_mean(h->stream, model_dev(h), dXq, M, dmean);
+  if (int rc = stage_out_finish(h, dmean, mean, M, where)) return rc;
+  if (int rc = sync(h)) return rc;
+  HIPCHK(h, hipGetLastError());
+  return TGP_OK;
+}
+
+int tgp_eta(tgp_handle h, double* eta) {
+  if (!h || !eta) return TGP_ERR_ARG;
+  if (!h->have_data) return fail(h, TGP_ERR_STATE, "model has no data: call tgp_set_data first");
+  if (int rc = set_device(h)) return rc;
+  HIPCHK(h, h->s_out1.reserve(h->N * sizeof(double)));
+  HIPCHK(h, h->s_small.reserve(64));
+  launch_predict_mean(h->stream, model_dev(h), h->d_X.as<double>(), h->N, h->s_out1.as<double>());
+  launch_min_value(h->stream, h->s_out1.as<double>(), h->N, h->s_small.as<double>());
+  HIPCHK(h, hipMemcpyAsync(eta, h->s_small.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (int rc = sync(h)) return rc;
+  HIPCHK(h, hipGetLastError());
+  return TGP_OK;
+}
+
+int tgp_acq_values(tgp_handle h, int acq_kind, double param, const double* Xq, int64_t M, double* out,
+                   int where) {
+  if (acq_kind < 0 || acq_kind > 2) return fail(h, TGP_ERR_ARG, "unknown acquisition kind %d", acq_kind);
+  if (M > 0 && !out) return fail(h, TGP_ERR_ARG, "out is NULL");
+  return sweep_common(h, Xq, M, nullptr, nullptr, out, acq_kind, param, where, false, 0, nullptr, nullptr,
+                      nullptr);
+}
+
+int tgp_acq_argmax(tgp_handle h, int acq_kind, double param, const double* Xq, int64_t M,
+                   int64_t index_base, double* best_val, int64_t* best_idx, double* best_x, int where) {
+  if (acq_kind < 0 || acq_kind > 2) return fail(h, TGP_ERR_ARG, "unknown acquisition kind %d", acq_kind);
+  return sweep_common(h, Xq, M, nullptr, nullptr, nullptr, acq_kind, param, where, true, index_base,
+                      best_val, best_idx, best_x);
+}
+
+int tgp_acq_topk(tgp_handle h, int acq_kind, double param, const double* Xq, int64_t M,
+                 int64_t index_base, int k, double* vals, int64_t* idx, int where) {
+  if (!h) return TGP_ERR_ARG;
+  if (k < 1 || k > 1024) return fail(h, TGP_ERR_ARG, "k must be in 1..1024");
+  if (M < k) return fail(h, TGP_ERR_SHAPE, "top-k needs M >= k (M=%lld, k=%d)", (long long)M, k);
+  if (acq_kind < 0 || acq_kind > 2) return fail(h, TGP_ERR_ARG, "unknown acquisition kind %d", acq_kind);
+  if (!h->have_data) return fail(h, TGP_ERR_STATE, "model has no data: call tgp_set_data first");
+  if (int rc = set_device(h)) return rc;
+  // acquisition values stay on the device (8 B / candidate), then k extraction passes
+  HIPCHK(h, h->s_out3.reserve((size_t)M * sizeof(double)));
+  double* dvals = h->s_out3.as<double>();
+  {
+    const double* dXq;
+    if (int rc = stage_in(h, h->s_in, Xq, (size_t)M * h->d, where, &dXq)) return rc;
+    SweepArgs a{};
+    a.m = model_dev(h);
+    a.Xq = dXq;
+    a.M = M;
+    a.acq_out = dvals;
+    a.acq_kind = acq_kind;
+    a.acq_param = param;
+    HIPCHK(h, launch_sweep_timed(h, a, false));
+  }
+  HIPCHK(h, h->s_blkv.reserve(512 * sizeof(double)));
+  HIPCHK(h, h->s_blki.reserve(512 * sizeof(int64_t)));
+  HIPCHK(h, h->s_small.reserve(64));
+  double* fv = h->s_small.as<double>();
+  int64_t* fi = (int64_t*)(fv + 1);
+  double pv = 0.0;
+  int64_t pi = 0;
+  for (int t = 0; t < k; ++t) {
+    launch_topk_pass(h->stream, dvals, M, index_base, pv, pi, t == 0, h->s_blkv.as<double>(),
+                     h->s_blki.as<int64_t>(), fv, fi);
+    HIPCHK(h, hipMemcpyAsync(&pv, fv, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(&pi, fi, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    if (int rc = sync(h)) return rc;
+    vals[t] = pv;
+    idx[t] = pi;
+  }
+  HIPCHK(h, hipGetLastError());
+  return TGP_OK;
+}
+
+int tgp_sample_box(tgp_handle h, uint64_t seed, int64_t first, int64_t M, const double* lower,
+                   const double* upper, double* out_device) {
+  if (!h) return TGP_ERR_ARG;
+  if (M < 0 || !lower || !upper || (M > 0 && !out_device)) return fail(h, TGP_ERR_ARG, "bad arguments");
+  if (M == 0) return TGP_OK;
+  if (int rc = set_device(h)) return rc;
+  HIPCHK(h, h->s_small.reserve(2 * MAX_D * sizeof(double) + 64));
+  double* dl = h->s_small.as<double>() + 8;
+  double* du = dl + MAX_D;
+  HIPCHK(h, hipMemcpyAsync(dl, lower, h->d * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(du, upper, h->d * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  launch_sample_box(h->stream, seed, first, M, h->d, dl, du, out_device);
+  if (int rc = sync(h)) return rc;
+  HIPCHK(h, hipGetLastError());
+  return TGP_OK;
+}
+
+static int joint_common(tgp_handle h, const double* Xq, int64_t G, int q, int where, const double** dXq,
+                        double** dmean, double** dcov, double* mean, double* cov, bool force_dev_out) {
+  if (!h) return TGP_ERR_ARG;
+  if (!h->have_data) return fail(h, TGP_ERR_STATE, "model has no data: call tgp_set_data first");
+  if (q < 1 || q > MAX_Q) return fail(h, TGP_ERR_SHAPE, "q must be in 1..%d, got %d", MAX_Q, q);
+  if (G < 0 || (G > 0 && !Xq)) return fail(h, TGP_ERR_ARG, "bad arguments");
+  if (int rc = set_device(h)) return rc;
+  if (int rc = stage_in(h, h->s_in, Xq, (size_t)G * q * h->d, where, dXq)) return rc;
+  if (force_dev_out) {
+    HIPCHK(h, h->s_out1.reserve((size_t)G * q * sizeof(double)));
+    HIPCHK(h, h->s_out2.reserve((size_t)G * q * q * sizeof(double)));
+    *dmean = h->s_out1.as<double>();
+    *dcov = h->s_out2.as<double>();
+  } else {
+    if (int rc = stage_out_prepare(h, h->s_out1, mean, (size_t)G * q, where, dmean)) return rc;
+    if (int rc = stage_out_prepare(h, h->s_out2, cov, (size_t)G * q * q, where, dcov)) return rc;
+  }
+  SweepArgs a{};
+  a.m = model_dev(h);
+  a.Xq = *dXq;
+  a.M = G * q;
+  a.G = G;
+  a.q = q;
+  a.mean_out = *dmean;
+  a.cov_out = *dcov;
+  a.acq_kind = -1;
+  HIPCHK(h, launch_sweep_timed(h, a, true));
+  return TGP_OK;
+}
+
+int tgp_predict_joint(tgp_handle h, const double* Xq, int64_t G, int q, double* mean, double* cov,
+                      int where) {
+  const double* dXq;
+  double *dmean, *dcov;
+  if (G == 0) return h ? TGP_OK : TGP_ERR_ARG;
+  if (int rc = joint_common(h, Xq, G, q, where, &dXq, &dmean, &dcov, mean, cov, false)) return rc;
+  if (int rc = stage_out_finish(h, dmean, mean, (size_t)G * q, where)) return rc;
+  if (int rc = stage_out_finish(h, dcov, cov, (size_t)G * q * q, where)) return rc;
+  if (int rc = sync(h)) return rc;
+  HIPCHK(h, hipGetLastError());
+  return TGP_OK;
+}
+
+int tgp_qei(tgp_handle h, const double* Xq, int64_t G, int q, const double* eps, int S, double eta,
+            double jitter, double* out, int where) {
+  if (!h) return TGP_ERR_ARG;
+  if (!(jitter >= 0.0)) return fail(h, TGP_ERR_ARG, "jitter must be >= 0");
+  if (S < 1 || !eps) return fail(h, TGP_ERR_ARG, "need S >= 1 draws");
+  if (G == 0) return TGP_OK;
+  if (!out) return fail(h, TGP_ERR_ARG, "out is NULL");
+  const double* dXq;
+  double *dmean, *dcov;
+  // chunk the groups so the [G,q,q] covariances stay within a bounded scratch (<= ~1 GiB)
+  const int64_t chunk = std::max<int64_t>(1, (int64_t)(1ull << 30) / ((int64_t)q * q * 8));
+  if (int rc = set_device(h)) return rc;
+  const double* deps;
+  if (int rc = stage_in(h, h->s_in2, eps, (size_t)q * S, where, &deps)) return rc;
+  HIPCHK(h, h->d_info.reserve(sizeof(int)));
+  HIPCHK(h, hipMemsetAsync(h->d_info.p, 0, sizeof(int), h->stream));
+  double total_ms = 0.0;
+  int launches = 0;
+  for (int64_t g0 = 0; g0 < G; g0 += chunk) {
+    const int64_t gc = std::min(chunk, G - g0);
+    if (int rc = joint_common(h, Xq + g0 * q * h->d, gc, q, where, &dXq, &dmean, &dcov, nullptr, nullptr, true))
+      return rc;
+    double* dout;
+    if (int rc = stage_out_prepare(h, h->s_out3, out + g0, gc, where, &dout)) return rc;
+    launch_qei_tail(h->stream, dmean, dcov, gc, q, deps, S, eta, jitter, dout, h->d_info.as<int>());
+    if (int rc = stage_out_finish(h, dout, out + g0, gc, where)) return rc;
+    if (int rc = sync(h)) return rc;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) total_ms += ms;
+    ++launches;
+  }
+  h->last_ms = total_ms;
+  h->last_launches = launches;
+  int info = 0;
+  HIPCHK(h, hipMemcpy(&info, h->d_info.p, sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(h, hipGetLastError());
+  if (info != 0)
+    return fail(h, TGP_ERR_NOT_PD, "qEI: cov + jitter*I not positive definite for group %d", info - 1);
+  return TGP_OK;
+}
+
+// ---- trajectories -----------------------------------------------------------------------------
+static TrajDev traj_dev(tgp_traj t) {
+  TrajDev td;
+  td.m = model_dev(t->h);
+  td.F = t->F;
+  td.B = t->B;
+  td.rffW = t->d_W.as<double>();
+  td.rffb = t->d_b.as<double>();
+  td.ws = t->d_ws.as<double>();
+  td.v = t->d_v.as<double>();
+  return td;
+}
+
+int tgp_traj_create(tgp_handle h, const double* rff_W, const double* rff_b, int F, const double* w,
+                    const double* xi, int B, tgp_traj* out) {
+  if (!h || !out) return TGP_ERR_ARG;
+  *out = nullptr;
+  if (!h->have_data) return fail(h, TGP_ERR_STATE, "model has no data: call tgp_set_data first");
+  if (F < 1 || B < 1 || !rff_W || !rff_b || !w || !xi) return fail(h, TGP_ERR_ARG, "bad arguments");
+  if (int rc = set_device(h)) return rc;
+  tgp_traj t = new (std::nothrow) tgp_traj_s();
+  if (!t) return fail(h, TGP_ERR_ALLOC, "host allocation failed");
+  t->h = h;
+  t->F = F;
+  t->B = B;
+  const int d = h->d, dp = h->dp;
+  const int64_t N = h->N, Npad = h->Npad;
+  std::vector<double> Wp((size_t)F * dp, 0.0), ws((size_t)F * B);
+  for (int f = 0; f < F; ++f)
+    for (int c = 0; c < d; ++c) Wp[(size_t)f * dp + c] = rff_W[(size_t)f * d + c];
+  const double scale = std::sqrt(2.0 * h->variance / (double)F);
+  for (size_t e = 0; e < (size_t)F * B; ++e) ws[e] = scale * w[e];
+  // u = err + sqrt(noise) xi   (host, [N][B]) ; diff = u - Phi_Z w (device)
+  std::vector<double> errh((size_t)N);
+  hipError_t e;
+#define TCHK(expr)                                                            \
+  if ((e = (expr)) != hipSuccess) {                                           \
+    tgp_traj_destroy(t);                                                      \
+    return fail(h, e == hipErrorOutOfMemory ? TGP_ERR_ALLOC : TGP_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e)); \
+  }
+  TCHK(t->d_W.reserve(Wp.size() * sizeof(double)));
+  TCHK(t->d_b.reserve((size_t)F * sizeof(double)));
+  TCHK(t->d_ws.reserve(ws.size() * sizeof(double)));
+  TCHK(t->d_v.reserve((size_t)Npad * B * sizeof(double)));
+  TCHK(hipMemcpy(t->d_W.p, Wp.data(), Wp.size() * sizeof(double), hipMemcpyHostToDevice));
+  TCHK(hipMemcpy(t->d_b.p, rff_b, (size_t)F * sizeof(double), hipMemcpyHostToDevice));
+  TCHK(hipMemcpy(t->d_ws.p, ws.data(), ws.size() * sizeof(double), hipMemcpyHostToDevice));
+  TCHK(hipMemcpy(errh.data(), h->d_err.p, (size_t)N * sizeof(double), hipMemcpyDeviceToHost));
+  // Phi_Z w  -> s_out1 [N][B]
+  TCHK(h->s_out1.reserve((size_t)N * B * sizeof(double)));
+  TrajDev td = traj_dev(t);
+  launch_rff_project(h->stream, td, h->d_X.as<double>(), N, h->s_out1.as<double>());
+  std::vector<double> proj((size_t)N * B);
+  TCHK(hipMemcpyAsync(proj.data(), h->s_out1.p, proj.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  TCHK(hipStreamSynchronize(h->stream));
+  // per trajectory: diff_b (padded) -> tmp1 ; tmp2 = W diff ; v_b = Wt tmp2
+  const double sn = std::sqrt(h->noise);
+  std::vector<double> diff((size_t)Npad, 0.0), vhost((size_t)Npad * B, 0.0), vb((size_t)Npad);
+  for (int b = 0; b < B; ++b) {
+    for (int64_t i = 0; i < N; ++i) diff[i] = errh[i] + sn * xi[i * B + b] - proj[i * B + b];
+    TCHK(hipMemcpy(h->d_tmp1.p, diff.data(), (size_t)Npad * sizeof(double), hipMemcpyHostToDevice));
+    launch_trmv(h->stream, h->d_W.as<double>(), Npad, Npad, h->d_tmp1.as<double>(), h->d_tmp2.as<double>(), true);
+    launch_trmv(h->stream, h->d_A.as<double>(), Npad, Npad, h->d_tmp2.as<double>(), h->d_tmp1.as<double>(), false);
+    TCHK(hipMemcpyAsync(vb.data(), h->d_tmp1.p, (size_t)Npad * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    TCHK(hipStreamSynchronize(h->stream));
+    for (int64_t i = 0; i < N; ++i) vhost[i * B + b] = vb[i];
+  }
+  TCHK(hipMemcpy(t->d_v.p, vhost.data(), vhost.size() * sizeof(double), hipMemcpyHostToDevice));
+  TCHK(hipGetLastError());
+#undef TCHK
+  *out = t;
+  return TGP_OK;
+}
+
+int tgp_traj_destroy(tgp_traj t) {
+  if (!t) return TGP_OK;
+  if (t->h) (void)hipSetDevice(t->h->device);
+  t->d_W.release();
+  t->d_b.release();
+  t->d_ws.release();
+  t->d_v.release();
+  delete t;
+  return TGP_OK;
+}
+
+int tgp_traj_get_v(tgp_traj t, double* v) {
+  if (!t || !v) return TGP_ERR_ARG;
+  tgp_handle h = t->h;
+  if (int rc = set_device(h)) return rc;
+  HIPCHK(h, hipMemcpy(v, t->d_v.p, (size_t)h->N * t->B * sizeof(double), hipMemcpyDeviceToHost));
+  return TGP_OK;
+}
+
+int tgp_traj_eval(tgp_traj t, const double* Xq, int64_t M, int per_traj_inputs, double* out, int where) {
+  if (!t) return TGP_ERR_ARG;
+  tgp_handle h = t->h;
+  if (M < 0 || (M > 0 && (!Xq || !out))) return fail(h, TGP_ERR_ARG, "bad arguments");
+  if (M == 0) return TGP_OK;
+  if (!per_traj_inputs && t->B > 16)
+    return fail(h, TGP_ERR_SHAPE, "shared-input evaluation supports B <= 16 trajectories, got %d", t->B);
+  if (int rc = set_device(h)) return rc;
+  const size_t nin = (size_t)M * (per_traj_inputs ? t->B : 1) * h->d;
+  const double* dXq;
+  double* dout;
+  if (int rc = stage_in(h, h->s_in, Xq, nin, where, &dXq)) return rc;
+  if (int rc = stage_out_prepare(h, h->s_out1, out, (size_t)M * t->B, where, &dout)) return rc;
+  (void)hipEventRecord(h->ev0, h->stream);
+  launch_traj_eval(h->stream, traj_dev(t), dXq, M, per_traj_inputs, dout, nullptr, nullptr, 0);
+  (void)hipEventRecord(h->ev1, h->stream);
+  h->last_launches = 1;
+  h->last_ms = -1.0;
+  if (int rc = stage_out_finish(h, dout, out, (size_t)M * t->B, where)) return rc;
+  if (int rc = sync(h)) return rc;
+  HIPCHK(h, hipGetLastError());
+  return TGP_OK;
+}
+
+int tgp_traj_argmin(tgp_traj t, const double* Xq, int64_t M, int64_t index_base, double* best_val,
+                    int64_t* best_idx, int where) {
+  if (!t) return TGP_ERR_ARG;
+  tgp_handle h = t->h;
+  if (M < 1 || !Xq) return fail(h, TGP_ERR_SHAPE, "arg-min needs M >= 1 candidates");
+  if (t->B > 16) return fail(h, TGP_ERR_SHAPE, "supports B <= 16 trajectories per call, got %d", t->B);
+  if (int rc = set_device(h)) return rc;
+  const double* dXq;
+  if (int rc = stage_in(h, h->s_in, Xq, (size_t)M * h->d, where, &dXq)) return rc;
+  const int64_t grid = traj_grid(M);
+  const int B = t->B;
+  HIPCHK(h, h->s_blkv.reserve((size_t)grid * B * sizeof(double)));
+  HIPCHK(h, h->s_blki.reserve((size_t)grid * B * sizeof(int64_t)));
+  HIPCHK(h, h->s_small.reserve(64 + 2 * 16 * 8));
+  double* fv = h->s_small.as<double>();
+  int64_t* fi = (int64_t*)(fv + 16);
+  (void)hipEventRecord(h->ev0, h->stream);
+  launch_traj_eval(h->stream, traj_dev(t), dXq, M, 0, nullptr, h->s_blkv.as<double>(),
+                   h->s_blki.as<int64_t>(), index_base);
+  (void)hipEventRecord(h->ev1, h->stream);
+  h->last_launches = 1;
+  h->last_ms = -1.0;
+  launch_argmin_final_multi(h->stream, h->s_blkv.as<double>(), h->s_blki.as<int64_t>(), grid, B, fv, fi);
+  if (best_val) HIPCHK(h, hipMemcpyAsync(best_val, fv, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (best_idx) HIPCHK(h, hipMemcpyAsync(best_idx, fi, B * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+  if (int rc = sync(h)) return rc;
+  HIPCHK(h, hipGetLastError());
+  return TGP_OK;
+}
+
+int tgp_last_kernel_ms(tgp_handle h, double* ms, int* launches) {
+  if (!h) return TGP_ERR_ARG;
+  if (h->last_ms < 0.0) {
+    float f = 0.f;
+    if (hipEventElapsedTime(&f, h->ev0, h->ev1) == hipSuccess) h->last_ms = f;
+    else h->last_ms = 0.0;
+  }
+  if (ms) *ms = h->last_ms;
+  if (launches) *launches = h->last_launches;
+  return TGP_OK;
+}
+
+}  // extern "C"

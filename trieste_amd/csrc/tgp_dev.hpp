@@ -1,0 +1,181 @@
+// Device-side helpers shared by the gfx950 kernels of libtgp (stationary kernels, normal cdf/pdf,
+// acquisition tails, Philox, wave reductions).  CDNA4 only: 64-lane wavefronts, f64 MFMA.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tgp {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+constexpr int KIND_RBF = 0, KIND_M12 = 1, KIND_M32 = 2, KIND_M52 = 3;
+constexpr int ACQ_EI = 0, ACQ_PI = 1, ACQ_NLCB = 2;
+constexpr double VAR_FLOOR = 1e-12;  // reference interface.py:123
+
+// v_mfma_f64_16x16x4_f64: D(16x16) += A(16x4) * B(4x16).
+// lane l holds A[i = l&15][k = l>>4], B[k = l>>4][j = l&15];
+// D reg r of lane l is D[row = (l>>4) + 4r][col = l&15]   (f64 layout, not the f32 one).
+__device__ __forceinline__ v4d mfma_f64(double a, double b, v4d c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// ---- fast fp64 math for the per-entry kernel evaluation ---------------------------------------
+// The libm-grade sqrt/exp hipcc inlines cost ~45 VALU instructions per K* entry, most of it
+// special-case handling (scaling, class tests, overflow selects) that cannot trigger here:
+// sqrt is only called on [1e-36, 1e300] and exp only on (-inf, 0].  These versions keep full
+// double accuracy (<= 2 ulp, checked against the oracle in tests/test_gpu_parity.py) at roughly
+// half the instructions.
+typedef const __attribute__((address_space(4))) double* cptr;  // read-only data, scalar-loadable
+__device__ __forceinline__ cptr as_const(const double* p) {
+  return (cptr)(const __attribute__((address_space(1))) double*)(p);
+}
+
+__device__ __forceinline__ double fast_sqrt_pos(double x) {
+  const double y = __builtin_amdgcn_rsq(x);  // v_rsq_f64
+  double g = x * y, h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  double dd = fma(-g, g, x);
+  g = fma(dd, h, g);
+  dd = fma(-g, g, x);
+  g = fma(dd, h, g);
+  return g;
+}
+
+// exp(x) for x <= 0.  n = rint(x / ln2), r = x - n ln2 (two-term Cody-Waite), degree-11
+// Chebyshev-fitted polynomial on |r| <= ln2/2 (relative error 4.2e-18), ldexp.
+__device__ __forceinline__ double fast_exp_nonpos(double x) {
+  x = fmax(x, -745.5);  // exp(-745.5) underflows to 0 through ldexp
+  const double n = rint(x * 1.4426950408889634);
+  double r = fma(n, -6.93147180369123816490e-01, x);
+  r = fma(n, -1.90821492927058770002e-10, r);
+  double p = 2.5110037605963777e-08;
+  p = fma(p, r, 2.763263963904103e-07);
+  p = fma(p, r, 2.755724091857897e-06);
+  p = fma(p, r, 2.4801485482328494e-05);
+  p = fma(p, r, 0.00019841269890047113);
+  p = fma(p, r, 0.0013888888952314775);
+  p = fma(p, r, 0.008333333333319601);
+  p = fma(p, r, 0.0416666666664881);
+  p = fma(p, r, 0.1666666666666668);
+  p = fma(p, r, 0.5000000000000019);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)n);
+}
+
+#ifdef TGP_LIBM_MATH
+#define TGP_SQRT(x) sqrt(x)
+#define TGP_EXPNEG(x) exp(x)
+#else
+#define TGP_SQRT(x) fast_sqrt_pos(x)
+#define TGP_EXPNEG(x) fast_exp_nonpos(x)
+#endif
+
+// ---- stationary kernels (gpflow Stationary / IsotropicStationary) -----
+// r2 = scaled squared distance (>= 0 by construction: difference form).
+template <int KIND>
+__device__ __forceinline__ double kernel_from_r2(double r2, double variance) {
+  if constexpr (KIND == KIND_RBF) {
+    return variance * TGP_EXPNEG(-0.5 * r2);
+  } else {
+    const double r2c = fmax(r2, 1e-36);  // gpflow: r = sqrt(max(r2, 1e-36))
+    const double r = TGP_SQRT(r2c);
+    if constexpr (KIND == KIND_M12) {
+      return variance * TGP_EXPNEG(-r);
+    } else if constexpr (KIND == KIND_M32) {
+      const double s = 1.7320508075688772 * r;
+      return variance * (1.0 + s) * TGP_EXPNEG(-s);
+    } else {
+      const double s = 2.23606797749979 * r;
+      return variance * fma(5.0 / 3.0, r2c, 1.0 + s) * TGP_EXPNEG(-s);
+    }
+  }
+}
+
+// runtime-kind form for the cold kernels (assembly of K, K** blocks, predict_mean)
+__device__ __forceinline__ double kernel_rt(int kind, double r2, double variance) {
+  switch (kind) {
+    case KIND_RBF: return kernel_from_r2<KIND_RBF>(r2, variance);
+    case KIND_M12: return kernel_from_r2<KIND_M12>(r2, variance);
+    case KIND_M32: return kernel_from_r2<KIND_M32>(r2, variance);
+    default: return kernel_from_r2<KIND_M52>(r2, variance);
+  }
+}
+
+// ---- normal distribution ------------------------------------------------------------------
+__device__ __forceinline__ double normal_cdf(double z) {
+  return 0.5 * erfc(-z * 0.7071067811865476);
+}
+__device__ __forceinline__ double normal_pdf(double z) {
+  return 0.3989422804014327 * exp(-0.5 * z * z);
+}
+
+// Acquisition tails on (mean, clipped var)  -- reference function.py:220-223, 509-510, 415-416.
+__device__ __forceinline__ double acq_tail(int acq, double param, double mean, double var) {
+  const double sd = sqrt(var);
+  if (acq == ACQ_EI) {
+    const double diff = param - mean;
+    const double z = diff / sd;
+    return diff * normal_cdf(z) + sd * normal_pdf(z);
+  } else if (acq == ACQ_PI) {
+    return normal_cdf((param - mean) / sd);
+  } else {
+    return -(mean - param * sd);
+  }
+}
+
+// ---- (value, index) ordering: larger value wins, ties -> smaller index (tf.math.argmax) -----
+// NaN never wins (TF's argmax would propagate NaN; a NaN acquisition value is an upstream bug).
+__device__ __forceinline__ bool better(double v, int64_t i, double bv, int64_t bi) {
+  return (v > bv) || (v == bv && i < bi);
+}
+
+__device__ __forceinline__ void wave_argmax(double& v, int64_t& i) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const double ov = __shfl_xor(v, off, 64);
+    const int64_t oi = __shfl_xor((long long)i, off, 64);
+    if (better(ov, oi, v, i)) {
+      v = ov;
+      i = oi;
+    }
+  }
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// ---- Philox4x32-10 -------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// uniform double in [0,1) with 53 random bits, a pure function of (seed, element index)
+__device__ __forceinline__ double philox_uniform(uint64_t seed, uint64_t elem) {
+  uint32_t o[4];
+  philox4x32_10((uint32_t)elem, (uint32_t)(elem >> 32), 0x7467705fu, 0u, (uint32_t)seed,
+                (uint32_t)(seed >> 32), o);
+  const uint64_t bits = ((uint64_t)o[0] << 32) | o[1];
+  return (double)(bits >> 11) * (1.0 / 9007199254740992.0);
+}
+
+}  // namespace tgp

@@ -1,0 +1,104 @@
+// Internal launch interface between tgp_api.hip (host side of the C-ABI) and the kernel TUs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tgp {
+
+constexpr int SW_BM = 128;  // rows of W per tile        (sweep kernel)
+constexpr int SW_BN = 128;  // candidates per workgroup
+constexpr int SW_BK = 16;   // k-step
+constexpr int NPAD_MULT = 128;
+constexpr int LEAF = 64;    // Cholesky / inverse leaf block
+constexpr int MAX_D = 32;
+constexpr int MAX_Q = 64;
+
+inline int dpad_of(int d) {
+  if (d <= 2) return 2;
+  if (d <= 4) return 4;
+  if (d <= 6) return 6;
+  if (d <= 8) return 8;
+  if (d <= 16) return 16;
+  return 32;
+}
+
+struct ModelDev {       // device-resident model state (all pointers device)
+  int kind, d, dp;      // kernel kind, input dim, padded dim
+  int64_t N, Npad;
+  double variance, noise, mean_const;
+  const double* ls;     // [dp] lengthscales padded with 1.0
+  const double* Xs;     // [Npad][dp]  X / ls, zero padded
+  const double* Wt;     // [Npad][Npad] Wt[k][i] = (L^-1)[i][k], zero outside the N x N lower part
+  const double* alpha;  // [Npad] K^-1 (Y - c), zero padded
+};
+
+struct SweepArgs {
+  ModelDev m;
+  const double* Xq;   // [M][d] raw candidates (device)
+  int64_t M;
+  double* mean_out;   // [M] or null
+  double* var_out;    // [M] or null
+  double* acq_out;    // [M] or null
+  int acq_kind;       // -1: none
+  double acq_param;
+  double* blk_val;    // [grid] or null : per-workgroup best acquisition value
+  int64_t* blk_idx;   // [grid]
+  int64_t index_base;
+  // joint mode
+  int q;              // group size (joint mode only)
+  int64_t G;          // number of groups
+  double* cov_out;    // [G][q][q]
+};
+
+// ---- linalg (tgp_kernels_linalg.hip) ----
+void launch_scale_inputs(hipStream_t s, const double* X, const double* ls, double* Xs, int64_t N,
+                         int64_t Npad, int d, int dp);
+void launch_assemble_K(hipStream_t s, const double* Xs, double* A, int64_t N, int64_t Npad, int dp,
+                       int kind, double variance, double noise);
+void launch_leaf(hipStream_t s, const double* A, double* L, double* W, int64_t ld, int64_t off,
+                 int* info);
+// C[m x n] = alpha * A[m x k] * op(B) + beta * C ;  TB: B stored [n x k] (row-major), else [k x n]
+void launch_gemm(hipStream_t s, bool tb, int m, int n, int k, double alpha, const double* A, int64_t lda,
+                 const double* B, int64_t ldb, double beta, double* C, int64_t ldc, bool lower_only);
+void launch_transpose_mask(hipStream_t s, const double* W, double* Wt, int64_t N, int64_t Npad);
+void launch_zero(hipStream_t s, double* p, int64_t n);
+void launch_center(hipStream_t s, const double* Y, double c, double* err, int64_t N, int64_t Npad);
+// y[i] = sum_k M[i][k] x[k] over k in [klo(i), khi(i)] ; lower: k<=i ; upper: k>=i
+void launch_trmv(hipStream_t s, const double* Mx, int64_t ld, int64_t n, const double* x, double* y,
+                 bool lower);
+void launch_axpby_vec(hipStream_t s, int64_t n, double a, const double* x, double b, const double* y,
+                      double* out);
+
+// ---- sweep (tgp_kernels_sweep_*.hip) ----
+int64_t sweep_grid(const SweepArgs& a, bool joint);
+
+// ---- misc (tgp_kernels_misc.hip) ----
+void launch_predict_mean(hipStream_t s, const ModelDev& m, const double* Xq, int64_t M, double* mean);
+void launch_argmax_final(hipStream_t s, const double* blk_val, const int64_t* blk_idx, int64_t n,
+                         double* out_val, int64_t* out_idx);
+void launch_min_value(hipStream_t s, const double* v, int64_t n, double* out);
+void launch_topk_pass(hipStream_t s, const double* vals, int64_t M, int64_t index_base, double pv,
+                      int64_t pi, int first, double* scratch_val, int64_t* scratch_idx,
+                      double* out_val, int64_t* out_idx);
+void launch_sample_box(hipStream_t s, uint64_t seed, int64_t first, int64_t M, int d,
+                       const double* lower, const double* upper, double* out);
+void launch_qei_tail(hipStream_t s, const double* mean, const double* cov, int64_t G, int q,
+                     const double* eps, int S, double eta, double jitter, double* out, int* info);
+// trajectories
+struct TrajDev {
+  ModelDev m;
+  int F, B;
+  const double* rffW;  // [F][dp] zero padded
+  const double* rffb;  // [F]
+  const double* ws;    // [F][B]  sqrt(2 variance / F) * w
+  const double* v;     // [Npad][B] canonical weights, zero padded
+};
+void launch_rff_project(hipStream_t s, const TrajDev& t, const double* Xs_pts, int64_t npts,
+                        double* out /*[npts][B]*/);
+void launch_traj_eval(hipStream_t s, const TrajDev& t, const double* Xq, int64_t M, int per_traj,
+                      double* out, double* blk_val, int64_t* blk_idx, int64_t index_base);
+int64_t traj_grid(int64_t M);
+void launch_argmin_final_multi(hipStream_t s, const double* blk_val, const int64_t* blk_idx,
+                               int64_t nblk, int B, double* out_val, int64_t* out_idx);
+
+}  // namespace tgp

@@ -1,0 +1,414 @@
+// Cold-path and tail kernels for gfx950: posterior mean only, (value, index) reductions, top-k
+// passes, Philox candidate sampling, the batch Monte-Carlo EI tail and decoupled-trajectory
+// evaluation.
+#include "tgp_dev.hpp"
+#include "tgp_internal.hpp"
+
+namespace tgp {
+
+// ---------------------------------------------------------------------------------------------
+// mean[j] = sum_k k(x_j, X_k) alpha_k + c.  One thread per candidate, training rows via scalar
+// loads.  == the mean half of GPflowPredictor.predict_encoded (interface.py:119-124); used for
+// eta = min_i mean(X_i) (function.py:145-149) where no variance is needed.
+template <int DP>
+__global__ __launch_bounds__(256) void predict_mean_kernel(ModelDev m, const double* __restrict__ Xq,
+                                                           int64_t M, double* __restrict__ mean) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool valid = j < M;
+  const int d = m.d;
+  double xq[DP];
+#pragma unroll
+  for (int c = 0; c < DP; ++c) xq[c] = (c < d && valid) ? Xq[j * d + c] / as_const(m.ls)[c] : 0.0;
+  double acc = 0.0;
+  const cptr xs = as_const(m.Xs);
+  const cptr al = as_const(m.alpha);
+  for (int64_t k = 0; k < m.N; ++k) {
+    double r2 = 0.0;
+#pragma unroll
+    for (int c = 0; c < DP; ++c) {
+      const double t = xq[c] - xs[k * DP + c];
+      r2 = fma(t, t, r2);
+    }
+    acc = fma(kernel_rt(m.kind, r2, m.variance), al[k], acc);
+  }
+  if (valid) mean[j] = acc + m.mean_const;
+}
+
+void launch_predict_mean(hipStream_t s, const ModelDev& m, const double* Xq, int64_t M, double* mean) {
+  dim3 g((unsigned)((M + 255) / 256)), b(256);
+  switch (m.dp) {
+    case 2: hipLaunchKernelGGL(predict_mean_kernel<2>, g, b, 0, s, m, Xq, M, mean); break;
+    case 4: hipLaunchKernelGGL(predict_mean_kernel<4>, g, b, 0, s, m, Xq, M, mean); break;
+    case 6: hipLaunchKernelGGL(predict_mean_kernel<6>, g, b, 0, s, m, Xq, M, mean); break;
+    case 8: hipLaunchKernelGGL(predict_mean_kernel<8>, g, b, 0, s, m, Xq, M, mean); break;
+    case 16: hipLaunchKernelGGL(predict_mean_kernel<16>, g, b, 0, s, m, Xq, M, mean); break;
+    default: hipLaunchKernelGGL(predict_mean_kernel<32>, g, b, 0, s, m, Xq, M, mean); break;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// final (max value, min index) over per-workgroup partials: one workgroup.
+__global__ __launch_bounds__(256) void argmax_final_kernel(const double* __restrict__ bv,
+                                                           const int64_t* __restrict__ bi, int64_t n,
+                                                           double* out_val, int64_t* out_idx) {
+  __shared__ double sv[4];
+  __shared__ int64_t si[4];
+  double v = -INFINITY;
+  int64_t i = INT64_MAX;
+  for (int64_t t = threadIdx.x; t < n; t += 256) {
+    if (better(bv[t], bi[t], v, i)) {
+      v = bv[t];
+      i = bi[t];
+    }
+  }
+  wave_argmax(v, i);
+  if ((threadIdx.x & 63) == 0) {
+    sv[threadIdx.x >> 6] = v;
+    si[threadIdx.x >> 6] = i;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (better(sv[w], si[w], v, i)) {
+        v = sv[w];
+        i = si[w];
+      }
+    *out_val = v;
+    *out_idx = i;
+  }
+}
+void launch_argmax_final(hipStream_t s, const double* blk_val, const int64_t* blk_idx, int64_t n,
+                         double* out_val, int64_t* out_idx) {
+  hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(256), 0, s, blk_val, blk_idx, n, out_val,
+                     out_idx);
+}
+
+__global__ __launch_bounds__(256) void min_value_kernel(const double* __restrict__ v, int64_t n,
+                                                        double* out) {
+  __shared__ double sv[4];
+  double m = INFINITY;
+  for (int64_t t = threadIdx.x; t < n; t += 256) m = fmin(m, v[t]);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = fmin(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) sv[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = fmin(fmin(sv[0], sv[1]), fmin(sv[2], sv[3]));
+}
+void launch_min_value(hipStream_t s, const double* v, int64_t n, double* out) {
+  hipLaunchKernelGGL(min_value_kernel, dim3(1), dim3(256), 0, s, v, n, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// One top-k pass: best element strictly after (pv, pi) in the order (value desc, index asc).
+// == one extraction step of tf.math.top_k in generate_initial_points (optimizer.py:326-335).
+constexpr int TOPK_BLOCKS = 512;
+__global__ __launch_bounds__(256) void topk_pass_kernel(const double* __restrict__ vals, int64_t M,
+                                                        int64_t index_base, double pv, int64_t pi,
+                                                        int first, double* __restrict__ sv,
+                                                        int64_t* __restrict__ si) {
+  __shared__ double wv[4];
+  __shared__ int64_t wi[4];
+  double v = -INFINITY;
+  int64_t i = INT64_MAX;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < M; t += (int64_t)TOPK_BLOCKS * 256) {
+    const double x = vals[t];
+    const int64_t xi = index_base + t;
+    if (x != x) continue;
+    const bool after = first || (x < pv) || (x == pv && xi > pi);
+    if (after && better(x, xi, v, i)) {
+      v = x;
+      i = xi;
+    }
+  }
+  wave_argmax(v, i);
+  if ((threadIdx.x & 63) == 0) {
+    wv[threadIdx.x >> 6] = v;
+    wi[threadIdx.x >> 6] = i;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (better(wv[w], wi[w], v, i)) {
+        v = wv[w];
+        i = wi[w];
+      }
+    sv[blockIdx.x] = v;
+    si[blockIdx.x] = i;
+  }
+}
+void launch_topk_pass(hipStream_t s, const double* vals, int64_t M, int64_t index_base, double pv,
+                      int64_t pi, int first, double* scratch_val, int64_t* scratch_idx,
+                      double* out_val, int64_t* out_idx) {
+  hipLaunchKernelGGL(topk_pass_kernel, dim3(TOPK_BLOCKS), dim3(256), 0, s, vals, M, index_base, pv, pi,
+                     first, scratch_val, scratch_idx);
+  launch_argmax_final(s, scratch_val, scratch_idx, TOPK_BLOCKS, out_val, out_idx);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Box.sample (reference space.py:843-867) on device: uniform in [lower, upper).
+__global__ void sample_box_kernel(uint64_t seed, int64_t first, int64_t M, int d,
+                                  const double* __restrict__ lower, const double* __restrict__ upper,
+                                  double* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= M * d) return;
+  const int64_t row = t / d;
+  const int c = (int)(t % d);
+  const double u = philox_uniform(seed, (uint64_t)((first + row) * d + c));
+  out[t] = fma(u, upper[c] - lower[c], lower[c]);
+}
+void launch_sample_box(hipStream_t s, uint64_t seed, int64_t first, int64_t M, int d,
+                       const double* lower, const double* upper, double* out) {
+  const int64_t n = M * d;
+  hipLaunchKernelGGL(sample_box_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, seed, first,
+                     M, d, lower, upper, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Batch Monte-Carlo EI tail, one workgroup per group of q points:
+//   Lq = chol(cov + jitter I);  samples_s = mean + Lq eps[:, s];  out = mean_s max(eta - min_j, 0)
+// == BatchReparametrizationSampler.sample (sampler.py:278-287) + batch_monte_carlo_expected_
+// improvement.__call__ (function.py:1183-1186).  (SURVEY K2 batched, K8.)
+__global__ __launch_bounds__(256) void qei_tail_kernel(const double* __restrict__ mean,
+                                                       const double* __restrict__ cov, int64_t G, int q,
+                                                       const double* __restrict__ eps, int S, double eta,
+                                                       double jitter, double* __restrict__ out,
+                                                       int* __restrict__ info) {
+  __shared__ double Lq[MAX_Q][MAX_Q + 1];
+  __shared__ double mu[MAX_Q];
+  __shared__ double red[4];
+  const int64_t g = blockIdx.x;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < q * q; e += 256) {
+    const int i = e / q, j = e % q;
+    Lq[i][j] = cov[(g * q + i) * q + j] + (i == j ? jitter : 0.0);
+  }
+  if (tid < q) mu[tid] = mean[g * q + tid];
+  // right-looking Cholesky in LDS (q <= 64)
+  for (int j = 0; j < q; ++j) {
+    __syncthreads();
+    double dj = Lq[j][j];
+    if (!(dj > 0.0)) {
+      if (tid == 0) atomicCAS(info, 0, (int)(g % 2000000000) + 1);
+      dj = 1.0;
+    }
+    const double sd = sqrt(dj);
+    __syncthreads();
+    if (tid < q) {
+      if (tid == j) Lq[j][j] = sd;
+      else if (tid > j) Lq[tid][j] = Lq[tid][j] / sd;
+    }
+    __syncthreads();
+    const int i = tid >> 2;
+    if (i > j && i < q) {
+      const double lij = Lq[i][j];
+      for (int k = j + 1 + (tid & 3); k <= i; k += 4) Lq[i][k] = fma(-lij, Lq[k][j], Lq[i][k]);
+    }
+  }
+  __syncthreads();
+  double acc = 0.0;
+  for (int s = tid; s < S; s += 256) {
+    double mn = INFINITY;
+    for (int j = 0; j < q; ++j) {
+      double v = mu[j];
+      for (int k = 0; k <= j; ++k) v = fma(Lq[j][k], eps[(int64_t)k * S + s], v);
+      mn = fmin(mn, v);
+    }
+    acc += fmax(eta - mn, 0.0);
+  }
+  acc = wave_sum(acc);
+  if ((tid & 63) == 0) red[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) out[g] = (red[0] + red[1] + red[2] + red[3]) / (double)S;
+}
+void launch_qei_tail(hipStream_t s, const double* mean, const double* cov, int64_t G, int q,
+                     const double* eps, int S, double eta, double jitter, double* out, int* info) {
+  hipLaunchKernelGGL(qei_tail_kernel, dim3((unsigned)G), dim3(256), 0, s, mean, cov, G, q, eps, S, eta,
+                     jitter, out, info);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Decoupled trajectories.  f_b(x) = sum_f phi_f(x) ws[f][b] + sum_k k(x, X_k) v[k][b] + c with
+// phi_f(x) = cos((x / ls) . W_f + b_f) (the sqrt(2 variance / F) factor is folded into ws).
+// == ResampleableDecoupledFeatureFunctions.call (sampler.py:846-855) + gpflux
+// RandomFourierFeaturesCosine + feature_decomposition_trajectory.__call__ (sampler.py:923-936).
+// One thread per candidate; basis rows, training rows and weights via scalar loads; the
+// [M, F + N] feature matrix is never materialised.  
+constexpr int TRAJ_MAXB = 16;
+
+template <int DP, int BP>
+__global__ __launch_bounds__(256) void traj_eval_kernel(TrajDev t, const double* __restrict__ Xq,
+                                                        int64_t M, int per_traj, int rff_only,
+                                                        double* __restrict__ out,
+                                                        double* __restrict__ blk_val,
+                                                        int64_t* __restrict__ blk_idx,
+                                                        int64_t index_base) {
+  // per_traj: logical item = (candidate j, trajectory b) with its own input row; else item = j.
+  const int B = t.B, d = t.m.d;
+  const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t nitems = per_traj ? M * B : M;
+  const bool valid = item < nitems;
+  const int myb = per_traj ? (int)(item % B) : 0;
+  double xq[DP];
+#pragma unroll
+  for (int c = 0; c < DP; ++c) xq[c] = (c < d && valid) ? Xq[item * d + c] / as_const(t.m.ls)[c] : 0.0;
+  double acc[BP];
+#pragma unroll
+  for (int b = 0; b < BP; ++b) acc[b] = 0.0;
+
+  const cptr W = as_const(t.rffW);
+  const cptr bb = as_const(t.rffb);
+  const cptr ws = as_const(t.ws);
+  for (int f = 0; f < t.F; ++f) {
+    double arg = bb[f];
+#pragma unroll
+    for (int c = 0; c < DP; ++c) arg = fma(xq[c], W[(int64_t)f * DP + c], arg);
+    const double ph = cos(arg);
+    if (per_traj) {
+      acc[0] = fma(ph, t.ws[(int64_t)f * B + myb], acc[0]);
+    } else {
+#pragma unroll
+      for (int b = 0; b < BP; ++b)
+        if (b < B) acc[b] = fma(ph, ws[(int64_t)f * B + b], acc[b]);
+    }
+  }
+  if (!rff_only) {
+    const cptr xs = as_const(t.m.Xs);
+    const cptr vv = as_const(t.v);
+    for (int64_t k = 0; k < t.m.N; ++k) {
+      double r2 = 0.0;
+#pragma unroll
+      for (int c = 0; c < DP; ++c) {
+        const double tt = xq[c] - xs[k * DP + c];
+        r2 = fma(tt, tt, r2);
+      }
+      const double kv = kernel_rt(t.m.kind, r2, t.m.variance);
+      if (per_traj) {
+        acc[0] = fma(kv, t.v[k * B + myb], acc[0]);
+      } else {
+#pragma unroll
+        for (int b = 0; b < BP; ++b)
+          if (b < B) acc[b] = fma(kv, vv[k * B + b], acc[b]);
+      }
+    }
+  }
+  const double c0 = rff_only ? 0.0 : t.m.mean_const;
+  if (out && valid) {
+    if (per_traj) out[item] = acc[0] + c0;
+    else {
+#pragma unroll
+      for (int b = 0; b < BP; ++b)
+        if (b < B) out[item * B + b] = acc[b] + c0;
+    }
+  }
+  if (blk_val) {  // per-workgroup arg-min per trajectory (shared-input mode only)
+    __shared__ double wv[4][TRAJ_MAXB];
+    __shared__ int64_t wi[4][TRAJ_MAXB];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int b = 0; b < BP; ++b) {
+      if (b < B) {
+        double v = valid ? -(acc[b] + c0) : -INFINITY;  // arg-min == arg-max of the negation
+        if (v != v) v = -INFINITY;
+        int64_t i = valid ? index_base + item : INT64_MAX;
+        wave_argmax(v, i);
+        if (lane == 0) {
+          wv[w][b] = v;
+          wi[w][b] = i;
+        }
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < B) {
+      const int b = threadIdx.x;
+      double v = wv[0][b];
+      int64_t i = wi[0][b];
+      for (int ww = 1; ww < 4; ++ww)
+        if (better(wv[ww][b], wi[ww][b], v, i)) {
+          v = wv[ww][b];
+          i = wi[ww][b];
+        }
+      blk_val[(int64_t)blockIdx.x * B + b] = -v;
+      blk_idx[(int64_t)blockIdx.x * B + b] = i;
+    }
+  }
+}
+
+template <int DP>
+static void launch_traj_bp(hipStream_t s, const TrajDev& t, const double* Xq, int64_t M, int per_traj,
+                           int rff_only, double* out, double* bv, int64_t* bi, int64_t base) {
+  const int64_t nitems = per_traj ? M * t.B : M;
+  dim3 g((unsigned)((nitems + 255) / 256)), b(256);
+  const int B = per_traj ? 1 : t.B;
+  if (B <= 1) hipLaunchKernelGGL((traj_eval_kernel<DP, 1>), g, b, 0, s, t, Xq, M, per_traj, rff_only, out, bv, bi, base);
+  else if (B <= 2) hipLaunchKernelGGL((traj_eval_kernel<DP, 2>), g, b, 0, s, t, Xq, M, per_traj, rff_only, out, bv, bi, base);
+  else if (B <= 4) hipLaunchKernelGGL((traj_eval_kernel<DP, 4>), g, b, 0, s, t, Xq, M, per_traj, rff_only, out, bv, bi, base);
+  else if (B <= 8) hipLaunchKernelGGL((traj_eval_kernel<DP, 8>), g, b, 0, s, t, Xq, M, per_traj, rff_only, out, bv, bi, base);
+  else hipLaunchKernelGGL((traj_eval_kernel<DP, 16>), g, b, 0, s, t, Xq, M, per_traj, rff_only, out, bv, bi, base);
+}
+
+static void launch_traj_any(hipStream_t s, const TrajDev& t, const double* Xq, int64_t M, int per_traj,
+                            int rff_only, double* out, double* bv, int64_t* bi, int64_t base) {
+  switch (t.m.dp) {
+    case 2: launch_traj_bp<2>(s, t, Xq, M, per_traj, rff_only, out, bv, bi, base); break;
+    case 4: launch_traj_bp<4>(s, t, Xq, M, per_traj, rff_only, out, bv, bi, base); break;
+    case 6: launch_traj_bp<6>(s, t, Xq, M, per_traj, rff_only, out, bv, bi, base); break;
+    case 8: launch_traj_bp<8>(s, t, Xq, M, per_traj, rff_only, out, bv, bi, base); break;
+    case 16: launch_traj_bp<16>(s, t, Xq, M, per_traj, rff_only, out, bv, bi, base); break;
+    default: launch_traj_bp<32>(s, t, Xq, M, per_traj, rff_only, out, bv, bi, base); break;
+  }
+}
+
+int64_t traj_grid(int64_t M) { return (M + 255) / 256; }
+
+void launch_traj_eval(hipStream_t s, const TrajDev& t, const double* Xq, int64_t M, int per_traj,
+                      double* out, double* blk_val, int64_t* blk_idx, int64_t index_base) {
+  launch_traj_any(s, t, Xq, M, per_traj, 0, out, blk_val, blk_idx, index_base);
+}
+
+// Phi_Z w at a set of RAW points (the training inputs): out [npts][B] = sum_f phi_f(x) ws[f][b]
+// (sampler.py:726 `phi_Z @ prior_weights`).
+void launch_rff_project(hipStream_t s, const TrajDev& t, const double* X_raw, int64_t npts, double* out) {
+  launch_traj_any(s, t, X_raw, npts, 0, 1, out, nullptr, nullptr, 0);
+}
+
+// final arg-min over per-workgroup partials for B trajectories: one workgroup per trajectory.
+__global__ __launch_bounds__(256) void argmin_final_multi_kernel(const double* __restrict__ bv,
+                                                                 const int64_t* __restrict__ bi,
+                                                                 int64_t nblk, int B, double* out_val,
+                                                                 int64_t* out_idx) {
+  __shared__ double sv[4];
+  __shared__ int64_t si[4];
+  const int b = blockIdx.x;
+  double v = -INFINITY;
+  int64_t i = INT64_MAX;
+  for (int64_t t = threadIdx.x; t < nblk; t += 256) {
+    const double x = -bv[t * B + b];
+    const int64_t xi = bi[t * B + b];
+    if (better(x, xi, v, i)) {
+      v = x;
+      i = xi;
+    }
+  }
+  wave_argmax(v, i);
+  if ((threadIdx.x & 63) == 0) {
+    sv[threadIdx.x >> 6] = v;
+    si[threadIdx.x >> 6] = i;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (better(sv[w], si[w], v, i)) {
+        v = sv[w];
+        i = si[w];
+      }
+    out_val[b] = -v;
+    out_idx[b] = i;
+  }
+}
+void launch_argmin_final_multi(hipStream_t s, const double* blk_val, const int64_t* blk_idx,
+                               int64_t nblk, int B, double* out_val, int64_t* out_idx) {
+  hipLaunchKernelGGL(argmin_final_multi_kernel, dim3((unsigned)B), dim3(256), 0, s, blk_val, blk_idx,
+                     nblk, B, out_val, out_idx);
+}
+
+}  // namespace tgp

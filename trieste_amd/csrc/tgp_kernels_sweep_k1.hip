@@ -1,0 +1,3 @@
+// sweep kernels for kernel kind 1 (see tgp_kernels_sweep.inc)
+#define TGP_SWEEP_KIND 1
+#include "tgp_kernels_sweep.inc"

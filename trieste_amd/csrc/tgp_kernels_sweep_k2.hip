@@ -1,0 +1,3 @@
+// sweep kernels for kernel kind 2 (see tgp_kernels_sweep.inc)
+#define TGP_SWEEP_KIND 2
+#include "tgp_kernels_sweep.inc"

@@ -1,0 +1,3 @@
+// sweep kernels for kernel kind 3 (see tgp_kernels_sweep.inc)
+#define TGP_SWEEP_KIND 3
+#include "tgp_kernels_sweep.inc"

@@ -1,0 +1,271 @@
+"""Thin object wrapper over the C-ABI: one :class:`GPEngine` == one GPR model resident on one GPU.
+
+Arrays may be numpy float64 arrays (host; staged by the library) or torch float64 CUDA tensors
+(device; passed by pointer, outputs are torch tensors on the same device).  torch is plumbing
+only: device memory, streams and torch.distributed.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+
+_NP = np.float64
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+class _Arg:
+    """Pointer + residency of one input array (keeps the backing object alive)."""
+
+    def __init__(self, x, shape_tail: Optional[Tuple[int, ...]] = None):
+        if _is_torch(x):
+            import torch
+
+            if x.dtype != torch.float64:
+                x = x.to(torch.float64)
+            if x.is_cuda:
+                x = x.contiguous()
+                self.keep, self.ptr, self.where = x, x.data_ptr(), _lib.DEVICE
+                self.shape, self.device = tuple(x.shape), x.device
+                return
+            x = x.numpy()
+        a = np.ascontiguousarray(x, dtype=_NP)
+        self.keep, self.ptr, self.where = a, a.ctypes.data, _lib.HOST
+        self.shape, self.device = a.shape, None
+
+
+class GPEngine:
+    def __init__(self, d: int, kernel: str = "matern52", device: int = 0):
+        self._lib = _lib.load()
+        if kernel not in _lib.KERNELS:
+            raise ValueError(f"unknown kernel {kernel!r}; choose from {sorted(_lib.KERNELS)}")
+        h = C.c_void_p()
+        rc = self._lib.tgp_create(int(device), int(d), _lib.KERNELS[kernel], C.byref(h))
+        _lib.check(self._lib, None, rc)
+        self._h = h
+        self.d, self.kernel, self.device = int(d), kernel, int(device)
+        self.N = 0
+
+    # -- lifetime ------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.tgp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        _lib.check(self._lib, self._h, rc)
+
+    def use_torch_stream(self):
+        """Queue this engine's kernels on torch's current CUDA stream of its device."""
+        import torch
+
+        self._chk(self._lib.tgp_set_stream(self._h, C.c_void_p(
+            torch.cuda.current_stream(self.device).cuda_stream)))
+
+    def set_variant(self, v: int):
+        self._chk(self._lib.tgp_set_variant(self._h, int(v)))
+
+    # -- model state -----------------------------------------------------------------------------
+    def set_hyper(self, variance: float, lengthscales, noise_variance: float, mean_const: float = 0.0):
+        ls = np.ascontiguousarray(np.broadcast_to(np.asarray(lengthscales, dtype=_NP), (self.d,)))
+        self._chk(self._lib.tgp_set_hyper(self._h, float(variance), ls.ctypes.data,
+                                          float(noise_variance), float(mean_const)))
+        self.N = 0
+
+    def set_data(self, X, Y):
+        ax = _Arg(X)
+        ay = _Arg(Y)
+        if len(ax.shape) != 2 or ax.shape[1] != self.d:
+            raise ValueError(f"X must be [N, {self.d}], got {ax.shape}")
+        n = ax.shape[0]
+        if int(np.prod(ay.shape)) != n:
+            raise ValueError(f"Y must hold N={n} observations, got shape {ay.shape}")
+        if ax.where != ay.where:
+            raise ValueError("X and Y must both be host arrays or both device tensors")
+        self._chk(self._lib.tgp_set_data(self._h, ax.ptr, ay.ptr, n, ax.where))
+        self.N = n
+
+    def get_factor(self):
+        """(L, W = L^-1, alpha) as numpy arrays (tests / diagnostics)."""
+        n = self.N
+        L, W, al = np.empty((n, n)), np.empty((n, n)), np.empty(n)
+        self._chk(self._lib.tgp_get_factor(self._h, L.ctypes.data, W.ctypes.data, al.ctypes.data, _lib.HOST))
+        return L, W, al
+
+    # -- outputs ---------------------------------------------------------------------------------
+    @staticmethod
+    def _out(arg: _Arg, shape):
+        if arg.where == _lib.DEVICE:
+            import torch
+
+            t = torch.empty(shape, dtype=torch.float64, device=arg.device)
+            return t, t.data_ptr()
+        a = np.empty(shape, dtype=_NP)
+        return a, a.ctypes.data
+
+    def _flat(self, Xq):
+        a = _Arg(Xq)
+        if len(a.shape) < 1 or a.shape[-1] != self.d:
+            raise ValueError(f"query points must have trailing dimension {self.d}, got {a.shape}")
+        lead = a.shape[:-1]
+        return a, lead, int(np.prod(lead)) if lead else 1
+
+    def predict(self, Xq):
+        a, lead, M = self._flat(Xq)
+        mean, pm = self._out(a, lead)
+        var, pv = self._out(a, lead)
+        self._chk(self._lib.tgp_predict(self._h, a.ptr, M, pm, pv, a.where))
+        return mean, var
+
+    def predict_mean(self, Xq):
+        a, lead, M = self._flat(Xq)
+        mean, pm = self._out(a, lead)
+        self._chk(self._lib.tgp_predict_mean(self._h, a.ptr, M, pm, a.where))
+        return mean
+
+    def predict_joint(self, Xq):
+        a = _Arg(Xq)
+        if len(a.shape) < 2 or a.shape[-1] != self.d:
+            raise ValueError(f"joint query points must be [..., q, {self.d}], got {a.shape}")
+        lead, q = a.shape[:-2], a.shape[-2]
+        G = int(np.prod(lead)) if lead else 1
+        mean, pm = self._out(a, lead + (q,))
+        cov, pc = self._out(a, lead + (q, q))
+        self._chk(self._lib.tgp_predict_joint(self._h, a.ptr, G, q, pm, pc, a.where))
+        return mean, cov
+
+    def eta(self) -> float:
+        v = C.c_double()
+        self._chk(self._lib.tgp_eta(self._h, C.byref(v)))
+        return v.value
+
+    def acq_values(self, acq: str, param: float, Xq):
+        a, lead, M = self._flat(Xq)
+        out, po = self._out(a, lead)
+        self._chk(self._lib.tgp_acq_values(self._h, _lib.ACQ[acq], float(param), a.ptr, M, po, a.where))
+        return out
+
+    def acq_argmax(self, acq: str, param: float, Xq, index_base: int = 0):
+        """-> (best value, global index, best point [d] as numpy)."""
+        a, _, M = self._flat(Xq)
+        bv, bi = C.c_double(), C.c_int64()
+        bx = np.empty(self.d)
+        self._chk(self._lib.tgp_acq_argmax(self._h, _lib.ACQ[acq], float(param), a.ptr, M, int(index_base),
+                                           C.byref(bv), C.byref(bi), bx.ctypes.data, a.where))
+        return bv.value, bi.value, bx
+
+    def acq_topk(self, acq: str, param: float, Xq, k: int, index_base: int = 0):
+        a, _, M = self._flat(Xq)
+        vals, idx = np.empty(k), np.empty(k, dtype=np.int64)
+        self._chk(self._lib.tgp_acq_topk(self._h, _lib.ACQ[acq], float(param), a.ptr, M, int(index_base),
+                                         int(k), vals.ctypes.data, idx.ctypes.data, a.where))
+        return vals, idx
+
+    def sample_box(self, seed: int, first: int, M: int, lower, upper):
+        """Uniform candidates [M, d] generated on the device (torch CUDA tensor)."""
+        import torch
+
+        lo = np.ascontiguousarray(np.broadcast_to(np.asarray(lower, dtype=_NP), (self.d,)))
+        up = np.ascontiguousarray(np.broadcast_to(np.asarray(upper, dtype=_NP), (self.d,)))
+        out = torch.empty((M, self.d), dtype=torch.float64, device=f"cuda:{self.device}")
+        self._chk(self._lib.tgp_sample_box(self._h, int(seed), int(first), int(M), lo.ctypes.data,
+                                           up.ctypes.data, out.data_ptr()))
+        return out
+
+    def qei(self, Xq, eps, eta: float, jitter: float = 1e-6):
+        a = _Arg(Xq)
+        if len(a.shape) < 2 or a.shape[-1] != self.d:
+            raise ValueError(f"batch query points must be [..., q, {self.d}], got {a.shape}")
+        lead, q = a.shape[:-2], a.shape[-2]
+        G = int(np.prod(lead)) if lead else 1
+        e = _Arg(eps)
+        if len(e.shape) != 2 or e.shape[0] != q:
+            raise ValueError(f"eps must be [q={q}, S], got {e.shape}")
+        if e.where != a.where:
+            raise ValueError("Xq and eps must live in the same place (both host or both device)")
+        out, po = self._out(a, lead)
+        self._chk(self._lib.tgp_qei(self._h, a.ptr, G, q, e.ptr, e.shape[1], float(eta), float(jitter), po,
+                                    a.where))
+        return out
+
+    def last_kernel_ms(self):
+        ms, n = C.c_double(), C.c_int()
+        self._chk(self._lib.tgp_last_kernel_ms(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    # -- trajectories ----------------------------------------------------------------------------
+    def trajectory(self, rff_W, rff_b, w, xi) -> "Trajectory":
+        return Trajectory(self, rff_W, rff_b, w, xi)
+
+
+class Trajectory:
+    """B decoupled trajectories sharing one RFF basis (tgp_traj_*)."""
+
+    def __init__(self, eng: GPEngine, rff_W, rff_b, w, xi):
+        self._eng = eng
+        Wf = np.ascontiguousarray(rff_W, dtype=_NP)
+        bf = np.ascontiguousarray(rff_b, dtype=_NP).reshape(-1)
+        F = Wf.shape[0]
+        if Wf.shape != (F, eng.d) or bf.shape != (F,):
+            raise ValueError("rff_W must be [F, d] and rff_b [F]")
+        w = np.ascontiguousarray(np.asarray(w, dtype=_NP).reshape(F, -1))
+        B = w.shape[1]
+        xi = np.ascontiguousarray(np.asarray(xi, dtype=_NP).reshape(eng.N, -1))
+        if xi.shape[1] != B:
+            raise ValueError(f"xi must be [N, B={B}], got {xi.shape}")
+        t = C.c_void_p()
+        rc = eng._lib.tgp_traj_create(eng._h, Wf.ctypes.data, bf.ctypes.data, F, w.ctypes.data,
+                                      xi.ctypes.data, B, C.byref(t))
+        eng._chk(rc)
+        self._t, self.F, self.B = t, F, B
+
+    def close(self):
+        if getattr(self, "_t", None):
+            self._eng._lib.tgp_traj_destroy(self._t)
+            self._t = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def v(self):
+        out = np.empty((self._eng.N, self.B))
+        self._eng._chk(self._eng._lib.tgp_traj_get_v(self._t, out.ctypes.data))
+        return out
+
+    def __call__(self, Xq):
+        """Xq [M, d] (shared) or [M, B, d] (per-trajectory inputs) -> [M, B]."""
+        a = _Arg(Xq)
+        d = self._eng.d
+        if len(a.shape) == 2 and a.shape[1] == d:
+            per, M = 0, a.shape[0]
+        elif len(a.shape) == 3 and a.shape[1] == self.B and a.shape[2] == d:
+            per, M = 1, a.shape[0]
+        else:
+            raise ValueError(f"trajectory inputs must be [M, {d}] or [M, {self.B}, {d}], got {a.shape}")
+        out, po = GPEngine._out(a, (M, self.B))
+        self._eng._chk(self._eng._lib.tgp_traj_eval(self._t, a.ptr, M, per, po, a.where))
+        return out
+
+    def argmin(self, Xq, index_base: int = 0):
+        a = _Arg(Xq)
+        if len(a.shape) != 2 or a.shape[1] != self._eng.d:
+            raise ValueError("arg-min candidates must be [M, d]")
+        vals, idx = np.empty(self.B), np.empty(self.B, dtype=np.int64)
+        self._eng._chk(self._eng._lib.tgp_traj_argmin(self._t, a.ptr, a.shape[0], int(index_base),
+                                                      vals.ctypes.data, idx.ctypes.data, a.where))
+        return vals, idx
