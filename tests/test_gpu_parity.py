@@ -14,10 +14,11 @@ pytestmark = pytest.mark.gpu
 CASES = load_goldens()
 
 
-def _engine(kind, d, variance, ls, noise, c, X, Y):
+def _engine(kind, d, variance, ls, noise, c, X, Y, variant=0):
     from trieste_amd.engine import GPEngine
 
     eng = GPEngine(d, kind)
+    eng.set_variant(variant)
     eng.set_hyper(variance, ls, noise, c)
     eng.set_data(X, Y)
     return eng
@@ -83,12 +84,13 @@ def _problem(obj, d, kind, N, noise, M=1500, seed=5678):
     return X, Y, ls, c, st, Xq
 
 
+@pytest.mark.parametrize("variant", [0, 1], ids=["ws", "v1"])
 @pytest.mark.parametrize("cfg", CONFIGS, ids=[c[0] for c in CONFIGS])
-def test_sweep_matches_oracle(cfg):
+def test_sweep_matches_oracle(cfg, variant):
     _, obj, d, kind, N, noise = cfg
     X, Y, ls, c, st, Xq = _problem(obj, d, kind, N, noise)
     floor = cancellation_floor(N, 1.0, noise)
-    eng = _engine(kind, d, 1.0, ls, noise, c, X, Y)
+    eng = _engine(kind, d, 1.0, ls, noise, c, X, Y, variant)
     mean, var = eng.predict(Xq)
     om, ov = O.predict(st, Xq)
     assert_close(mean, om, atol=floor * 100, what="mean")

@@ -1,0 +1,19 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from oracle import gp_oracle as O
+from trieste_amd.engine import GPEngine
+d, N, M = 8, 4096, 1 << 16
+X, Y = O.synthetic_problem(O.ackley, d, N)
+eng = GPEngine(d, "matern52")
+eng.set_hyper(1.0, O.default_lengthscales(d), 1e-2, float(Y.mean()))
+eng.set_data(X, Y)
+eta = eng.eta()
+Xq = eng.sample_box(5678, 0, M, 0.0, 1.0)
+for name, v in (("v1", 1), ("ws", 0), ("ws skip-gen", 0 | (1 << 8)), ("ws skip-W", 0 | (2 << 8)), ("ws skip-gen+W", 0 | (3 << 8)),
+                ("ws skip-mfma", 0 | (4 << 8)), ("ws skip-all", 0 | (7 << 8))):
+    eng.set_variant(v)
+    eng.acq_argmax("ei", eta, Xq)
+    eng.acq_argmax("ei", eta, Xq)
+    ms, _ = eng.last_kernel_ms()
+    print(f"{name:16s}: {ms:8.2f} ms  -> {M*float(N)*N/ms*1e-9:6.2f} TF", flush=True)

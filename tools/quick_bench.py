@@ -32,8 +32,9 @@ def run(kind, d, N, M, noise=1e-2, variant=0, reps=3):
 
 if __name__ == "__main__":
     print(torch.cuda.get_device_name(0))
-    run("matern52", 8, 4096, 1 << 17)
-    run("matern52", 8, 4096, 1 << 20, reps=2)
-    run("rbf", 6, 1024, 1 << 20, reps=2)
+    for v in (1, 0):
+        run("matern52", 8, 4096, 1 << 17, variant=v)
+        run("matern52", 8, 4096, 1 << 20, reps=2, variant=v)
+        run("rbf", 6, 1024, 1 << 20, reps=2, variant=v)
     run("matern52", 6, 2048, 1 << 18)
     run("matern52", 16, 8192, 1 << 17, reps=2)

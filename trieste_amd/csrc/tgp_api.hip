@@ -20,6 +20,10 @@ hipError_t launch_sweep_kind0(hipStream_t, const SweepArgs&, bool, int64_t);
 hipError_t launch_sweep_kind1(hipStream_t, const SweepArgs&, bool, int64_t);
 hipError_t launch_sweep_kind2(hipStream_t, const SweepArgs&, bool, int64_t);
 hipError_t launch_sweep_kind3(hipStream_t, const SweepArgs&, bool, int64_t);
+hipError_t launch_sweep_ws_kind0(hipStream_t, const SweepArgs&, int64_t);
+hipError_t launch_sweep_ws_kind1(hipStream_t, const SweepArgs&, int64_t);
+hipError_t launch_sweep_ws_kind2(hipStream_t, const SweepArgs&, int64_t);
+hipError_t launch_sweep_ws_kind3(hipStream_t, const SweepArgs&, int64_t);
 }  // namespace tgp
 
 using namespace tgp;
@@ -52,7 +56,7 @@ struct DevBuf {  // grow-only device buffer
 }  // namespace
 
 struct tgp_handle_s {
-  int device = 0, d = 0, dp = 0, kind = 0;
+  int device = 0, d = 0, dp = 0, kind = 0, num_cu = 256;
   hipStream_t stream = nullptr;
   std::string err;
   // hyper-parameters
@@ -64,7 +68,7 @@ struct tgp_handle_s {
   // model state on device
   DevBuf d_ls, d_X, d_Y, d_Xs, d_A, d_L, d_W, d_alpha, d_err, d_tmp1, d_tmp2, d_info;
   // scratch
-  DevBuf s_in, s_in2, s_out1, s_out2, s_out3, s_blkv, s_blki, s_small;
+  DevBuf s_in, s_in2, s_out1, s_out2, s_out3, s_blkv, s_blki, s_small, s_kcache;
   // timing of the dominant kernel
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double last_ms = 0.0;
@@ -162,13 +166,34 @@ int set_device(tgp_handle h) {
 hipError_t launch_sweep_timed(tgp_handle h, const SweepArgs& a, bool joint) {
   const int64_t grid = sweep_grid(a, joint);
   if (grid <= 0) return hipSuccess;
-  (void)hipEventRecord(h->ev0, h->stream);
   hipError_t e;
-  switch (h->kind) {
-    case TGP_RBF: e = launch_sweep_kind0(h->stream, a, joint, grid); break;
-    case TGP_MATERN12: e = launch_sweep_kind1(h->stream, a, joint, grid); break;
-    case TGP_MATERN32: e = launch_sweep_kind2(h->stream, a, joint, grid); break;
-    default: e = launch_sweep_kind3(h->stream, a, joint, grid); break;
+  // variant 0 (default): wave-specialised kernel for plain sweeps, v1 kernel for joint mode;
+  // variant 1: force the v1 (uniform-wave, 128x128) kernel everywhere.
+  const bool ws = !joint && (h->variant & 0xff) != 1;
+  SweepArgs& am = const_cast<SweepArgs&>(a);
+  am.dbg = h->variant >> 8;
+  int64_t wgrid = grid;
+  if (ws) {
+    wgrid = grid < h->num_cu ? grid : h->num_cu;  // persistent: one workgroup per CU
+    hipError_t ea = h->s_kcache.reserve((size_t)wgrid * (size_t)h->Npad * SW_BN * sizeof(double));
+    if (ea != hipSuccess) return ea;
+    am.kcache = h->s_kcache.as<double>();
+  }
+  (void)hipEventRecord(h->ev0, h->stream);
+  if (ws) {
+    switch (h->kind) {
+      case TGP_RBF: e = launch_sweep_ws_kind0(h->stream, a, wgrid); break;
+      case TGP_MATERN12: e = launch_sweep_ws_kind1(h->stream, a, wgrid); break;
+      case TGP_MATERN32: e = launch_sweep_ws_kind2(h->stream, a, wgrid); break;
+      default: e = launch_sweep_ws_kind3(h->stream, a, wgrid); break;
+    }
+  } else {
+    switch (h->kind) {
+      case TGP_RBF: e = launch_sweep_kind0(h->stream, a, joint, grid); break;
+      case TGP_MATERN12: e = launch_sweep_kind1(h->stream, a, joint, grid); break;
+      case TGP_MATERN32: e = launch_sweep_kind2(h->stream, a, joint, grid); break;
+      default: e = launch_sweep_kind3(h->stream, a, joint, grid); break;
+    }
   }
   (void)hipEventRecord(h->ev1, h->stream);
   h->last_launches = 1;
@@ -247,6 +272,11 @@ int tgp_create(int device_id, int d, int kernel_kind, tgp_handle* out) {
     delete h;
     return fail(nullptr, TGP_ERR_HIP, "device init failed: %s", hipGetErrorString(e));
   }
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
+      h->num_cu = prop.multiProcessorCount;
+  }
   *out = h;
   return TGP_OK;
 }
@@ -257,7 +287,7 @@ int tgp_destroy(tgp_handle h) {
   (void)hipStreamSynchronize(h->stream);
   for (DevBuf* b : {&h->d_ls, &h->d_X, &h->d_Y, &h->d_Xs, &h->d_A, &h->d_L, &h->d_W, &h->d_alpha,
                     &h->d_err, &h->d_tmp1, &h->d_tmp2, &h->d_info, &h->s_in, &h->s_in2, &h->s_out1,
-                    &h->s_out2, &h->s_out3, &h->s_blkv, &h->s_blki, &h->s_small})
+                    &h->s_out2, &h->s_out3, &h->s_blkv, &h->s_blki, &h->s_small, &h->s_kcache})
     b->release();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);

@@ -8,7 +8,7 @@ namespace tgp {
 constexpr int SW_BM = 128;  // rows of W per tile        (sweep kernel)
 constexpr int SW_BN = 128;  // candidates per workgroup
 constexpr int SW_BK = 16;   // k-step
-constexpr int NPAD_MULT = 128;
+constexpr int NPAD_MULT = 256;  // row-block of the wave-specialised sweep (also a multiple of SW_BM)
 constexpr int LEAF = 64;    // Cholesky / inverse leaf block
 constexpr int MAX_D = 32;
 constexpr int MAX_Q = 64;
@@ -48,6 +48,8 @@ struct SweepArgs {
   int q;              // group size (joint mode only)
   int64_t G;          // number of groups
   double* cov_out;    // [G][q][q]
+  double* kcache;     // [grid][Npad][128] K* slabs of the wave-specialised sweep (device scratch)
+  int dbg;            // development only: bit0 skip K* generation, bit1 skip W loads, bit2 skip MFMA
 };
 
 // ---- linalg (tgp_kernels_linalg.hip) ----
@@ -71,6 +73,7 @@ void launch_axpby_vec(hipStream_t s, int64_t n, double a, const double* x, doubl
 
 // ---- sweep (tgp_kernels_sweep_*.hip) ----
 int64_t sweep_grid(const SweepArgs& a, bool joint);
+constexpr int WS_MAX_GRID = 256;  // persistent workgroups of the wave-specialised sweep (1 per CU)
 
 // ---- misc (tgp_kernels_misc.hip) ----
 void launch_predict_mean(hipStream_t s, const ModelDev& m, const double* Xq, int64_t M, double* mean);
