@@ -1,0 +1,68 @@
+"""Candidate sharding and the cross-rank arg-max / arg-min merge.
+
+The reference has no multi-device path.  The sweep shards naturally over
+candidates: rank r evaluates the contiguous block [lo_r, hi_r) with ``index_base = lo_r`` so that
+global indices -- and therefore tf.math.argmax's first-index tie-break -- are preserved, and the
+only exchange is one all-gather of (value, index) pairs over RCCL/xGMI (16 B per rank and per
+vectorised function), merged with the lexicographic rule (max value, min index).
+Model state is replicated: every rank runs the same deterministic `update`.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+
+def shard_range(M: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block of ceil(M / world) candidates for `rank`."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError(f"bad rank/world {rank}/{world}")
+    per = -(-M // world)
+    lo = min(rank * per, M)
+    return lo, min(lo + per, M)
+
+
+def merge_best(vals: np.ndarray, idxs: np.ndarray, minimize: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+    """Merge per-rank winners.  vals/idxs: [world, V].  Larger value wins (smaller if
+    ``minimize``); ties go to the smaller global index; NaN / empty shards (idx < 0) never win."""
+    vals = np.asarray(vals, dtype=np.float64)
+    idxs = np.asarray(idxs, dtype=np.int64)
+    if vals.ndim == 1:
+        vals, idxs = vals[:, None], idxs[:, None]
+    key = -vals if minimize else vals
+    key = np.where(np.isnan(key) | (idxs < 0), -np.inf, key)
+    best = np.max(key, axis=0)
+    cand = np.where(key == best[None, :], idxs, np.iinfo(np.int64).max)
+    cand = np.where(idxs < 0, np.iinfo(np.int64).max, cand)
+    win_idx = np.min(cand, axis=0)
+    win_rank = np.argmin(cand, axis=0)
+    win_val = vals[win_rank, np.arange(vals.shape[1])]
+    return win_val, win_idx
+
+
+def all_gather_best(val, idx, minimize: bool = False, group=None, device=None):
+    """All-gather (value, index)[V] from every rank and merge.  With torch.distributed not
+    initialised (single process) this is the identity.  Uses the process group's backend:
+    "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests."""
+    import torch
+    import torch.distributed as dist
+
+    v = np.atleast_1d(np.asarray(val, dtype=np.float64))
+    i = np.atleast_1d(np.asarray(idx, dtype=np.int64))
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return v.copy(), i.copy()
+    world = dist.get_world_size(group)
+    backend = dist.get_backend(group)
+    dev = torch.device(device if device is not None else ("cuda" if backend == "nccl" else "cpu"))
+    # one message: the int64 index travels bit-cast inside the float64 payload
+    payload = torch.empty(2 * v.shape[0], dtype=torch.float64)
+    payload[: v.shape[0]] = torch.from_numpy(v)
+    payload[v.shape[0]:] = torch.from_numpy(i).view(torch.float64)
+    payload = payload.to(dev)
+    out = torch.empty(world * payload.numel(), dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(out, payload, group=group)
+    out = out.cpu().view(world, 2, v.shape[0])
+    vals = out[:, 0, :].numpy()
+    idxs = out[:, 1, :].contiguous().view(torch.int64).numpy()
+    return merge_best(vals, idxs, minimize)
