@@ -135,6 +135,11 @@ int tgp_sample_box(tgp_handle h, uint64_t seed, int64_t first, int64_t M, const 
 int tgp_qei(tgp_handle h, const double* Xq, int64_t G, int q, const double* eps, int S, double eta,
             double jitter, double* out, int where);
 
+/* == BatchReparametrizationSampler.sample (sampler.py:208-287) itself: out [G,S,q] = mean +
+ * (chol(cov + jitter*I) eps)^T for Xq [G,q,d], eps [q,S].  q <= 64. */
+int tgp_reparam_samples(tgp_handle h, const double* Xq, int64_t G, int q, const double* eps, int S,
+                        double jitter, double* out, int where);
+
 /* ---- decoupled Thompson trajectories ------------------------------------------------------ */
 /* == DecoupledTrajectorySampler._prepare_weight_sampler + weight_sampler(B)
  * (sampler.py:661-738) given the draws: rff_W [F,d], rff_b [F] (the RFF basis, gpflux

@@ -1,0 +1,156 @@
+"""TEST INFRASTRUCTURE: a stand-in for ``trieste_amd.engine.GPEngine`` backed by the numpy oracle.
+
+The product has no CPU path; to exercise the HOST logic (model wrapper, builders, optimizers, rules,
+Ask-Tell / BO loops) without a GPU, the tests substitute this class at the engine boundary -- the
+same seam the reference's tests use with their ``QuadraticMeanAndRBFKernel`` fakes
+(tests/util/models/gpflow/models.py:189-210).  It mirrors GPEngine's Python surface exactly.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from oracle import gp_oracle as O
+
+
+class FakeTrajectory:
+    def __init__(self, eng, W, b, w, xi):
+        self._eng = eng
+        self.W, self.b = np.asarray(W, float), np.asarray(b, float)
+        self.w = np.asarray(w, float).reshape(self.W.shape[0], -1)
+        self.F, self.B = self.W.shape[0], self.w.shape[1]
+        self._v = O.decoupled_weights(eng.state, self.W, self.b, self.w, np.asarray(xi, float).reshape(eng.N, -1))
+
+    def close(self):
+        pass
+
+    def v(self):
+        return self._v
+
+    def __call__(self, Xq):
+        return O.trajectory_eval(self._eng.state, self.W, self.b, self.w, self._v, np.asarray(Xq, float))
+
+    def argmin(self, Xq, index_base=0):
+        vals = self(np.asarray(Xq, float))
+        idx = np.argmin(vals, axis=0)
+        return vals[idx, np.arange(self.B)], idx + index_base
+
+
+class FakeEngine:
+    """Same constructor and methods as GPEngine; arithmetic by oracle/gp_oracle.py."""
+
+    created = 0
+
+    def __init__(self, d, kernel="matern52", device=0):
+        if kernel not in O.KERNEL_KINDS:
+            raise ValueError(f"unknown kernel {kernel!r}")
+        self.d, self.kernel, self.device, self.N = int(d), kernel, device, 0
+        self._hyper = None
+        self.state = None
+        FakeEngine.created += 1
+
+    def close(self):
+        pass
+
+    def use_torch_stream(self):
+        pass
+
+    def set_variant(self, v):
+        pass
+
+    def set_hyper(self, variance, lengthscales, noise_variance, mean_const=0.0):
+        if not (variance > 0 and noise_variance > 0):
+            raise ValueError("variance and noise_variance must be positive")
+        self._hyper = (float(variance), np.broadcast_to(np.asarray(lengthscales, float), (self.d,)).copy(),
+                       float(noise_variance), float(mean_const))
+        self.state, self.N = None, 0
+
+    def set_data(self, X, Y):
+        if self._hyper is None:
+            raise RuntimeError("tgp_set_hyper must be called before tgp_set_data")
+        X = np.asarray(X, float)
+        Y = np.asarray(Y, float).reshape(-1)
+        if X.ndim != 2 or X.shape[1] != self.d:
+            raise ValueError(f"X must be [N, {self.d}], got {X.shape}")
+        if Y.shape[0] != X.shape[0]:
+            raise ValueError("Y must hold N observations")
+        v, ls, s2, c = self._hyper
+        try:
+            self.state = O.gpr_update(self.kernel, v, ls, s2, c, X, Y)
+        except np.linalg.LinAlgError as e:
+            from trieste_amd._lib import NotPositiveDefiniteError
+
+            self.state = None
+            raise NotPositiveDefiniteError(str(e))
+        self.N = X.shape[0]
+
+    def _st(self):
+        if self.state is None:
+            raise RuntimeError("model has no data: call tgp_set_data first")
+        return self.state
+
+    def get_factor(self):
+        st = self._st()
+        W = np.linalg.inv(st.L)
+        return st.L, W, W.T @ (W @ st.err)
+
+    def predict(self, Xq):
+        return O.predict(self._st(), np.asarray(Xq, float))
+
+    def predict_mean(self, Xq):
+        return O.predict(self._st(), np.asarray(Xq, float))[0]
+
+    def predict_joint(self, Xq):
+        Xq = np.asarray(Xq, float)
+        if Xq.shape[-2] > 64:
+            raise ValueError("q must be in 1..64")
+        return O.predict_joint(self._st(), Xq)
+
+    def eta(self):
+        return O.eta_min_mean(self._st())
+
+    def acq_values(self, acq, param, Xq):
+        m, v = self.predict(Xq)
+        if acq == "ei":
+            return O.expected_improvement(m, v, param)
+        if acq == "pi":
+            return O.probability_of_improvement(m, v, param)
+        if acq == "nlcb":
+            return O.negative_lower_confidence_bound(m, v, param)
+        raise KeyError(acq)
+
+    def acq_argmax(self, acq, param, Xq, index_base=0):
+        Xq = np.asarray(Xq, float)
+        if Xq.shape[0] == 0:
+            raise ValueError("arg-max over an empty candidate set")
+        vals = self.acq_values(acq, param, Xq)
+        i = int(np.argmax(vals))
+        return float(vals[i]), i + index_base, Xq[i].copy()
+
+    def acq_topk(self, acq, param, Xq, k, index_base=0):
+        vals = self.acq_values(acq, param, np.asarray(Xq, float))
+        v, i = O.top_k(vals, k)
+        return v, i + index_base
+
+    def sample_box(self, seed, first, M, lower, upper):
+        rng = np.random.default_rng([seed, first])
+        lo = np.broadcast_to(np.asarray(lower, float), (self.d,))
+        up = np.broadcast_to(np.asarray(upper, float), (self.d,))
+        return rng.uniform(lo, up, size=(M, self.d))
+
+    def qei(self, Xq, eps, eta, jitter=1e-6):
+        Xq = np.asarray(Xq, float)
+        lead = Xq.shape[:-2]
+        out = O.batch_mc_ei(self._st(), Xq.reshape((-1,) + Xq.shape[-2:]), np.asarray(eps, float), eta, jitter)
+        return out.reshape(lead)
+
+    def reparam_samples(self, Xq, eps, jitter=1e-6):
+        Xq = np.asarray(Xq, float)
+        lead = Xq.shape[:-2]
+        s = O.batch_reparam_samples(self._st(), Xq.reshape((-1,) + Xq.shape[-2:]), np.asarray(eps, float), jitter)
+        return s.reshape(lead + s.shape[1:])
+
+    def last_kernel_ms(self):
+        return 0.0, 0
+
+    def trajectory(self, rff_W, rff_b, w, xi):
+        return FakeTrajectory(self, rff_W, rff_b, w, xi)

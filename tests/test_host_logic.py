@@ -1,0 +1,395 @@
+"""CPU tests of the host layer (model wrapper, builders, optimizers, rules, loops).
+
+Written after the reference's own tests for these surfaces (cited per test); the engine is replaced
+at its boundary by tests/fakes.py::FakeEngine (oracle-backed) -- no GPU, no HIP compute here.
+"""
+import math
+
+import numpy as np
+import pytest
+
+import trieste_amd.models as M
+from tests.fakes import FakeEngine
+from trieste_amd import objectives as OBJ
+from trieste_amd.acquisition import (BatchMonteCarloExpectedImprovement, DiscreteThompsonSampling,
+                                     EfficientGlobalOptimization, ExpectedImprovement, NegativeLowerConfidenceBound,
+                                     ProbabilityOfImprovement, RandomSampling, ThompsonSamplerFromTrajectory,
+                                     automatic_optimizer_selector, batchify_joint, batchify_vectorize,
+                                     expected_improvement, generate_initial_points, generate_random_search_optimizer,
+                                     optimize_discrete, split_acquisition_function, split_acquisition_function_calls)
+from trieste_amd.ask_tell_optimization import AskTellOptimizer
+from trieste_amd.bayesian_optimizer import BayesianOptimizer
+from trieste_amd.data import OBJECTIVE, Dataset
+from trieste_amd.space import Box, DiscreteSearchSpace
+
+
+@pytest.fixture(autouse=True)
+def fake_engine(monkeypatch):
+    monkeypatch.setattr(M, "GPEngine", FakeEngine)
+
+
+def _model(n=12, d=2, kernel=None, noise=1e-3, seed=0, objective=OBJ.scaled_branin):
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(size=(n, d))
+    data = Dataset(x, objective(x))
+    gpr = M.build_gpr(data, Box([0.0] * d, [1.0] * d), likelihood_variance=noise, kernel=kernel)
+    return M.GaussianProcessRegression(gpr), data
+
+
+# ---- data / space / objectives (reference tests/unit/test_data.py, test_space.py, objectives) --------
+def test_dataset_shape_checks_and_concat():
+    with pytest.raises(ValueError):
+        Dataset(np.zeros(3), np.zeros(3))
+    with pytest.raises(ValueError):
+        Dataset(np.zeros((3, 2)), np.zeros((4, 1)))
+    with pytest.raises(ValueError):
+        Dataset(np.zeros((3, 0)), np.zeros((3, 1)))
+    a = Dataset(np.ones((2, 3)), np.zeros((2, 1)))
+    b = Dataset(np.zeros((1, 3)), np.ones((1, 1)))
+    c = a + b
+    assert len(c) == 3 and c.query_points.shape == (3, 3) and c.observations[-1, 0] == 1.0
+    with pytest.raises(ValueError):
+        a + Dataset(np.zeros((1, 2)), np.ones((1, 1)))
+
+
+def test_box_and_discrete_space():
+    box = Box([0.0, -1.0], [1.0, 2.0])
+    s = box.sample(500, seed=3)
+    assert s.shape == (500, 2) and np.all(s >= box.lower) and np.all(s <= box.upper)
+    np.testing.assert_array_equal(s, box.sample(500, seed=3))
+    assert not np.array_equal(s, box.sample(500, seed=4))
+    assert box.sample(0).shape == (0, 2)
+    with pytest.raises(ValueError):
+        box.sample(-1)
+    with pytest.raises(ValueError):
+        Box([0.0], [0.0])
+    assert (box ** 3).dimension == 6
+    assert [0.5, 0.0] in box and [2.0, 0.0] not in box
+    pts = np.arange(12.0).reshape(6, 2)
+    ds = DiscreteSearchSpace(pts)
+    assert ds.dimension == 2 and [2.0, 3.0] in ds and [2.0, 2.0] not in ds
+    assert ds.sample(100).shape == (6, 2) and ds.sample(3).shape == (3, 2)
+
+
+def test_objective_known_answers():
+    """objective(minimizers) == minimum, atol 1e-4 (reference test_single_objectives.py:64-72)."""
+    np.testing.assert_allclose(OBJ.branin(OBJ.BRANIN_MINIMIZERS)[:, 0], OBJ.BRANIN_MINIMUM[0], atol=1e-4)
+    np.testing.assert_allclose(OBJ.scaled_branin(OBJ.BRANIN_MINIMIZERS)[:, 0], OBJ.SCALED_BRANIN_MINIMUM[0], atol=1e-4)
+    np.testing.assert_allclose(OBJ.hartmann_6(OBJ.HARTMANN_6_MINIMIZER), [OBJ.HARTMANN_6_MINIMUM], atol=1e-4)
+    np.testing.assert_allclose(OBJ.ackley_5(np.full((1, 5), 0.5)), [[0.0]], atol=1e-4)
+    np.testing.assert_allclose(OBJ.ackley(np.full((1, 8), 0.5)), [[0.0]], atol=1e-4)
+    assert OBJ.hartmann_6(np.zeros((4, 3, 6))).shape == (4, 3, 1)
+
+
+# ---- model wrapper (reference tests/unit/models/gpflow/test_models.py, test_builders.py) --------------
+def test_build_gpr_defaults():
+    rng = np.random.default_rng(1)
+    x = rng.uniform(size=(20, 3))
+    data = Dataset(x, OBJ.ackley(x))
+    space = Box([0.0] * 3, [1.0, 2.0, 1.0])
+    gpr = M.build_gpr(data, space)
+    assert gpr.kernel.kind == "matern52"
+    np.testing.assert_allclose(gpr.kernel.lengthscales, 0.2 * np.array([1.0, 2.0, 1.0]) * math.sqrt(3))
+    np.testing.assert_allclose(gpr.kernel.variance, np.var(data.observations))
+    np.testing.assert_allclose(gpr.likelihood_variance, np.var(data.observations) / 100.0)
+    np.testing.assert_allclose(gpr.mean_function.c, np.mean(data.observations))
+    assert M.build_gpr(data, space, likelihood_variance=1e-7).likelihood_variance == 1e-7
+    with pytest.raises(ValueError):
+        M.build_gpr(data)
+
+
+def test_model_predict_shapes_update_and_errors():
+    model, data = _model()
+    q = np.random.default_rng(2).uniform(size=(7, 2))
+    m, v = model.predict(q)
+    assert m.shape == (7, 1) and v.shape == (7, 1) and np.all(v >= 1e-12)
+    m3, v3 = model.predict(q.reshape(7, 1, 2))
+    assert m3.shape == (7, 1, 1)
+    jm, jc = model.predict_joint(q.reshape(1, 7, 2))
+    assert jm.shape == (1, 7, 1) and jc.shape == (1, 1, 7, 7)
+    np.testing.assert_allclose(np.diagonal(jc[0, 0]), v[:, 0], rtol=1e-6, atol=1e-9)
+    ym, yv = model.predict_y(q)
+    np.testing.assert_allclose(yv - model.get_observation_noise(), v, atol=1e-12)
+    # update == a fresh model on the new data (reference test_models.py:117-139)
+    x2 = np.random.default_rng(3).uniform(size=(5, 2))
+    new = data + Dataset(x2, OBJ.scaled_branin(x2))
+    model.update(new)
+    fresh = M.GaussianProcessRegression(M.GPR((new.query_points, new.observations), model.get_kernel(),
+                                              model.get_mean_function(), model.get_observation_noise()))
+    for a, b in zip(model.predict(q), fresh.predict(q)):
+        np.testing.assert_allclose(a, b, rtol=1e-10)
+    assert len(model.get_internal_data()) == 17
+    with pytest.raises(ValueError):
+        model.update(Dataset(np.zeros((3, 3)), np.zeros((3, 1))))  # reference models.py:176-182
+    with pytest.raises(ValueError):
+        model.update(Dataset(np.zeros((3, 2)), np.zeros((3, 2))))
+    with pytest.raises(ValueError):
+        M.GaussianProcessRegression(M.build_gpr(data, Box([0, 0], [1, 1])), num_rff_features=0)
+
+
+# ---- acquisition functions (reference tests/unit/acquisition/function/test_function.py) ------------
+def test_expected_improvement_builder_uses_min_posterior_mean_and_updates_in_place():
+    model, data = _model()
+    builder = ExpectedImprovement()
+    with pytest.raises(ValueError):
+        builder.prepare_acquisition_function(model, dataset=None)
+    fn = builder.prepare_acquisition_function(model, dataset=data)
+    assert isinstance(fn, expected_improvement)
+    np.testing.assert_allclose(fn.eta, np.min(model.predict(data.query_points)[0]), rtol=1e-12)
+    x = np.random.default_rng(5).uniform(size=(9, 1, 2))
+    before = fn(x)
+    assert before.shape == (9, 1)
+    x2 = np.array([[0.5, 0.1]])
+    model.update(data + Dataset(x2, OBJ.scaled_branin(x2) - 3.0))
+    fn2 = builder.update_acquisition_function(fn, model, dataset=model.get_internal_data())
+    assert fn2 is fn  # same object, updated in place (reference test_function.py:196)
+    assert fn.eta < -1.0 and not np.allclose(fn(x), before)
+    with pytest.raises(ValueError):  # batch size != 1 (reference test_function.py:282-287)
+        fn(np.zeros((4, 2, 2)))
+
+
+def test_expected_improvement_matches_monte_carlo():
+    """Analytic EI vs a Monte-Carlo estimate from N(mean, var), rtol 0.01 (reference :290-332)."""
+    model, data = _model(n=8, noise=1e-2)
+    fn = ExpectedImprovement().prepare_acquisition_function(model, dataset=data)
+    xs = np.random.default_rng(6).uniform(size=(11, 1, 2))
+    ei = fn(xs)[:, 0]
+    mean, var = model.predict(xs[:, 0, :])
+    samples = mean[:, 0][None, :] + np.sqrt(var[:, 0])[None, :] * np.random.default_rng(7).standard_normal((400000, 11))
+    mc = np.mean(np.maximum(fn.eta - samples, 0.0), axis=0)
+    np.testing.assert_allclose(ei, mc, rtol=0.02, atol=2e-4)
+
+
+def test_pi_and_lcb_builders():
+    model, data = _model()
+    x = np.random.default_rng(8).uniform(size=(5, 1, 2))
+    pi = ProbabilityOfImprovement().prepare_acquisition_function(model, dataset=data)(x)
+    assert pi.shape == (5, 1) and np.all((pi >= 0) & (pi <= 1))
+    m, v = model.predict(x[:, 0, :])
+    lcb = NegativeLowerConfidenceBound(1.96).prepare_acquisition_function(model, dataset=data)(x)
+    np.testing.assert_allclose(lcb, -(m - 1.96 * np.sqrt(v)), rtol=1e-12)
+    with pytest.raises(ValueError):
+        NegativeLowerConfidenceBound(-1.0).prepare_acquisition_function(model, dataset=data)
+
+
+def test_batch_mc_ei_close_to_ei_for_q1_and_fixed_between_calls():
+    """qEI at q = 1 vs analytic EI, rtol 0.06 (reference test_function.py:1359-1371)."""
+    model, data = _model(n=8, noise=1e-2)
+    ei = ExpectedImprovement().prepare_acquisition_function(model, dataset=data)
+    qei = BatchMonteCarloExpectedImprovement(20000).prepare_acquisition_function(model, dataset=data)
+    xs = np.random.default_rng(9).uniform(size=(6, 1, 2))
+    a, b = qei(xs), ei(xs)
+    assert a.shape == (6, 1)
+    np.testing.assert_allclose(a, b, rtol=0.06, atol=1e-4)
+    np.testing.assert_array_equal(qei(xs), a)  # eps fixed until the sampler is reset
+    with pytest.raises(ValueError):
+        qei(np.zeros((3, 2, 2)))  # batch size changed
+    qei.update(ei.eta)
+    assert not np.array_equal(qei(xs), a)  # reset -> new draws
+    with pytest.raises(ValueError):
+        BatchMonteCarloExpectedImprovement(0)
+    with pytest.raises(ValueError):
+        BatchMonteCarloExpectedImprovement(10, jitter=-1.0)
+
+
+# ---- optimizers (reference tests/unit/acquisition/test_optimizer.py) ----------------------------
+def _quadratic(shift):
+    return lambda x: -np.sum((np.asarray(x) - shift) ** 2, axis=-1)  # [..., B, D] -> [..., B]; max at shift
+
+
+def test_optimize_discrete_and_random_search_generic_path():
+    pts = np.stack(np.meshgrid(np.linspace(0, 1, 11), np.linspace(0, 1, 11)), -1).reshape(-1, 2)
+    space = DiscreteSearchSpace(pts)
+    shift = np.array([0.3, 0.8])
+    for opt in (optimize_discrete, split_acquisition_function_calls(optimize_discrete, 97)):
+        np.testing.assert_allclose(opt(space, _quadratic(shift)), [shift], atol=1e-12)
+    # vectorised: V functions maximised together (reference :115-146)
+    shifts = np.array([[0.1, 0.2], [0.9, 0.5], [0.5, 0.5]])
+    vec = lambda x: -np.sum((x - shifts) ** 2, axis=-1)  # [M, 3, D] -> [M, 3]
+    np.testing.assert_allclose(batchify_vectorize(optimize_discrete, 3)(space, vec), shifts, atol=1e-12)
+    with pytest.raises(ValueError):
+        optimize_discrete(space, (vec, 2))  # wrong trailing dimension
+    box = Box([0, 0], [1, 1])
+    got = generate_random_search_optimizer(20000, seed=1)(box, _quadratic(shift))
+    np.testing.assert_allclose(got, [shift], atol=0.02)
+    np.testing.assert_allclose(automatic_optimizer_selector(box, _quadratic(shift)), [shift], atol=0.05)
+    with pytest.raises(ValueError):
+        generate_random_search_optimizer(0)
+
+
+def test_first_index_wins_ties():
+    pts = np.array([[0.0], [1.0], [2.0], [1.0]])
+    const = lambda x: np.zeros(x.shape[:-1])
+    np.testing.assert_array_equal(optimize_discrete(DiscreteSearchSpace(pts), const), [[0.0]])
+
+
+def test_split_acquisition_function_equivalence():
+    """reference test_optimizer.py:873-913: chunked calls == one call; chunk length from ELEMENTS."""
+    calls = []
+
+    def f(x):
+        calls.append(x.shape[0])
+        return np.sum(x, axis=(-1, -2))[:, None]
+
+    x = np.random.default_rng(0).uniform(size=(25, 1, 3))
+    np.testing.assert_array_equal(split_acquisition_function(f, 10)(x), f(x))
+    calls.clear()
+    split_acquisition_function(f, 10)(x)  # 3 elements per row -> ceil(10/3) = 4 rows per call
+    assert calls == [4] * 6 + [1]
+    with pytest.raises(ValueError):
+        split_acquisition_function(f, 0)
+
+
+def test_generate_initial_points_running_top_k():
+    """reference test_optimizer.py:948-1009."""
+    shift = np.array([0.25, 0.75])
+    space = Box([0, 0], [1, 1])
+    batches = [space.sample(300, seed=s) for s in range(4)]
+    got = generate_initial_points(7, lambda sp: iter(batches), space, _quadratic(shift))
+    assert got.shape == (7, 1, 2)
+    allpts = np.concatenate(batches)
+    order = np.argsort(np.sum((allpts - shift) ** 2, -1), kind="stable")[:7]
+    np.testing.assert_allclose(got[:, 0, :], allpts[order])
+    with pytest.raises(ValueError):
+        generate_initial_points(3, lambda sp: iter([]), space, _quadratic(shift))
+
+
+def test_fused_path_is_used_for_engine_backed_functions_and_agrees_with_generic():
+    model, data = _model(n=15)
+    fn = ExpectedImprovement().prepare_acquisition_function(model, dataset=data)
+    space = DiscreteSearchSpace(np.random.default_rng(4).uniform(size=(400, 2)))
+    fused = optimize_discrete(space, fn)
+    generic = optimize_discrete(space, lambda x: fn(x))  # hides .argmax -> generic evaluate + arg-max
+    np.testing.assert_array_equal(fused, generic)
+    tk = generate_initial_points(5, lambda sp: iter([space.points]), space, fn)
+    vals = fn(space.points[:, None, :])[:, 0]
+    np.testing.assert_array_equal(tk[:, 0, :], space.points[np.argsort(-vals, kind="stable")[:5]])
+
+
+# ---- rules (reference tests/unit/acquisition/test_rule.py) ---------------------------------------
+def test_ego_defaults_and_acquire():
+    with pytest.raises(ValueError):
+        EfficientGlobalOptimization(num_query_points=0)
+    with pytest.raises(ValueError):
+        EfficientGlobalOptimization(num_query_points=2)  # needs a batch builder
+    model, data = _model(n=10)
+    space = DiscreteSearchSpace(np.random.default_rng(11).uniform(size=(300, 2)))
+    ego = EfficientGlobalOptimization()
+    pt = ego.acquire_single(space, model, dataset=data)
+    assert pt.shape == (1, 2) and pt[0] in space
+    ei = ego.acquisition_function
+    vals = ei(space.points[:, None, :])[:, 0]
+    np.testing.assert_array_equal(pt[0], space.points[np.argmax(vals)])
+    fn_before = ego.acquisition_function
+    ego.acquire_single(space, model, dataset=data)
+    assert ego.acquisition_function is fn_before  # updated, not rebuilt
+
+
+def test_ego_batch_with_joint_builder():
+    model, data = _model(n=10)
+    ego = EfficientGlobalOptimization(BatchMonteCarloExpectedImprovement(64), num_query_points=3,
+                                      optimizer=generate_random_search_optimizer(300, seed=2))
+    pts = ego.acquire_single(Box([0, 0], [1, 1]), model, dataset=data)
+    assert pts.shape == (3, 2) and np.all((pts >= 0) & (pts <= 1))
+
+
+def test_discrete_thompson_sampling_and_random_sampling():
+    model, data = _model(n=10)
+    box = Box([0, 0], [1, 1])
+    with pytest.raises(ValueError):
+        DiscreteThompsonSampling(0, 1)
+    with pytest.raises(ValueError):
+        DiscreteThompsonSampling(10, 0)
+    with pytest.raises(ValueError):
+        DiscreteThompsonSampling(10, 1, ThompsonSamplerFromTrajectory(sample_min_value=True))
+    dts = DiscreteThompsonSampling(500, 5, ThompsonSamplerFromTrajectory(), seed=3)
+    pts = dts.acquire_single(box, model, dataset=data)
+    assert pts.shape == (5, 2) and np.all((pts >= 0) & (pts <= 1))
+    with pytest.raises(ValueError):
+        dts.acquire(box, {"foo": model}, datasets={"foo": data})
+    with pytest.raises(ValueError):
+        dts.acquire(box, {OBJECTIVE: model}, datasets=None)
+    # Thompson samples' values are at most the min predictive mean + noise-ish
+    # (reference tests/unit/acquisition/test_sampler.py:194-215): min over a trajectory <= mean somewhere
+    smin = ThompsonSamplerFromTrajectory(sample_min_value=True).sample(model, 8, box.sample(400, seed=5))
+    assert smin.shape == (8, 1)
+    assert RandomSampling(4).acquire_single(box, model).shape == (4, 2)
+    # exact sampler on a small candidate set
+    pts2 = DiscreteThompsonSampling(40, 3).acquire_single(box, model, dataset=data)
+    assert pts2.shape == (3, 2)
+
+
+def test_trajectory_fixed_batch_size_and_resample():
+    model, _ = _model(n=10)
+    sampler = model.trajectory_sampler()
+    traj = sampler.get_trajectory()
+    x = np.random.default_rng(0).uniform(size=(20, 2, 2))
+    y = traj(x)
+    assert y.shape == (20, 2, 1)
+    np.testing.assert_array_equal(traj(x), y)  # repeatable
+    with pytest.raises(ValueError):
+        traj(np.zeros((20, 3, 2)))  # batch size is fixed (reference sampler.py:913-921)
+    sampler.resample_trajectory(traj)
+    assert not np.allclose(traj(x), y)
+    # trajectories track the posterior mean on average (reference test_models.py:638-681, loose)
+    model2, _ = _model(n=30, noise=1e-3)
+    xs = np.random.default_rng(1).uniform(size=(50, 2))
+    s = model2.trajectory_sampler()
+    t = s.get_trajectory()
+    vals = t(np.repeat(xs[:, None, :], 16, axis=1))[..., 0]
+    np.testing.assert_allclose(vals.mean(1), model2.predict(xs)[0][:, 0], atol=0.5)
+
+
+# ---- loops (reference tests/unit/test_ask_tell_optimization.py, test_bayesian_optimizer.py) ---------
+def test_ask_tell_reduces_scaled_branin():
+    """BASELINE config C1 plumbing on the host logic: Ask-Tell + EGO(EI) + random-search sweep."""
+    space = Box([0, 0], [1, 1])
+    x0 = space.sample(6, seed=0)
+    data = Dataset(x0, OBJ.scaled_branin(x0))
+    model = M.GaussianProcessRegression(M.build_gpr(data, space, likelihood_variance=1e-5))
+    rule = EfficientGlobalOptimization(optimizer=generate_random_search_optimizer(3000, seed=1))
+    opt = AskTellOptimizer(space, data, model, rule)
+    for _ in range(14):
+        q = opt.ask()
+        assert q.shape == (1, 2)
+        opt.tell(Dataset(q, OBJ.scaled_branin(q)))
+    assert len(opt.dataset) == 20
+    assert np.min(opt.dataset.observations) < -0.9  # global minimum -1.047
+    with pytest.raises(ValueError):
+        opt.tell({"wrong": data})
+    with pytest.raises(ValueError):
+        AskTellOptimizer(space, {OBJECTIVE: data}, {"m": model})
+
+
+def test_bayesian_optimizer_ok_and_err_paths():
+    space = Box([0, 0], [1, 1])
+    x0 = space.sample(5, seed=2)
+    data = Dataset(x0, OBJ.scaled_branin(x0))
+    model = M.GaussianProcessRegression(M.build_gpr(data, space, likelihood_variance=1e-4))
+    bo = BayesianOptimizer(OBJ.mk_observer(OBJ.scaled_branin), space)
+    rule = EfficientGlobalOptimization(optimizer=generate_random_search_optimizer(1000, seed=3))
+    res = bo.optimize(4, data, model, rule)
+    assert res.final_result.is_ok and len(res.try_get_final_dataset()) == 9 and len(res.history) == 4
+
+    class Broken(RandomSampling):
+        def acquire(self, *a, **k):
+            raise RuntimeError("boom")
+
+    bad = bo.optimize(3, data, model, Broken())
+    assert bad.final_result.is_err and len(bad.history) == 1
+    with pytest.raises(RuntimeError):
+        bad.try_get_final_dataset()
+    with pytest.raises(ValueError):
+        bo.optimize(-1, data, model)
+    assert bo.optimize(0, data, model).final_result.is_ok
+
+
+def test_not_positive_definite_surfaces_as_err():
+    """A failed Cholesky must not abort the loop (reference bayesian_optimizer.py:855-875)."""
+    from trieste_amd._lib import NotPositiveDefiniteError
+
+    space = Box([0, 0], [1, 1])
+    x0 = np.array([[0.5, 0.5], [0.5, 0.5], [0.2, 0.1]])
+    gpr = M.GPR((x0, OBJ.scaled_branin(x0)), M.Matern52(1.0, [0.3, 0.3]), M.Constant(0.0), 1e-30)
+    with pytest.raises(NotPositiveDefiniteError):
+        M.GaussianProcessRegression(gpr)

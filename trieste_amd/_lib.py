@@ -44,6 +44,7 @@ SIGNATURES = {
     "tgp_sample_box": (C.c_int, [_vp, C.c_uint64, C.c_int64, C.c_int64, _vp, _vp, _vp]),
     "tgp_qei": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, C.c_int, C.c_double, C.c_double, _vp,
                           C.c_int]),
+    "tgp_reparam_samples": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, C.c_int, C.c_double, _vp, C.c_int]),
     "tgp_traj_create": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, C.POINTER(_vp)]),
     "tgp_traj_destroy": (C.c_int, [_vp]),
     "tgp_traj_get_v": (C.c_int, [_vp, _vp]),

@@ -1,0 +1,212 @@
+"""Acquisition functions of the hot path (reference trieste/acquisition/function/function.py):
+ExpectedImprovement / expected_improvement (96-223), BatchMonteCarloExpectedImprovement /
+batch_monte_carlo_expected_improvement (1074-1186), plus the sibling tails on the same posterior
+ProbabilityOfImprovement (481-515, "probability_below_threshold") and NegativeLowerConfidenceBound
+(328-418).  Values are computed by libtgp's fused kernels; the objects also expose the fused
+device arg-max / top-k used by :mod:`trieste_amd.acquisition.optimizer`.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+
+from ..data import Dataset
+from ..sampler import JITTER
+from .interface import AcquisitionFunctionClass, SingleModelAcquisitionBuilder
+
+
+def _require_engine(model, who: str):
+    if not hasattr(model, "engine"):
+        raise TypeError(f"{who} needs an engine-backed model (trieste_amd.models.GaussianProcessRegression); "
+                        f"received {model!r}.  There is no CPU evaluation path.")
+    return model.engine
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+class _posterior_tail(AcquisitionFunctionClass):
+    """Shared machinery of the analytic single-point acquisition functions: squeeze the batch
+    axis (must be 1), call the fused kernel, restore [..., 1]."""
+
+    _acq = "ei"
+
+    def __init__(self, model, param: float):
+        self._model = model
+        self._engine = _require_engine(model, type(self).__name__)
+        self._param = float(np.asarray(param).reshape(()))
+
+    def _points(self, x):
+        if not _is_torch(x):
+            x = np.asarray(x, dtype=np.float64)
+        if len(x.shape) < 2 or x.shape[-2] != 1:
+            raise ValueError(f"This acquisition function only supports batch sizes of one, got input shape {tuple(x.shape)}")
+        return x[..., 0, :]
+
+    def __call__(self, x):
+        return self._engine.acq_values(self._acq, self._param, self._points(x))[..., None]
+
+    # fused sweeps (no [M] values written to HBM / returned to the host)
+    def argmax(self, points, index_base: int = 0):
+        """points [M, D] -> (value, global index, point [D])."""
+        return self._engine.acq_argmax(self._acq, self._param, points, index_base)
+
+    def top_k(self, points, k: int, index_base: int = 0):
+        return self._engine.acq_topk(self._acq, self._param, points, k, index_base)
+
+
+class expected_improvement(_posterior_tail):
+    r"""x -> E[max(eta - f(x), 0)] (function.py:190-223)."""
+
+    _acq = "ei"
+
+    def __init__(self, model, eta):
+        super().__init__(model, eta)
+
+    def update(self, eta) -> None:
+        """Update eta in place (no rebuild; the reference avoids retracing the same way)."""
+        self._param = float(np.asarray(eta).reshape(()))
+
+    @property
+    def eta(self) -> float:
+        return self._param
+
+
+class probability_below_threshold(_posterior_tail):
+    r"""x -> P(f(x) < threshold) (function.py:481-515)."""
+
+    _acq = "pi"
+
+    def update(self, threshold) -> None:
+        self._param = float(np.asarray(threshold).reshape(()))
+
+
+class negative_lower_confidence_bound(_posterior_tail):
+    r"""x -> -(mean(x) - beta * sqrt(var(x))) (function.py:389-418)."""
+
+    _acq = "nlcb"
+
+    def __init__(self, model, beta: float = 1.96):
+        if beta < 0:
+            raise ValueError(f"Standard deviation scaling parameter beta must not be negative, got {beta}")
+        super().__init__(model, beta)
+
+
+def _eta_from(model, dataset: Optional[Dataset]) -> float:
+    """min over the dataset's query points of the posterior MEAN (function.py:145-149)."""
+    if dataset is None or len(dataset) == 0:
+        raise ValueError("Dataset must be populated.")
+    eng = _require_engine(model, "ExpectedImprovement")
+    data = model.get_internal_data()
+    if dataset.query_points.shape == data.query_points.shape and np.array_equal(dataset.query_points, data.query_points):
+        return eng.eta()  # the model's own training inputs: fused on the device
+    return float(np.min(eng.predict_mean(dataset.query_points)))
+
+
+class ExpectedImprovement(SingleModelAcquisitionBuilder):
+    """Builder for EI where the "best" value is the minimum posterior mean at the observed points
+    (function.py:96-187).  Explicit search-space constraints are outside the engine's path."""
+
+    def __init__(self, search_space=None):
+        if search_space is not None and getattr(search_space, "has_constraints", False):
+            raise NotImplementedError("constrained search spaces are outside the engine's path")
+        self._search_space = search_space
+
+    def __repr__(self) -> str:
+        return f"ExpectedImprovement({self._search_space!r})"
+
+    def prepare_acquisition_function(self, model, dataset: Optional[Dataset] = None):
+        return expected_improvement(model, _eta_from(model, dataset))
+
+    def update_acquisition_function(self, function, model, dataset: Optional[Dataset] = None):
+        if not isinstance(function, expected_improvement):
+            raise ValueError("function must be an expected_improvement instance")
+        function.update(_eta_from(model, dataset))
+        return function
+
+
+class ProbabilityOfImprovement(SingleModelAcquisitionBuilder):
+    """PI with threshold = min posterior mean at the observed points."""
+
+    def __repr__(self) -> str:
+        return "ProbabilityOfImprovement()"
+
+    def prepare_acquisition_function(self, model, dataset: Optional[Dataset] = None):
+        return probability_below_threshold(model, _eta_from(model, dataset))
+
+    def update_acquisition_function(self, function, model, dataset: Optional[Dataset] = None):
+        function.update(_eta_from(model, dataset))
+        return function
+
+
+class NegativeLowerConfidenceBound(SingleModelAcquisitionBuilder):
+    def __init__(self, beta: float = 1.96):
+        self._beta = beta
+
+    def __repr__(self) -> str:
+        return f"NegativeLowerConfidenceBound({self._beta!r})"
+
+    def prepare_acquisition_function(self, model, dataset: Optional[Dataset] = None):
+        return negative_lower_confidence_bound(model, self._beta)
+
+    def update_acquisition_function(self, function, model, dataset: Optional[Dataset] = None):
+        return function  # no state depends on the data
+
+
+class batch_monte_carlo_expected_improvement(AcquisitionFunctionClass):
+    """qEI = mean_S max(eta - min_q samples, 0) with reparametrised joint samples
+    (function.py:1150-1186)."""
+
+    def __init__(self, sample_size: int, model, eta, jitter: float):
+        if not hasattr(model, "reparam_sampler"):
+            raise ValueError("The batch Monte-Carlo expected improvement acquisition function only supports models "
+                             f"that implement a reparam_sampler method; received {model!r}")
+        self._sample_size = sample_size
+        self._engine = _require_engine(model, type(self).__name__)
+        self._sampler = model.reparam_sampler(sample_size)
+        self._eta = float(np.asarray(eta).reshape(()))
+        self._jitter = jitter
+
+    def update(self, eta) -> None:
+        """New eta and fresh draws (reference resets the reparam sampler)."""
+        self._eta = float(np.asarray(eta).reshape(()))
+        self._sampler.reset_sampler()
+
+    def __call__(self, x):
+        """x [..., B, D] -> [..., 1]."""
+        if not _is_torch(x):
+            x = np.asarray(x, dtype=np.float64)
+        if len(x.shape) < 2:
+            raise ValueError(f"x must be [..., B, D], got shape {tuple(x.shape)}")
+        eps = self._sampler.eps(int(x.shape[-2]))
+        if _is_torch(x) and x.is_cuda:
+            import torch
+
+            eps = torch.from_numpy(eps).to(x.device)
+        return self._engine.qei(x, eps, self._eta, self._jitter)[..., None]
+
+
+class BatchMonteCarloExpectedImprovement(SingleModelAcquisitionBuilder):
+    """Builder for qEI (function.py:1074-1147)."""
+
+    def __init__(self, sample_size: int, *, jitter: float = JITTER):
+        if sample_size <= 0:
+            raise ValueError(f"sample_size must be positive, got {sample_size}")
+        if jitter < 0:
+            raise ValueError(f"jitter must be non-negative, got {jitter}")
+        self._sample_size = sample_size
+        self._jitter = jitter
+
+    def __repr__(self) -> str:
+        return f"BatchMonteCarloExpectedImprovement({self._sample_size!r}, jitter={self._jitter!r})"
+
+    def prepare_acquisition_function(self, model, dataset: Optional[Dataset] = None):
+        return batch_monte_carlo_expected_improvement(self._sample_size, model, _eta_from(model, dataset), self._jitter)
+
+    def update_acquisition_function(self, function, model, dataset: Optional[Dataset] = None):
+        if not isinstance(function, batch_monte_carlo_expected_improvement):
+            raise ValueError("function must be a batch_monte_carlo_expected_improvement instance")
+        function.update(_eta_from(model, dataset))
+        return function

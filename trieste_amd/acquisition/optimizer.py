@@ -1,0 +1,174 @@
+"""Acquisition optimizers of the hot path: the candidate sweep + arg-max
+(reference trieste/acquisition/optimizer.py: automatic_optimizer_selector 90-121,
+_get_max_discrete_points 124-150, optimize_discrete 153-170, generate_initial_points 247-341,
+batchify_joint / batchify_vectorize 897-970, generate_random_search_optimizer 973-1011).
+
+An ``AcquisitionOptimizer`` is ``(search_space, acquisition_function | (function, V)) -> points [V or 1, D]``
+and *maximises*.  When the function is one of this package's engine-backed objects (it exposes
+``argmax`` / ``top_k``) the sweep runs fused on the GPU: predict + acquisition + arg-max without
+the [M] values ever being written out.  Any other callable takes the generic path (evaluate, then
+arg-max on the values it returned).
+
+Not here: gradient-based refinement of the sweep winners (``generate_continuous_optimizer``,
+optimizer.py:344-745) -- SURVEY.md section 8f ranks it as the first follow-up; Box spaces are
+swept by random search instead.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple, Union
+
+import numpy as np
+
+from ..space import Box, DiscreteSearchSpace, SearchSpace
+
+NUM_SAMPLES_MIN = 5000   # optimizer.py:46-66
+NUM_SAMPLES_DIM = 1000
+NUM_RUNS_DIM = 10
+
+
+class FailedOptimizationError(Exception):
+    """Raised when an acquisition optimizer fails (optimizer.py:69-70)."""
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+def _split(target_func) -> Tuple[Callable, int]:
+    if isinstance(target_func, tuple):
+        fn, V = target_func
+    else:
+        fn, V = target_func, 1
+    if V < 0:
+        raise ValueError(f"vectorization must be positive, got {V}")
+    return fn, V
+
+
+def _to_host(x) -> np.ndarray:
+    return x.cpu().numpy() if _is_torch(x) else np.asarray(x)
+
+
+def _get_max_discrete_points(points, target_func) -> np.ndarray:
+    """points [M, 1, D] -> the V maximisers [V, D]; first index wins ties (tf.math.argmax)."""
+    fn, V = _split(target_func)
+    if V == 1 and hasattr(fn, "argmax"):  # fused device sweep
+        _, _, x = fn.argmax(points[:, 0, :])
+        return np.asarray(x)[None, :]
+    if _is_torch(points):
+        tiled = points.repeat(1, V, 1)
+    else:
+        tiled = np.tile(points, [1, V, 1])
+    values = _to_host(fn(tiled))
+    if values.ndim != 2 or values.shape[1] != V:
+        raise ValueError(f"The result of function target_func has shape {values.shape}, however, expected a "
+                         f"trailing dimension of size {V}.")
+    best = np.argmax(values, axis=0)  # [V], first index on ties
+    host_pts = _to_host(tiled)
+    return host_pts[best, np.arange(V), :]
+
+
+def optimize_discrete(space: DiscreteSearchSpace, target_func) -> np.ndarray:
+    """Evaluate every point of a discrete space (optimizer.py:153-170)."""
+    return _get_max_discrete_points(space.points[:, None, :], target_func)
+
+
+def generate_random_search_optimizer(num_samples: int = NUM_SAMPLES_MIN, seed: Optional[int] = None,
+                                     on_device: bool = True):
+    """Random-search optimizer over ``num_samples`` points of the space (optimizer.py:973-1011).
+    With an engine-backed acquisition function and a Box the candidates are generated on the GPU
+    (Philox) so a 10^6..10^8-candidate sweep never touches the host."""
+    if num_samples <= 0:
+        raise ValueError(f"num_samples must be positive, got {num_samples}")
+
+    def optimize_random(space: SearchSpace, target_func) -> np.ndarray:
+        fn, V = _split(target_func)
+        eng = getattr(fn, "_engine", None)
+        if on_device and V == 1 and eng is not None and hasattr(fn, "argmax") and isinstance(space, Box) \
+                and hasattr(eng, "sample_box"):
+            pts = space.sample_device(eng, num_samples, seed=0 if seed is None else seed)
+            _, _, x = fn.argmax(pts)
+            return np.asarray(x)[None, :]
+        points = space.sample(num_samples, seed=seed)[:, None, :]
+        return _get_max_discrete_points(points, target_func)
+
+    return optimize_random
+
+
+def automatic_optimizer_selector(space: SearchSpace, target_func) -> np.ndarray:
+    """Pick an optimizer for the space (optimizer.py:90-121): exhaustive for discrete spaces; for a
+    Box a random-search sweep of max(5000, 1000 * D) points (the reference follows the same initial
+    sweep with L-BFGS-B refinement, which is follow-up work here)."""
+    if isinstance(space, DiscreteSearchSpace):
+        return optimize_discrete(space, target_func)
+    if isinstance(space, Box):
+        num_samples = max(NUM_SAMPLES_MIN, NUM_SAMPLES_DIM * space.dimension)
+        return generate_random_search_optimizer(num_samples)(space, target_func)
+    raise NotImplementedError(f"No optimizer currently supports acquisition function maximisation over search "
+                              f"spaces of type {space}. Try specifying the optimize_random optimizer")
+
+
+def generate_initial_points(num_initial_points: int, initial_sampler, space: SearchSpace, target_func,
+                            vectorization: int = 1) -> np.ndarray:
+    """Best ``num_initial_points`` of the candidates produced by ``initial_sampler(space)`` (an
+    iterable of [M_b, D] batches): running top-k, descending, ties by lower index
+    (optimizer.py:247-341).  Returns [k, V, D]."""
+    top_vals = None  # [V, k]
+    top_pts = None   # [V, k, D]
+    for candidates in initial_sampler(space):
+        cand = _to_host(candidates)
+        if cand.ndim != 2:
+            raise ValueError(f"The initial samples must be a tensor of rank 2, got a tensor of rank {cand.ndim}.")
+        if vectorization == 1 and hasattr(target_func, "top_k"):
+            k = min(num_initial_points, cand.shape[0])
+            v, i = target_func.top_k(candidates, k)
+            vals, pts = np.asarray(v)[None, :], cand[np.asarray(i)][None, :, :]
+        else:
+            tiled = np.tile(cand[:, None, :], [1, vectorization, 1])
+            values = _to_host(target_func(tiled))
+            if values.ndim != 2 or values.shape[1] != vectorization:
+                raise ValueError(f"The result of function target_func has shape {values.shape}, however, expected "
+                                 f"a trailing dimension of size {vectorization}.")
+            vals, pts = values.T, np.transpose(tiled, [1, 0, 2])
+        top_vals = vals if top_vals is None else np.concatenate([top_vals, vals], axis=1)
+        top_pts = pts if top_pts is None else np.concatenate([top_pts, pts], axis=1)
+        k = min(num_initial_points, top_vals.shape[1])
+        order = np.stack([np.lexsort((np.arange(top_vals.shape[1]), -top_vals[v]))[:k]
+                          for v in range(top_vals.shape[0])])
+        top_vals = np.take_along_axis(top_vals, order, axis=1)
+        top_pts = np.take_along_axis(top_pts, order[:, :, None], axis=1)
+    if top_pts is None:
+        raise ValueError("No initial point generated!")
+    return np.transpose(top_pts, [1, 0, 2])
+
+
+def batchify_joint(batch_size_one_optimizer, batch_size: int):
+    """Optimise the B points of a batch acquisition function jointly over space**B
+    (optimizer.py:897-934)."""
+    if batch_size <= 0:
+        raise ValueError(f"batch_size must be positive, got {batch_size}")
+
+    def optimizer(search_space: SearchSpace, f) -> np.ndarray:
+        if isinstance(f, tuple):
+            raise ValueError("batchify_joint cannot be applied to a vectorized acquisition function")
+        expanded = search_space ** batch_size
+
+        def target_func_with_vectorized_inputs(x):  # [..., 1, B * D] -> [..., 1]
+            return f(x.reshape(tuple(x.shape[:-2]) + (batch_size, -1)))
+
+        pts = batch_size_one_optimizer(expanded, target_func_with_vectorized_inputs)  # [1, B * D]
+        return np.asarray(pts).reshape(batch_size, -1)
+
+    return optimizer
+
+
+def batchify_vectorize(batch_size_one_optimizer, batch_size: int):
+    """Optimise V independent functions at once (optimizer.py:937-970)."""
+    if batch_size <= 0:
+        raise ValueError(f"batch_size must be positive, got {batch_size}")
+
+    def optimizer(search_space: SearchSpace, f) -> np.ndarray:
+        if isinstance(f, tuple):
+            raise ValueError("batchify_vectorize cannot be applied to an already vectorized acquisition function")
+        return batch_size_one_optimizer(search_space, (f, batch_size))
+
+    return optimizer

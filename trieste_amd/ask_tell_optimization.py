@@ -1,0 +1,82 @@
+"""Ask-Tell loop (reference trieste/ask_tell_optimization.py:595-729), the caller side of the hot
+path: ``ask`` -> rule.acquire(...), ``tell`` -> datasets += new data; model.update; model.optimize.
+Only what the loop needs is restated; checkpoint records and TensorBoard logging are out of scope
+(SURVEY.md section 2 rows 15-16)."""
+from __future__ import annotations
+
+import copy
+from typing import Mapping, Optional, Union
+
+from .acquisition.rule import AcquisitionRule, EfficientGlobalOptimization
+from .data import OBJECTIVE, Dataset
+from .space import SearchSpace
+
+
+def _as_map(x):
+    return x if isinstance(x, Mapping) else {OBJECTIVE: x}
+
+
+class AskTellOptimizer:
+    def __init__(self, search_space: SearchSpace, datasets: Union[Mapping, Dataset], models,
+                 acquisition_rule: Optional[AcquisitionRule] = None, *, fit_model: bool = True,
+                 track_data: bool = True):
+        self._search_space = search_space
+        self._datasets = dict(_as_map(datasets))
+        self._models = dict(_as_map(models))
+        if not self._datasets or not self._models:
+            raise ValueError("dicts of datasets and models must be populated.")
+        if self._datasets.keys() != self._models.keys():
+            raise ValueError(f"datasets and models should contain the same keys. Got {self._datasets.keys()} and "
+                             f"{self._models.keys()} respectively.")
+        if acquisition_rule is None:
+            if self._datasets.keys() != {OBJECTIVE}:
+                raise ValueError(f"Default acquisition rule EfficientGlobalOptimization requires tag {OBJECTIVE!r}, "
+                                 f"got keys {self._datasets.keys()}")
+            acquisition_rule = EfficientGlobalOptimization()
+        self._acquisition_rule = acquisition_rule
+        self._track_data = track_data
+        self._fit_model = fit_model
+        if fit_model:
+            for tag, model in self._models.items():
+                model.update(self._datasets[tag])
+                model.optimize(self._datasets[tag])
+
+    def __repr__(self) -> str:
+        return (f"AskTellOptimizer({self._search_space!r}, {self._datasets!r}, {self._models!r}, "
+                f"{self._acquisition_rule!r})")
+
+    @property
+    def datasets(self) -> Mapping:
+        return self._datasets
+
+    @property
+    def dataset(self) -> Dataset:
+        if len(self._datasets) == 1:
+            return next(iter(self._datasets.values()))
+        raise ValueError(f"Expected a single dataset, found {len(self._datasets)}")
+
+    @property
+    def models(self) -> Mapping:
+        return self._models
+
+    @property
+    def model(self):
+        if len(self._models) == 1:
+            return next(iter(self._models.values()))
+        raise ValueError(f"Expected a single model, found {len(self._models)}")
+
+    def ask(self):
+        """Suggest the next query point(s) (ask_tell_optimization.py:595-640)."""
+        return self._acquisition_rule.acquire(self._search_space, self._models, datasets=self._datasets)
+
+    def tell(self, new_data: Union[Mapping, Dataset]) -> None:
+        """Add observations and refresh the models (ask_tell_optimization.py:642-729)."""
+        new_data = _as_map(new_data)
+        if self._datasets.keys() != new_data.keys():
+            raise ValueError(f"new_data keys {new_data.keys()} doesn't match dataset keys {self._datasets.keys()}")
+        for tag, ds in new_data.items():
+            self._datasets[tag] = (self._datasets[tag] + ds) if self._track_data else ds
+        for tag, model in self._models.items():
+            model.update(self._datasets[tag])
+            if self._fit_model:
+                model.optimize(self._datasets[tag])

@@ -1,0 +1,121 @@
+"""Bayesian optimisation loop (reference trieste/bayesian_optimizer.py:570-883): per step
+acquire -> observe -> datasets += new -> model.update -> model.optimize, with the whole step
+wrapped so a failure (e.g. a non-positive-definite Cholesky) is returned as ``Err`` together with
+the history so far (855-875) instead of propagating."""
+from __future__ import annotations
+
+import copy
+import traceback
+from dataclasses import dataclass, field
+from typing import Callable, List, Mapping, Optional, Union
+
+from .acquisition.rule import AcquisitionRule, EfficientGlobalOptimization
+from .data import OBJECTIVE, Dataset
+from .space import SearchSpace
+
+
+@dataclass
+class Ok:
+    value: object
+
+    is_ok = True
+    is_err = False
+
+    def unwrap(self):
+        return self.value
+
+
+@dataclass
+class Err:
+    error: Exception
+
+    is_ok = False
+    is_err = True
+
+    def unwrap(self):
+        raise self.error
+
+
+@dataclass
+class Record:
+    datasets: Mapping
+    models: Mapping
+
+    @property
+    def dataset(self) -> Dataset:
+        return next(iter(self.datasets.values()))
+
+    @property
+    def model(self):
+        return next(iter(self.models.values()))
+
+
+@dataclass
+class OptimizationResult:
+    final_result: Union[Ok, Err]
+    history: List[Record] = field(default_factory=list)
+
+    def try_get_final_datasets(self) -> Mapping:
+        return self.final_result.unwrap().datasets
+
+    def try_get_final_dataset(self) -> Dataset:
+        return self.final_result.unwrap().dataset
+
+    def try_get_final_models(self) -> Mapping:
+        return self.final_result.unwrap().models
+
+    def try_get_final_model(self):
+        return self.final_result.unwrap().model
+
+
+def _as_map(x):
+    return x if isinstance(x, Mapping) else {OBJECTIVE: x}
+
+
+class BayesianOptimizer:
+    def __init__(self, observer: Callable, search_space: SearchSpace):
+        self._observer = observer
+        self._search_space = search_space
+
+    def __repr__(self) -> str:
+        return f"BayesianOptimizer({self._observer!r}, {self._search_space!r})"
+
+    def optimize(self, num_steps: int, datasets, models, acquisition_rule: Optional[AcquisitionRule] = None, *,
+                 track_state: bool = True, fit_model: bool = True, fit_initial_model: bool = True,
+                 early_stop_callback: Optional[Callable] = None) -> OptimizationResult:
+        datasets = dict(_as_map(datasets))
+        models = dict(_as_map(models))
+        if num_steps < 0:
+            raise ValueError(f"num_steps must be at least 0, got {num_steps}")
+        if datasets.keys() != models.keys():
+            raise ValueError(f"datasets and models should contain the same keys. Got {datasets.keys()} and "
+                             f"{models.keys()} respectively.")
+        if not datasets:
+            raise ValueError("dicts of datasets and models must be populated.")
+        if acquisition_rule is None:
+            if datasets.keys() != {OBJECTIVE}:
+                raise ValueError(f"Default acquisition rule EfficientGlobalOptimization requires tag {OBJECTIVE!r}, "
+                                 f"got keys {datasets.keys()}")
+            acquisition_rule = EfficientGlobalOptimization()
+        history: List[Record] = []
+        for step in range(1, num_steps + 1):
+            try:
+                if track_state:
+                    history.append(Record(dict(datasets), models))
+                if step == 1 and fit_model and fit_initial_model:
+                    for tag, model in models.items():
+                        model.update(datasets[tag])
+                        model.optimize(datasets[tag])
+                points = acquisition_rule.acquire(self._search_space, models, datasets=datasets)
+                observed = _as_map(self._observer(points))
+                datasets = {tag: datasets[tag] + observed[tag] for tag in datasets}
+                for tag, model in models.items():
+                    model.update(datasets[tag])
+                    if fit_model:
+                        model.optimize(datasets[tag])
+                if early_stop_callback is not None and early_stop_callback(datasets, models):
+                    break
+            except Exception as error:  # noqa: BLE001 -- the reference returns Err for any failure
+                traceback.print_exc()
+                return OptimizationResult(Err(error), history)
+        return OptimizationResult(Ok(Record(datasets, models)), history)

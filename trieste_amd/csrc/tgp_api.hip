@@ -642,7 +642,7 @@ int tgp_qei(tgp_handle h, const double* Xq, int64_t G, int q, const double* eps,
       return rc;
     double* dout;
     if (int rc = stage_out_prepare(h, h->s_out3, out + g0, gc, where, &dout)) return rc;
-    launch_qei_tail(h->stream, dmean, dcov, gc, q, deps, S, eta, jitter, dout, h->d_info.as<int>());
+    launch_qei_tail(h->stream, dmean, dcov, gc, q, deps, S, eta, jitter, dout, nullptr, h->d_info.as<int>());
     if (int rc = stage_out_finish(h, dout, out + g0, gc, where)) return rc;
     if (int rc = sync(h)) return rc;
     float ms = 0.f;
@@ -656,6 +656,39 @@ int tgp_qei(tgp_handle h, const double* Xq, int64_t G, int q, const double* eps,
   HIPCHK(h, hipGetLastError());
   if (info != 0)
     return fail(h, TGP_ERR_NOT_PD, "qEI: cov + jitter*I not positive definite for group %d", info - 1);
+  return TGP_OK;
+}
+
+int tgp_reparam_samples(tgp_handle h, const double* Xq, int64_t G, int q, const double* eps, int S,
+                        double jitter, double* out, int where) {
+  if (!h) return TGP_ERR_ARG;
+  if (!(jitter >= 0.0)) return fail(h, TGP_ERR_ARG, "jitter must be >= 0");
+  if (S < 1 || !eps) return fail(h, TGP_ERR_ARG, "need S >= 1 draws");
+  if (G == 0) return TGP_OK;
+  if (!out) return fail(h, TGP_ERR_ARG, "out is NULL");
+  const double* dXq;
+  double *dmean, *dcov;
+  const int64_t chunk = std::max<int64_t>(1, (int64_t)(1ull << 28) / ((int64_t)q * std::max(q, S) * 8));
+  if (int rc = set_device(h)) return rc;
+  const double* deps;
+  if (int rc = stage_in(h, h->s_in2, eps, (size_t)q * S, where, &deps)) return rc;
+  HIPCHK(h, h->d_info.reserve(sizeof(int)));
+  HIPCHK(h, hipMemsetAsync(h->d_info.p, 0, sizeof(int), h->stream));
+  for (int64_t g0 = 0; g0 < G; g0 += chunk) {
+    const int64_t gc = std::min(chunk, G - g0);
+    if (int rc = joint_common(h, Xq + g0 * q * h->d, gc, q, where, &dXq, &dmean, &dcov, nullptr, nullptr, true))
+      return rc;
+    double* dout;
+    if (int rc = stage_out_prepare(h, h->s_out3, out + g0 * S * q, (size_t)gc * S * q, where, &dout)) return rc;
+    launch_qei_tail(h->stream, dmean, dcov, gc, q, deps, S, 0.0, jitter, nullptr, dout, h->d_info.as<int>());
+    if (int rc = stage_out_finish(h, dout, out + g0 * S * q, (size_t)gc * S * q, where)) return rc;
+    if (int rc = sync(h)) return rc;
+  }
+  int info = 0;
+  HIPCHK(h, hipMemcpy(&info, h->d_info.p, sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(h, hipGetLastError());
+  if (info != 0)
+    return fail(h, TGP_ERR_NOT_PD, "reparam samples: cov + jitter*I not positive definite for group %d", info - 1);
   return TGP_OK;
 }
 

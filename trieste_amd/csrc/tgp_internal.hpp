@@ -86,7 +86,8 @@ void launch_topk_pass(hipStream_t s, const double* vals, int64_t M, int64_t inde
 void launch_sample_box(hipStream_t s, uint64_t seed, int64_t first, int64_t M, int d,
                        const double* lower, const double* upper, double* out);
 void launch_qei_tail(hipStream_t s, const double* mean, const double* cov, int64_t G, int q,
-                     const double* eps, int S, double eta, double jitter, double* out, int* info);
+                     const double* eps, int S, double eta, double jitter, double* out, double* samples_out,
+                     int* info);
 // trajectories
 struct TrajDev {
   ModelDev m;

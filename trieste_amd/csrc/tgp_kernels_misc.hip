@@ -172,6 +172,7 @@ __global__ __launch_bounds__(256) void qei_tail_kernel(const double* __restrict_
                                                        const double* __restrict__ cov, int64_t G, int q,
                                                        const double* __restrict__ eps, int S, double eta,
                                                        double jitter, double* __restrict__ out,
+                                                       double* __restrict__ samples_out,
                                                        int* __restrict__ info) {
   __shared__ double Lq[MAX_Q][MAX_Q + 1];
   __shared__ double mu[MAX_Q];
@@ -211,6 +212,7 @@ __global__ __launch_bounds__(256) void qei_tail_kernel(const double* __restrict_
     for (int j = 0; j < q; ++j) {
       double v = mu[j];
       for (int k = 0; k <= j; ++k) v = fma(Lq[j][k], eps[(int64_t)k * S + s], v);
+      if (samples_out) samples_out[(g * S + s) * q + j] = v;  // [G][S][q]
       mn = fmin(mn, v);
     }
     acc += fmax(eta - mn, 0.0);
@@ -218,12 +220,13 @@ __global__ __launch_bounds__(256) void qei_tail_kernel(const double* __restrict_
   acc = wave_sum(acc);
   if ((tid & 63) == 0) red[tid >> 6] = acc;
   __syncthreads();
-  if (tid == 0) out[g] = (red[0] + red[1] + red[2] + red[3]) / (double)S;
+  if (tid == 0 && out) out[g] = (red[0] + red[1] + red[2] + red[3]) / (double)S;
 }
 void launch_qei_tail(hipStream_t s, const double* mean, const double* cov, int64_t G, int q,
-                     const double* eps, int S, double eta, double jitter, double* out, int* info) {
+                     const double* eps, int S, double eta, double jitter, double* out, double* samples_out,
+                     int* info) {
   hipLaunchKernelGGL(qei_tail_kernel, dim3((unsigned)G), dim3(256), 0, s, mean, cov, G, q, eps, S, eta,
-                     jitter, out, info);
+                     jitter, out, samples_out, info);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -200,6 +200,23 @@ class GPEngine:
                                     a.where))
         return out
 
+    def reparam_samples(self, Xq, eps, jitter: float = 1e-6):
+        """Xq [..., q, d], eps [q, S] -> samples [..., S, q]."""
+        a = _Arg(Xq)
+        if len(a.shape) < 2 or a.shape[-1] != self.d:
+            raise ValueError(f"batch query points must be [..., q, {self.d}], got {a.shape}")
+        lead, q = a.shape[:-2], a.shape[-2]
+        G = int(np.prod(lead)) if lead else 1
+        e = _Arg(eps)
+        if len(e.shape) != 2 or e.shape[0] != q:
+            raise ValueError(f"eps must be [q={q}, S], got {e.shape}")
+        if e.where != a.where:
+            raise ValueError("Xq and eps must live in the same place (both host or both device)")
+        S = e.shape[1]
+        out, po = self._out(a, lead + (S, q))
+        self._chk(self._lib.tgp_reparam_samples(self._h, a.ptr, G, q, e.ptr, S, float(jitter), po, a.where))
+        return out
+
     def last_kernel_ms(self):
         ms, n = C.c_double(), C.c_int()
         self._chk(self._lib.tgp_last_kernel_ms(self._h, C.byref(ms), C.byref(n)))

@@ -1,0 +1,170 @@
+"""Model samplers of the hot path (reference trieste/models/gpflow/sampler.py):
+``BatchReparametrizationSampler`` (167-287) and the decoupled trajectory sampler
+(``DecoupledTrajectorySampler`` 594-738, ``feature_decomposition_trajectory`` 858-953).
+
+The random draws (eps; the RFF basis W, b; the weights w, xi) are made HERE with numpy's PCG64 and
+handed to the engine -- TF's Philox streams are not reproducible outside TF, so parity is defined
+with the draws as explicit inputs.  All arithmetic on them runs on the GPU.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import numpy as np
+
+JITTER = 1e-6  # reference utils/misc.py:180-183
+
+
+class BatchReparametrizationSampler:
+    r"""x -> mu(x) + L(x) eps with eps ~ N(0, 1) fixed until :meth:`reset_sampler`, so samples form
+    a continuous surface (reference sampler.py:167-287)."""
+
+    def __init__(self, sample_size: int, model, qmc: bool = False, seed: Optional[int] = None):
+        if sample_size <= 0:
+            raise ValueError(f"sample_size must be positive, got {sample_size}")
+        if not hasattr(model, "predict_joint"):
+            raise NotImplementedError(
+                f"BatchReparametrizationSampler only works with models that support predict_joint; received {model!r}")
+        if qmc:
+            raise NotImplementedError("QMC (Sobol) draws are not implemented; the reference default is qmc=False")
+        self._sample_size = sample_size
+        self._model = model
+        self._rng = np.random.default_rng(seed)
+        self._eps: Optional[np.ndarray] = None  # [B, S]
+        self._initialized = False
+
+    def __repr__(self) -> str:
+        return f"BatchReparametrizationSampler({self._sample_size!r}, {self._model!r})"
+
+    @property
+    def sample_size(self) -> int:
+        return self._sample_size
+
+    def reset_sampler(self) -> None:
+        """Resample eps on the next call (reference ReparametrizationSampler.reset_sampler)."""
+        self._initialized = False
+
+    def eps(self, batch_size: int) -> np.ndarray:
+        """The fixed draws [B, S] for this batch size (drawn on first use / after a reset)."""
+        if batch_size <= 0:
+            raise ValueError(f"batch size must be positive, got {batch_size}")
+        if not self._initialized or self._eps is None:
+            self._eps = self._rng.standard_normal((batch_size, self._sample_size))
+            self._initialized = True
+        elif self._eps.shape[0] != batch_size:
+            raise ValueError(f"{type(self).__name__} requires a fixed batch size. Got batch size {batch_size} "
+                             f"but previous batch size was {self._eps.shape[0]}.")
+        return self._eps
+
+    def sample(self, at, *, jitter: float = JITTER):
+        """at [..., B, D] -> samples [..., S, B, 1]; identical across calls for the same ``at``."""
+        at = np.asarray(at, dtype=np.float64)
+        if at.ndim < 2:
+            raise ValueError(f"at must have rank >= 2, got shape {at.shape}")
+        if jitter < 0:
+            raise ValueError(f"jitter must be non-negative, got {jitter}")
+        eps = self.eps(at.shape[-2])
+        return self._model.engine.reparam_samples(at, eps, jitter)[..., None]
+
+
+# ---- decoupled trajectories -------------------------------------------------------------------
+_MATERN_DOF = {"matern12": 1, "matern32": 3, "matern52": 5}
+
+
+def sample_rff_basis(kind: str, num_features: int, dim: int, rng: np.random.Generator):
+    """Spectral draws of gpflux ``RandomFourierFeaturesCosine``: W [F, D] rows ~ N(0, I) for the
+    squared exponential, multivariate Student-t with 2 nu degrees of freedom for Matern-nu
+    (N(0, I) * sqrt(dof / chi2_dof), one chi2 per feature); b [F] ~ U(0, 2 pi)."""
+    W = rng.standard_normal((num_features, dim))
+    if kind != "rbf":
+        dof = _MATERN_DOF[kind]
+        W = W * np.sqrt(dof / rng.chisquare(dof, size=(num_features, 1)))
+    b = rng.uniform(0.0, 2.0 * math.pi, size=num_features)
+    return W, b
+
+
+class decoupled_trajectory:
+    """A batch of B approximate posterior draws f_b(x) = sum_f phi_f(x) w_fb + sum_j k(x, X_j) v_jb + m(x)
+    (reference ``feature_decomposition_trajectory`` sampler.py:858-953).  The batch size is fixed by
+    the first call; weights are (re)sampled lazily."""
+
+    def __init__(self, sampler: "DecoupledTrajectorySampler"):
+        self._sampler = sampler
+        self._traj = None  # engine Trajectory
+        self._batch_size = 0
+
+    def _ensure(self, B: int) -> None:
+        if self._traj is None:
+            self._batch_size = B
+            self.resample()
+        elif B != self._batch_size:
+            raise ValueError(f"This trajectory only supports batch sizes of {self._batch_size}. If you wish to change "
+                             "the batch size you must get a new trajectory by calling the get_trajectory method of "
+                             "the trajectory sampler.")
+
+    def resample(self) -> None:
+        """New weights (w, xi) for the current basis; v is solved on the GPU from the cached factor."""
+        s = self._sampler
+        if self._batch_size == 0:
+            raise ValueError("the trajectory has not been evaluated yet: its batch size is unknown")
+        w = s._rng.standard_normal((s._num_features, self._batch_size))
+        xi = s._rng.standard_normal((s._model.engine.N, self._batch_size))
+        if self._traj is not None:
+            self._traj.close()
+        self._traj = s._model.engine.trajectory(s._W, s._b, w, xi)
+
+    def __call__(self, x):
+        """x [N, B, D] -> [N, B, 1]."""
+        x = x if type(x).__module__.startswith("torch") else np.asarray(x, dtype=np.float64)
+        if len(x.shape) != 3:
+            raise ValueError(f"trajectory inputs must be [N, B, D], got shape {tuple(x.shape)}")
+        self._ensure(int(x.shape[1]))
+        if x.shape[1] == 1:
+            return self._traj(x[:, 0, :])[..., None]
+        return self._traj(x)[..., None]
+
+    def argmin_over(self, at):
+        """Fused evaluate + arg-min over shared candidates at [N, D] for every trajectory of the
+        batch -> (values [B], indices [B]); the [N, B] evaluations never leave the GPU."""
+        self._ensure(self._batch_size or 1)
+        return self._traj.argmin(at)
+
+
+class DecoupledTrajectorySampler:
+    """Decoupled (RFF prior + canonical update) trajectory sampler for an exact GPR
+    (reference sampler.py:594-738).  The RFF basis is drawn once; ``get_trajectory`` returns a
+    trajectory with fresh weights, ``resample_trajectory`` redraws weights in place,
+    ``update_trajectory`` redraws the basis too (after a model update)."""
+
+    def __init__(self, model, num_features: int = 1000, seed: Optional[int] = None):
+        for attr in ("get_kernel", "get_observation_noise", "get_internal_data", "engine"):
+            if not hasattr(model, attr):
+                raise NotImplementedError(
+                    "DecoupledTrajectorySampler only works with models that support get_kernel, "
+                    f"get_observation_noise and get_internal_data on this engine; but received {model!r}.")
+        if num_features <= 0:
+            raise ValueError(f"num_features must be positive, got {num_features}")
+        self._model = model
+        self._num_features = num_features
+        self._rng = np.random.default_rng(seed)
+        self._resample_basis()
+
+    def __repr__(self) -> str:
+        return f"DecoupledTrajectorySampler({self._model!r}, {self._num_features!r})"
+
+    def _resample_basis(self) -> None:
+        k = self._model.get_kernel()
+        self._W, self._b = sample_rff_basis(k.kind, self._num_features, self._model.engine.d, self._rng)
+
+    def get_trajectory(self) -> decoupled_trajectory:
+        return decoupled_trajectory(self)
+
+    def resample_trajectory(self, trajectory: decoupled_trajectory) -> decoupled_trajectory:
+        trajectory.resample()
+        return trajectory
+
+    def update_trajectory(self, trajectory: decoupled_trajectory) -> decoupled_trajectory:
+        self._resample_basis()
+        trajectory.resample()
+        return trajectory
