@@ -84,7 +84,7 @@ def _problem(obj, d, kind, N, noise, M=1500, seed=5678):
     return X, Y, ls, c, st, Xq
 
 
-@pytest.mark.parametrize("variant", [0, 1], ids=["ws", "v1"])
+@pytest.mark.parametrize("variant", [0, 1, 2], ids=["u16", "v1", "ws"])
 @pytest.mark.parametrize("cfg", CONFIGS, ids=[c[0] for c in CONFIGS])
 def test_sweep_matches_oracle(cfg, variant):
     _, obj, d, kind, N, noise = cfg

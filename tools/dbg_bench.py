@@ -10,10 +10,9 @@ eng.set_hyper(1.0, O.default_lengthscales(d), 1e-2, float(Y.mean()))
 eng.set_data(X, Y)
 eta = eng.eta()
 Xq = eng.sample_box(5678, 0, M, 0.0, 1.0)
-for name, v in (("v1", 1), ("ws", 0), ("ws skip-gen", 0 | (1 << 8)), ("ws skip-W", 0 | (2 << 8)), ("ws skip-gen+W", 0 | (3 << 8)),
-                ("ws skip-mfma", 0 | (4 << 8)), ("ws skip-all", 0 | (7 << 8))):
+for name, v in (("v1 (4 waves, 128x128)", 1), ("ws (8 MFMA + 4 producer waves)", 2), ("u16 (default)", 0), ("u16 (default)", 0)):
     eng.set_variant(v)
-    eng.acq_argmax("ei", eta, Xq)
-    eng.acq_argmax("ei", eta, Xq)
+    r0 = eng.acq_argmax("ei", eta, Xq)
+    r1 = eng.acq_argmax("ei", eta, Xq)
     ms, _ = eng.last_kernel_ms()
-    print(f"{name:16s}: {ms:8.2f} ms  -> {M*float(N)*N/ms*1e-9:6.2f} TF", flush=True)
+    print(f"{name:42s}: {ms:8.2f} ms  -> {M*float(N)*N/ms*1e-9:6.2f} TF  best={r1[0]:.12e}@{r1[1]}", flush=True)
