@@ -94,7 +94,9 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: trieste_amd has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # launched by torch.distributed.run (also with --nproc-per-node 1): one process per GPU over RCCL
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
@@ -123,24 +125,24 @@ def main():
 
     def step():
         val, idx, _ = eng.acq_argmax("ei", eta, Xq, index_base=rank * M)
-        gv, gi = all_gather_best(val, idx, device=f"cuda:{local_rank}")
+        gv, gi = all_gather_best(val, idx, device=f"cuda:{local_rank}", force=use_dist)
         return float(gv[0]), int(gi[0])
 
     for _ in range(args.warmup):
         best = step()
     kernel_ms = []
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         best = step()
         kernel_ms.append(eng.last_kernel_ms()[0])  # HIP events on the launch stream, this launch
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -181,14 +183,14 @@ def main():
             "roofline": {
                 "bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                "kernel": "sweep_ws_kernel" if args.variant != 1 else "sweep_kernel",
+                "kernel": {0: "sweep_u16_kernel", 1: "sweep_kernel", 2: "sweep_ws_kernel"}.get(args.variant & 0xff, "?"),
                 "kernel_ms": k_ms, "flops_per_candidate": algorithmic_flops_per_candidate(N, d, kernel),
             },
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(obj_name, d, kernel, N, noise)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

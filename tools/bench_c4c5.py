@@ -1,0 +1,44 @@
+"""Timing of BASELINE configs C4 (batch MC-EI) and C5 (decoupled Thompson) on one GPU (development aid)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from oracle import gp_oracle as O
+from trieste_amd.engine import GPEngine
+
+def c4(G=20000, q=50, S=512, N=2048, d=6):
+    X, Y = O.synthetic_problem(O.hartmann_6, d, N)
+    eng = GPEngine(d, "matern52"); eng.set_hyper(1.0, O.default_lengthscales(d), 1e-2, float(Y.mean())); eng.set_data(X, Y)
+    eta = eng.eta()
+    rng = np.random.default_rng(91011)
+    eps = torch.from_numpy(rng.standard_normal((q, S))).cuda()
+    Xq = eng.sample_box(5678, 0, G * q, 0.0, 1.0).reshape(G, q, d)
+    eng.use_torch_stream()
+    for _ in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        out = eng.qei(Xq, eps, eta, 1e-6)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+    ms_joint, nl = eng.last_kernel_ms()
+    flops = G * (q * float(N) * N + q * q * N)
+    print(f"C4 qEI: G={G} q={q} S={S} N={N}: wall {1e3*(t1-t0):.1f} ms (joint kernel {ms_joint:.1f} ms x{nl}) -> {G/(t1-t0):.3e} q-batches/s, "
+          f"{G*q/(t1-t0):.3e} points/s, {flops/(t1-t0)*1e-12:.1f} TF algorithmic; mean qEI {float(out.mean()):.4e}", flush=True)
+
+def c5(M=1 << 20, F=2048, N=8192, d=16, B=4):
+    X, Y = O.synthetic_problem(O.ackley, d, N)
+    eng = GPEngine(d, "matern52"); eng.set_hyper(1.0, O.default_lengthscales(d), 1e-2, float(Y.mean()))
+    t0 = time.perf_counter(); eng.set_data(X, Y); t1 = time.perf_counter()
+    rng = np.random.default_rng(7)
+    W = rng.standard_t(5, size=(F, d)); b = rng.uniform(0, 2 * np.pi, F)
+    w = rng.standard_normal((F, B)); xi = rng.standard_normal((N, B))
+    t2 = time.perf_counter(); traj = eng.trajectory(W, b, w, xi); t3 = time.perf_counter()
+    Xq = eng.sample_box(5678, 0, M, 0.0, 1.0)
+    for _ in range(2):
+        torch.cuda.synchronize(); t4 = time.perf_counter()
+        vals, idx = traj.argmin(Xq)
+        torch.cuda.synchronize(); t5 = time.perf_counter()
+    ms, _ = eng.last_kernel_ms()
+    print(f"C5 TS: M={M} F={F} N={N} d={d} B={B}: update {1e3*(t1-t0):.0f} ms, weights {1e3*(t3-t2):.0f} ms, "
+          f"argmin wall {1e3*(t5-t4):.1f} ms (kernel {ms:.1f}) -> {M*B/(t5-t4):.3e} candidate-trajectory evals/s; idx {idx}", flush=True)
+
+if __name__ == "__main__":
+    c4()
+    c5()

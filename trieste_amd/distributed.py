@@ -41,7 +41,7 @@ def merge_best(vals: np.ndarray, idxs: np.ndarray, minimize: bool = False) -> Tu
     return win_val, win_idx
 
 
-def all_gather_best(val, idx, minimize: bool = False, group=None, device=None):
+def all_gather_best(val, idx, minimize: bool = False, group=None, device=None, force: bool = False):
     """All-gather (value, index)[V] from every rank and merge.  With torch.distributed not
     initialised (single process) this is the identity.  Uses the process group's backend:
     "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests."""
@@ -50,7 +50,7 @@ def all_gather_best(val, idx, minimize: bool = False, group=None, device=None):
 
     v = np.atleast_1d(np.asarray(val, dtype=np.float64))
     i = np.atleast_1d(np.asarray(idx, dtype=np.int64))
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return v.copy(), i.copy()
     world = dist.get_world_size(group)
     backend = dist.get_backend(group)
