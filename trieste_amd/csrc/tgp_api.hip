@@ -24,10 +24,10 @@ hipError_t launch_sweep_ws_kind0(hipStream_t, const SweepArgs&, int64_t);
 hipError_t launch_sweep_ws_kind1(hipStream_t, const SweepArgs&, int64_t);
 hipError_t launch_sweep_ws_kind2(hipStream_t, const SweepArgs&, int64_t);
 hipError_t launch_sweep_ws_kind3(hipStream_t, const SweepArgs&, int64_t);
-hipError_t launch_sweep_u16_kind0(hipStream_t, const SweepArgs&, int64_t);
-hipError_t launch_sweep_u16_kind1(hipStream_t, const SweepArgs&, int64_t);
-hipError_t launch_sweep_u16_kind2(hipStream_t, const SweepArgs&, int64_t);
-hipError_t launch_sweep_u16_kind3(hipStream_t, const SweepArgs&, int64_t);
+hipError_t launch_sweep_u16_kind0(hipStream_t, const SweepArgs&, bool, int64_t);
+hipError_t launch_sweep_u16_kind1(hipStream_t, const SweepArgs&, bool, int64_t);
+hipError_t launch_sweep_u16_kind2(hipStream_t, const SweepArgs&, bool, int64_t);
+hipError_t launch_sweep_u16_kind3(hipStream_t, const SweepArgs&, bool, int64_t);
 }  // namespace tgp
 
 using namespace tgp;
@@ -72,7 +72,7 @@ struct tgp_handle_s {
   // model state on device
   DevBuf d_ls, d_X, d_Y, d_Xs, d_A, d_L, d_W, d_alpha, d_err, d_tmp1, d_tmp2, d_info;
   // scratch
-  DevBuf s_in, s_in2, s_out1, s_out2, s_out3, s_blkv, s_blki, s_small, s_kcache, s_ssq;
+  DevBuf s_in, s_in2, s_out1, s_out2, s_out3, s_blkv, s_blki, s_small, s_kcache, s_ssq, s_aslab;
   // timing of the dominant kernel
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double last_ms = 0.0;
@@ -171,9 +171,9 @@ hipError_t launch_sweep_timed(tgp_handle h, const SweepArgs& a, bool joint) {
   const int64_t grid = sweep_grid(a, joint);
   if (grid <= 0) return hipSuccess;
   hipError_t e;
-  // variant 0 (default): uniform 16-wave kernel for plain sweeps, v1 kernel for joint mode;
-  // 1: force the v1 (4-wave, 128x128) kernel; 2: wave-specialised (8 MFMA + 4 producer waves) kernel.
-  const bool ws = !joint && (h->variant & 0xff) != 1;
+  // variant 0 (default): uniform 16-wave kernel (plain and joint mode); 1: the v1 (4-wave, 128x128)
+  // kernel; 2: wave-specialised (8 MFMA + 4 producer waves) kernel for plain sweeps, v1 for joint.
+  const bool ws = (h->variant & 0xff) != 1 && !(joint && (h->variant & 0xff) == 2);  // persistent kernels
   SweepArgs& am = const_cast<SweepArgs&>(a);
   am.dbg = h->variant >> 8;
   int64_t wgrid = grid;
@@ -182,6 +182,11 @@ hipError_t launch_sweep_timed(tgp_handle h, const SweepArgs& a, bool joint) {
     hipError_t ea = h->s_kcache.reserve((size_t)wgrid * (size_t)h->Npad * SW_BN * sizeof(double));
     if (ea != hipSuccess) return ea;
     am.kcache = h->s_kcache.as<double>();
+    if (joint) {
+      ea = h->s_aslab.reserve((size_t)wgrid * (size_t)h->Npad * SW_BN * sizeof(double));
+      if (ea != hipSuccess) return ea;
+      am.aslab = h->s_aslab.as<double>();
+    }
     ea = h->s_ssq.reserve((size_t)wgrid * SW_BN * MAX_D * sizeof(double));  // scaled-candidate scratch
     if (ea != hipSuccess) return ea;
     am.ssq_scratch = h->s_ssq.as<double>();
@@ -196,10 +201,10 @@ hipError_t launch_sweep_timed(tgp_handle h, const SweepArgs& a, bool joint) {
     }
   } else if (ws) {  // default: uniform 16-wave kernel
     switch (h->kind) {
-      case TGP_RBF: e = launch_sweep_u16_kind0(h->stream, a, wgrid); break;
-      case TGP_MATERN12: e = launch_sweep_u16_kind1(h->stream, a, wgrid); break;
-      case TGP_MATERN32: e = launch_sweep_u16_kind2(h->stream, a, wgrid); break;
-      default: e = launch_sweep_u16_kind3(h->stream, a, wgrid); break;
+      case TGP_RBF: e = launch_sweep_u16_kind0(h->stream, a, joint, wgrid); break;
+      case TGP_MATERN12: e = launch_sweep_u16_kind1(h->stream, a, joint, wgrid); break;
+      case TGP_MATERN32: e = launch_sweep_u16_kind2(h->stream, a, joint, wgrid); break;
+      default: e = launch_sweep_u16_kind3(h->stream, a, joint, wgrid); break;
     }
   } else {
     switch (h->kind) {
@@ -301,7 +306,7 @@ int tgp_destroy(tgp_handle h) {
   (void)hipStreamSynchronize(h->stream);
   for (DevBuf* b : {&h->d_ls, &h->d_X, &h->d_Y, &h->d_Xs, &h->d_A, &h->d_L, &h->d_W, &h->d_alpha,
                     &h->d_err, &h->d_tmp1, &h->d_tmp2, &h->d_info, &h->s_in, &h->s_in2, &h->s_out1,
-                    &h->s_out2, &h->s_out3, &h->s_blkv, &h->s_blki, &h->s_small, &h->s_kcache, &h->s_ssq})
+                    &h->s_out2, &h->s_out3, &h->s_blkv, &h->s_blki, &h->s_small, &h->s_kcache, &h->s_ssq, &h->s_aslab})
     b->release();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);

@@ -49,6 +49,7 @@ struct SweepArgs {
   int64_t G;          // number of groups
   double* cov_out;    // [G][q][q]
   double* kcache;     // [grid][Npad][128] K* slabs of the wave-specialised sweep (device scratch)
+  double* aslab;      // [grid][Npad][128] C = W K* slabs of joint mode (device scratch)
   double* ssq_scratch; // [grid][8 waves][4][64] column-norm partials of the flag-synchronised sweep
   int dbg;            // development only: bit0 skip K* generation, bit1 skip W loads, bit2 skip MFMA
 };
