@@ -107,6 +107,14 @@ int tgp_eta(tgp_handle h, double* eta);
 int tgp_acq_values(tgp_handle h, int acq_kind, double param, const double* Xq, int64_t M,
                    double* out, int where);
 
+/* Acquisition value AND its gradient w.r.t. the query point, val [P], grad [P,d] -- what
+ * tfp.math.value_and_gradient(_objective_value, x) yields inside the L-BFGS-B refinement of
+ * generate_continuous_optimizer (optimizer.py:344-745, call at :628-629).  Analytic: d mean/dx =
+ * sum_k alpha_k dk_k/dx, d var/dx = -2 (K^-1 kstar)^T dkstar/dx; zero variance-gradient where the 1e-12 clip is
+ * active (tf.clip_by_value). */
+int tgp_acq_value_grad(tgp_handle h, int acq_kind, double param, const double* Xq, int64_t P, double* val,
+                       double* grad, int where);
+
 /* Fused predict + acquisition + arg-max (== _get_max_discrete_points, optimizer.py:124-150, over
  * `optimize_discrete` / `generate_random_search_optimizer` candidates).  First index wins ties
  * (tf.math.argmax).  Outputs are HOST: best_val, best_idx (= index_base + local index), best_x [d]

@@ -219,6 +219,58 @@ def ei_values(state: GPRState, Xq: np.ndarray, eta: float) -> np.ndarray:
     return expected_improvement(m, v, eta)
 
 
+def _kernel_dr2(kind, variance, r2):
+    """d k / d (r^2) of the stationary kernels (analytic; the reference gets it by TF autodiff)."""
+    if kind == "rbf":
+        return -0.5 * variance * np.exp(-0.5 * r2)
+    r = np.sqrt(np.maximum(r2, 1e-36))
+    if kind == "matern12":
+        return -0.5 * variance * np.exp(-r) / r
+    if kind == "matern32":
+        return -1.5 * variance * np.exp(-math.sqrt(3.0) * r)
+    s = math.sqrt(5.0) * r
+    return -(5.0 / 6.0) * variance * (1.0 + s) * np.exp(-s)
+
+
+def acq_value_and_grad(state: GPRState, acq: str, param: float, Xq: np.ndarray):
+    """Acquisition value [P] and gradient [P, d] w.r.t. the query points -- the quantity
+    tfp.math.value_and_gradient produces in the reference's L-BFGS-B refinement
+    (acquisition/optimizer.py:628-629) -- in analytic form: d mean = sum_k alpha_k dk_k,
+    d var = -2 (K^-1 k*)^T dk*, chain rule through EI / PI / -LCB; the variance clip has zero
+    gradient (tf.clip_by_value)."""
+    Xq = np.asarray(Xq, dtype=np.float64)
+    ls = state.lengthscales
+    A = Xq / ls
+    B = state.X / ls
+    diff = A[:, None, :] - B[None, :, :]                      # [P, N, d]
+    r2 = np.sum(diff * diff, axis=-1)                          # difference form (exact zero at coincidence)
+    Kq = kernel_from_r2(state.kind, state.variance, r2)        # [P, N]
+    alpha = _solve_triangular(state.L.T, _solve_triangular(state.L, state.err, lower=True), lower=False)
+    Z = _solve_triangular(state.L.T, _solve_triangular(state.L, Kq.T, lower=True), lower=False).T  # [P, N]
+    mu = Kq @ alpha + state.mean_const
+    var_raw = state.variance - np.sum(Kq * Z, axis=1)
+    clipped = ~(var_raw > VAR_FLOOR)
+    var = np.where(clipped, VAR_FLOOR, var_raw)
+    dk = (2.0 * _kernel_dr2(state.kind, state.variance, r2))[:, :, None] * diff / ls  # [P, N, d]
+    dmu = np.einsum("pnd,n->pd", dk, alpha)
+    dvar = np.where(clipped[:, None], 0.0, -2.0 * np.einsum("pnd,pn->pd", dk, Z))
+    sd = np.sqrt(var)
+    if acq == "ei":
+        z = (param - mu) / sd
+        val = (param - mu) * normal_cdf(z) + sd * normal_pdf(z)
+        g = -normal_cdf(z)[:, None] * dmu + (normal_pdf(z) / (2.0 * sd))[:, None] * dvar
+    elif acq == "pi":
+        z = (param - mu) / sd
+        val = normal_cdf(z)
+        g = (-normal_pdf(z) / sd)[:, None] * dmu + (-normal_pdf(z) * z / (2.0 * var))[:, None] * dvar
+    elif acq == "nlcb":
+        val = -(mu - param * sd)
+        g = -dmu + (param / (2.0 * sd))[:, None] * dvar
+    else:
+        raise KeyError(acq)
+    return val, g
+
+
 # --------------------------------------------------------------------------------------
 # A.5 batch Monte-Carlo EI (sampler.py:208-287 + function.py:1181-1186); eps passed in.
 # --------------------------------------------------------------------------------------

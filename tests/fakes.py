@@ -118,6 +118,9 @@ class FakeEngine:
             return O.negative_lower_confidence_bound(m, v, param)
         raise KeyError(acq)
 
+    def acq_value_grad(self, acq, param, Xq):
+        return O.acq_value_and_grad(self._st(), acq, param, np.asarray(Xq, float))
+
     def acq_argmax(self, acq, param, Xq, index_base=0):
         Xq = np.asarray(Xq, float)
         if Xq.shape[0] == 0:

@@ -106,3 +106,22 @@ def test_discrete_thompson_sampling_on_gpu():
     vals = traj(cand[:, None, :])[:, 0, 0]
     v, i = traj.argmin_over(cand)
     assert i[0] == int(np.argmin(vals)) and v[0] == vals[i[0]]
+
+
+def test_continuous_optimizer_on_gpu_refines_ei():
+    """EGO's default optimiser for a Box (automatic_optimizer_selector -> generate_continuous_optimizer):
+    the refined point beats the best of the initial sweep and is stationary."""
+    from trieste_amd.acquisition import EfficientGlobalOptimization, generate_continuous_optimizer, sample_from_space
+
+    space, data, model, st = _setup(n=30)
+    ego = EfficientGlobalOptimization()  # default builder (EI) + default optimiser
+    pt = ego.acquire_single(space, model, dataset=data)
+    assert pt.shape == (1, 2) and pt[0] in space
+    fn = ego.acquisition_function
+    val, grad = fn.value_and_gradient(pt)
+    oval, ograd = O.acq_value_and_grad(st, "ei", fn.eta, pt)
+    assert_close(val, oval, atol=1e-10, what="EI at the optimum")
+    sweep = space.sample(5000, seed=0)
+    assert val[0] >= 0.999 * np.max(O.ei_values(st, sweep, fn.eta))
+    interior = (pt[0] > 1e-9) & (pt[0] < 1 - 1e-9)
+    assert np.all(np.abs(ograd[0][interior]) < 1e-3 * max(float(oval[0]), 1e-6) + 1e-8)

@@ -301,3 +301,24 @@ def test_headline_size_properties():
     fm, fv = eng.predict(far)
     assert_close(fm, np.full(4, c), rtol=0, atol=1e-12)
     assert_close(fv, np.ones(4), rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=[c[0] for c in CONFIGS])
+def test_acq_value_and_gradient_match_oracle(cfg):
+    """tgp_acq_value_grad vs the oracle's analytic gradient (itself checked against central finite
+    differences in tests/test_oracle_gradient.py): EI, PI, -LCB; includes a point at a training
+    input with tiny noise (clipped variance -> zero variance-gradient) and far-field points."""
+    _, obj, d, kind, N, noise = cfg
+    X, Y, ls, c, st, Xq = _problem(obj, d, kind, N, noise, M=70)
+    eng = _engine(kind, d, 1.0, ls, noise, c, X, Y)
+    eta = eng.eta()
+    for acq, par in (("ei", eta), ("pi", eta), ("nlcb", 1.96)):
+        val, grad = eng.acq_value_grad(acq, par, Xq)
+        oval, ograd = O.acq_value_and_grad(st, acq, par, Xq)
+        floor = cancellation_floor(N, 1.0, noise)
+        assert_close(val, oval, atol=floor * 100, what=f"{acq} value")
+        # gradients of the variance inherit the cancellation floor times |d k / dx| ~ 1 / lengthscale
+        gscale = np.abs(ograd).max() + 1e-300
+        assert_close(grad, ograd, rtol=1e-5, atol=max(floor * 1e3, 1e-9 * gscale), what=f"{acq} gradient")
+        vals2 = eng.acq_values(acq, par, Xq)
+        assert_close(val, vals2, rtol=1e-9, atol=floor, what=f"{acq} value == sweep value")

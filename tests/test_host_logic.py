@@ -266,6 +266,41 @@ def test_fused_path_is_used_for_engine_backed_functions_and_agrees_with_generic(
     np.testing.assert_array_equal(tk[:, 0, :], space.points[np.argsort(-vals, kind="stable")[:5]])
 
 
+def test_continuous_optimizer_refines_the_sweep_winner():
+    """reference test_optimizer.py (generate_continuous_optimizer cases): argument checks, and the
+    refined point is a local maximiser: at least as good as the best initial sample, inside the box,
+    with a vanishing projected gradient."""
+    from trieste_amd.acquisition import FailedOptimizationError, generate_continuous_optimizer, sample_from_space
+
+    with pytest.raises(ValueError):
+        generate_continuous_optimizer(num_optimization_runs=0)
+    with pytest.raises(ValueError):
+        generate_continuous_optimizer(num_initial_samples=5, num_optimization_runs=10)
+    with pytest.raises(ValueError):
+        generate_continuous_optimizer(num_recovery_runs=-1)
+    model, data = _model(n=14, noise=1e-3)
+    fn = ExpectedImprovement().prepare_acquisition_function(model, dataset=data)
+    box = Box([0, 0], [1, 1])
+    opt = generate_continuous_optimizer(sample_from_space(2000, batch_size=500, seed=5), num_optimization_runs=6)
+    x = opt(box, fn)
+    assert x.shape == (1, 2) and x[0] in box
+    init = np.concatenate(list(sample_from_space(2000, batch_size=500, seed=5)(box)))
+    best_init = np.max(fn(init[:, None, :]))
+    val, grad = fn.value_and_gradient(x)
+    assert val[0] >= best_init - 1e-12
+    interior = (x[0] > 1e-9) & (x[0] < 1 - 1e-9)
+    assert np.all(np.abs(grad[0][interior]) < 1e-4 * max(1.0, float(val[0]) * 1e3))
+    with pytest.raises(TypeError):
+        opt(box, lambda z: np.zeros(z.shape[:-1]))  # no gradient available -> loud failure
+    with pytest.raises(NotImplementedError):
+        opt(box, (fn, 2))
+    # the default selector now refines on a Box
+    y = automatic_optimizer_selector(box, fn)
+    assert fn.value_and_gradient(y)[0][0] >= best_init - 1e-9
+    with pytest.raises(ValueError):
+        generate_continuous_optimizer(optimizer_args={"method": "BFGS"})(box, fn)
+
+
 # ---- rules (reference tests/unit/acquisition/test_rule.py) ---------------------------------------
 def test_ego_defaults_and_acquire():
     with pytest.raises(ValueError):

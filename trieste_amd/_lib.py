@@ -37,6 +37,7 @@ SIGNATURES = {
     "tgp_predict_joint": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, C.c_int]),
     "tgp_eta": (C.c_int, [_vp, _dp]),
     "tgp_acq_values": (C.c_int, [_vp, C.c_int, C.c_double, _vp, C.c_int64, _vp, C.c_int]),
+    "tgp_acq_value_grad": (C.c_int, [_vp, C.c_int, C.c_double, _vp, C.c_int64, _vp, _vp, C.c_int]),
     "tgp_acq_argmax": (C.c_int, [_vp, C.c_int, C.c_double, _vp, C.c_int64, C.c_int64, _dp, _ip, _vp,
                                  C.c_int]),
     "tgp_acq_topk": (C.c_int, [_vp, C.c_int, C.c_double, _vp, C.c_int64, C.c_int64, C.c_int, _vp, _vp,

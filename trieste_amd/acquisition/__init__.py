@@ -3,8 +3,9 @@ from .function import (BatchMonteCarloExpectedImprovement, ExpectedImprovement, 
                        ProbabilityOfImprovement, batch_monte_carlo_expected_improvement, expected_improvement,
                        negative_lower_confidence_bound, probability_below_threshold)
 from .interface import AcquisitionFunctionBuilder, AcquisitionFunctionClass, SingleModelAcquisitionBuilder
-from .optimizer import (automatic_optimizer_selector, batchify_joint, batchify_vectorize, generate_initial_points,
-                        generate_random_search_optimizer, optimize_discrete)
+from .optimizer import (FailedOptimizationError, automatic_optimizer_selector, batchify_joint, batchify_vectorize,
+                        generate_continuous_optimizer, generate_initial_points, generate_random_search_optimizer,
+                        optimize_discrete, sample_from_space)
 from .rule import AcquisitionRule, DiscreteThompsonSampling, EfficientGlobalOptimization, RandomSampling
 from .sampler import ExactThompsonSampler, ThompsonSampler, ThompsonSamplerFromTrajectory
 from .utils import select_nth_output, split_acquisition_function, split_acquisition_function_calls

@@ -48,6 +48,11 @@ class _posterior_tail(AcquisitionFunctionClass):
     def __call__(self, x):
         return self._engine.acq_values(self._acq, self._param, self._points(x))[..., None]
 
+    def value_and_gradient(self, points):
+        """points [P, D] -> (values [P], d value / d point [P, D]): the pair
+        tfp.math.value_and_gradient feeds L-BFGS-B with in the reference (optimizer.py:628-629)."""
+        return self._engine.acq_value_grad(self._acq, self._param, points)
+
     # fused sweeps (no [M] values written to HBM / returned to the host)
     def argmax(self, points, index_base: int = 0):
         """points [M, D] -> (value, global index, point [D])."""

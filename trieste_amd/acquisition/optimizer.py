@@ -9,15 +9,18 @@ and *maximises*.  When the function is one of this package's engine-backed objec
 the [M] values ever being written out.  Any other callable takes the generic path (evaluate, then
 arg-max on the values it returned).
 
-Not here: gradient-based refinement of the sweep winners (``generate_continuous_optimizer``,
-optimizer.py:344-745) -- SURVEY.md section 8f ranks it as the first follow-up; Box spaces are
-swept by random search instead.
+Gradient refinement of the sweep winners (``generate_continuous_optimizer``, optimizer.py:344-745) is
+here too: the best ``num_optimization_runs`` points of the initial sweep start as many L-BFGS-B runs
+(scipy), each in its own greenlet so that the value-and-gradient evaluations of one iteration of ALL
+runs go to the GPU as a single batch (``tgp_acq_value_grad``); the reference obtains the gradient by
+TensorFlow autodiff (optimizer.py:628-629), the engine computes the same derivative analytically.
 """
 from __future__ import annotations
 
-from typing import Callable, Optional, Tuple, Union
+from typing import Any, Callable, Dict, Iterator, Optional, Tuple, Union
 
 import numpy as np
+import scipy.optimize as spo
 
 from ..space import Box, DiscreteSearchSpace, SearchSpace
 
@@ -96,12 +99,16 @@ def generate_random_search_optimizer(num_samples: int = NUM_SAMPLES_MIN, seed: O
 
 def automatic_optimizer_selector(space: SearchSpace, target_func) -> np.ndarray:
     """Pick an optimizer for the space (optimizer.py:90-121): exhaustive for discrete spaces; for a
-    Box a random-search sweep of max(5000, 1000 * D) points (the reference follows the same initial
-    sweep with L-BFGS-B refinement, which is follow-up work here)."""
+    Box the continuous optimizer with max(5000, 1000 * D) initial samples and 10 * D L-BFGS-B runs.
+    Functions that expose no gradient (foreign callables, qEI) are swept by random search only."""
     if isinstance(space, DiscreteSearchSpace):
         return optimize_discrete(space, target_func)
     if isinstance(space, Box):
         num_samples = max(NUM_SAMPLES_MIN, NUM_SAMPLES_DIM * space.dimension)
+        fn, V = _split(target_func)
+        if V == 1 and hasattr(fn, "value_and_gradient"):
+            return generate_continuous_optimizer(num_initial_samples=num_samples,
+                                                 num_optimization_runs=NUM_RUNS_DIM * space.dimension)(space, target_func)
         return generate_random_search_optimizer(num_samples)(space, target_func)
     raise NotImplementedError(f"No optimizer currently supports acquisition function maximisation over search "
                               f"spaces of type {space}. Try specifying the optimize_random optimizer")
@@ -139,6 +146,123 @@ def generate_initial_points(num_initial_points: int, initial_sampler, space: Sea
     if top_pts is None:
         raise ValueError("No initial point generated!")
     return np.transpose(top_pts, [1, 0, 2])
+
+
+def sample_from_space(num_samples: int, batch_size: Optional[int] = None, seed: Optional[int] = None):
+    """An initial-point sampler yielding ``num_samples`` points of the space in batches
+    (optimizer.py:196-244)."""
+    if num_samples <= 0:
+        raise ValueError(f"num_samples must be positive, got {num_samples}")
+    if batch_size is not None and batch_size <= 0:
+        raise ValueError(f"batch_size must be positive, got {batch_size}")
+    bs = batch_size or num_samples
+
+    def sampler(space: SearchSpace) -> Iterator[np.ndarray]:
+        done, it = 0, 0
+        while done < num_samples:
+            n = min(bs, num_samples - done)
+            yield space.sample(n, seed=None if seed is None else seed + it)
+            done += n
+            it += 1
+
+    return sampler
+
+
+def _perform_parallel_continuous_optimization(fn, space: Box, starting_points: np.ndarray,
+                                              optimizer_args: Dict[str, Any]):
+    """L-BFGS-B from every row of ``starting_points`` [R, D] at once (optimizer.py:563-698): each run
+    lives in a greenlet that hands its current iterate to the parent; the parent evaluates value
+    and gradient of ALL pending iterates in one device call and resumes the runs.  Maximises ``fn``
+    (scipy minimises its negation).  Returns (successes [R], values [R], points [R, D], nfev [R])."""
+    import greenlet
+
+    starts = np.asarray(starting_points, dtype=np.float64)
+    R, D = starts.shape
+    bounds = spo.Bounds(space.lower, space.upper)
+    args = dict(optimizer_args or {})
+    for forbidden in ("method", "jac", "bounds"):
+        if forbidden in args:
+            raise ValueError(f"optimizer_args must not set {forbidden!r}")
+
+    class _Run(greenlet.greenlet):
+        def run(self, start):
+            seen = {"x": None, "f": None, "g": None}
+
+            def value_and_gradient(x):
+                if seen["x"] is None or not np.array_equal(seen["x"], x):
+                    seen["x"] = np.array(x, dtype=np.float64)
+                    seen["f"], seen["g"] = self.parent.switch(seen["x"])
+                return seen["f"], seen["g"]
+
+            return spo.minimize(lambda x: value_and_gradient(x)[0], start, jac=lambda x: value_and_gradient(x)[1],
+                                bounds=bounds, method="L-BFGS-B", **args)
+
+    runs = [_Run() for _ in range(R)]
+    pending = [run.switch(starts[i]) for i, run in enumerate(runs)]
+    batch_x = np.zeros((R, D))
+    while True:
+        active = [i for i, res in enumerate(pending) if not isinstance(res, spo.OptimizeResult)]
+        if not active:
+            break
+        for i in active:
+            batch_x[i] = pending[i]
+        vals, grads = fn.value_and_gradient(batch_x[active])
+        vals, grads = -_to_host(vals), -_to_host(grads)
+        for j, i in enumerate(active):
+            if runs[i].dead:  # a crashed run is skipped, like the reference does
+                continue
+            pending[i] = runs[i].switch(float(vals[j]), np.array(grads[j], dtype=np.float64))
+    successes = np.array([bool(r.success) for r in pending])
+    values = np.array([-float(r.fun) for r in pending])
+    points = np.stack([np.asarray(r.x, dtype=np.float64) for r in pending])
+    nfev = np.array([int(r.nfev) for r in pending])
+    return successes, values, points, nfev
+
+
+def generate_continuous_optimizer(num_initial_samples=NUM_SAMPLES_MIN, num_optimization_runs: int = 10,
+                                  num_recovery_runs: int = 10, optimizer_args: Optional[Dict[str, Any]] = None):
+    """Gradient-based optimizer for a Box and batches of size one (optimizer.py:344-560): sweep
+    ``num_initial_samples`` random points (or the batches of a sampler callable), start L-BFGS-B from
+    the best ``num_optimization_runs`` of them, fall back to ``num_recovery_runs`` random starts if
+    every run fails, raise :class:`FailedOptimizationError` if those fail too.  The acquisition
+    function must expose ``value_and_gradient`` (the engine-backed EI / PI / -LCB do)."""
+    if num_optimization_runs <= 0:
+        raise ValueError(f"num_optimization_runs must be positive, got {num_optimization_runs}")
+    if not callable(num_initial_samples) and num_initial_samples < num_optimization_runs:
+        raise ValueError(f"num_initial_samples {num_initial_samples} must be at least num_optimization_runs "
+                         f"{num_optimization_runs}")
+    if num_recovery_runs < 0:
+        raise ValueError(f"num_recovery_runs must be zero or greater, got {num_recovery_runs}")
+
+    def optimize_continuous(space: Box, target_func) -> np.ndarray:
+        fn, V = _split(target_func)
+        if V <= 0:
+            raise ValueError(f"vectorization must be positive, got {V}")
+        if V != 1:
+            raise NotImplementedError("vectorized continuous optimisation is outside the engine's path")
+        if not isinstance(space, Box):
+            raise NotImplementedError("the continuous optimizer supports Box search spaces")
+        if not hasattr(fn, "value_and_gradient"):
+            raise TypeError("generate_continuous_optimizer needs an acquisition function exposing "
+                            "value_and_gradient (there is no autodiff on this engine)")
+        sampler = num_initial_samples if callable(num_initial_samples) else sample_from_space(num_initial_samples)
+        initial_points = generate_initial_points(num_optimization_runs, sampler, space, fn)  # [k, 1, D]
+        if len(initial_points) < num_optimization_runs:
+            raise ValueError(f"Not enough initial points generated ({len(initial_points)} for "
+                             f"{num_optimization_runs} optimization runs)")
+        successes, values, points, _ = _perform_parallel_continuous_optimization(
+            fn, space, initial_points[:, 0, :], optimizer_args or {})
+        if num_recovery_runs and not np.any(successes):
+            rs, rv, rp, _ = _perform_parallel_continuous_optimization(
+                fn, space, space.sample(num_recovery_runs), optimizer_args or {})
+            successes, values, points = (np.concatenate([successes, rs]), np.concatenate([values, rv]),
+                                         np.concatenate([points, rp]))
+        if not np.any(successes):
+            raise FailedOptimizationError(f"Acquisition function optimization failed, even after "
+                                          f"{num_recovery_runs + num_optimization_runs} restarts.")
+        return points[int(np.argmax(values))][None, :]
+
+    return optimize_continuous
 
 
 def batchify_joint(batch_size_one_optimizer, batch_size: int):

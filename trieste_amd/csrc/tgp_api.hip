@@ -72,7 +72,7 @@ struct tgp_handle_s {
   // model state on device
   DevBuf d_ls, d_X, d_Y, d_Xs, d_A, d_L, d_W, d_alpha, d_err, d_tmp1, d_tmp2, d_info;
   // scratch
-  DevBuf s_in, s_in2, s_out1, s_out2, s_out3, s_blkv, s_blki, s_small, s_kcache, s_ssq, s_aslab;
+  DevBuf s_in, s_in2, s_out1, s_out2, s_out3, s_blkv, s_blki, s_small, s_kcache, s_ssq, s_aslab, s_grad;
   // timing of the dominant kernel
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double last_ms = 0.0;
@@ -306,7 +306,7 @@ int tgp_destroy(tgp_handle h) {
   (void)hipStreamSynchronize(h->stream);
   for (DevBuf* b : {&h->d_ls, &h->d_X, &h->d_Y, &h->d_Xs, &h->d_A, &h->d_L, &h->d_W, &h->d_alpha,
                     &h->d_err, &h->d_tmp1, &h->d_tmp2, &h->d_info, &h->s_in, &h->s_in2, &h->s_out1,
-                    &h->s_out2, &h->s_out3, &h->s_blkv, &h->s_blki, &h->s_small, &h->s_kcache, &h->s_ssq, &h->s_aslab})
+                    &h->s_out2, &h->s_out3, &h->s_blkv, &h->s_blki, &h->s_small, &h->s_kcache, &h->s_ssq, &h->s_aslab, &h->s_grad})
     b->release();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -525,6 +525,39 @@ int tgp_acq_values(tgp_handle h, int acq_kind, double param, const double* Xq, i
   if (M > 0 && !out) return fail(h, TGP_ERR_ARG, "out is NULL");
   return sweep_common(h, Xq, M, nullptr, nullptr, out, acq_kind, param, where, false, 0, nullptr, nullptr,
                       nullptr);
+}
+
+int tgp_acq_value_grad(tgp_handle h, int acq_kind, double param, const double* Xq, int64_t P, double* val,
+                       double* grad, int where) {
+  if (!h) return TGP_ERR_ARG;
+  if (acq_kind < 0 || acq_kind > 2) return fail(h, TGP_ERR_ARG, "unknown acquisition kind %d", acq_kind);
+  if (!h->have_data) return fail(h, TGP_ERR_STATE, "model has no data: call tgp_set_data first");
+  if (P < 0 || (P > 0 && (!Xq || !val || !grad))) return fail(h, TGP_ERR_ARG, "bad arguments");
+  if (P == 0) return TGP_OK;
+  if (int rc = set_device(h)) return rc;
+  const int64_t Ppad = ((P + 63) / 64) * 64, Npad = h->Npad;
+  const double* dXq;
+  double *dval, *dgrad;
+  if (int rc = stage_in(h, h->s_in, Xq, (size_t)P * h->d, where, &dXq)) return rc;
+  if (int rc = stage_out_prepare(h, h->s_out1, val, P, where, &dval)) return rc;
+  if (int rc = stage_out_prepare(h, h->s_out2, grad, (size_t)P * h->d, where, &dgrad)) return rc;
+  HIPCHK(h, h->s_grad.reserve((size_t)3 * Npad * Ppad * sizeof(double)));
+  double* B = h->s_grad.as<double>();
+  double* C1 = B + (size_t)Npad * Ppad;
+  double* Z = C1 + (size_t)Npad * Ppad;
+  const ModelDev m = model_dev(h);
+  launch_kstar_t(h->stream, m, dXq, P, Ppad, B);
+  // C1 = W B (W = L^-1, lower triangular incl. explicit zeros), Z = W^T C1 = K^-1 k*
+  launch_gemm(h->stream, false, (int)Npad, (int)Ppad, (int)Npad, 1.0, h->d_W.as<double>(), Npad, B, Ppad, 0.0, C1,
+              Ppad, false);
+  launch_gemm(h->stream, false, (int)Npad, (int)Ppad, (int)Npad, 1.0, h->d_A.as<double>(), Npad, C1, Ppad, 0.0, Z,
+              Ppad, false);
+  launch_grad_tail(h->stream, m, dXq, P, Ppad, B, C1, Z, acq_kind, param, dval, dgrad);
+  if (int rc = stage_out_finish(h, dval, val, P, where)) return rc;
+  if (int rc = stage_out_finish(h, dgrad, grad, (size_t)P * h->d, where)) return rc;
+  if (int rc = sync(h)) return rc;
+  HIPCHK(h, hipGetLastError());
+  return TGP_OK;
 }
 
 int tgp_acq_argmax(tgp_handle h, int acq_kind, double param, const double* Xq, int64_t M,

@@ -90,6 +90,11 @@ void launch_sample_box(hipStream_t s, uint64_t seed, int64_t first, int64_t M, i
 void launch_qei_tail(hipStream_t s, const double* mean, const double* cov, int64_t G, int q,
                      const double* eps, int S, double eta, double jitter, double* out, double* samples_out,
                      int* info);
+// gradients (tgp_kernels_grad.hip)
+void launch_kstar_t(hipStream_t s, const ModelDev& m, const double* Xq, int64_t P, int64_t Ppad, double* B);
+void launch_grad_tail(hipStream_t s, const ModelDev& m, const double* Xq, int64_t P, int64_t Ppad,
+                      const double* B, const double* C1, const double* Z, int acq, double param, double* val,
+                      double* grad);
 // trajectories
 struct TrajDev {
   ModelDev m;

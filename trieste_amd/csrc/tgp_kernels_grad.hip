@@ -1,0 +1,140 @@
+// Acquisition value AND gradient w.r.t. the query point, for the L-BFGS-B refinement of the sweep
+// winners (reference trieste/acquisition/optimizer.py:344-745: generate_continuous_optimizer /
+// _perform_parallel_continuous_optimization, where the gradient comes from
+// tfp.math.value_and_gradient at :628-629).  Analytic form of the same derivative:
+//     d mean / dx = sum_k alpha_k dk_k/dx,     d var / dx = -2 sum_k z_k dk_k/dx,   z = K^-1 k*
+// with z = W^T (W k*) from the cached inverse factor (two f64-MFMA GEMMs over the P query points),
+// then the chain rule through EI / PI / -LCB.  P is small (tens to hundreds of L-BFGS-B iterates).
+#include "tgp_dev.hpp"
+#include "tgp_internal.hpp"
+
+namespace tgp {
+
+// B[k][p] = k(X_k, x_p), k-major [Npad][Ppad], zero padded.
+__global__ void kstar_t_kernel(ModelDev m, const double* __restrict__ Xq, int64_t P, int64_t Ppad,
+                               double* __restrict__ B) {
+  const int64_t p = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int64_t k = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (p >= Ppad || k >= m.Npad) return;
+  double v = 0.0;
+  if (p < P && k < m.N) {
+    double r2 = 0.0;
+    for (int c = 0; c < m.d; ++c) {
+      const double t = Xq[p * m.d + c] / m.ls[c] - m.Xs[k * m.dp + c];
+      r2 = fma(t, t, r2);
+    }
+    v = kernel_rt(m.kind, r2, m.variance);
+  }
+  B[k * Ppad + p] = v;
+}
+
+// d k / d (r^2) divided by the variance-free shape: returns variance * f'(r2).
+__device__ __forceinline__ double kernel_dr2(int kind, double r2, double variance) {
+  if (kind == KIND_RBF) return -0.5 * variance * exp(-0.5 * r2);
+  const double r = sqrt(fmax(r2, 1e-36));
+  if (kind == KIND_M12) return -0.5 * variance * exp(-r) / r;
+  if (kind == KIND_M32) {
+    const double s = 1.7320508075688772 * r;
+    return -1.5 * variance * exp(-s);
+  }
+  const double s = 2.23606797749979 * r;
+  return -(5.0 / 6.0) * variance * (1.0 + s) * exp(-s);
+}
+
+constexpr int GT_THREADS = 256;
+
+// one workgroup per query point
+__global__ __launch_bounds__(GT_THREADS) void grad_tail_kernel(ModelDev m, const double* __restrict__ Xq,
+                                                               int64_t P, int64_t Ppad,
+                                                               const double* __restrict__ B,
+                                                               const double* __restrict__ C1,
+                                                               const double* __restrict__ Z, int acq,
+                                                               double param, double* __restrict__ val,
+                                                               double* __restrict__ grad) {
+  __shared__ double red[4][2 + 2 * MAX_D];
+  const int64_t p = blockIdx.x;
+  const int d = m.d, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  double xs[MAX_D];
+  for (int c = 0; c < d; ++c) xs[c] = Xq[p * d + c] / m.ls[c];
+  double mean = 0.0, ssq = 0.0;
+  double gm[MAX_D], gv[MAX_D];
+  for (int c = 0; c < d; ++c) gm[c] = gv[c] = 0.0;
+  for (int64_t k = tid; k < m.N; k += GT_THREADS) {
+    const double kv = B[k * Ppad + p], ck = C1[k * Ppad + p], zk = Z[k * Ppad + p];
+    const double al = m.alpha[k];
+    mean = fma(kv, al, mean);
+    ssq = fma(ck, ck, ssq);
+    double r2 = 0.0;
+    for (int c = 0; c < d; ++c) {
+      const double t = xs[c] - m.Xs[k * m.dp + c];
+      r2 = fma(t, t, r2);
+    }
+    const double f1 = 2.0 * kernel_dr2(m.kind, r2, m.variance);
+    for (int c = 0; c < d; ++c) {
+      const double dk = f1 * (xs[c] - m.Xs[k * m.dp + c]) / m.ls[c];
+      gm[c] = fma(al, dk, gm[c]);
+      gv[c] = fma(zk, dk, gv[c]);
+    }
+  }
+  mean = wave_sum(mean);
+  ssq = wave_sum(ssq);
+  for (int c = 0; c < d; ++c) {
+    gm[c] = wave_sum(gm[c]);
+    gv[c] = wave_sum(gv[c]);
+  }
+  if (lane == 0) {
+    red[w][0] = mean;
+    red[w][1] = ssq;
+    for (int c = 0; c < d; ++c) {
+      red[w][2 + c] = gm[c];
+      red[w][2 + MAX_D + c] = gv[c];
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    auto tot = [&](int j) { return (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]); };
+    const double mu = tot(0) + m.mean_const;
+    const double var_raw = m.variance - tot(1);
+    const bool clipped = !(var_raw > VAR_FLOOR);
+    const double var = clipped ? VAR_FLOOR : var_raw;
+    const double sd = sqrt(var);
+    double v, dv_dmu, dv_dvar;
+    if (acq == ACQ_EI) {
+      const double z = (param - mu) / sd;
+      const double cdf = normal_cdf(z), pdf = normal_pdf(z);
+      v = (param - mu) * cdf + sd * pdf;
+      dv_dmu = -cdf;
+      dv_dvar = pdf / (2.0 * sd);
+    } else if (acq == ACQ_PI) {
+      const double z = (param - mu) / sd;
+      const double pdf = normal_pdf(z);
+      v = normal_cdf(z);
+      dv_dmu = -pdf / sd;
+      dv_dvar = -pdf * z / (2.0 * var);
+    } else {
+      v = -(mu - param * sd);
+      dv_dmu = -1.0;
+      dv_dvar = param / (2.0 * sd);
+    }
+    val[p] = v;
+    for (int c = 0; c < d; ++c) {
+      const double dmu = tot(2 + c);
+      const double dvar = clipped ? 0.0 : -2.0 * tot(2 + MAX_D + c);  // clip_by_value has zero gradient
+      grad[p * d + c] = dv_dmu * dmu + dv_dvar * dvar;
+    }
+  }
+}
+
+void launch_kstar_t(hipStream_t s, const ModelDev& m, const double* Xq, int64_t P, int64_t Ppad, double* B) {
+  dim3 grid((unsigned)(Ppad / 64), (unsigned)(m.Npad / 4));
+  hipLaunchKernelGGL(kstar_t_kernel, grid, dim3(256), 0, s, m, Xq, P, Ppad, B);
+}
+
+void launch_grad_tail(hipStream_t s, const ModelDev& m, const double* Xq, int64_t P, int64_t Ppad,
+                      const double* B, const double* C1, const double* Z, int acq, double param, double* val,
+                      double* grad) {
+  hipLaunchKernelGGL(grad_tail_kernel, dim3((unsigned)P), dim3(GT_THREADS), 0, s, m, Xq, P, Ppad, B, C1, Z, acq,
+                     param, val, grad);
+}
+
+}  // namespace tgp

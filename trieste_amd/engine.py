@@ -157,6 +157,14 @@ class GPEngine:
         self._chk(self._lib.tgp_acq_values(self._h, _lib.ACQ[acq], float(param), a.ptr, M, po, a.where))
         return out
 
+    def acq_value_grad(self, acq: str, param: float, Xq):
+        """Xq [P, d] -> (values [P], gradients [P, d]) of the acquisition function."""
+        a, lead, P = self._flat(Xq)
+        val, pv = self._out(a, lead)
+        grad, pg = self._out(a, lead + (self.d,))
+        self._chk(self._lib.tgp_acq_value_grad(self._h, _lib.ACQ[acq], float(param), a.ptr, P, pv, pg, a.where))
+        return val, grad
+
     def acq_argmax(self, acq: str, param: float, Xq, index_base: int = 0):
         """-> (best value, global index, best point [d] as numpy)."""
         a, _, M = self._flat(Xq)
