@@ -81,6 +81,13 @@ int tgp_set_hyper(tgp_handle h, double variance, const double* lengthscales, dou
 int tgp_set_data(tgp_handle h, const double* X, const double* Y, int64_t N, int where);
 
 int tgp_get_sizes(tgp_handle h, int64_t* N, int* d);
+/* Negative log marginal likelihood of the current (hyper-parameters, data) and its gradient:
+ * value (host scalar); grad (host [d + 3], may be NULL) = d/d lengthscales[d], d/d variance,
+ * d/d noise_variance, d/d mean_const, all in the natural (constrained) parameters.  This is the
+ * likelihood part of the loss gpflow's Scipy optimizer minimises in
+ * GaussianProcessRegression.optimize_encoded (models/gpflow/models.py:256-292); priors and
+ * parameter transforms are host-side scalars. */
+int tgp_nlml(tgp_handle h, double* value, double* grad);
 /* Read back the cache (tests / checkpoint-free restore checks): any pointer may be NULL.
  * L [N,N] lower (upper = 0), Winv [N,N] = L^-1, alpha [N].  `where` applies to all three. */
 int tgp_get_factor(tgp_handle h, double* L, double* Winv, double* alpha, int where);

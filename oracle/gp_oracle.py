@@ -271,6 +271,31 @@ def acq_value_and_grad(state: GPRState, acq: str, param: float, Xq: np.ndarray):
     return val, g
 
 
+def nlml_and_grad(state: GPRState):
+    """Negative log marginal likelihood of (hyper-parameters, data) and its gradient w.r.t.
+    (lengthscales [d], variance, noise, mean) -- the likelihood part of gpflow GPR.training_loss that
+    GaussianProcessRegression.optimize_encoded minimises (reference models/gpflow/models.py:256-292).
+    nlml = 1/2 err^T K^-1 err + sum log L_ii + N/2 log 2 pi;  d/d theta = 1/2 tr((K^-1 - a a^T) dK/d theta)."""
+    N, d = state.N, state.d
+    ls = state.lengthscales
+    alpha = _solve_triangular(state.L.T, _solve_triangular(state.L, state.err, lower=True), lower=False)
+    Linv = _solve_triangular(state.L, np.eye(N), lower=True)
+    G = Linv.T @ Linv - np.outer(alpha, alpha)
+    value = 0.5 * state.err @ alpha + np.sum(np.log(np.diag(state.L))) + 0.5 * N * math.log(2.0 * math.pi)
+    A = state.X / ls
+    diff2 = (A[:, None, :] - A[None, :, :]) ** 2          # [N, N, d] scaled squared differences
+    r2 = diff2.sum(-1)
+    Kf = kernel_from_r2(state.kind, state.variance, r2)
+    f1 = _kernel_dr2(state.kind, state.variance, r2)
+    grad = np.empty(d + 3)
+    for c in range(d):
+        grad[c] = 0.5 * np.sum(G * f1 * (-2.0 * diff2[:, :, c] / ls[c]))
+    grad[d] = 0.5 * np.sum(G * Kf) / state.variance
+    grad[d + 1] = 0.5 * np.trace(G)
+    grad[d + 2] = -np.sum(alpha)
+    return float(value), grad
+
+
 # --------------------------------------------------------------------------------------
 # A.5 batch Monte-Carlo EI (sampler.py:208-287 + function.py:1181-1186); eps passed in.
 # --------------------------------------------------------------------------------------

@@ -88,6 +88,9 @@ class FakeEngine:
             raise RuntimeError("model has no data: call tgp_set_data first")
         return self.state
 
+    def nlml(self):
+        return O.nlml_and_grad(self._st())
+
     def get_factor(self):
         st = self._st()
         W = np.linalg.inv(st.L)

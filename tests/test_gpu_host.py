@@ -125,3 +125,34 @@ def test_continuous_optimizer_on_gpu_refines_ei():
     assert val[0] >= 0.999 * np.max(O.ei_values(st, sweep, fn.eta))
     interior = (pt[0] > 1e-9) & (pt[0] < 1 - 1e-9)
     assert np.all(np.abs(ograd[0][interior]) < 1e-3 * max(float(oval[0]), 1e-6) + 1e-8)
+
+
+def test_model_optimize_on_gpu_matches_an_oracle_driven_fit():
+    """GaussianProcessRegression.optimize on the engine lands at the same MAP loss as the same host
+    optimiser driven by the oracle."""
+    import trieste_amd.models as M
+    from tests.fakes import FakeEngine
+    from trieste_amd.data import Dataset
+    from trieste_amd.space import Box
+
+    rng = np.random.default_rng(3)
+    x = rng.uniform(size=(80, 3))
+    K = O.kernel_matrix("matern52", 1.5, np.array([0.2, 0.5, 1.0]), x) + 1e-3 * np.eye(80)
+    y = np.linalg.cholesky(K) @ rng.standard_normal(80)
+    data = Dataset(x, y[:, None])
+    space = Box([0, 0, 0], [1, 1, 1])
+    gpu = M.GaussianProcessRegression(M.build_gpr(data, space, likelihood_variance=1e-3), num_kernel_samples=0)
+    before = gpu.training_loss()
+    gpu.optimize(data)
+    after = gpu.training_loss()
+    assert after < before
+    real = M.GPEngine
+    try:
+        M.GPEngine = FakeEngine
+        cpu = M.GaussianProcessRegression(M.build_gpr(data, space, likelihood_variance=1e-3), num_kernel_samples=0)
+        cpu.optimize(data)
+        cpu_loss = cpu.training_loss()
+    finally:
+        M.GPEngine = real
+    assert abs(after - cpu_loss) < 1e-3 * max(1.0, abs(cpu_loss))
+    np.testing.assert_allclose(gpu.get_kernel().lengthscales, cpu.get_kernel().lengthscales, rtol=1e-2)

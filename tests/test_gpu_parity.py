@@ -322,3 +322,15 @@ def test_acq_value_and_gradient_match_oracle(cfg):
         assert_close(grad, ograd, rtol=1e-5, atol=max(floor * 1e3, 1e-9 * gscale), what=f"{acq} gradient")
         vals2 = eng.acq_values(acq, par, Xq)
         assert_close(val, vals2, rtol=1e-9, atol=floor, what=f"{acq} value == sweep value")
+
+
+@pytest.mark.parametrize("cfg", CONFIGS[:5], ids=[c[0] for c in CONFIGS[:5]])
+def test_nlml_value_and_gradient_match_oracle(cfg):
+    """tgp_nlml vs the oracle (whose gradient is finite-difference checked in test_oracle_gradient.py)."""
+    _, obj, d, kind, N, noise = cfg
+    X, Y, ls, c, st, _ = _problem(obj, d, kind, N, noise, M=8)
+    eng = _engine(kind, d, 1.0, ls, noise, c, X, Y)
+    val, grad = eng.nlml()
+    oval, ograd = O.nlml_and_grad(st)
+    assert_close(val, oval, rtol=1e-9, atol=1e-7, what="nlml")
+    assert_close(grad, ograd, rtol=1e-5, atol=1e-7 * np.abs(ograd).max() + 1e-6 / noise * 1e-6, what="nlml gradient")

@@ -428,3 +428,42 @@ def test_not_positive_definite_surfaces_as_err():
     gpr = M.GPR((x0, OBJ.scaled_branin(x0)), M.Matern52(1.0, [0.3, 0.3]), M.Constant(0.0), 1e-30)
     with pytest.raises(NotPositiveDefiniteError):
         M.GaussianProcessRegression(gpr)
+
+
+# ---- hyper-parameter fitting (reference tests/unit/models/gpflow/test_models.py:99-216, 463-598) --------
+def test_optimize_decreases_the_loss_and_recovers_lengthscales():
+    rng = np.random.default_rng(0)
+    d, n = 2, 60
+    x = rng.uniform(size=(n, d))
+    true_ls = np.array([0.15, 0.6])
+    from oracle import gp_oracle as O
+
+    K = O.kernel_matrix("matern52", 1.0, true_ls, x) + 1e-4 * np.eye(n)
+    y = np.linalg.cholesky(K) @ rng.standard_normal(n)
+    data = Dataset(x, y[:, None])
+    gpr = M.build_gpr(data, Box([0, 0], [1, 1]), likelihood_variance=1e-4)
+    assert gpr.kernel.lengthscales_prior is not None and gpr.kernel.variance_prior is not None
+    model = M.GaussianProcessRegression(gpr, num_kernel_samples=5)
+    before = model.training_loss()
+    res = model.optimize(data)
+    after = model.training_loss()
+    assert after < before - 1.0 and np.isfinite(res.fun)
+    ls = model.get_kernel().lengthscales
+    assert ls[0] < ls[1] and 0.05 < ls[0] < 0.4 and 0.25 < ls[1] < 1.5  # anisotropy recovered
+    # the cache was refreshed at the optimum: predictions interpolate the data
+    m, v = model.predict(x)
+    assert np.max(np.abs(m[:, 0] - y)) < 0.05 and np.all(v < 0.01)
+    # noise is only trained when asked to
+    assert model.get_observation_noise() == 1e-4
+    gpr2 = M.build_gpr(data, Box([0, 0], [1, 1]), trainable_likelihood=True)
+    m2 = M.GaussianProcessRegression(gpr2, num_kernel_samples=0)
+    n0 = m2.get_observation_noise()
+    m2.optimize(data)
+    assert m2.get_observation_noise() != n0
+
+
+def test_find_best_model_initialization_never_gets_worse():
+    model, data = _model(n=25, noise=1e-3)
+    before = model.training_loss()
+    model.find_best_model_initialization(12, seed=1)
+    assert model.training_loss() <= before + 1e-9

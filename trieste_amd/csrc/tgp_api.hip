@@ -402,6 +402,31 @@ int tgp_set_data(tgp_handle h, const double* X, const double* Y, int64_t N, int 
   return TGP_OK;
 }
 
+int tgp_nlml(tgp_handle h, double* value, double* grad) {
+  if (!h || !value) return TGP_ERR_ARG;
+  if (!h->have_data) return fail(h, TGP_ERR_STATE, "no factorisation: call tgp_set_data first");
+  if (int rc = set_device(h)) return rc;
+  const int64_t Npad = h->Npad;
+  const int np = h->d + 4;
+  HIPCHK(h, h->s_small.reserve(64 + (MAX_D + 8) * sizeof(double)));
+  HIPCHK(h, h->s_blkv.reserve((size_t)nlml_blocks(Npad) * (MAX_D + 2) * sizeof(double)));
+  HIPCHK(h, h->s_grad.reserve((size_t)Npad * Npad * sizeof(double)));
+  double* Kinv = h->s_grad.as<double>();
+  double* out = h->s_small.as<double>() + 8;
+  // Kinv = W^T W  (Wt is in d_A, W in d_W; both carry explicit zeros outside their triangles)
+  launch_gemm(h->stream, false, (int)Npad, (int)Npad, (int)Npad, 1.0, h->d_A.as<double>(), Npad, h->d_W.as<double>(),
+              Npad, 0.0, Kinv, Npad, false);
+  launch_nlml(h->stream, model_dev(h), Kinv, h->d_L.as<double>(), h->d_err.as<double>(), h->s_blkv.as<double>(), out);
+  std::vector<double> host((size_t)np);
+  HIPCHK(h, hipMemcpyAsync(host.data(), out, (size_t)np * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (int rc = sync(h)) return rc;
+  HIPCHK(h, hipGetLastError());
+  *value = host[0];
+  if (grad)
+    for (int c = 0; c < h->d + 3; ++c) grad[c] = host[1 + c];
+  return TGP_OK;
+}
+
 int tgp_get_sizes(tgp_handle h, int64_t* N, int* d) {
   if (!h) return TGP_ERR_ARG;
   if (N) *N = h->have_data ? h->N : 0;

@@ -95,6 +95,9 @@ void launch_kstar_t(hipStream_t s, const ModelDev& m, const double* Xq, int64_t 
 void launch_grad_tail(hipStream_t s, const ModelDev& m, const double* Xq, int64_t P, int64_t Ppad,
                       const double* B, const double* C1, const double* Z, int acq, double param, double* val,
                       double* grad);
+int64_t nlml_blocks(int64_t Npad);
+void launch_nlml(hipStream_t s, const ModelDev& m, const double* Kinv, const double* L, const double* err,
+                 double* partial, double* out);
 // trajectories
 struct TrajDev {
   ModelDev m;

@@ -138,3 +138,91 @@ void launch_grad_tail(hipStream_t s, const ModelDev& m, const double* Xq, int64_
 }
 
 }  // namespace tgp
+
+// =============================================================================================
+// Negative log marginal likelihood and its gradient w.r.t. (lengthscales[d], variance, noise, mean)
+// -- the loss gpflow.optimizers.Scipy minimises inside GaussianProcessRegression.optimize_encoded
+// (reference trieste/models/gpflow/models.py:256-292; gpflow GPR.training_loss = -log p(y) - log
+// prior).  The engine provides the likelihood part:
+//     nlml = 1/2 err^T alpha + sum_i log L_ii + N/2 log(2 pi)
+//     d nlml / d theta = 1/2 sum_ij (Kinv_ij - alpha_i alpha_j) dK_ij / d theta,   Kinv = W^T W
+// (the reference differentiates the Cholesky-based expression by TF autodiff; same derivative).
+namespace tgp {
+
+constexpr int NG_MAXP = MAX_D + 2;  // d lengthscales + variance + noise
+
+__global__ __launch_bounds__(256) void nlml_grad_kernel(ModelDev m, const double* __restrict__ Kinv,
+                                                        double* __restrict__ partial) {
+  __shared__ double red[4][NG_MAXP];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int64_t j = (int64_t)blockIdx.x * 16 + (tid & 15);
+  const int64_t i = (int64_t)blockIdx.y * 16 + (tid >> 4);
+  const int d = m.d;
+  double acc[NG_MAXP];
+  for (int c = 0; c < d + 2; ++c) acc[c] = 0.0;
+  if (i < m.N && j < m.N) {
+    const double G = Kinv[i * m.Npad + j] - m.alpha[i] * m.alpha[j];
+    double r2 = 0.0, ds2[MAX_D];
+    for (int c = 0; c < d; ++c) {
+      const double t = m.Xs[i * m.dp + c] - m.Xs[j * m.dp + c];
+      ds2[c] = t * t;
+      r2 += ds2[c];
+    }
+    const double f1 = kernel_dr2(m.kind, r2, m.variance);         // variance * f'(r2)
+    const double kij = kernel_rt(m.kind, r2, m.variance);         // without the noise
+    for (int c = 0; c < d; ++c) acc[c] = G * f1 * (-2.0 * ds2[c] / m.ls[c]);
+    acc[d] = G * kij / m.variance;
+    acc[d + 1] = (i == j) ? G : 0.0;
+  }
+  for (int c = 0; c < d + 2; ++c) {
+    const double s = wave_sum(acc[c]);
+    if (lane == 0) red[w][c] = s;
+  }
+  __syncthreads();
+  if (tid < d + 2) {
+    const int64_t b = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+    partial[b * NG_MAXP + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+  }
+}
+
+// out[0] = nlml, out[1..d] = d/d lengthscale, out[d+1] = d/d variance, out[d+2] = d/d noise,
+// out[d+3] = d/d mean.  One workgroup; fixed summation order.
+__global__ __launch_bounds__(256) void nlml_final_kernel(ModelDev m, const double* __restrict__ L,
+                                                         const double* __restrict__ err,
+                                                         const double* __restrict__ partial, int64_t nblocks,
+                                                         double* __restrict__ out) {
+  __shared__ double red[4][NG_MAXP + 3];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int d = m.d, np = d + 2;
+  double acc[NG_MAXP + 3];
+  for (int c = 0; c < np + 3; ++c) acc[c] = 0.0;
+  for (int64_t b = tid; b < nblocks; b += 256)
+    for (int c = 0; c < np; ++c) acc[c] += partial[b * NG_MAXP + c];
+  for (int64_t i = tid; i < m.N; i += 256) {
+    acc[np] += err[i] * m.alpha[i];
+    acc[np + 1] += log(L[i * m.Npad + i]);
+    acc[np + 2] += m.alpha[i];
+  }
+  for (int c = 0; c < np + 3; ++c) {
+    const double s = wave_sum(acc[c]);
+    if (lane == 0) red[w][c] = s;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    auto tot = [&](int c) { return (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]); };
+    out[0] = 0.5 * tot(np) + tot(np + 1) + 0.5 * (double)m.N * 1.8378770664093453;  // log(2 pi)
+    for (int c = 0; c < np; ++c) out[1 + c] = 0.5 * tot(c);
+    out[1 + np] = -tot(np + 2);
+  }
+}
+
+int64_t nlml_blocks(int64_t Npad) { return (Npad / 16) * (Npad / 16); }
+
+void launch_nlml(hipStream_t s, const ModelDev& m, const double* Kinv, const double* L, const double* err,
+                 double* partial, double* out) {
+  dim3 grid((unsigned)(m.Npad / 16), (unsigned)(m.Npad / 16));
+  hipLaunchKernelGGL(nlml_grad_kernel, grid, dim3(256), 0, s, m, Kinv, partial);
+  hipLaunchKernelGGL(nlml_final_kernel, dim3(1), dim3(256), 0, s, m, L, err, partial, nlml_blocks(m.Npad), out);
+}
+
+}  // namespace tgp

@@ -97,6 +97,13 @@ class GPEngine:
         self._chk(self._lib.tgp_set_data(self._h, ax.ptr, ay.ptr, n, ax.where))
         self.N = n
 
+    def nlml(self):
+        """(negative log marginal likelihood, gradient [d + 3] w.r.t. lengthscales, variance, noise, mean)."""
+        v = C.c_double()
+        g = np.empty(self.d + 3)
+        self._chk(self._lib.tgp_nlml(self._h, C.byref(v), g.ctypes.data))
+        return v.value, g
+
     def get_factor(self):
         """(L, W = L^-1, alpha) as numpy arrays (tests / diagnostics)."""
         n = self.N

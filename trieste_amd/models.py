@@ -20,6 +20,7 @@ from .space import SearchSpace
 
 KERNEL_LENGTHSCALE = 0.2  # builders.py:41
 SIGNAL_NOISE_RATIO_LIKELIHOOD = 10.0  # builders.py:78
+KERNEL_PRIOR_SCALE = 1.0  # builders.py:49
 
 
 # ---- parameter records standing in for gpflow.kernels.* / gpflow.models.GPR ----------------------
@@ -30,6 +31,10 @@ class Kernel:
     variance: float = 1.0
     lengthscales: np.ndarray = field(default_factory=lambda: np.array(1.0))
     kind: str = "matern52"
+    # LogNormal(loc, scale) priors on the (constrained) parameters, as build_gpr sets them
+    # (reference builders.py:401-408); None = no prior.
+    variance_prior: Optional[Tuple[float, float]] = None
+    lengthscales_prior: Optional[Tuple[np.ndarray, float]] = None
 
     def __post_init__(self):
         self.variance = float(self.variance)
@@ -76,6 +81,7 @@ class GPR:
     kernel: Kernel
     mean_function: Constant = field(default_factory=Constant)
     likelihood_variance: float = 1.0
+    trainable_likelihood: bool = False  # build_gpr default: the noise variance is not trained
 
     def __post_init__(self):
         x = np.asarray(self.data[0], dtype=np.float64)
@@ -95,8 +101,8 @@ def build_gpr(data: Dataset, search_space: Optional[SearchSpace] = None, kernel_
     """Sensible initial hyper-parameters (reference builders.py:85-155): Matern-5/2 with variance =
     empirical variance, lengthscales = 0.2 * (upper - lower) * sqrt(D) (1.0 on collapsed
     dimensions), constant mean = empirical mean, noise variance = variance / 10^2 unless given.
-    ``kernel_priors`` / ``trainable_likelihood`` only matter for hyper-parameter fitting, which is
-    outside this engine's path; they are accepted and ignored."""
+    ``kernel_priors`` puts LogNormal(log(initial value), 1) priors on variance and lengthscales (MAP
+    fitting); the noise variance is trained only if ``trainable_likelihood``."""
     y = np.asarray(data.observations, dtype=np.float64)
     emp_mean, emp_var = float(np.mean(y)), float(np.var(y))
     if kernel is None:
@@ -106,13 +112,16 @@ def build_gpr(data: Dataset, search_space: Optional[SearchSpace] = None, kernel_
         ls = KERNEL_LENGTHSCALE * span * math.sqrt(search_space.dimension)
         ls = np.where(span == 0.0, 1.0, ls)
         kernel = Matern52(emp_var, ls)
+        if kernel_priors:
+            kernel.lengthscales_prior = (np.log(ls), KERNEL_PRIOR_SCALE)
+            kernel.variance_prior = (math.log(emp_var), KERNEL_PRIOR_SCALE)
     if likelihood_variance is None:
         noise = emp_var / SIGNAL_NOISE_RATIO_LIKELIHOOD ** 2
     else:
         if not likelihood_variance > 0:
             raise ValueError("likelihood_variance must be positive")
         noise = float(likelihood_variance)
-    return GPR((data.query_points, data.observations), kernel, Constant(emp_mean), noise)
+    return GPR((data.query_points, data.observations), kernel, Constant(emp_mean), noise, trainable_likelihood)
 
 
 # ---- the model wrapper ------------------------------------------------------------------------
@@ -121,8 +130,8 @@ class GaussianProcessRegression:
     backed by :class:`~trieste_amd.engine.GPEngine`.
 
     ``update`` refreshes the posterior cache (K + s2 I -> L, L^-1, alpha) and does NOT train
-    (reference interfaces.py:103-109); ``optimize`` (hyper-parameter fitting) is not part of this
-    engine's path and keeps the current hyper-parameters.
+    (reference interfaces.py:103-109); ``optimize`` fits the hyper-parameters (MAP with the
+    build_gpr priors) and then refreshes the cache (models.py:290-291).
     """
 
     def __init__(self, model: GPR, optimizer=None, num_kernel_samples: int = 10, num_rff_features: int = 1000,
@@ -206,10 +215,100 @@ class GaussianProcessRegression:
         self._engine.set_data(qp, obs[:, 0])
 
     def optimize(self, dataset: Dataset):
-        """Hyper-parameter fitting (models.py:256-321) is follow-up work: the
-        hyper-parameters are kept and the posterior cache refreshed, as after a converged fit."""
+        """MAP / maximum-likelihood fit of (lengthscales, variance, constant mean[, noise variance])
+        on ``dataset`` (reference models.py:256-321): first ``find_best_model_initialization`` --
+        ``num_kernel_samples`` x (#parameters with a prior) draws from the priors, keep the best loss --
+        then L-BFGS-B (scipy, as gpflow.optimizers.Scipy) on the log-parameters; every loss / gradient
+        evaluation is one `update` + one `tgp_nlml` on the GPU.  The loss is
+        -log p(y | theta) - sum log LogNormal(theta) with the prior density taken on the constrained
+        parameter (GPflow additionally adds the log-Jacobian of its softplus transform; the optimum of
+        the likelihood term is identical, the MAP shift differs by that Jacobian).  The posterior cache
+        is refreshed at the optimum.  Returns the scipy OptimizeResult."""
+        import scipy.optimize as spo
+
         self.update(dataset)
-        return None
+        k = self._model.kernel
+        d = self._engine.d
+        n_prior = (d if k.lengthscales_prior is not None else 0) + (1 if k.variance_prior is not None else 0)
+        if min(n_prior, self._num_kernel_samples) >= 1:
+            self.find_best_model_initialization(self._num_kernel_samples * n_prior)
+        train_noise = self._model.trainable_likelihood
+
+        def pack():
+            ls = np.broadcast_to(k.lengthscales, (d,))
+            u = [np.log(ls), [math.log(k.variance)], [self._model.mean_function.c]]
+            if train_noise:
+                u.append([math.log(self._model.likelihood_variance)])
+            return np.concatenate([np.asarray(p, dtype=np.float64).reshape(-1) for p in u])
+
+        def loss_and_grad(u):
+            ls, var, c = np.exp(u[:d]), math.exp(u[d]), float(u[d + 1])
+            noise = math.exp(u[d + 2]) if train_noise else self._model.likelihood_variance
+            try:
+                value, g = self._loss_at(ls, var, noise, c)
+            except ArithmeticError:  # failed Cholesky: a badly specified kernel (reference :312-315)
+                return 1e100, np.zeros_like(u)
+            gu = np.concatenate([g[:d] * ls, [g[d] * var], [g[d + 2]]])
+            if train_noise:
+                gu = np.concatenate([gu, [g[d + 1] * noise]])
+            return value, gu
+
+        u0 = pack()
+        res = spo.minimize(loss_and_grad, u0, jac=True, method="L-BFGS-B")
+        best = res.x if res.fun <= loss_and_grad(u0)[0] else u0
+        self.set_hyperparameters(variance=math.exp(best[d]), lengthscales=np.exp(best[:d]), mean=float(best[d + 1]),
+                                 likelihood_variance=math.exp(best[d + 2]) if train_noise else None)
+        return res
+
+    def _loss_at(self, ls, var, noise, c):
+        """-log p(y | theta) - log p(theta) and its gradient [d + 3] w.r.t. (ls, var, noise, mean) at the
+        given hyper-parameters (the engine is left at those hyper-parameters)."""
+        x, y = self._model.data
+        self._engine.set_hyper(var, ls, noise, c)
+        self._engine.set_data(x, y[:, 0])
+        value, g = self._engine.nlml()
+        g = np.array(g, dtype=np.float64)
+        k = self._model.kernel
+        if k.lengthscales_prior is not None:
+            loc, s = k.lengthscales_prior
+            z = (np.log(ls) - loc) / s
+            value += float(np.sum(np.log(ls) + math.log(s * math.sqrt(2 * math.pi)) + 0.5 * z * z))
+            g[: len(ls)] += (1.0 + z / s) / ls
+        if k.variance_prior is not None:
+            loc, s = k.variance_prior
+            z = (math.log(var) - loc) / s
+            value += math.log(var) + math.log(s * math.sqrt(2 * math.pi)) + 0.5 * z * z
+            g[len(ls)] += (1.0 + z / s) / var
+        return value, g
+
+    def training_loss(self) -> float:
+        """The loss of the current hyper-parameters (gpflow ``GPR.training_loss``)."""
+        k = self._model.kernel
+        ls = np.broadcast_to(k.lengthscales, (self._engine.d,))
+        return self._loss_at(ls, k.variance, self._model.likelihood_variance, self._model.mean_function.c)[0]
+
+    def find_best_model_initialization(self, num_kernel_samples: int, seed: Optional[int] = None) -> None:
+        """Evaluate ``num_kernel_samples`` hyper-parameter draws from the priors and keep the best
+        (reference models.py:294-321); a failed Cholesky counts as loss 1e100."""
+        k = self._model.kernel
+        d = self._engine.d
+        rng = np.random.default_rng(seed)
+        noise, c = self._model.likelihood_variance, self._model.mean_function.c
+        best_ls, best_var = np.array(np.broadcast_to(k.lengthscales, (d,))), k.variance
+        best = self._loss_at(best_ls, best_var, noise, c)[0]
+        for _ in range(num_kernel_samples):
+            ls = np.exp(rng.normal(k.lengthscales_prior[0], k.lengthscales_prior[1])) \
+                if k.lengthscales_prior is not None else best_ls
+            ls = np.broadcast_to(ls, (d,))
+            var = math.exp(rng.normal(k.variance_prior[0], k.variance_prior[1])) \
+                if k.variance_prior is not None else best_var
+            try:
+                loss = self._loss_at(ls, var, noise, c)[0]
+            except ArithmeticError:
+                loss = 1e100
+            if loss < best:
+                best, best_ls, best_var = loss, np.array(ls), var
+        self.set_hyperparameters(variance=best_var, lengthscales=best_ls)
 
     def set_hyperparameters(self, variance=None, lengthscales=None, likelihood_variance=None, mean=None) -> None:
         """Assign hyper-parameters (what a fit would do) and refresh the cache."""
