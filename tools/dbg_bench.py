@@ -10,9 +10,11 @@ eng.set_hyper(1.0, O.default_lengthscales(d), 1e-2, float(Y.mean()))
 eng.set_data(X, Y)
 eta = eng.eta()
 Xq = eng.sample_box(5678, 0, M, 0.0, 1.0)
-for name, v in (("v1 (4 waves, 128x128)", 1), ("ws (8 MFMA + 4 producer waves)", 2), ("u16 (default)", 0), ("u16 (default)", 0)):
+Xfar = eng.sample_box(5678, 0, M, 10.0, 11.0)
+for name, v, xq in (("u16", 0, Xq), ("u16 skip-gen", (1 << 8), Xq), ("u16 no diagonal skipping", (8 << 8), Xq),
+                    ("u16 far candidates (K* underflows to 0)", 0, Xfar), ("u16", 0, Xq)):
     eng.set_variant(v)
-    r0 = eng.acq_argmax("ei", eta, Xq)
-    r1 = eng.acq_argmax("ei", eta, Xq)
+    r0 = eng.acq_argmax("ei", eta, xq)
+    r1 = eng.acq_argmax("ei", eta, xq)
     ms, _ = eng.last_kernel_ms()
-    print(f"{name:42s}: {ms:8.2f} ms  -> {M*float(N)*N/ms*1e-9:6.2f} TF  best={r1[0]:.12e}@{r1[1]}", flush=True)
+    print(f"{name:42s}: {ms:8.2f} ms  -> {M*float(N)*N/ms*1e-9:6.2f} TF  best={r1[0]:.6e}@{r1[1]}", flush=True)
