@@ -70,7 +70,7 @@ struct tgp_handle_s {
   int64_t N = 0, Npad = 0;
   int variant = 0;
   // model state on device
-  DevBuf d_ls, d_X, d_Y, d_Xs, d_A, d_L, d_W, d_alpha, d_err, d_tmp1, d_tmp2, d_info;
+  DevBuf d_xn, d_ls, d_X, d_Y, d_Xs, d_A, d_L, d_W, d_alpha, d_err, d_tmp1, d_tmp2, d_info;
   // scratch
   DevBuf s_in, s_in2, s_out1, s_out2, s_out3, s_blkv, s_blki, s_small, s_kcache, s_ssq, s_aslab, s_grad;
   // timing of the dominant kernel
@@ -118,6 +118,7 @@ ModelDev model_dev(tgp_handle h) {
   m.mean_const = h->mean_const;
   m.ls = h->d_ls.as<double>();
   m.Xs = h->d_Xs.as<double>();
+  m.xn = h->d_xn.as<double>();
   m.Wt = h->d_A.as<double>();  // A is recycled as Wt after the factorisation
   m.alpha = h->d_alpha.as<double>();
   return m;
@@ -304,7 +305,7 @@ int tgp_destroy(tgp_handle h) {
   if (!h) return TGP_OK;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
-  for (DevBuf* b : {&h->d_ls, &h->d_X, &h->d_Y, &h->d_Xs, &h->d_A, &h->d_L, &h->d_W, &h->d_alpha,
+  for (DevBuf* b : {&h->d_xn, &h->d_ls, &h->d_X, &h->d_Y, &h->d_Xs, &h->d_A, &h->d_L, &h->d_W, &h->d_alpha,
                     &h->d_err, &h->d_tmp1, &h->d_tmp2, &h->d_info, &h->s_in, &h->s_in2, &h->s_out1,
                     &h->s_out2, &h->s_out3, &h->s_blkv, &h->s_blki, &h->s_small, &h->s_kcache, &h->s_ssq, &h->s_aslab, &h->s_grad})
     b->release();
@@ -361,6 +362,7 @@ int tgp_set_data(tgp_handle h, const double* X, const double* Y, int64_t N, int 
   HIPCHK(h, h->d_X.reserve((size_t)N * d * sizeof(double)));
   HIPCHK(h, h->d_Y.reserve((size_t)N * sizeof(double)));
   HIPCHK(h, h->d_Xs.reserve((size_t)Npad * dp * sizeof(double)));
+  HIPCHK(h, h->d_xn.reserve((size_t)Npad * sizeof(double)));
   HIPCHK(h, h->d_A.reserve(nn));
   HIPCHK(h, h->d_L.reserve(nn));
   HIPCHK(h, h->d_W.reserve(nn));
@@ -380,6 +382,7 @@ int tgp_set_data(tgp_handle h, const double* X, const double* Y, int64_t N, int 
   double* L = h->d_L.as<double>();
   double* W = h->d_W.as<double>();
   launch_scale_inputs(s, h->d_X.as<double>(), h->d_ls.as<double>(), h->d_Xs.as<double>(), N, Npad, d, dp);
+  launch_row_norms(s, h->d_Xs.as<double>(), h->d_xn.as<double>(), Npad, dp);
   launch_assemble_K(s, h->d_Xs.as<double>(), A, N, Npad, dp, h->kind, h->variance, h->noise);
   HIPCHK(h, hipMemsetAsync(L, 0, nn, s));
   HIPCHK(h, hipMemsetAsync(W, 0, nn, s));

@@ -28,6 +28,7 @@ struct ModelDev {       // device-resident model state (all pointers device)
   double variance, noise, mean_const;
   const double* ls;     // [dp] lengthscales padded with 1.0
   const double* Xs;     // [Npad][dp]  X / ls, zero padded
+  const double* xn;     // [Npad] |Xs_k|^2 (dot-product form of the distances in the trajectory kernel)
   const double* Wt;     // [Npad][Npad] Wt[k][i] = (L^-1)[i][k], zero outside the N x N lower part
   const double* alpha;  // [Npad] K^-1 (Y - c), zero padded
 };
@@ -67,6 +68,7 @@ void launch_gemm(hipStream_t s, bool tb, int m, int n, int k, double alpha, cons
 void launch_transpose_mask(hipStream_t s, const double* W, double* Wt, int64_t N, int64_t Npad);
 void launch_zero(hipStream_t s, double* p, int64_t n);
 void launch_center(hipStream_t s, const double* Y, double c, double* err, int64_t N, int64_t Npad);
+void launch_row_norms(hipStream_t s, const double* Xs, double* xn, int64_t Npad, int dp);
 // y[i] = sum_k M[i][k] x[k] over k in [klo(i), khi(i)] ; lower: k<=i ; upper: k>=i
 void launch_trmv(hipStream_t s, const double* Mx, int64_t ld, int64_t n, const double* x, double* y,
                  bool lower);

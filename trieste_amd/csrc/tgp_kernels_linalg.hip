@@ -244,6 +244,17 @@ void launch_center(hipStream_t s, const double* Y, double c, double* err, int64_
                      Npad);
 }
 
+__global__ void row_norms_kernel(const double* __restrict__ Xs, double* __restrict__ xn, int64_t Npad, int dp) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= Npad) return;
+  double s = 0.0;
+  for (int c = 0; c < dp; ++c) s = fma(Xs[t * dp + c], Xs[t * dp + c], s);
+  xn[t] = s;
+}
+void launch_row_norms(hipStream_t s, const double* Xs, double* xn, int64_t Npad, int dp) {
+  hipLaunchKernelGGL(row_norms_kernel, dim3((unsigned)((Npad + 255) / 256)), dim3(256), 0, s, Xs, xn, Npad, dp);
+}
+
 // one wave per row: y[i] = sum_{k in tri range} M[i][k] x[k]
 __global__ __launch_bounds__(256) void trmv_kernel(const double* __restrict__ Mx, int64_t ld, int64_t n,
                                                    const double* __restrict__ x, double* __restrict__ y,

@@ -1,0 +1,168 @@
+// Decoupled Thompson trajectories on gfx950.
+//   f_b(x) = sum_f phi_f(x) ws[f][b] + sum_k k(x, X_k) v[k][b] + c,   phi_f(x) = cos((x / ls) . W_f + b_f)
+// (the sqrt(2 variance / F) factor is folded into ws).  == ResampleableDecoupledFeatureFunctions.call
+// (reference sampler.py:846-855) + gpflux RandomFourierFeaturesCosine + feature_decomposition_
+// trajectory.__call__ (sampler.py:923-936).  One thread per candidate; basis rows, training rows and
+// weights come through scalar loads; the [M, F + N] feature matrix is never materialised (SURVEY
+// K10, K11).  The kernel is fp64-VALU bound, so the per-pair instruction count is what matters:
+// distances use r2 = |a|^2 + |b|^2 - 2 a.b (D fused multiply-adds instead of 2 D), sqrt / exp / cos
+// are the branch-free forms of tgp_dev.hpp.
+#include "tgp_dev.hpp"
+#include "tgp_internal.hpp"
+
+namespace tgp {
+
+constexpr int TRAJ_MAXB = 16;
+
+template <int KIND, int DP, int BP>
+__global__ __launch_bounds__(256) void traj_eval_kernel(TrajDev t, const double* __restrict__ Xq,
+                                                        int64_t M, int per_traj, int rff_only,
+                                                        double* __restrict__ out,
+                                                        double* __restrict__ blk_val,
+                                                        int64_t* __restrict__ blk_idx,
+                                                        int64_t index_base) {
+  // per_traj: logical item = (candidate j, trajectory b) with its own input row; else item = j.
+  const int B = t.B, d = t.m.d;
+  const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t nitems = per_traj ? M * B : M;
+  const bool valid = item < nitems;
+  const int myb = per_traj ? (int)(item % B) : 0;
+  double xq[DP];
+  double nb = 0.0;
+#pragma unroll
+  for (int c = 0; c < DP; ++c) {
+    xq[c] = (c < d && valid) ? Xq[item * d + c] / as_const(t.m.ls)[c] : 0.0;
+    nb = fma(xq[c], xq[c], nb);
+  }
+  double acc[BP];
+#pragma unroll
+  for (int b = 0; b < BP; ++b) acc[b] = 0.0;
+
+  const cptr W = as_const(t.rffW);
+  const cptr bb = as_const(t.rffb);
+  const cptr ws = as_const(t.ws);
+#pragma unroll 2
+  for (int f = 0; f < t.F; ++f) {
+    double arg = bb[f];
+#pragma unroll
+    for (int c = 0; c < DP; ++c) arg = fma(xq[c], W[(int64_t)f * DP + c], arg);
+    const double ph = fast_cos(arg);
+    if (per_traj) {
+      acc[0] = fma(ph, t.ws[(int64_t)f * B + myb], acc[0]);
+    } else {
+#pragma unroll
+      for (int b = 0; b < BP; ++b)
+        if (b < B) acc[b] = fma(ph, ws[(int64_t)f * B + b], acc[b]);
+    }
+  }
+  if (!rff_only) {
+    const cptr xs = as_const(t.m.Xs);
+    const cptr xn = as_const(t.m.xn);
+    const cptr vv = as_const(t.v);
+    const double variance = t.m.variance;
+#pragma unroll 2
+    for (int64_t k = 0; k < t.m.N; ++k) {
+      double dot = 0.0;
+#pragma unroll
+      for (int c = 0; c < DP; ++c) dot = fma(xq[c], xs[k * DP + c], dot);
+      const double r2 = fmax(fma(-2.0, dot, nb + xn[k]), 0.0);
+      const double kv = kernel_from_r2<KIND>(r2, variance);
+      if (per_traj) {
+        acc[0] = fma(kv, t.v[k * B + myb], acc[0]);
+      } else {
+#pragma unroll
+        for (int b = 0; b < BP; ++b)
+          if (b < B) acc[b] = fma(kv, vv[k * B + b], acc[b]);
+      }
+    }
+  }
+  const double c0 = rff_only ? 0.0 : t.m.mean_const;
+  if (out && valid) {
+    if (per_traj) out[item] = acc[0] + c0;
+    else {
+#pragma unroll
+      for (int b = 0; b < BP; ++b)
+        if (b < B) out[item * B + b] = acc[b] + c0;
+    }
+  }
+  if (blk_val) {  // per-workgroup arg-min per trajectory (shared-input mode only)
+    __shared__ double wv[4][TRAJ_MAXB];
+    __shared__ int64_t wi[4][TRAJ_MAXB];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int b = 0; b < BP; ++b) {
+      if (b < B) {
+        double v = valid ? -(acc[b] + c0) : -INFINITY;  // arg-min == arg-max of the negation
+        if (v != v) v = -INFINITY;
+        int64_t i = valid ? index_base + item : INT64_MAX;
+        wave_argmax(v, i);
+        if (lane == 0) {
+          wv[w][b] = v;
+          wi[w][b] = i;
+        }
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < B) {
+      const int b = threadIdx.x;
+      double v = wv[0][b];
+      int64_t i = wi[0][b];
+      for (int ww = 1; ww < 4; ++ww)
+        if (better(wv[ww][b], wi[ww][b], v, i)) {
+          v = wv[ww][b];
+          i = wi[ww][b];
+        }
+      blk_val[(int64_t)blockIdx.x * B + b] = -v;
+      blk_idx[(int64_t)blockIdx.x * B + b] = i;
+    }
+  }
+}
+
+template <int KIND, int DP>
+static void launch_traj_bp(hipStream_t s, const TrajDev& t, const double* Xq, int64_t M, int per_traj,
+                           int rff_only, double* out, double* bv, int64_t* bi, int64_t base) {
+  const int64_t nitems = per_traj ? M * t.B : M;
+  dim3 g((unsigned)((nitems + 255) / 256)), b(256);
+  const int B = per_traj ? 1 : t.B;
+  if (B <= 1) hipLaunchKernelGGL((traj_eval_kernel<KIND, DP, 1>), g, b, 0, s, t, Xq, M, per_traj, rff_only, out, bv, bi, base);
+  else if (B <= 4) hipLaunchKernelGGL((traj_eval_kernel<KIND, DP, 4>), g, b, 0, s, t, Xq, M, per_traj, rff_only, out, bv, bi, base);
+  else hipLaunchKernelGGL((traj_eval_kernel<KIND, DP, 16>), g, b, 0, s, t, Xq, M, per_traj, rff_only, out, bv, bi, base);
+}
+
+template <int KIND>
+static void launch_traj_dp(hipStream_t s, const TrajDev& t, const double* Xq, int64_t M, int per_traj,
+                           int rff_only, double* out, double* bv, int64_t* bi, int64_t base) {
+  switch (t.m.dp) {
+    case 2: launch_traj_bp<KIND, 2>(s, t, Xq, M, per_traj, rff_only, out, bv, bi, base); break;
+    case 4: launch_traj_bp<KIND, 4>(s, t, Xq, M, per_traj, rff_only, out, bv, bi, base); break;
+    case 6: launch_traj_bp<KIND, 6>(s, t, Xq, M, per_traj, rff_only, out, bv, bi, base); break;
+    case 8: launch_traj_bp<KIND, 8>(s, t, Xq, M, per_traj, rff_only, out, bv, bi, base); break;
+    case 16: launch_traj_bp<KIND, 16>(s, t, Xq, M, per_traj, rff_only, out, bv, bi, base); break;
+    default: launch_traj_bp<KIND, 32>(s, t, Xq, M, per_traj, rff_only, out, bv, bi, base); break;
+  }
+}
+
+static void launch_traj_any(hipStream_t s, const TrajDev& t, const double* Xq, int64_t M, int per_traj,
+                            int rff_only, double* out, double* bv, int64_t* bi, int64_t base) {
+  switch (t.m.kind) {
+    case KIND_RBF: launch_traj_dp<KIND_RBF>(s, t, Xq, M, per_traj, rff_only, out, bv, bi, base); break;
+    case KIND_M12: launch_traj_dp<KIND_M12>(s, t, Xq, M, per_traj, rff_only, out, bv, bi, base); break;
+    case KIND_M32: launch_traj_dp<KIND_M32>(s, t, Xq, M, per_traj, rff_only, out, bv, bi, base); break;
+    default: launch_traj_dp<KIND_M52>(s, t, Xq, M, per_traj, rff_only, out, bv, bi, base); break;
+  }
+}
+
+int64_t traj_grid(int64_t M) { return (M + 255) / 256; }
+
+void launch_traj_eval(hipStream_t s, const TrajDev& t, const double* Xq, int64_t M, int per_traj,
+                      double* out, double* blk_val, int64_t* blk_idx, int64_t index_base) {
+  launch_traj_any(s, t, Xq, M, per_traj, 0, out, blk_val, blk_idx, index_base);
+}
+
+// Phi_Z w at a set of RAW points (the training inputs): out [npts][B] = sum_f phi_f(x) ws[f][b]
+// (sampler.py:726 `phi_Z @ prior_weights`).
+void launch_rff_project(hipStream_t s, const TrajDev& t, const double* X_raw, int64_t npts, double* out) {
+  launch_traj_any(s, t, X_raw, npts, 0, 1, out, nullptr, nullptr, 0);
+}
+
+}  // namespace tgp
