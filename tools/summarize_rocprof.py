@@ -14,8 +14,8 @@ for path in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{rnd}_*", "
     tag = os.path.basename(os.path.dirname(path))
     db = sqlite3.connect(path)
     cur = db.cursor()
-    lines.append(f"==== {tag}: rocprofv3 --kernel-trace --stats equivalent (view top_kernels; durations in ns)")
-    lines.append(f"{'kernel':100s} {'calls':>6s} {'total_ns':>14s} {'avg_ns':>14s} {'pct':>7s}")
+    lines.append(f"==== {tag}: rocprofv3 --kernel-trace --stats equivalent (view top_kernels; durations in us)")
+    lines.append(f"{'kernel':100s} {'calls':>6s} {'total_us':>14s} {'avg_us':>14s} {'pct':>7s}")
     for name, calls, total, avg, pct in cur.execute("select * from top_kernels limit 14"):
         lines.append(f"{name[:100]:100s} {calls:6d} {total:14.0f} {avg:14.0f} {pct:7.2f}")
     rows = list(cur.execute(

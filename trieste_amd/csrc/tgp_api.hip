@@ -11,6 +11,7 @@
 #include <limits>
 #include <new>
 #include <string>
+#include <chrono>
 #include <vector>
 
 #include "tgp_internal.hpp"
@@ -243,13 +244,13 @@ void chol_inv(tgp_handle h, int64_t lo, int64_t hi) {
   double* L21 = L + mid * ld + lo;
   double* W11 = W + lo * ld + lo;
   double* A22 = A + mid * ld + mid;
-  launch_gemm(h->stream, true, s2, s1, s1, 1.0, A21, ld, W11, ld, 0.0, L21, ld, false);
+  launch_gemm(h->stream, true, s2, s1, s1, 1.0, A21, ld, W11, ld, 0.0, L21, ld, false, 1);
   launch_gemm(h->stream, true, s2, s2, s1, -1.0, L21, ld, L21, ld, 1.0, A22, ld, true);
   chol_inv(h, mid, hi);
   double* W22 = W + mid * ld + mid;
   double* W21 = W + mid * ld + lo;
-  launch_gemm(h->stream, false, s2, s1, s1, 1.0, L21, ld, W11, ld, 0.0, A21, ld, false);
-  launch_gemm(h->stream, false, s2, s1, s2, -1.0, W22, ld, A21, ld, 0.0, W21, ld, false);
+  launch_gemm(h->stream, false, s2, s1, s1, 1.0, L21, ld, W11, ld, 0.0, A21, ld, false, 2);
+  launch_gemm(h->stream, false, s2, s1, s2, -1.0, W22, ld, A21, ld, 0.0, W21, ld, false, 3);
 }
 
 }  // namespace
@@ -386,7 +387,18 @@ int tgp_set_data(tgp_handle h, const double* X, const double* Y, int64_t N, int 
   launch_assemble_K(s, h->d_Xs.as<double>(), A, N, Npad, dp, h->kind, h->variance, h->noise);
   HIPCHK(h, hipMemsetAsync(L, 0, nn, s));
   HIPCHK(h, hipMemsetAsync(W, 0, nn, s));
+  static const bool timing = getenv("TGP_TIMING") != nullptr;  // development aid: enqueue vs execution time
+  std::chrono::steady_clock::time_point tq0;
+  if (timing) { (void)hipStreamSynchronize(s); tq0 = std::chrono::steady_clock::now(); }
   chol_inv(h, 0, Npad);
+  if (timing) {
+    const auto tq1 = std::chrono::steady_clock::now();
+    (void)hipStreamSynchronize(s);
+    const auto tq2 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[tgp] chol_inv N=%lld: enqueue %.3f ms, total %.3f ms\n", (long long)Npad,
+            std::chrono::duration<double, std::milli>(tq1 - tq0).count(),
+            std::chrono::duration<double, std::milli>(tq2 - tq0).count());
+  }
   // err = Y - c (zero padded)  -- gpflow GPRPosterior._precompute: err = Y - mean_function(X)
   launch_center(s, h->d_Y.as<double>(), h->mean_const, h->d_err.as<double>(), N, Npad);
   // Wt (into A, dead now) = masked transpose of W; alpha = Wt (W err)
@@ -418,7 +430,7 @@ int tgp_nlml(tgp_handle h, double* value, double* grad) {
   double* out = h->s_small.as<double>() + 8;
   // Kinv = W^T W  (Wt is in d_A, W in d_W; both carry explicit zeros outside their triangles)
   launch_gemm(h->stream, false, (int)Npad, (int)Npad, (int)Npad, 1.0, h->d_A.as<double>(), Npad, h->d_W.as<double>(),
-              Npad, 0.0, Kinv, Npad, false);
+              Npad, 0.0, Kinv, Npad, false, 4);
   launch_nlml(h->stream, model_dev(h), Kinv, h->d_L.as<double>(), h->d_err.as<double>(), h->s_blkv.as<double>(), out);
   std::vector<double> host((size_t)np);
   HIPCHK(h, hipMemcpyAsync(host.data(), out, (size_t)np * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -577,9 +589,9 @@ int tgp_acq_value_grad(tgp_handle h, int acq_kind, double param, const double* X
   launch_kstar_t(h->stream, m, dXq, P, Ppad, B);
   // C1 = W B (W = L^-1, lower triangular incl. explicit zeros), Z = W^T C1 = K^-1 k*
   launch_gemm(h->stream, false, (int)Npad, (int)Ppad, (int)Npad, 1.0, h->d_W.as<double>(), Npad, B, Ppad, 0.0, C1,
-              Ppad, false);
+              Ppad, false, 3);
   launch_gemm(h->stream, false, (int)Npad, (int)Ppad, (int)Npad, 1.0, h->d_A.as<double>(), Npad, C1, Ppad, 0.0, Z,
-              Ppad, false);
+              Ppad, false, 5);
   launch_grad_tail(h->stream, m, dXq, P, Ppad, B, C1, Z, acq_kind, param, dval, dgrad);
   if (int rc = stage_out_finish(h, dval, val, P, where)) return rc;
   if (int rc = stage_out_finish(h, dgrad, grad, (size_t)P * h->d, where)) return rc;

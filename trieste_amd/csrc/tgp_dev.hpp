@@ -44,6 +44,25 @@ __device__ __forceinline__ double fast_sqrt_pos(double x) {
   return g;
 }
 
+// sqrt(x) and 1/sqrt(x) together (x > 0, normal range): the coupled Goldschmidt pair of the routine
+// above, g -> sqrt(x), h -> 1 / (2 sqrt(x)); both within ~1 ulp.
+__device__ __forceinline__ void sqrt_and_rsqrt(double x, double& g_out, double& rs_out) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  const double dd = fma(-g, g, x);
+  g = fma(dd, h, g);
+  r = fma(-h, g, 0.5);   // one more correction of h against the final g
+  h = fma(h, r, h);
+  g_out = g;
+  rs_out = h + h;
+}
+
 // exp(x) for x <= 0.  n = rint(x / ln2), r = x - n ln2 (two-term Cody-Waite), degree-11
 // Chebyshev-fitted polynomial on |r| <= ln2/2 (relative error 4.2e-18), ldexp.
 __device__ __forceinline__ double fast_exp_nonpos(double x) {

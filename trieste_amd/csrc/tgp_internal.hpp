@@ -64,7 +64,7 @@ void launch_leaf(hipStream_t s, const double* A, double* L, double* W, int64_t l
                  int* info);
 // C[m x n] = alpha * A[m x k] * op(B) + beta * C ;  TB: B stored [n x k] (row-major), else [k x n]
 void launch_gemm(hipStream_t s, bool tb, int m, int n, int k, double alpha, const double* A, int64_t lda,
-                 const double* B, int64_t ldb, double beta, double* C, int64_t ldc, bool lower_only);
+                 const double* B, int64_t ldb, double beta, double* C, int64_t ldc, bool lower_only, int tri = 0);
 void launch_transpose_mask(hipStream_t s, const double* W, double* Wt, int64_t N, int64_t Npad);
 void launch_zero(hipStream_t s, double* p, int64_t n);
 void launch_center(hipStream_t s, const double* Y, double c, double* err, int64_t N, int64_t Npad);

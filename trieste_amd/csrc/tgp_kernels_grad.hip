@@ -151,37 +151,58 @@ namespace tgp {
 
 constexpr int NG_MAXP = MAX_D + 2;  // d lengthscales + variance + noise
 
+// One workgroup per 64x64 tile of (i, j) pairs: lane -> j (coalesced Kinv rows, X_j in registers),
+// wave -> 16 rows i (wave-uniform: X_i, alpha_i come through scalar loads).  One wave reduction per
+// parameter per workgroup at the end.
+template <int DP>
 __global__ __launch_bounds__(256) void nlml_grad_kernel(ModelDev m, const double* __restrict__ Kinv,
                                                         double* __restrict__ partial) {
-  __shared__ double red[4][NG_MAXP];
+  __shared__ double red[4][DP + 2];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int64_t j = (int64_t)blockIdx.x * 16 + (tid & 15);
-  const int64_t i = (int64_t)blockIdx.y * 16 + (tid >> 4);
+  const int64_t j = (int64_t)blockIdx.x * 64 + lane;
+  const int64_t i0 = (int64_t)blockIdx.y * 64 + w * 16;
   const int d = m.d;
-  double acc[NG_MAXP];
-  for (int c = 0; c < d + 2; ++c) acc[c] = 0.0;
-  if (i < m.N && j < m.N) {
-    const double G = Kinv[i * m.Npad + j] - m.alpha[i] * m.alpha[j];
-    double r2 = 0.0, ds2[MAX_D];
-    for (int c = 0; c < d; ++c) {
-      const double t = m.Xs[i * m.dp + c] - m.Xs[j * m.dp + c];
+  const bool jv = j < m.N;
+  double xj[DP], acc[DP + 2];
+#pragma unroll
+  for (int c = 0; c < DP; ++c) xj[c] = m.Xs[j * DP + c];  // j < Npad always; padding rows are zero
+#pragma unroll
+  for (int c = 0; c < DP + 2; ++c) acc[c] = 0.0;
+  const double aj = m.alpha[j];
+  const cptr xs = as_const(m.Xs);
+  const cptr al = as_const(m.alpha);
+  for (int r = 0; r < 16; ++r) {
+    const int64_t i = i0 + r;
+    if (i >= m.N) break;  // wave-uniform
+    const double G = jv ? Kinv[i * m.Npad + j] - al[i] * aj : 0.0;
+    double r2 = 0.0, ds2[DP];
+#pragma unroll
+    for (int c = 0; c < DP; ++c) {
+      const double t = xs[i * DP + c] - xj[c];
       ds2[c] = t * t;
       r2 += ds2[c];
     }
-    const double f1 = kernel_dr2(m.kind, r2, m.variance);         // variance * f'(r2)
-    const double kij = kernel_rt(m.kind, r2, m.variance);         // without the noise
-    for (int c = 0; c < d; ++c) acc[c] = G * f1 * (-2.0 * ds2[c] / m.ls[c]);
-    acc[d] = G * kij / m.variance;
-    acc[d + 1] = (i == j) ? G : 0.0;
+    const double f1 = G * kernel_dr2(m.kind, r2, m.variance);  // variance * f'(r2)
+    const double kij = kernel_rt(m.kind, r2, m.variance);      // without the noise
+#pragma unroll
+    for (int c = 0; c < DP; ++c) acc[c] = fma(f1, ds2[c], acc[c]);
+    acc[DP] = fma(G, kij, acc[DP]);
+    acc[DP + 1] += (i == j) ? G : 0.0;
   }
-  for (int c = 0; c < d + 2; ++c) {
+#pragma unroll
+  for (int c = 0; c < DP + 2; ++c) {
     const double s = wave_sum(acc[c]);
     if (lane == 0) red[w][c] = s;
   }
   __syncthreads();
   if (tid < d + 2) {
+    // slot order of `partial`: d lengthscale terms, variance, noise
+    const int src = tid < d ? tid : DP + (tid - d);
+    double v = (red[0][src] + red[1][src]) + (red[2][src] + red[3][src]);
+    if (tid < d) v *= -2.0 / m.ls[tid];
+    else if (tid == d) v /= m.variance;
     const int64_t b = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
-    partial[b * NG_MAXP + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    partial[b * NG_MAXP + tid] = v;
   }
 }
 
@@ -216,12 +237,19 @@ __global__ __launch_bounds__(256) void nlml_final_kernel(ModelDev m, const doubl
   }
 }
 
-int64_t nlml_blocks(int64_t Npad) { return (Npad / 16) * (Npad / 16); }
+int64_t nlml_blocks(int64_t Npad) { return (Npad / 64) * (Npad / 64); }
 
 void launch_nlml(hipStream_t s, const ModelDev& m, const double* Kinv, const double* L, const double* err,
                  double* partial, double* out) {
-  dim3 grid((unsigned)(m.Npad / 16), (unsigned)(m.Npad / 16));
-  hipLaunchKernelGGL(nlml_grad_kernel, grid, dim3(256), 0, s, m, Kinv, partial);
+  dim3 grid((unsigned)(m.Npad / 64), (unsigned)(m.Npad / 64));
+  switch (m.dp) {
+    case 2: hipLaunchKernelGGL(nlml_grad_kernel<2>, grid, dim3(256), 0, s, m, Kinv, partial); break;
+    case 4: hipLaunchKernelGGL(nlml_grad_kernel<4>, grid, dim3(256), 0, s, m, Kinv, partial); break;
+    case 6: hipLaunchKernelGGL(nlml_grad_kernel<6>, grid, dim3(256), 0, s, m, Kinv, partial); break;
+    case 8: hipLaunchKernelGGL(nlml_grad_kernel<8>, grid, dim3(256), 0, s, m, Kinv, partial); break;
+    case 16: hipLaunchKernelGGL(nlml_grad_kernel<16>, grid, dim3(256), 0, s, m, Kinv, partial); break;
+    default: hipLaunchKernelGGL(nlml_grad_kernel<32>, grid, dim3(256), 0, s, m, Kinv, partial); break;
+  }
   hipLaunchKernelGGL(nlml_final_kernel, dim3(1), dim3(256), 0, s, m, L, err, partial, nlml_blocks(m.Npad), out);
 }
 

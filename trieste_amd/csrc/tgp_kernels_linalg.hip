@@ -5,6 +5,7 @@
 // Replaces (reference call sites): self.model.kernel(x) and tf.linalg.cholesky(K + s) inside
 // gpflow GPRPosterior._precompute reached from trieste/models/gpflow/models.py:171-186 ->
 // interface.py:108-112.  
+#include <cstdlib>
 #include "tgp_dev.hpp"
 #include "tgp_internal.hpp"
 
@@ -57,58 +58,75 @@ void launch_assemble_K(hipStream_t s, const double* Xs, double* A, int64_t N, in
 }
 
 // ---------------------------------------------------------------------------------------------
-// Leaf: Cholesky of a 64x64 diagonal block and the inverse of its factor, one workgroup.
+// Leaf: Cholesky factor L of a 64x64 diagonal block AND W = L^-1, one workgroup of 256 threads.
 // info: 0 = ok, else 1 + global index of the first non-positive pivot.
+//
+// Register-resident right-looking elimination.  Thread (i = tid >> 2, p = tid & 3) owns the 16
+// entries {A[i][p + 4m]} of row i of the (symmetric) trailing matrix and the same 16 entries of
+// row i of T, which starts as the identity and ends as L^-1 (T <- L_j^-1 T for j = 0..63 is the
+// same rank-1 update shape as the trailing update, so both ride on one broadcast per step).
+// Step j (fully unrolled, so every register index is static):
+//   owners of column j of A and of row j of T publish them through a double-buffered LDS strip,
+//   ONE barrier, then every thread applies
+//       A[i][k] -= A[i][j] A[k][j] / d_j   (k > j)        T[i][c] -= A[i][j] T[j][c] / d_j   (i > j, c <= j)
+//   and the owner of (i, j) overwrites its dead A register with L[i][j] = A[i][j] / sqrt(d_j).
+// 17 fused multiply-adds and ~10 LDS reads per thread per step; the upper triangle of A is updated
+// too (never read back) which removes every row/column predicate except "k > j" in one register.
 __global__ __launch_bounds__(256) void leaf_kernel(const double* __restrict__ A, double* __restrict__ L,
                                                    double* __restrict__ W, int64_t ld, int64_t off,
                                                    int* __restrict__ info) {
-  __shared__ double S[LEAF][LEAF + 1];
-  __shared__ double T[LEAF][LEAF + 1];
+  // strips are laid out [p][m] so that a thread's 16 entries are contiguous (b128 reads)
+  __shared__ __attribute__((aligned(16))) double colbuf[2][LEAF];
+  __shared__ __attribute__((aligned(16))) double rowbuf[2][LEAF];
   const int tid = threadIdx.x;
-  for (int e = tid; e < LEAF * LEAF; e += 256) {
-    const int i = e >> 6, j = e & 63;
-    S[i][j] = (j <= i) ? A[(off + i) * ld + off + j] : 0.0;
-    T[i][j] = 0.0;
+  const int i = tid >> 2, p = tid & 3;
+  double a[16], t[16], myrs = 1.0;
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {
+    const int k = p + 4 * m;
+    // symmetric fill from the lower triangle (the upper one of the global block is not trusted)
+    a[m] = (k <= i) ? A[(off + i) * ld + off + k] : A[(off + k) * ld + off + i];
+    t[m] = (k == i) ? 1.0 : 0.0;
   }
+#pragma unroll
   for (int j = 0; j < LEAF; ++j) {
-    __syncthreads();  // loads / trailing update of step j-1 complete
-    double dj = S[j][j];
+    const int jm = j >> 2, jp = j & 3, bsel = j & 1;
+    if (p == jp) colbuf[bsel][(i & 3) * 16 + (i >> 2)] = a[jm];
+    if (i == j) {
+#pragma unroll
+      for (int m = 0; m <= jm; ++m) rowbuf[bsel][p * 16 + m] = t[m];
+    }
+    __syncthreads();
+    double dj = colbuf[bsel][jp * 16 + jm];
     if (!(dj > 0.0)) {  // also catches NaN
       if (tid == 0) atomicCAS(info, 0, (int)(off + j) + 1);
       dj = 1.0;
     }
-    const double sd = sqrt(dj);
-    __syncthreads();
-    if (tid < LEAF) {
-      if (tid == j) S[j][j] = sd;
-      else if (tid > j) S[tid][j] = S[tid][j] / sd;
+    double sd, rs;
+    sqrt_and_rsqrt(dj, sd, rs);  // ~15 instructions instead of the ~100 of three IEEE divisions + sqrt
+    const double inv = rs * rs;
+    const double lij = colbuf[bsel][(i & 3) * 16 + (i >> 2)];
+    const double f = lij * inv;
+    // trailing update of A, columns k = p + 4m > j
+#pragma unroll
+    for (int m = jm; m < 16; ++m) {
+      const double ck = colbuf[bsel][p * 16 + m];
+      const double upd = fma(-f, ck, a[m]);
+      a[m] = (m > jm || p > jp) ? upd : a[m];
     }
-    __syncthreads();
-    // trailing update of the lower triangle: S[i][k] -= S[i][j] * S[k][j], j < k <= i
-    const int i = tid >> 2;
-    if (i > j) {
-      const double lij = S[i][j];
-      for (int k = j + 1 + (tid & 3); k <= i; k += 4) S[i][k] = fma(-lij, S[k][j], S[i][k]);
-    }
+    if (p == jp) a[jm] = (i == j) ? sd : lij * rs;  // L[i][j] (rows i < j hold garbage, masked on store)
+    // T <- L_j^-1 T: rows i > j take -L[i][j] * (row j / sd) = -(lij / dj) * (unscaled row j); the
+    // 1/sd scaling of row j itself is deferred to the store (branch-free: no register-array copies).
+    const double ft = (i > j) ? f : 0.0;
+    myrs = (i == j) ? rs : myrs;
+#pragma unroll
+    for (int m = 0; m <= jm; ++m) t[m] = fma(-ft, rowbuf[bsel][p * 16 + m], t[m]);
   }
-  __syncthreads();
-  // T = S^-1 by forward substitution, one column per lane of wave 0.
-  if (tid < LEAF) {
-    const int c = tid;
-    for (int i = 0; i < LEAF; ++i) {
-      double acc = (i == c) ? 1.0 : 0.0;
-      for (int k = 0; k < i; ++k) {
-        const double t = (k >= c) ? T[k][c] : 0.0;
-        acc = fma(-S[i][k], t, acc);
-      }
-      if (i >= c) T[i][c] = acc / S[i][i];
-    }
-  }
-  __syncthreads();
-  for (int e = tid; e < LEAF * LEAF; e += 256) {
-    const int i = e >> 6, j = e & 63;
-    L[(off + i) * ld + off + j] = (j <= i) ? S[i][j] : 0.0;
-    W[(off + i) * ld + off + j] = (j <= i) ? T[i][j] : 0.0;
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {
+    const int k = p + 4 * m;
+    L[(off + i) * ld + off + k] = (k <= i) ? a[m] : 0.0;
+    W[(off + i) * ld + off + k] = (k <= i) ? t[m] * myrs : 0.0;
   }
 }
 
@@ -122,18 +140,24 @@ void launch_leaf(hipStream_t s, const double* A, double* L, double* W, int64_t l
 // v_mfma_f64_16x16x4_f64.  m, n multiples of 64; k multiple of 16.  Operand tiles are staged in
 // LDS k-major ([k][m] / [k][n]) with a +16-double row pad so that the 4 k-rows a fragment read
 // touches fall on disjoint bank halves.
-constexpr int GB = 64, GK = 16, GLD = GB + 16;
+constexpr int GB = 64, GLD = GB + 16;
 
-template <bool TB>
+
+// `tri` prunes the k range per output tile when one operand is lower triangular (the factor
+// recursion of tgp_api.hip):  1: B^T with B lower (k < (tn+1) 64);  2: B lower, not transposed
+// (k >= tn 64);  3: A lower (k < (tm+1) 64);  4: A upper and B lower (k >= max(tm, tn) 64);
+// 5: A upper (k >= tm 64).  Global loads of step k0+16 are in flight while the
+// MFMAs of step k0 run (register prefetch), so a step costs max(load, math) instead of the sum.
+template <bool TB, int GKT>
 __global__ __launch_bounds__(256) void gemm_kernel(int m, int n, int k, double alpha,
                                                    const double* __restrict__ A, int64_t lda,
                                                    const double* __restrict__ B, int64_t ldb,
                                                    double beta, double* __restrict__ C, int64_t ldc,
-                                                   int lower_only) {
+                                                   int lower_only, int tri) {
   const int tn = blockIdx.x, tm = blockIdx.y;
   if (lower_only && tn > tm) return;
-  __shared__ double As[GK][GLD];
-  __shared__ double Bs[GK][GLD];
+  __shared__ double As[GKT][GLD];
+  __shared__ double Bs[GKT][GLD];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = w >> 1, wn = w & 1;
   v4d acc[2][2];
@@ -142,30 +166,51 @@ __global__ __launch_bounds__(256) void gemm_kernel(int m, int n, int k, double a
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
 
+  int klo = 0, khi = k;
+  if (tri == 1) khi = min(k, (tn + 1) * GB);
+  else if (tri == 2) klo = min(k, tn * GB);
+  else if (tri == 3) khi = min(k, (tm + 1) * GB);
+  else if (tri == 4) klo = min(k, max(tm, tn) * GB);
+  else if (tri == 5) klo = min(k, tm * GB);
+
   const double* Ab = A + (int64_t)tm * GB * lda;
   const double* Bb = TB ? B + (int64_t)tn * GB * ldb : B + (int64_t)tn * GB;
   const int lr = tid >> 2, lk = (tid & 3) * 4;       // [row][k..k+3] loader (A, and B when TB)
   const int br = tid >> 4, bc = (tid & 15) * 4;      // [k][n..n+3] loader (B when !TB)
+  constexpr int NS = GKT / 16;                       // 16-deep k slices per step
 
-  for (int k0 = 0; k0 < k; k0 += GK) {
-    {
-      const double* src = Ab + (int64_t)lr * lda + k0 + lk;
-      const v2d x0 = *(const v2d*)src, x1 = *(const v2d*)(src + 2);
-      As[lk + 0][lr] = x0.x; As[lk + 1][lr] = x0.y; As[lk + 2][lr] = x1.x; As[lk + 3][lr] = x1.y;
+  v2d a0[NS], a1[NS], b0[NS], b1[NS];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+      const double* sa = Ab + (int64_t)lr * lda + k0 + q * 16 + lk;
+      a0[q] = *(const v2d*)sa;
+      a1[q] = *(const v2d*)(sa + 2);
+      const double* sb = TB ? Bb + (int64_t)lr * ldb + k0 + q * 16 + lk
+                            : Bb + (int64_t)(k0 + q * 16 + br) * ldb + bc;
+      b0[q] = *(const v2d*)sb;
+      b1[q] = *(const v2d*)(sb + 2);
     }
-    if (TB) {
-      const double* src = Bb + (int64_t)lr * ldb + k0 + lk;
-      const v2d x0 = *(const v2d*)src, x1 = *(const v2d*)(src + 2);
-      Bs[lk + 0][lr] = x0.x; Bs[lk + 1][lr] = x0.y; Bs[lk + 2][lr] = x1.x; Bs[lk + 3][lr] = x1.y;
-    } else {
-      const double* src = Bb + (int64_t)(k0 + br) * ldb + bc;
-      const v2d x0 = *(const v2d*)src, x1 = *(const v2d*)(src + 2);
-      *(v2d*)&Bs[br][bc] = x0;
-      *(v2d*)&Bs[br][bc + 2] = x1;
+  };
+  if (klo < khi) fetch(klo);
+  for (int k0 = klo; k0 < khi; k0 += GKT) {
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+      const int kq = q * 16;
+      As[kq + lk + 0][lr] = a0[q].x; As[kq + lk + 1][lr] = a0[q].y;
+      As[kq + lk + 2][lr] = a1[q].x; As[kq + lk + 3][lr] = a1[q].y;
+      if (TB) {
+        Bs[kq + lk + 0][lr] = b0[q].x; Bs[kq + lk + 1][lr] = b0[q].y;
+        Bs[kq + lk + 2][lr] = b1[q].x; Bs[kq + lk + 3][lr] = b1[q].y;
+      } else {
+        *(v2d*)&Bs[kq + br][bc] = b0[q];
+        *(v2d*)&Bs[kq + br][bc + 2] = b1[q];
+      }
     }
     __syncthreads();
+    if (k0 + GKT < khi) fetch(k0 + GKT);
 #pragma unroll
-    for (int k4 = 0; k4 < GK / 4; ++k4) {
+    for (int k4 = 0; k4 < GKT / 4; ++k4) {
       const int kr = k4 * 4 + (lane >> 4);
       double a[2], b[2];
 #pragma unroll
@@ -194,16 +239,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(int m, int n, int k, double a
       }
 }
 
+// k must be a multiple of 32 (all call sites pass multiples of 64).
+// Measured (profiles/r01_update_breakdown.txt): a dependent kernel costs ~5 us on this part however
+// small it is, and the 64x64-tile kernel is L2/MALL-bandwidth bound (8 flop per byte) on the large
+// nodes of the recursion; splitting k over more waves did not change either and was dropped.
 void launch_gemm(hipStream_t s, bool tb, int m, int n, int k, double alpha, const double* A,
                  int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc,
-                 bool lower_only) {
+                 bool lower_only, int tri) {
   dim3 grid((unsigned)(n / GB), (unsigned)(m / GB));
-  if (tb)
-    hipLaunchKernelGGL(gemm_kernel<true>, grid, dim3(256), 0, s, m, n, k, alpha, A, lda, B, ldb, beta,
-                       C, ldc, lower_only ? 1 : 0);
-  else
-    hipLaunchKernelGGL(gemm_kernel<false>, grid, dim3(256), 0, s, m, n, k, alpha, A, lda, B, ldb, beta,
-                       C, ldc, lower_only ? 1 : 0);
+  const int lo = lower_only ? 1 : 0;
+  // few workgroups: the k loop of one workgroup is the critical path -> deeper steps (fewer barriers,
+  // more loads in flight); many workgroups: 16-deep steps keep 4 workgroups resident per CU.
+  const bool deep = (int64_t)grid.x * grid.y <= 512 && k % 32 == 0;
+  if (tb) {
+    if (deep) hipLaunchKernelGGL((gemm_kernel<true, 32>), grid, dim3(256), 0, s, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lo, tri);
+    else hipLaunchKernelGGL((gemm_kernel<true, 16>), grid, dim3(256), 0, s, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lo, tri);
+  } else {
+    if (deep) hipLaunchKernelGGL((gemm_kernel<false, 32>), grid, dim3(256), 0, s, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lo, tri);
+    else hipLaunchKernelGGL((gemm_kernel<false, 16>), grid, dim3(256), 0, s, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lo, tri);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
