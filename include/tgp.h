@@ -56,7 +56,9 @@ enum tgp_where { TGP_HOST = 0, TGP_DEVICE = 1 };
 enum tgp_acq {
   TGP_ACQ_EI = 0,   /* expected_improvement.__call__            function.py:215-223; param = eta   */
   TGP_ACQ_PI = 1,   /* probability_below_threshold / PoF         function.py:509-510; param = thr  */
-  TGP_ACQ_NLCB = 2  /* negative_lower_confidence_bound           function.py:415-416; param = beta */
+  TGP_ACQ_NLCB = 2, /* negative_lower_confidence_bound           function.py:415-416; param = beta */
+  TGP_ACQ_AEI = 3   /* augmented_expected_improvement.__call__  function.py:312-325; param = eta,
+                       noise variance = the model's likelihood variance (tgp_set_hyper)        */
 };
 
 /* ---- lifetime ------------------------------------------------------------------------- */
@@ -155,6 +157,12 @@ int tgp_qei(tgp_handle h, const double* Xq, int64_t G, int q, const double* eps,
 int tgp_reparam_samples(tgp_handle h, const double* Xq, int64_t G, int q, const double* eps, int S,
                         double jitter, double* out, int where);
 
+/* == GaussianProcessRegression.covariance_between_points_encoded (models/gpflow/models.py:188-254):
+ * out [P1,P2] = k(X1, X2) - (L^-1 k(X, X1))^T (L^-1 k(X, X2)); no clipping (the reference applies
+ * none here).  X1 [P1,d], X2 [P2,d]. */
+int tgp_cov_between(tgp_handle h, const double* X1, int64_t P1, const double* X2, int64_t P2, double* out,
+                    int where);
+
 /* ---- decoupled Thompson trajectories ------------------------------------------------------ */
 /* == DecoupledTrajectorySampler._prepare_weight_sampler + weight_sampler(B)
  * (sampler.py:661-738) given the draws: rff_W [F,d], rff_b [F] (the RFF basis, gpflux
@@ -170,6 +178,11 @@ int tgp_traj_get_v(tgp_traj t, double* v);
  * trajectories (per_traj_inputs = 0) or [M,B,d] (= 1); out [M,B]. */
 int tgp_traj_eval(tgp_traj t, const double* Xq, int64_t M, int per_traj_inputs, double* out,
                   int where);
+/* Value and gradient of each trajectory at ITS OWN point: Xq [P,B,d] -> val [P,B], grad [P,B,d].
+ * == what tfp.math.value_and_gradient (acquisition/optimizer.py:628-629) yields for the
+ * (negated) trajectories built by Greedy/ParallelContinuousThompsonSampling
+ * (acquisition/function/continuous_thompson_sampling.py:30-245); the sign flip is the host's. */
+int tgp_traj_value_grad(tgp_traj t, const double* Xq, int64_t P, double* val, double* grad, int where);
 /* == ThompsonSamplerFromTrajectory.sample (acquisition/sampler.py:262-271) for B trajectories:
  * arg-min over Xq [M,d]; host outputs best_val [B], best_idx [B] (first index wins ties). */
 int tgp_traj_argmin(tgp_traj t, const double* Xq, int64_t M, int64_t index_base, double* best_val,

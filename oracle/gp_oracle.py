@@ -214,6 +214,12 @@ def negative_lower_confidence_bound(mean, var, beta=1.96):
     return -(np.asarray(mean) - beta * np.sqrt(var))
 
 
+def augmented_expected_improvement(mean, var, eta, noise):
+    """function.py:312-325: EI * (1 - sqrt(noise) / sqrt(noise + var))."""
+    var = np.asarray(var, dtype=np.float64)
+    return expected_improvement(mean, var, eta) * (1.0 - math.sqrt(noise) / np.sqrt(noise + var))
+
+
 def ei_values(state: GPRState, Xq: np.ndarray, eta: float) -> np.ndarray:
     m, v = predict(state, Xq)
     return expected_improvement(m, v, eta)
@@ -266,6 +272,14 @@ def acq_value_and_grad(state: GPRState, acq: str, param: float, Xq: np.ndarray):
     elif acq == "nlcb":
         val = -(mu - param * sd)
         g = -dmu + (param / (2.0 * sd))[:, None] * dvar
+    elif acq == "aei":
+        z = (param - mu) / sd
+        ei = (param - mu) * normal_cdf(z) + sd * normal_pdf(z)
+        sn, st = math.sqrt(state.noise), np.sqrt(state.noise + var)
+        aug = 1.0 - sn / st
+        daug = 0.5 * sn / (st * (state.noise + var))
+        val = ei * aug
+        g = (-normal_cdf(z) * aug)[:, None] * dmu + (normal_pdf(z) / (2.0 * sd) * aug + ei * daug)[:, None] * dvar
     else:
         raise KeyError(acq)
     return val, g
@@ -318,6 +332,41 @@ def batch_mc_ei(state: GPRState, Xq: np.ndarray, eps: np.ndarray, eta: float,
     return np.mean(np.maximum(eta - np.min(s, axis=-1), 0.0), axis=-1)
 
 
+def independent_reparam_samples(state: GPRState, Xq: np.ndarray, eps: np.ndarray) -> np.ndarray:
+    """IndependentReparametrizationSampler.sample (sampler.py:117-164): Xq [M, d], eps [S] ->
+    samples [M, S] = mean + sqrt(var) * eps (marginal posteriors, no cross-covariance)."""
+    m, v = predict(state, Xq)
+    return m[:, None] + np.sqrt(v)[:, None] * np.asarray(eps, dtype=np.float64)[None, :]
+
+
+def conditional_predict_joint(state: GPRState, Xq: np.ndarray, X_add: np.ndarray, Y_add: np.ndarray):
+    """models.py:418-484: joint posterior at Xq [M, d] conditioned also on additional (noisy)
+    observations (X_add [n, d], Y_add [n]):  from the joint predict at [X_add; Xq],
+    L_add = chol(cov_add + noise I), A = L_add^-1 cov_cross, cov' = cov_qp - A^T A,
+    mean' = mean_qp + A^T L_add^-1 (Y_add - mean_add)."""
+    X_add = np.asarray(X_add, dtype=np.float64)
+    n = X_add.shape[0]
+    mean, cov = predict_joint(state, np.concatenate([X_add, np.asarray(Xq, dtype=np.float64)], axis=0))
+    L_add = _cholesky(cov[:n, :n] + state.noise * np.eye(n), lower=True)
+    A = _solve_triangular(L_add, cov[:n, n:], lower=True)
+    AM = _solve_triangular(L_add, np.asarray(Y_add, dtype=np.float64).reshape(n) - mean[:n], lower=True)
+    return mean[n:] + A.T @ AM, cov[n:, n:] - A.T @ A
+
+
+def conditional_predict_f(state: GPRState, Xq: np.ndarray, X_add: np.ndarray, Y_add: np.ndarray):
+    """models.py:355-416: marginal version; uses predict (CLIPPED variance) at Xq, predict_joint
+    at X_add and covariance_between_points(X_add, Xq)."""
+    X_add = np.asarray(X_add, dtype=np.float64)
+    n = X_add.shape[0]
+    mean_add, cov_add = predict_joint(state, X_add)
+    mean_qp, var_qp = predict(state, Xq)
+    cross = covariance_between_points(state, X_add, np.asarray(Xq, dtype=np.float64))  # [n, M]
+    L_add = _cholesky(cov_add + state.noise * np.eye(n), lower=True)
+    A = _solve_triangular(L_add, cross, lower=True)
+    AM = _solve_triangular(L_add, np.asarray(Y_add, dtype=np.float64).reshape(n) - mean_add, lower=True)
+    return mean_qp + A.T @ AM, var_qp - np.sum(A * A, axis=0)
+
+
 # --------------------------------------------------------------------------------------
 # A.6 decoupled trajectories (sampler.py:661-738, 801-806, 841-855, 901-936;
 # gpflux RandomFourierFeaturesCosine, gpflux.math.compute_A_inv_b); draws passed in.
@@ -358,6 +407,34 @@ def trajectory_eval(state: GPRState, W, b, w, v, Xq: np.ndarray) -> np.ndarray:
         Kx = kernel_matrix(state.kind, state.variance, state.lengthscales, Xq[:, bb, :], state.X)
         out[:, bb] = phi @ w[:, bb] + Kx @ v[:, bb] + state.mean_const
     return out
+
+
+def trajectory_value_and_grad(state: GPRState, W, b, w, v, Xq: np.ndarray):
+    """Value [P, B] and gradient [P, B, d] of the trajectories at per-trajectory points Xq [P, B, d]
+    -- what tfp.math.value_and_gradient gives the L-BFGS-B refinement of
+    Greedy/ParallelContinuousThompsonSampling (continuous_thompson_sampling.py:30-245 through
+    acquisition/optimizer.py:628-629); analytic: d phi_f = -sqrt(2 var / F) sin(.) W_f / ls,
+    d k(x, X_k) = 2 k'(r2) (x - X_k) / ls^2."""
+    w = np.asarray(w, dtype=np.float64).reshape(W.shape[0], -1)
+    v = np.asarray(v, dtype=np.float64).reshape(state.N, -1)
+    Xq = np.asarray(Xq, dtype=np.float64)
+    P, B, d = Xq.shape
+    ls = state.lengthscales
+    F = W.shape[0]
+    val = np.empty((P, B))
+    grad = np.empty((P, B, d))
+    for bb in range(B):
+        A = Xq[:, bb, :] / ls
+        arg = A @ W.T + b                                           # [P, F]
+        c = math.sqrt(2.0 * state.variance / F)
+        diff = A[:, None, :] - (state.X / ls)[None, :, :]           # [P, N, d]
+        r2 = np.sum(diff * diff, axis=-1)
+        Kx = kernel_from_r2(state.kind, state.variance, r2)
+        val[:, bb] = c * np.cos(arg) @ w[:, bb] + Kx @ v[:, bb] + state.mean_const
+        dphi = -c * (np.sin(arg) * w[:, bb][None, :]) @ W / ls      # [P, d]
+        dk = (2.0 * _kernel_dr2(state.kind, state.variance, r2))[:, :, None] * diff / ls
+        grad[:, bb, :] = dphi + np.einsum("pnd,n->pd", dk, v[:, bb])
+    return val, grad
 
 
 # --------------------------------------------------------------------------------------

@@ -125,13 +125,20 @@ def make_case(name, kind, d, N, variance, ls, noise, mean_const, seed, M=6, q=3,
     # eta = min posterior mean at the training inputs
     tm = [post([x])[0][0] for x in X]
     eta = min(tm)
-    ei, pi_, lcb = [], [], []
+    ei, pi_, lcb, aei = [], [], [], []
     for m, v in zip(mean, var):
         sd = mp.sqrt(v)
         z = (eta - m) / sd
         ei.append((eta - m) * mp.ncdf(z) + sd * mp.npdf(z))
         pi_.append(mp.ncdf(z))
         lcb.append(-(m - mp.mpf("1.96") * sd))
+        aei.append(ei[-1] * (1 - mp.sqrt(mpf(noise)) / mp.sqrt(mpf(noise) + v)))
+
+    # cross-covariance between the first 2 and the next 3 candidates (models.py:188-254): a block of
+    # the raw (unclipped) joint posterior covariance of their union
+    n1, n2 = 2, min(3, len(Xq) - 2)
+    _, cu = post([Xq[a] for a in range(n1 + n2)])
+    cov12 = [[f64(cu[a, n1 + b_]) for b_ in range(n2)] for a in range(n1)]
 
     # joint posterior for G=2 groups of q points, + qEI given eps
     G = 2
@@ -191,6 +198,7 @@ def make_case(name, kind, d, N, variance, ls, noise, mean_const, seed, M=6, q=3,
         "mean": [f64(m) for m in mean], "var_raw": [f64(v) for v in var_raw],
         "var": [f64(v) for v in var], "eta": f64(eta),
         "ei": [f64(v) for v in ei], "pi": [f64(v) for v in pi_], "nlcb": [f64(v) for v in lcb],
+        "aei": [f64(v) for v in aei], "cov12": cov12,
         "Xg": Xg.tolist(), "eps": eps.tolist(), "joint_mean": jm, "joint_cov": jc, "qei": qei,
         "jitter": 1e-6,
         "rff_W": Wf.tolist(), "rff_b": bf.tolist(), "traj_w": w.tolist(), "traj_xi": xi.tolist(),

@@ -29,6 +29,9 @@ class FakeTrajectory:
     def __call__(self, Xq):
         return O.trajectory_eval(self._eng.state, self.W, self.b, self.w, self._v, np.asarray(Xq, float))
 
+    def value_and_gradient(self, Xq):
+        return O.trajectory_value_and_grad(self._eng.state, self.W, self.b, self.w, self._v, np.asarray(Xq, float))
+
     def argmin(self, Xq, index_base=0):
         vals = self(np.asarray(Xq, float))
         idx = np.argmin(vals, axis=0)
@@ -108,6 +111,9 @@ class FakeEngine:
             raise ValueError("q must be in 1..64")
         return O.predict_joint(self._st(), Xq)
 
+    def cov_between(self, X1, X2):
+        return O.covariance_between_points(self._st(), np.asarray(X1, float), np.asarray(X2, float))
+
     def eta(self):
         return O.eta_min_mean(self._st())
 
@@ -119,6 +125,8 @@ class FakeEngine:
             return O.probability_of_improvement(m, v, param)
         if acq == "nlcb":
             return O.negative_lower_confidence_bound(m, v, param)
+        if acq == "aei":
+            return O.augmented_expected_improvement(m, v, param, self.state.noise)
         raise KeyError(acq)
 
     def acq_value_grad(self, acq, param, Xq):

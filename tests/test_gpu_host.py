@@ -156,3 +156,69 @@ def test_model_optimize_on_gpu_matches_an_oracle_driven_fit():
         M.GPEngine = real
     assert abs(after - cpu_loss) < 1e-3 * max(1.0, abs(cpu_loss))
     np.testing.assert_allclose(gpu.get_kernel().lengthscales, cpu.get_kernel().lengthscales, rtol=1e-2)
+
+
+def test_sibling_tails_and_continuous_thompson_on_gpu():
+    """SURVEY 8(f) rank 3 on the real engine: augmented EI and Monte-Carlo EI against the oracle, and
+    the continuous Thompson-sampling builders through EGO with the gradient optimizer."""
+    from trieste_amd.acquisition import (AugmentedExpectedImprovement, EfficientGlobalOptimization,
+                                         GreedyContinuousThompsonSampling, MonteCarloExpectedImprovement,
+                                         ParallelContinuousThompsonSampling, generate_continuous_optimizer)
+
+    space, data, model, st = _setup(n=40, noise=1e-2)
+    x = space.sample(200, seed=3)
+    eta = O.eta_min_mean(st)
+    aei = AugmentedExpectedImprovement().prepare_acquisition_function(model, dataset=data)
+    m, v = O.predict(st, x)
+    assert_close(aei(x[:, None, :])[:, 0], O.augmented_expected_improvement(m, v, eta, st.noise), atol=1e-12, what="aei")
+    mc = MonteCarloExpectedImprovement(256)
+    fn = mc.prepare_acquisition_function(model, dataset=data)
+    eps = fn._sampler.eps(1)
+    ref = O.batch_mc_ei(st, x[:, None, :], eps, fn._eta, 1e-6)
+    assert_close(fn(x[:, None, :])[:, 0], ref, atol=1e-12, what="mc-ei")
+    # eta of MC-EI: min over the data of the sample mean
+    smp = O.batch_reparam_samples(st, data.query_points[:, None, :], eps, 1e-6)  # [N, S, 1]
+    assert_close(fn._eta, float(np.min(smp.mean(axis=1))), atol=1e-10, what="mc-ei eta")
+    opt = generate_continuous_optimizer(num_initial_samples=2000, num_optimization_runs=5)
+    rule = EfficientGlobalOptimization(ParallelContinuousThompsonSampling(), optimizer=opt, num_query_points=4)
+    pts = rule.acquire_single(space, model, dataset=data)
+    assert pts.shape == (4, 2) and all(p in space for p in pts)
+    neg = rule.acquisition_function
+    best = np.diag(neg(np.tile(pts[:, None, :], [1, 4, 1])))
+    rnd = neg(np.tile(space.sample(2000, seed=9)[:, None, :], [1, 4, 1]))
+    assert np.all(best >= rnd.max(0) - 1e-9)  # each point maximises ITS negated trajectory
+    val, grad = neg.value_and_gradient(np.tile(pts[:, None, :], [1, 4, 1]))
+    for b in range(4):  # interior maximisers are stationary points of their own trajectory
+        interior = (pts[b] > 1e-6) & (pts[b] < 1 - 1e-6)
+        assert np.all(np.abs(grad[b, b][interior]) < 1e-3 * max(1.0, abs(val[b, b])))
+    rule = EfficientGlobalOptimization(GreedyContinuousThompsonSampling(), optimizer=opt, num_query_points=2)
+    assert rule.acquire_single(space, model, dataset=data).shape == (2, 2)
+
+
+def test_fantasising_surfaces_on_gpu_equal_refit():
+    """covariance_between_points / conditional_predict_* on the real engine
+    against the oracle and against a refit on the augmented data."""
+    import trieste_amd.models as M
+    from trieste_amd.data import Dataset
+
+    space, data, model, st = _setup(n=60, noise=1e-2)
+    rng = np.random.default_rng(5)
+    xq, xa, ya = rng.uniform(size=(90, 2)), rng.uniform(size=(5, 2)), rng.standard_normal((5, 1))
+    cov = model.covariance_between_points(xa, xq)
+    assert cov.shape == (1, 5, 90)
+    assert_close(cov[0], O.covariance_between_points(st, xa, xq), atol=1e-11, what="cov between")
+    m, v = model.conditional_predict_f(xq, Dataset(xa, ya))
+    om, ov = O.conditional_predict_f(st, xq, xa, ya[:, 0])
+    assert_close(m[:, 0], om, atol=1e-9, what="conditional mean")
+    assert_close(v[:, 0], ov, atol=1e-10, what="conditional variance")
+    mj, cj = model.conditional_predict_joint(xq, Dataset(xa, ya))  # 95 points: the wide joint path
+    omj, ocj = O.conditional_predict_joint(st, xq, xa, ya[:, 0])
+    assert_close(mj[:, 0], omj, atol=1e-9, what="conditional joint mean")
+    assert_close(cj[0], ocj, atol=1e-10, what="conditional joint cov")
+    aug = data + Dataset(xa, ya)
+    refit = M.GaussianProcessRegression(M.GPR(data=(aug.query_points, aug.observations), kernel=model.get_kernel(),
+                                              mean_function=model.get_mean_function(),
+                                              likelihood_variance=model.get_observation_noise()))
+    rm, rv = refit.predict(xq)
+    assert_close(m, rm, atol=1e-8, what="conditional == refit mean")
+    assert_close(v, rv, atol=1e-9, what="conditional == refit var")

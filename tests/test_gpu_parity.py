@@ -46,8 +46,11 @@ def test_engine_matches_mpmath_goldens(c):
         assert_close(eng.acq_values("ei", c["eta"], Xq), c["ei"], atol=floor, what="ei")
         assert_close(eng.acq_values("pi", c["eta"], Xq), c["pi"], atol=max(floor, 1e-300) * 1e3, what="pi")
         assert_close(eng.acq_values("nlcb", 1.96, Xq), c["nlcb"], atol=floor * 10, what="nlcb")
+        assert_close(eng.acq_values("aei", c["eta"], Xq), c["aei"], atol=floor, what="aei")
         assert_close(eng.qei(np.array(c["Xg"]), np.array(c["eps"]), c["eta"], c["jitter"]), c["qei"],
                      atol=floor * 10, what="qei")
+    n1, n2 = len(c["cov12"]), len(c["cov12"][0])
+    assert_close(eng.cov_between(Xq[:n1], Xq[n1:n1 + n2]), c["cov12"], atol=floor, what="cov12")
     jm, jc = eng.predict_joint(np.array(c["Xg"]))
     assert_close(jm, c["joint_mean"], atol=floor * 10, what="joint mean")
     assert_close(jc, c["joint_cov"], atol=floor, what="joint cov")
@@ -312,7 +315,7 @@ def test_acq_value_and_gradient_match_oracle(cfg):
     X, Y, ls, c, st, Xq = _problem(obj, d, kind, N, noise, M=70)
     eng = _engine(kind, d, 1.0, ls, noise, c, X, Y)
     eta = eng.eta()
-    for acq, par in (("ei", eta), ("pi", eta), ("nlcb", 1.96)):
+    for acq, par in (("ei", eta), ("pi", eta), ("nlcb", 1.96), ("aei", eta)):
         val, grad = eng.acq_value_grad(acq, par, Xq)
         oval, ograd = O.acq_value_and_grad(st, acq, par, Xq)
         floor = cancellation_floor(N, 1.0, noise)
@@ -334,3 +337,52 @@ def test_nlml_value_and_gradient_match_oracle(cfg):
     oval, ograd = O.nlml_and_grad(st)
     assert_close(val, oval, rtol=1e-9, atol=1e-7, what="nlml")
     assert_close(grad, ograd, rtol=1e-5, atol=1e-7 * np.abs(ograd).max() + 1e-6 / noise * 1e-6, what="nlml gradient")
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=[c[0] for c in CONFIGS])
+def test_covariance_between_points_matches_oracle(cfg):
+    """tgp_cov_between (models.py:188-254) vs the oracle at ragged sizes (1, 63, 64, 65, 130 points),
+    its transpose symmetry, and its diagonal against predict's unclipped variance."""
+    _, obj, d, kind, N, noise = cfg
+    X, Y, ls, c, st, Xq = _problem(obj, d, kind, N, noise, M=200)
+    eng = _engine(kind, d, 1.0, ls, noise, c, X, Y)
+    floor = cancellation_floor(N, 1.0, noise)
+    for p1, p2 in ((1, 1), (63, 65), (64, 130), (5, 200)):
+        X1, X2 = Xq[:p1], Xq[200 - p2:]
+        cov = eng.cov_between(X1, X2)
+        assert cov.shape == (p1, p2)
+        assert_close(cov, O.covariance_between_points(st, X1, X2), atol=floor * 10, what=f"cov {p1}x{p2}")
+        assert_close(eng.cov_between(X2, X1), cov.T, rtol=1e-12, atol=floor, what="cov symmetry")
+    _, var_raw = O.predict(st, Xq[:70], clip=False)
+    assert_close(np.diag(eng.cov_between(Xq[:70], Xq[:70])), var_raw, atol=floor * 10, what="diag == raw variance")
+    # training inputs with themselves: K - K (K + noise I)^-1 K, tiny for tiny noise
+    Xt = X[:33]
+    assert_close(eng.cov_between(Xt, Xt), O.covariance_between_points(st, Xt, Xt), atol=floor * 10, what="cov at data")
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=[c[0] for c in CONFIGS])
+def test_trajectory_value_and_gradient_match_oracle(cfg):
+    """tgp_traj_value_grad vs the oracle's analytic gradient (finite-difference checked in
+    tests/test_oracle_gradient.py), per-trajectory inputs [P, B, d]; values also vs tgp_traj_eval."""
+    _, obj, d, kind, N, noise = cfg
+    X, Y, ls, c, st, _ = _problem(obj, d, kind, N, noise, M=8)
+    eng = _engine(kind, d, 1.0, ls, noise, c, X, Y)
+    rng = np.random.default_rng(99)
+    F, B, P = 300, 3, 37
+    from trieste_amd.sampler import sample_rff_basis
+
+    W, b = sample_rff_basis(kind, F, d, rng)
+    w, xi = rng.standard_normal((F, B)), rng.standard_normal((N, B))
+    traj = eng.trajectory(W, b, w, xi)
+    v = traj.v()
+    Xp = rng.uniform(size=(P, B, d))
+    Xp[0, 0] = X[3]  # at a training input (r = 0: Matern-1/2 has a kink there; value still defined)
+    val, grad = traj.value_and_gradient(Xp)
+    oval, ograd = O.trajectory_value_and_grad(st, W, b, w, v, Xp)
+    scale = max(1.0, np.abs(v).max())
+    assert_close(val, oval, rtol=1e-7, atol=1e-8 * scale, what="trajectory value")
+    assert_close(val, traj(Xp), rtol=1e-10, atol=1e-9 * scale, what="value == traj_eval")
+    gs = np.abs(ograd).max()
+    skip0 = kind == "matern12"  # d k / dx is discontinuous at r = 0 for Matern-1/2
+    sl = slice(1, None) if skip0 else slice(None)
+    assert_close(grad[sl], ograd[sl], rtol=1e-6, atol=1e-8 * gs, what="trajectory gradient")

@@ -11,7 +11,9 @@ import pytest
 import trieste_amd.models as M
 from tests.fakes import FakeEngine
 from trieste_amd import objectives as OBJ
-from trieste_amd.acquisition import (BatchMonteCarloExpectedImprovement, DiscreteThompsonSampling,
+from trieste_amd.acquisition import (AugmentedExpectedImprovement, GreedyContinuousThompsonSampling,
+                                     MonteCarloExpectedImprovement, ParallelContinuousThompsonSampling,
+                                     generate_continuous_optimizer, BatchMonteCarloExpectedImprovement, DiscreteThompsonSampling,
                                      EfficientGlobalOptimization, ExpectedImprovement, NegativeLowerConfidenceBound,
                                      ProbabilityOfImprovement, RandomSampling, ThompsonSamplerFromTrajectory,
                                      automatic_optimizer_selector, batchify_joint, batchify_vectorize,
@@ -292,8 +294,8 @@ def test_continuous_optimizer_refines_the_sweep_winner():
     assert np.all(np.abs(grad[0][interior]) < 1e-4 * max(1.0, float(val[0]) * 1e3))
     with pytest.raises(TypeError):
         opt(box, lambda z: np.zeros(z.shape[:-1]))  # no gradient available -> loud failure
-    with pytest.raises(NotImplementedError):
-        opt(box, (fn, 2))
+    with pytest.raises(ValueError):
+        opt(box, (fn, 2))  # a batch-size-one function cannot be vectorized
     # the default selector now refines on a Box
     y = automatic_optimizer_selector(box, fn)
     assert fn.value_and_gradient(y)[0][0] >= best_init - 1e-9
@@ -467,3 +469,157 @@ def test_find_best_model_initialization_never_gets_worse():
     before = model.training_loss()
     model.find_best_model_initialization(12, seed=1)
     assert model.training_loss() <= before + 1e-9
+
+
+# ---- sibling tails, continuous Thompson sampling, fantasising ------------------
+def test_augmented_ei_builder_penalises_low_variance_and_updates():
+    """reference test_function.py (AEI cases): raises without a noise-aware model / dataset, equals
+    EI * (1 - sqrt(noise) / sqrt(noise + var)), in-place update."""
+    model, data = _model(n=15, noise=1e-2)
+    with pytest.raises(ValueError):
+        AugmentedExpectedImprovement().prepare_acquisition_function(model, dataset=Dataset(np.zeros((0, 2)), np.zeros((0, 1))))
+    with pytest.raises(NotImplementedError):
+        class _NoNoise:
+            engine = model.engine
+        AugmentedExpectedImprovement().prepare_acquisition_function(_NoNoise(), dataset=data)
+    aei = AugmentedExpectedImprovement().prepare_acquisition_function(model, dataset=data)
+    ei = ExpectedImprovement().prepare_acquisition_function(model, dataset=data)
+    x = np.random.default_rng(3).uniform(size=(40, 1, 2))
+    _, var = model.predict(x[:, 0, :])
+    np.testing.assert_allclose(aei(x), ei(x) * (1 - math.sqrt(1e-2) / np.sqrt(1e-2 + var)), rtol=1e-12)
+    with pytest.raises(ValueError):
+        aei(np.zeros((3, 2, 2)))
+    again = AugmentedExpectedImprovement().update_acquisition_function(aei, model, dataset=data)
+    assert again is aei
+    v, g = aei.value_and_gradient(x[:5, 0, :])
+    np.testing.assert_allclose(v, aei(x[:5])[:, 0], rtol=1e-10)
+    assert g.shape == (5, 2)
+
+
+def test_monte_carlo_ei_tracks_ei_and_independent_sampler_is_continuous():
+    """reference test_function.py (MonteCarloExpectedImprovement cases) and test_sampler.py
+    (IndependentReparametrizationSampler: fixed draws, sample mean/variance, reset)."""
+    from trieste_amd.sampler import IndependentReparametrizationSampler
+
+    model, data = _model(n=15, noise=1e-3)
+    with pytest.raises(ValueError):
+        MonteCarloExpectedImprovement(0)
+    with pytest.raises(ValueError):
+        MonteCarloExpectedImprovement(10, jitter=-1.0)
+    builder = MonteCarloExpectedImprovement(4000)
+    fn = builder.prepare_acquisition_function(model, dataset=data)
+    ei = ExpectedImprovement().prepare_acquisition_function(model, dataset=data)
+    x = np.random.default_rng(5).uniform(size=(25, 1, 2))
+    np.testing.assert_allclose(fn(x), ei(x), atol=0.05 * float(np.max(ei(x))) + 5e-3)
+    np.testing.assert_array_equal(fn(x), fn(x))  # fixed draws between calls
+    before = fn(x)
+    assert builder.update_acquisition_function(fn, model, dataset=data) is fn
+    assert not np.array_equal(fn(x), before)  # update resets the sampler
+    with pytest.raises(ValueError):
+        fn(np.zeros((3, 2, 2)))
+    s = IndependentReparametrizationSampler(5000, model, seed=1)
+    pts = x[:6]
+    smp = s.sample(pts)
+    assert smp.shape == (6, 5000, 1, 1)
+    np.testing.assert_array_equal(smp, s.sample(pts))
+    m, v = model.predict(pts[:, 0, :])
+    np.testing.assert_allclose(smp.mean(1)[:, 0], m, atol=4 * np.sqrt(v.max() / 5000) + 1e-9)
+    np.testing.assert_allclose(smp.var(1)[:, 0], v, rtol=0.1, atol=1e-9)
+    s.reset_sampler()
+    assert not np.array_equal(smp, s.sample(pts))
+    with pytest.raises(ValueError):
+        s.sample(np.zeros((3, 2, 2)))
+
+
+def test_continuous_thompson_sampling_builders_with_ego():
+    """reference test_continuous_thompson_sampling.py: builders negate the model's trajectory, greedy
+    resamples per batch element, parallel vectorizes; reference test_rule.py: EGO dispatch
+    (batchify_vectorize for vectorized builders, sequential loop for greedy ones)."""
+    model, data = _model(n=14, noise=1e-3)
+    box = Box([0.0, 0.0], [1.0, 1.0])
+    with pytest.raises(ValueError):
+        ParallelContinuousThompsonSampling().prepare_acquisition_function(object())
+    # negation: f_neg(x) == -trajectory(x)[..., 0]
+    b = ParallelContinuousThompsonSampling()
+    neg = b.prepare_acquisition_function(model, dataset=data)
+    x = np.random.default_rng(0).uniform(size=(9, 3, 2))
+    vals = neg(x)
+    assert vals.shape == (9, 3)
+    tr = b._trajectory
+    np.testing.assert_allclose(vals, -type(tr).__mro__[1].__call__(tr, x)[..., 0])
+    v, g = neg.value_and_gradient(x)
+    np.testing.assert_allclose(v, vals, rtol=1e-10, atol=1e-12)
+    h = 1e-6
+    e0 = np.array([h, 0.0])
+    np.testing.assert_allclose(g[..., 0], (neg(x + e0) - neg(x - e0)) / (2 * h), rtol=1e-5, atol=1e-6)
+    with pytest.raises(ValueError):
+        b.update_acquisition_function(lambda z: z, model, dataset=data)
+    assert b.update_acquisition_function(neg, model, dataset=data) is neg
+    assert not np.allclose(neg(x), vals)  # new basis + new weights
+    # EGO, vectorized: 3 independent trajectories -> 3 points, each a local maximiser of its own column
+    opt = generate_continuous_optimizer(num_initial_samples=300, num_optimization_runs=4)
+    rule = EfficientGlobalOptimization(ParallelContinuousThompsonSampling(), optimizer=opt, num_query_points=3)
+    pts = rule.acquire_single(box, model, dataset=data)
+    assert pts.shape == (3, 2) and all(p in box for p in pts)
+    fn = rule.acquisition_function
+    tiled = np.tile(pts[:, None, :], [1, 3, 1])
+    best = np.diag(fn(tiled))
+    rnd = fn(np.tile(box.sample(300, seed=1)[:, None, :], [1, 3, 1]))
+    assert np.all(best >= rnd.max(0) - 1e-9)
+    # EGO, greedy: one trajectory at a time, resampled between batch elements
+    rule = EfficientGlobalOptimization(GreedyContinuousThompsonSampling(), optimizer=opt, num_query_points=3)
+    pts = rule.acquire_single(box, model, dataset=data)
+    assert pts.shape == (3, 2) and len(np.unique(pts.round(6), axis=0)) > 1
+    pts2 = rule.acquire_single(box, model, dataset=data)  # second step: update path
+    assert pts2.shape == (3, 2)
+
+
+def test_covariance_between_points_and_conditional_predict_equal_refit():
+    """reference test_models.py (covariance_between_points, conditional_predict_* cases): cross-
+    covariance blocks agree with the joint posterior; conditioning on additional data equals
+    refitting the same hyper-parameters on the augmented data set; leading dimensions broadcast."""
+    model, data = _model(n=20, noise=1e-2)
+    rng = np.random.default_rng(8)
+    xq = rng.uniform(size=(7, 2))
+    x1 = rng.uniform(size=(2, 3, 2))
+    cov = model.covariance_between_points(x1, xq)
+    assert cov.shape == (2, 1, 3, 7)
+    _, joint = model.predict_joint(np.concatenate([x1[1], xq], axis=0))
+    np.testing.assert_allclose(cov[1, 0], joint[0, :3, 3:], rtol=1e-9, atol=1e-12)
+    with pytest.raises(ValueError):
+        model.covariance_between_points(x1, xq[None])
+    xa, ya = rng.uniform(size=(4, 2)), rng.standard_normal((4, 1))
+    add = Dataset(xa, ya)
+    refit = M.GaussianProcessRegression(M.GPR(data=((data + add).query_points, (data + add).observations),
+                                              kernel=model.get_kernel(), mean_function=model.get_mean_function(),
+                                              likelihood_variance=model.get_observation_noise()))
+    m_ref, c_ref = refit.predict_joint(xq)
+    m, c = model.conditional_predict_joint(xq, add)
+    assert m.shape == (7, 1) and c.shape == (1, 7, 7)
+    np.testing.assert_allclose(m, m_ref, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(c, c_ref, rtol=1e-7, atol=1e-10)
+    mf, vf = model.conditional_predict_f(xq, add)
+    np.testing.assert_allclose(mf, m_ref, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(vf[:, 0], np.diag(c_ref[0]), rtol=1e-7, atol=1e-10)
+    my, vy = model.conditional_predict_y(xq, add)
+    np.testing.assert_allclose(vy, vf + model.get_observation_noise())
+    # leading dimensions on the additional data
+    xb = np.stack([xa, xa[::-1]])
+    yb = np.stack([ya, ya[::-1]])
+    mb, vb = model.conditional_predict_f(xq, Dataset(xb, yb))
+    assert mb.shape == (2, 7, 1) and vb.shape == (2, 7, 1)
+    np.testing.assert_allclose(mb[0], mb[1], rtol=1e-9, atol=1e-11)  # permutation invariance
+    smp = model.conditional_predict_f_sample(xq, Dataset(xb, yb), 11)
+    assert smp.shape == (2, 11, 7, 1)
+    with pytest.raises(ValueError):
+        model.conditional_predict_f(xq[None], add)
+
+
+def test_predict_joint_wider_than_the_fused_kernel():
+    model, _ = _model(n=15, noise=1e-2)
+    x = np.random.default_rng(4).uniform(size=(70, 2))
+    m, c = model.predict_joint(x)
+    assert m.shape == (70, 1) and c.shape == (1, 70, 70)
+    m64, c64 = model.predict_joint(x[:64])
+    np.testing.assert_allclose(m[:64], m64, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(c[0, :64, :64], c64[0], rtol=1e-8, atol=1e-11)

@@ -32,6 +32,10 @@ def test_oracle_matches_mpmath(c):
     assert_close(O.expected_improvement(gm, gv, c["eta"]), c["ei"], atol=1e-300, what="ei(golden mv)")
     assert_close(O.probability_of_improvement(gm, gv, c["eta"]), c["pi"], atol=1e-300, what="pi")
     assert_close(O.negative_lower_confidence_bound(gm, gv), c["nlcb"], what="nlcb")
+    assert_close(O.augmented_expected_improvement(gm, gv, c["eta"], noise), c["aei"], atol=1e-300, what="aei")
+    # cross-covariance block (models.py:188-254)
+    n1, n2 = len(c["cov12"]), len(c["cov12"][0])
+    assert_close(O.covariance_between_points(st, Xq[:n1], Xq[n1:n1 + n2]), c["cov12"], atol=floor, what="cov12")
     # joint
     jm, jc = O.predict_joint(st, np.array(c["Xg"]))
     assert_close(jm, c["joint_mean"], atol=floor * 10, what="joint mean")

@@ -6,7 +6,7 @@ from oracle import gp_oracle as O
 
 
 @pytest.mark.parametrize("kind", ["rbf", "matern32", "matern52"])
-@pytest.mark.parametrize("acq", ["ei", "pi", "nlcb"])
+@pytest.mark.parametrize("acq", ["ei", "pi", "nlcb", "aei"])
 def test_gradient_matches_finite_differences(kind, acq):
     rng = np.random.default_rng(0)
     X, Y = O.synthetic_problem(O.hartmann_6, 6, 40)
@@ -15,7 +15,8 @@ def test_gradient_matches_finite_differences(kind, acq):
     Xq = rng.uniform(size=(6, 6))
     par = O.eta_min_mean(st) if acq != "nlcb" else 1.96
     tails = {"ei": O.expected_improvement, "pi": O.probability_of_improvement,
-             "nlcb": O.negative_lower_confidence_bound}
+             "nlcb": O.negative_lower_confidence_bound,
+             "aei": lambda m, v, p: O.augmented_expected_improvement(m, v, p, st.noise)}
 
     def f(x):
         m, v = O.predict(st, x)
@@ -34,3 +35,44 @@ def test_clipped_variance_has_zero_variance_gradient():
     val, grad = O.acq_value_and_grad(st, "nlcb", 2.0, X[:3])  # at training inputs: var clipped to 1e-12
     _, grad_mu = O.acq_value_and_grad(st, "nlcb", 0.0, X[:3])  # beta = 0: the pure mean gradient
     np.testing.assert_allclose(grad, grad_mu, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("kind", ["rbf", "matern12", "matern32", "matern52"])
+def test_trajectory_gradient_matches_finite_differences(kind):
+    rng = np.random.default_rng(1)
+    d, N, F, B, P = 4, 30, 64, 3, 5
+    X, Y = O.synthetic_problem(O.ackley, d, N)
+    ls = O.default_lengthscales(d) * np.linspace(0.7, 1.2, d)
+    st = O.gpr_update(kind, 0.9, ls, 1e-2, float(Y.mean()), X, Y)
+    W, b = rng.standard_normal((F, d)), rng.uniform(0, 2 * np.pi, F)
+    w, xi = rng.standard_normal((F, B)), rng.standard_normal((N, B))
+    v = O.decoupled_weights(st, W, b, w, xi)
+    Xq = rng.uniform(size=(P, B, d))
+    val, grad = O.trajectory_value_and_grad(st, W, b, w, v, Xq)
+    np.testing.assert_allclose(val, O.trajectory_eval(st, W, b, w, v, Xq), rtol=1e-12, atol=1e-12)
+    h = 1e-6
+    for c in range(d):
+        e = np.zeros(d); e[c] = h
+        num = (O.trajectory_eval(st, W, b, w, v, Xq + e) - O.trajectory_eval(st, W, b, w, v, Xq - e)) / (2 * h)
+        np.testing.assert_allclose(grad[:, :, c], num, rtol=2e-6, atol=1e-7 * np.abs(num).max())
+
+
+def test_conditional_predict_equals_refit_on_augmented_data():
+    """models.py:355-484: conditioning on additional noisy observations == refitting the same
+    hyper-parameters on the augmented data set (the identity the reference tests use,
+    tests/unit/models/gpflow/test_models.py conditional_predict tests)."""
+    rng = np.random.default_rng(2)
+    d, N, n, M = 3, 25, 4, 7
+    X, Y = O.synthetic_problem(O.ackley, d, N)
+    ls = O.default_lengthscales(d)
+    st = O.gpr_update("matern52", 1.1, ls, 1e-2, 0.3, X, Y)
+    Xa, Ya = rng.uniform(size=(n, d)), rng.standard_normal(n)
+    Xq = rng.uniform(size=(M, d))
+    st2 = O.gpr_update("matern52", 1.1, ls, 1e-2, 0.3, np.concatenate([X, Xa]), np.concatenate([Y, Ya]))
+    m_ref, c_ref = O.predict_joint(st2, Xq)
+    m, c = O.conditional_predict_joint(st, Xq, Xa, Ya)
+    np.testing.assert_allclose(m, m_ref, rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(c, c_ref, rtol=1e-8, atol=1e-10)
+    mf, vf = O.conditional_predict_f(st, Xq, Xa, Ya)
+    np.testing.assert_allclose(mf, m_ref, rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(vf, np.diag(c_ref), rtol=1e-8, atol=1e-10)

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libtgp.so")
 TGP_OK, TGP_ERR_SHAPE, TGP_ERR_NOT_PD, TGP_ERR_ALLOC, TGP_ERR_HIP, TGP_ERR_STATE, TGP_ERR_ARG = range(7)
 HOST, DEVICE = 0, 1
 KERNELS = {"rbf": 0, "squared_exponential": 0, "matern12": 1, "matern32": 2, "matern52": 3}
-ACQ = {"ei": 0, "pi": 1, "nlcb": 2}
+ACQ = {"ei": 0, "pi": 1, "nlcb": 2, "aei": 3}
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int64)
@@ -51,6 +51,8 @@ SIGNATURES = {
     "tgp_traj_destroy": (C.c_int, [_vp]),
     "tgp_traj_get_v": (C.c_int, [_vp, _vp]),
     "tgp_traj_eval": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, C.c_int]),
+    "tgp_traj_value_grad": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, C.c_int]),
+    "tgp_cov_between": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int]),
     "tgp_traj_argmin": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, _vp, _vp, C.c_int]),
     "tgp_last_kernel_ms": (C.c_int, [_vp, _dp, C.POINTER(C.c_int)]),
     "tgp_set_variant": (C.c_int, [_vp, C.c_int]),

@@ -1,8 +1,14 @@
 """Acquisition functions, optimizers, rules and samplers of the hot path."""
-from .function import (BatchMonteCarloExpectedImprovement, ExpectedImprovement, NegativeLowerConfidenceBound,
-                       ProbabilityOfImprovement, batch_monte_carlo_expected_improvement, expected_improvement,
-                       negative_lower_confidence_bound, probability_below_threshold)
-from .interface import AcquisitionFunctionBuilder, AcquisitionFunctionClass, SingleModelAcquisitionBuilder
+from .continuous_thompson_sampling import (GreedyContinuousThompsonSampling, ParallelContinuousThompsonSampling,
+                                           negate_trajectory_function)
+from .function import (AugmentedExpectedImprovement, BatchMonteCarloExpectedImprovement, ExpectedImprovement,
+                       MonteCarloExpectedImprovement, NegativeLowerConfidenceBound, ProbabilityOfImprovement,
+                       augmented_expected_improvement, batch_monte_carlo_expected_improvement, expected_improvement,
+                       monte_carlo_expected_improvement, negative_lower_confidence_bound,
+                       probability_below_threshold)
+from .interface import (AcquisitionFunctionBuilder, AcquisitionFunctionClass, GreedyAcquisitionFunctionBuilder,
+                        SingleModelAcquisitionBuilder, SingleModelGreedyAcquisitionBuilder,
+                        SingleModelVectorizedAcquisitionBuilder, VectorizedAcquisitionFunctionBuilder)
 from .optimizer import (FailedOptimizationError, automatic_optimizer_selector, batchify_joint, batchify_vectorize,
                         generate_continuous_optimizer, generate_initial_points, generate_random_search_optimizer,
                         optimize_discrete, sample_from_space)

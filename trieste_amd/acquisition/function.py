@@ -1,8 +1,8 @@
 """Acquisition functions of the hot path (reference trieste/acquisition/function/function.py):
 ExpectedImprovement / expected_improvement (96-223), BatchMonteCarloExpectedImprovement /
 batch_monte_carlo_expected_improvement (1074-1186), plus the sibling tails on the same posterior
-ProbabilityOfImprovement (481-515, "probability_below_threshold") and NegativeLowerConfidenceBound
-(328-418).  Values are computed by libtgp's fused kernels; the objects also expose the fused
+ProbabilityOfImprovement (481-515, "probability_below_threshold"), NegativeLowerConfidenceBound
+(328-418), AugmentedExpectedImprovement (226-325) and MonteCarloExpectedImprovement (786-920).  Values are computed by libtgp's fused kernels; the objects also expose the fused
 device arg-max / top-k used by :mod:`trieste_amd.acquisition.optimizer`.
 """
 from __future__ import annotations
@@ -99,6 +99,22 @@ class negative_lower_confidence_bound(_posterior_tail):
         super().__init__(model, beta)
 
 
+class augmented_expected_improvement(_posterior_tail):
+    r"""x -> EI(x) * (1 - sqrt(noise) / sqrt(noise + var(x))) (function.py:282-325); the observation
+    noise is the model's likelihood variance, read by the kernel from the engine's state."""
+
+    _acq = "aei"
+
+    def __init__(self, model, eta):
+        if not hasattr(model, "get_observation_noise"):
+            raise NotImplementedError("AugmentedExpectedImprovement only works with models that support "
+                                      f"get_observation_noise; received {model!r}")
+        super().__init__(model, eta)
+
+    def update(self, eta) -> None:
+        self._param = float(np.asarray(eta).reshape(()))
+
+
 def _eta_from(model, dataset: Optional[Dataset]) -> float:
     """min over the dataset's query points of the posterior MEAN (function.py:145-149)."""
     if dataset is None or len(dataset) == 0:
@@ -128,6 +144,25 @@ class ExpectedImprovement(SingleModelAcquisitionBuilder):
     def update_acquisition_function(self, function, model, dataset: Optional[Dataset] = None):
         if not isinstance(function, expected_improvement):
             raise ValueError("function must be an expected_improvement instance")
+        function.update(_eta_from(model, dataset))
+        return function
+
+
+class AugmentedExpectedImprovement(SingleModelAcquisitionBuilder):
+    """Builder for augmented EI for noisy problems (function.py:226-279)."""
+
+    def __repr__(self) -> str:
+        return "AugmentedExpectedImprovement()"
+
+    def prepare_acquisition_function(self, model, dataset: Optional[Dataset] = None):
+        if not hasattr(model, "get_observation_noise"):
+            raise NotImplementedError("AugmentedExpectedImprovement only works with models that support "
+                                      f"get_observation_noise; received {model!r}")
+        return augmented_expected_improvement(model, _eta_from(model, dataset))
+
+    def update_acquisition_function(self, function, model, dataset: Optional[Dataset] = None):
+        if not isinstance(function, augmented_expected_improvement):
+            raise ValueError("function must be an augmented_expected_improvement instance")
         function.update(_eta_from(model, dataset))
         return function
 
@@ -214,4 +249,66 @@ class BatchMonteCarloExpectedImprovement(SingleModelAcquisitionBuilder):
         if not isinstance(function, batch_monte_carlo_expected_improvement):
             raise ValueError("function must be a batch_monte_carlo_expected_improvement instance")
         function.update(_eta_from(model, dataset))
+        return function
+
+
+class monte_carlo_expected_improvement(AcquisitionFunctionClass):
+    r"""x -> mean_S max(eta - f_s(x), 0) from reparametrised samples (function.py:883-920).  For the
+    exact GPR ``model.reparam_sampler`` is the batch sampler at batch size one, so this is the qEI
+    kernel with q = 1."""
+
+    def __init__(self, sampler, eta, jitter: float = JITTER):
+        self._sampler = sampler
+        self._engine = _require_engine(sampler._model, type(self).__name__)
+        self._eta = float(np.asarray(eta).reshape(()))
+        self._jitter = jitter
+
+    def update(self, eta) -> None:
+        self._eta = float(np.asarray(eta).reshape(()))
+
+    def __call__(self, at):
+        if not _is_torch(at):
+            at = np.asarray(at, dtype=np.float64)
+        if len(at.shape) < 2 or at.shape[-2] != 1:
+            raise ValueError(f"This acquisition function only supports batch sizes of one, got input shape {tuple(at.shape)}")
+        eps = self._sampler.eps(1)
+        if _is_torch(at) and at.is_cuda:
+            import torch
+
+            eps = torch.from_numpy(eps).to(at.device)
+        return self._engine.qei(at, eps, self._eta, self._jitter)[..., None]
+
+
+class MonteCarloExpectedImprovement(SingleModelAcquisitionBuilder):
+    """Builder for Monte-Carlo EI; eta = min over the data of the SAMPLE mean (function.py:786-880)."""
+
+    def __init__(self, sample_size: int, *, jitter: float = JITTER):
+        if sample_size <= 0:
+            raise ValueError(f"sample_size must be positive, got {sample_size}")
+        if jitter < 0:
+            raise ValueError(f"jitter must be non-negative, got {jitter}")
+        self._sample_size = sample_size
+        self._jitter = jitter
+
+    def __repr__(self) -> str:
+        return f"MonteCarloExpectedImprovement({self._sample_size!r}, jitter={self._jitter!r})"
+
+    def _eta(self, sampler, dataset) -> float:
+        if dataset is None or len(dataset) == 0:
+            raise ValueError("Dataset must be populated.")
+        samples = sampler.sample(np.asarray(dataset.query_points)[..., None, :], jitter=self._jitter)  # [N, S, 1, 1]
+        return float(np.min(np.mean(np.asarray(samples), axis=-3)))
+
+    def prepare_acquisition_function(self, model, dataset: Optional[Dataset] = None):
+        if not hasattr(model, "reparam_sampler"):
+            raise ValueError("MonteCarloExpectedImprovement only supports models with a reparam_sampler method; "
+                             f"received {model!r}")
+        sampler = model.reparam_sampler(self._sample_size)
+        return monte_carlo_expected_improvement(sampler, self._eta(sampler, dataset), self._jitter)
+
+    def update_acquisition_function(self, function, model, dataset: Optional[Dataset] = None):
+        if not isinstance(function, monte_carlo_expected_improvement):
+            raise ValueError("function must be a monte_carlo_expected_improvement instance")
+        function._sampler.reset_sampler()
+        function.update(self._eta(function._sampler, dataset))
         return function

@@ -106,7 +106,7 @@ def automatic_optimizer_selector(space: SearchSpace, target_func) -> np.ndarray:
     if isinstance(space, Box):
         num_samples = max(NUM_SAMPLES_MIN, NUM_SAMPLES_DIM * space.dimension)
         fn, V = _split(target_func)
-        if V == 1 and hasattr(fn, "value_and_gradient"):
+        if hasattr(fn, "value_and_gradient"):
             return generate_continuous_optimizer(num_initial_samples=num_samples,
                                                  num_optimization_runs=NUM_RUNS_DIM * space.dimension)(space, target_func)
         return generate_random_search_optimizer(num_samples)(space, target_func)
@@ -170,15 +170,23 @@ def sample_from_space(num_samples: int, batch_size: Optional[int] = None, seed: 
 
 def _perform_parallel_continuous_optimization(fn, space: Box, starting_points: np.ndarray,
                                               optimizer_args: Dict[str, Any]):
-    """L-BFGS-B from every row of ``starting_points`` [R, D] at once (optimizer.py:563-698): each run
-    lives in a greenlet that hands its current iterate to the parent; the parent evaluates value
-    and gradient of ALL pending iterates in one device call and resumes the runs.  Maximises ``fn``
-    (scipy minimises its negation).  Returns (successes [R], values [R], points [R, D], nfev [R])."""
+    """L-BFGS-B from every start at once (optimizer.py:563-698): each run lives in a greenlet that
+    hands its current iterate to the parent; the parent evaluates value and gradient of ALL pending
+    iterates in one device call and resumes the runs.  Maximises ``fn`` (scipy minimises its
+    negation).  ``starting_points`` [R, D] for a batch-size-one function (``fn.value_and_gradient``
+    maps [P, D] -> ([P], [P, D])) or [R, V, D] for a vectorized one ([R, V, D] -> ([R, V], [R, V, D]),
+    column v being function v).  Returns (successes, values, points, nfev) shaped [R(, V)(, D)]."""
     import greenlet
 
     starts = np.asarray(starting_points, dtype=np.float64)
-    R, D = starts.shape
-    bounds = spo.Bounds(space.lower, space.upper)
+    vectorized = starts.ndim == 3
+    lead = starts.shape[:-1]
+    D = starts.shape[-1]
+    flat = starts.reshape(-1, D)
+    R = flat.shape[0]
+    lower = np.broadcast_to(np.asarray(space.lower, dtype=np.float64), (D,))
+    upper = np.broadcast_to(np.asarray(space.upper, dtype=np.float64), (D,))
+    bounds = spo.Bounds(lower, upper)
     args = dict(optimizer_args or {})
     for forbidden in ("method", "jac", "bounds"):
         if forbidden in args:
@@ -198,24 +206,29 @@ def _perform_parallel_continuous_optimization(fn, space: Box, starting_points: n
                                 bounds=bounds, method="L-BFGS-B", **args)
 
     runs = [_Run() for _ in range(R)]
-    pending = [run.switch(starts[i]) for i, run in enumerate(runs)]
-    batch_x = np.zeros((R, D))
+    pending = [run.switch(flat[i]) for i, run in enumerate(runs)]
+    batch_x = flat.copy()
     while True:
         active = [i for i, res in enumerate(pending) if not isinstance(res, spo.OptimizeResult)]
         if not active:
             break
         for i in active:
             batch_x[i] = pending[i]
-        vals, grads = fn.value_and_gradient(batch_x[active])
-        vals, grads = -_to_host(vals), -_to_host(grads)
+        if vectorized:  # slot (r, v) belongs to function v: evaluate the full tensor, finished slots idle
+            vals, grads = fn.value_and_gradient(batch_x.reshape(starts.shape))
+            vals, grads = -_to_host(vals).reshape(R), -_to_host(grads).reshape(R, D)
+            vals, grads = vals[active], grads[active]
+        else:
+            vals, grads = fn.value_and_gradient(batch_x[active])
+            vals, grads = -_to_host(vals), -_to_host(grads)
         for j, i in enumerate(active):
             if runs[i].dead:  # a crashed run is skipped, like the reference does
                 continue
             pending[i] = runs[i].switch(float(vals[j]), np.array(grads[j], dtype=np.float64))
-    successes = np.array([bool(r.success) for r in pending])
-    values = np.array([-float(r.fun) for r in pending])
-    points = np.stack([np.asarray(r.x, dtype=np.float64) for r in pending])
-    nfev = np.array([int(r.nfev) for r in pending])
+    successes = np.array([bool(r.success) for r in pending]).reshape(lead)
+    values = np.array([-float(r.fun) for r in pending]).reshape(lead)
+    points = np.stack([np.asarray(r.x, dtype=np.float64) for r in pending]).reshape(starts.shape)
+    nfev = np.array([int(r.nfev) for r in pending]).reshape(lead)
     return successes, values, points, nfev
 
 
@@ -238,29 +251,35 @@ def generate_continuous_optimizer(num_initial_samples=NUM_SAMPLES_MIN, num_optim
         fn, V = _split(target_func)
         if V <= 0:
             raise ValueError(f"vectorization must be positive, got {V}")
-        if V != 1:
-            raise NotImplementedError("vectorized continuous optimisation is outside the engine's path")
         if not isinstance(space, Box):
             raise NotImplementedError("the continuous optimizer supports Box search spaces")
         if not hasattr(fn, "value_and_gradient"):
             raise TypeError("generate_continuous_optimizer needs an acquisition function exposing "
                             "value_and_gradient (there is no autodiff on this engine)")
+        vectorized = isinstance(target_func, tuple)
         sampler = num_initial_samples if callable(num_initial_samples) else sample_from_space(num_initial_samples)
-        initial_points = generate_initial_points(num_optimization_runs, sampler, space, fn)  # [k, 1, D]
+        initial_points = generate_initial_points(num_optimization_runs, sampler, space, fn, V)  # [k, V, D]
         if len(initial_points) < num_optimization_runs:
             raise ValueError(f"Not enough initial points generated ({len(initial_points)} for "
                              f"{num_optimization_runs} optimization runs)")
-        successes, values, points, _ = _perform_parallel_continuous_optimization(
-            fn, space, initial_points[:, 0, :], optimizer_args or {})
-        if num_recovery_runs and not np.any(successes):
-            rs, rv, rp, _ = _perform_parallel_continuous_optimization(
-                fn, space, space.sample(num_recovery_runs), optimizer_args or {})
+        starts = initial_points if vectorized else initial_points[:, 0, :]
+        successes, values, points, _ = _perform_parallel_continuous_optimization(fn, space, starts, optimizer_args or {})
+        ok = bool(np.all(np.any(successes, axis=0)))  # at least one successful run for each function
+        if num_recovery_runs and not ok:
+            random_points = np.asarray(space.sample(num_recovery_runs), dtype=np.float64)
+            if vectorized:
+                random_points = np.tile(random_points[:, None, :], [1, V, 1])  # [num_recovery_runs, V, D]
+            rs, rv, rp, _ = _perform_parallel_continuous_optimization(fn, space, random_points, optimizer_args or {})
             successes, values, points = (np.concatenate([successes, rs]), np.concatenate([values, rv]),
                                          np.concatenate([points, rp]))
-        if not np.any(successes):
+            ok = bool(np.all(np.any(successes, axis=0)))
+        if not ok:
             raise FailedOptimizationError(f"Acquisition function optimization failed, even after "
                                           f"{num_recovery_runs + num_optimization_runs} restarts.")
-        return points[int(np.argmax(values))][None, :]
+        if not vectorized:
+            return points[int(np.argmax(values))][None, :]
+        best = np.argmax(values, axis=0)  # [V]
+        return points[best, np.arange(V), :]  # [V, D]
 
     return optimize_continuous
 

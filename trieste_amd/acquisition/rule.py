@@ -11,8 +11,9 @@ import numpy as np
 from ..data import OBJECTIVE
 from ..space import SearchSpace
 from .function import ExpectedImprovement
-from .interface import AcquisitionFunctionBuilder, SingleModelAcquisitionBuilder
-from .optimizer import automatic_optimizer_selector, batchify_joint
+from .interface import (AcquisitionFunctionBuilder, GreedyAcquisitionFunctionBuilder, SingleModelAcquisitionBuilder,
+                        SingleModelGreedyAcquisitionBuilder, VectorizedAcquisitionFunctionBuilder)
+from .optimizer import automatic_optimizer_selector, batchify_joint, batchify_vectorize
 from .sampler import ExactThompsonSampler, ThompsonSampler
 from .utils import select_nth_output
 
@@ -32,8 +33,9 @@ class AcquisitionRule(ABC):
 
 class EfficientGlobalOptimization(AcquisitionRule):
     """Efficient Global Optimization: build/update the acquisition function, maximise it with the
-    optimizer (rule.py:209-399).  ``num_query_points > 1`` with a (joint) batch builder wraps the
-    optimizer with :func:`batchify_joint`; greedy and vectorized builders are outside the path."""
+    optimizer (rule.py:209-399).  ``num_query_points > 1``: a joint batch builder wraps the
+    optimizer with :func:`batchify_joint`, a vectorized builder with :func:`batchify_vectorize`, a
+    greedy builder is re-updated with the pending points and re-optimised per batch element."""
 
     def __init__(self, builder=None, optimizer=None, num_query_points: int = 1,
                  initial_acquisition_function=None):
@@ -47,12 +49,16 @@ class EfficientGlobalOptimization(AcquisitionRule):
                                  "greater than 1")
         if optimizer is None:
             optimizer = automatic_optimizer_selector
-        if isinstance(builder, SingleModelAcquisitionBuilder):
+        if isinstance(builder, (SingleModelAcquisitionBuilder, SingleModelGreedyAcquisitionBuilder)):
             builder = builder.using(OBJECTIVE)
-        if not isinstance(builder, AcquisitionFunctionBuilder):
+        if not isinstance(builder, (AcquisitionFunctionBuilder, GreedyAcquisitionFunctionBuilder)):
             raise TypeError(f"unsupported acquisition builder {builder!r}")
         if num_query_points > 1:
-            optimizer = batchify_joint(optimizer, num_query_points)
+            if isinstance(builder, VectorizedAcquisitionFunctionBuilder):
+                optimizer = batchify_vectorize(optimizer, num_query_points)  # batch elements independently
+            elif isinstance(builder, AcquisitionFunctionBuilder):
+                optimizer = batchify_joint(optimizer, num_query_points)  # batch elements jointly
+            # greedy builders: sequentially, in acquire()
         self._builder = builder
         self._optimizer = optimizer
         self._num_query_points = num_query_points
@@ -72,7 +78,15 @@ class EfficientGlobalOptimization(AcquisitionRule):
         else:
             self._acquisition_function = self._builder.update_acquisition_function(
                 self._acquisition_function, models, datasets=datasets)
-        return self._optimizer(search_space, self._acquisition_function)
+        points = self._optimizer(search_space, self._acquisition_function)
+        if isinstance(self._builder, GreedyAcquisitionFunctionBuilder):
+            for _ in range(self._num_query_points - 1):  # greedily allocate the remaining batch elements
+                self._acquisition_function = self._builder.update_acquisition_function(
+                    self._acquisition_function, models, datasets=datasets, pending_points=points,
+                    new_optimization_step=False)
+                chosen_point = self._optimizer(search_space, self._acquisition_function)
+                points = np.concatenate([points, chosen_point], axis=0)
+        return points
 
 
 class RandomSampling(AcquisitionRule):

@@ -561,7 +561,7 @@ int tgp_eta(tgp_handle h, double* eta) {
 
 int tgp_acq_values(tgp_handle h, int acq_kind, double param, const double* Xq, int64_t M, double* out,
                    int where) {
-  if (acq_kind < 0 || acq_kind > 2) return fail(h, TGP_ERR_ARG, "unknown acquisition kind %d", acq_kind);
+  if (acq_kind < 0 || acq_kind > 3) return fail(h, TGP_ERR_ARG, "unknown acquisition kind %d", acq_kind);
   if (M > 0 && !out) return fail(h, TGP_ERR_ARG, "out is NULL");
   return sweep_common(h, Xq, M, nullptr, nullptr, out, acq_kind, param, where, false, 0, nullptr, nullptr,
                       nullptr);
@@ -570,7 +570,7 @@ int tgp_acq_values(tgp_handle h, int acq_kind, double param, const double* Xq, i
 int tgp_acq_value_grad(tgp_handle h, int acq_kind, double param, const double* Xq, int64_t P, double* val,
                        double* grad, int where) {
   if (!h) return TGP_ERR_ARG;
-  if (acq_kind < 0 || acq_kind > 2) return fail(h, TGP_ERR_ARG, "unknown acquisition kind %d", acq_kind);
+  if (acq_kind < 0 || acq_kind > 3) return fail(h, TGP_ERR_ARG, "unknown acquisition kind %d", acq_kind);
   if (!h->have_data) return fail(h, TGP_ERR_STATE, "model has no data: call tgp_set_data first");
   if (P < 0 || (P > 0 && (!Xq || !val || !grad))) return fail(h, TGP_ERR_ARG, "bad arguments");
   if (P == 0) return TGP_OK;
@@ -600,9 +600,45 @@ int tgp_acq_value_grad(tgp_handle h, int acq_kind, double param, const double* X
   return TGP_OK;
 }
 
+int tgp_cov_between(tgp_handle h, const double* X1, int64_t P1, const double* X2, int64_t P2, double* out,
+                    int where) {
+  if (!h) return TGP_ERR_ARG;
+  if (!h->have_data) return fail(h, TGP_ERR_STATE, "model has no data: call tgp_set_data first");
+  if (P1 < 0 || P2 < 0 || (P1 > 0 && P2 > 0 && (!X1 || !X2 || !out))) return fail(h, TGP_ERR_ARG, "bad arguments");
+  if (P1 == 0 || P2 == 0) return TGP_OK;
+  if (int rc = set_device(h)) return rc;
+  const int64_t P1p = ((P1 + 63) / 64) * 64, P2p = ((P2 + 63) / 64) * 64, Npad = h->Npad;
+  const double *d1, *d2;
+  double* dout;
+  if (int rc = stage_in(h, h->s_in, X1, (size_t)P1 * h->d, where, &d1)) return rc;
+  if (int rc = stage_in(h, h->s_in2, X2, (size_t)P2 * h->d, where, &d2)) return rc;
+  if (int rc = stage_out_prepare(h, h->s_out1, out, (size_t)P1 * P2, where, &dout)) return rc;
+  HIPCHK(h, h->s_grad.reserve(((size_t)Npad * (3 * P1p + 2 * P2p) + (size_t)P1p * P2p) * sizeof(double)));
+  double* B1 = h->s_grad.as<double>();
+  double* C1 = B1 + (size_t)Npad * P1p;
+  double* C1t = C1 + (size_t)Npad * P1p;
+  double* B2 = C1t + (size_t)Npad * P1p;
+  double* C2 = B2 + (size_t)Npad * P2p;
+  double* S = C2 + (size_t)Npad * P2p;
+  const ModelDev m = model_dev(h);
+  hipStream_t s = h->stream;
+  // A_i = L^-1 K(X, X_i) = W B_i;  S = A_1^T A_2  (the reference's two triangular solves + einsum)
+  launch_kstar_t(s, m, d1, P1, P1p, B1);
+  launch_gemm(s, false, (int)Npad, (int)P1p, (int)Npad, 1.0, h->d_W.as<double>(), Npad, B1, P1p, 0.0, C1, P1p, false, 3);
+  launch_kstar_t(s, m, d2, P2, P2p, B2);
+  launch_gemm(s, false, (int)Npad, (int)P2p, (int)Npad, 1.0, h->d_W.as<double>(), Npad, B2, P2p, 0.0, C2, P2p, false, 3);
+  launch_transpose(s, C1, Npad, P1p, P1p, C1t, Npad);
+  launch_gemm(s, false, (int)P1p, (int)P2p, (int)Npad, 1.0, C1t, Npad, C2, P2p, 0.0, S, P2p, false, 0);
+  launch_cov_tail(s, m, d1, P1, d2, P2, S, P2p, dout);
+  if (int rc = stage_out_finish(h, dout, out, (size_t)P1 * P2, where)) return rc;
+  if (int rc = sync(h)) return rc;
+  HIPCHK(h, hipGetLastError());
+  return TGP_OK;
+}
+
 int tgp_acq_argmax(tgp_handle h, int acq_kind, double param, const double* Xq, int64_t M,
                    int64_t index_base, double* best_val, int64_t* best_idx, double* best_x, int where) {
-  if (acq_kind < 0 || acq_kind > 2) return fail(h, TGP_ERR_ARG, "unknown acquisition kind %d", acq_kind);
+  if (acq_kind < 0 || acq_kind > 3) return fail(h, TGP_ERR_ARG, "unknown acquisition kind %d", acq_kind);
   return sweep_common(h, Xq, M, nullptr, nullptr, nullptr, acq_kind, param, where, true, index_base,
                       best_val, best_idx, best_x);
 }
@@ -612,7 +648,7 @@ int tgp_acq_topk(tgp_handle h, int acq_kind, double param, const double* Xq, int
   if (!h) return TGP_ERR_ARG;
   if (k < 1 || k > 1024) return fail(h, TGP_ERR_ARG, "k must be in 1..1024");
   if (M < k) return fail(h, TGP_ERR_SHAPE, "top-k needs M >= k (M=%lld, k=%d)", (long long)M, k);
-  if (acq_kind < 0 || acq_kind > 2) return fail(h, TGP_ERR_ARG, "unknown acquisition kind %d", acq_kind);
+  if (acq_kind < 0 || acq_kind > 3) return fail(h, TGP_ERR_ARG, "unknown acquisition kind %d", acq_kind);
   if (!h->have_data) return fail(h, TGP_ERR_STATE, "model has no data: call tgp_set_data first");
   if (int rc = set_device(h)) return rc;
   // acquisition values stay on the device (8 B / candidate), then k extraction passes
@@ -896,6 +932,26 @@ int tgp_traj_eval(tgp_traj t, const double* Xq, int64_t M, int per_traj_inputs, 
   h->last_launches = 1;
   h->last_ms = -1.0;
   if (int rc = stage_out_finish(h, dout, out, (size_t)M * t->B, where)) return rc;
+  if (int rc = sync(h)) return rc;
+  HIPCHK(h, hipGetLastError());
+  return TGP_OK;
+}
+
+int tgp_traj_value_grad(tgp_traj t, const double* Xq, int64_t P, double* val, double* grad, int where) {
+  if (!t) return TGP_ERR_ARG;
+  tgp_handle h = t->h;
+  if (P < 0 || (P > 0 && (!Xq || !val || !grad))) return fail(h, TGP_ERR_ARG, "bad arguments");
+  if (P == 0) return TGP_OK;
+  if (int rc = set_device(h)) return rc;
+  const int64_t nitems = P * t->B;
+  const double* dXq;
+  double *dval, *dgrad;
+  if (int rc = stage_in(h, h->s_in, Xq, (size_t)nitems * h->d, where, &dXq)) return rc;
+  if (int rc = stage_out_prepare(h, h->s_out1, val, (size_t)nitems, where, &dval)) return rc;
+  if (int rc = stage_out_prepare(h, h->s_out2, grad, (size_t)nitems * h->d, where, &dgrad)) return rc;
+  launch_traj_grad(h->stream, traj_dev(t), dXq, nitems, dval, dgrad);
+  if (int rc = stage_out_finish(h, dval, val, (size_t)nitems, where)) return rc;
+  if (int rc = stage_out_finish(h, dgrad, grad, (size_t)nitems * h->d, where)) return rc;
   if (int rc = sync(h)) return rc;
   HIPCHK(h, hipGetLastError());
   return TGP_OK;

@@ -10,7 +10,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
 constexpr int KIND_RBF = 0, KIND_M12 = 1, KIND_M32 = 2, KIND_M52 = 3;
-constexpr int ACQ_EI = 0, ACQ_PI = 1, ACQ_NLCB = 2;
+constexpr int ACQ_EI = 0, ACQ_PI = 1, ACQ_NLCB = 2, ACQ_AEI = 3;
 constexpr double VAR_FLOOR = 1e-12;  // reference interface.py:123
 
 // v_mfma_f64_16x16x4_f64: D(16x16) += A(16x4) * B(4x16).
@@ -160,13 +160,29 @@ __device__ __forceinline__ double normal_pdf(double z) {
   return 0.3989422804014327 * exp(-0.5 * z * z);
 }
 
-// Acquisition tails on (mean, clipped var)  -- reference function.py:220-223, 509-510, 415-416.
-__device__ __forceinline__ double acq_tail(int acq, double param, double mean, double var) {
+// d k / d (r^2) divided by the variance-free shape: returns variance * f'(r2).
+__device__ __forceinline__ double kernel_dr2(int kind, double r2, double variance) {
+  if (kind == KIND_RBF) return -0.5 * variance * exp(-0.5 * r2);
+  const double r = sqrt(fmax(r2, 1e-36));
+  if (kind == KIND_M12) return -0.5 * variance * exp(-r) / r;
+  if (kind == KIND_M32) {
+    const double s = 1.7320508075688772 * r;
+    return -1.5 * variance * exp(-s);
+  }
+  const double s = 2.23606797749979 * r;
+  return -(5.0 / 6.0) * variance * (1.0 + s) * exp(-s);
+}
+
+// Acquisition tails on (mean, clipped var)  -- reference function.py:220-223 (EI), 509-510 (PI),
+// 415-416 (negative LCB), 319-325 (augmented EI: EI * (1 - sqrt(noise) / sqrt(noise + var))).
+__device__ __forceinline__ double acq_tail(int acq, double param, double mean, double var, double noise) {
   const double sd = sqrt(var);
-  if (acq == ACQ_EI) {
+  if (acq == ACQ_EI || acq == ACQ_AEI) {
     const double diff = param - mean;
     const double z = diff / sd;
-    return diff * normal_cdf(z) + sd * normal_pdf(z);
+    const double ei = diff * normal_cdf(z) + sd * normal_pdf(z);
+    if (acq == ACQ_EI) return ei;
+    return ei * (1.0 - sqrt(noise) / sqrt(noise + var));
   } else if (acq == ACQ_PI) {
     return normal_cdf((param - mean) / sd);
   } else {

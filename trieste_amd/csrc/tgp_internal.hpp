@@ -68,6 +68,10 @@ void launch_gemm(hipStream_t s, bool tb, int m, int n, int k, double alpha, cons
 void launch_transpose_mask(hipStream_t s, const double* W, double* Wt, int64_t N, int64_t Npad);
 void launch_zero(hipStream_t s, double* p, int64_t n);
 void launch_center(hipStream_t s, const double* Y, double c, double* err, int64_t N, int64_t Npad);
+void launch_transpose(hipStream_t s, const double* src, int64_t rows, int64_t cols, int64_t lds, double* dst,
+                      int64_t ldd);
+void launch_cov_tail(hipStream_t s, const ModelDev& m, const double* X1, int64_t P1, const double* X2,
+                     int64_t P2, const double* S, int64_t lds, double* out);
 void launch_row_norms(hipStream_t s, const double* Xs, double* xn, int64_t Npad, int dp);
 // y[i] = sum_k M[i][k] x[k] over k in [klo(i), khi(i)] ; lower: k<=i ; upper: k>=i
 void launch_trmv(hipStream_t s, const double* Mx, int64_t ld, int64_t n, const double* x, double* y,
@@ -114,6 +118,8 @@ void launch_rff_project(hipStream_t s, const TrajDev& t, const double* Xs_pts, i
 void launch_traj_eval(hipStream_t s, const TrajDev& t, const double* Xq, int64_t M, int per_traj,
                       double* out, double* blk_val, int64_t* blk_idx, int64_t index_base);
 int64_t traj_grid(int64_t M);
+void launch_traj_grad(hipStream_t s, const TrajDev& t, const double* Xq, int64_t nitems, double* val,
+                      double* grad);
 void launch_argmin_final_multi(hipStream_t s, const double* blk_val, const int64_t* blk_idx,
                                int64_t nblk, int B, double* out_val, int64_t* out_idx);
 

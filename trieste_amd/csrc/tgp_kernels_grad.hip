@@ -28,17 +28,25 @@ __global__ void kstar_t_kernel(ModelDev m, const double* __restrict__ Xq, int64_
   B[k * Ppad + p] = v;
 }
 
-// d k / d (r^2) divided by the variance-free shape: returns variance * f'(r2).
-__device__ __forceinline__ double kernel_dr2(int kind, double r2, double variance) {
-  if (kind == KIND_RBF) return -0.5 * variance * exp(-0.5 * r2);
-  const double r = sqrt(fmax(r2, 1e-36));
-  if (kind == KIND_M12) return -0.5 * variance * exp(-r) / r;
-  if (kind == KIND_M32) {
-    const double s = 1.7320508075688772 * r;
-    return -1.5 * variance * exp(-s);
+// out[i][j] = k(x1_i, x2_j) - S[i][j]  (covariance_between_points, reference models.py:188-254)
+__global__ void cov_tail_kernel(ModelDev m, const double* __restrict__ X1, int64_t P1,
+                                const double* __restrict__ X2, int64_t P2, const double* __restrict__ S,
+                                int64_t lds, double* __restrict__ out) {
+  const int64_t j = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int64_t i = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (i >= P1 || j >= P2) return;
+  double r2 = 0.0;
+  for (int c = 0; c < m.d; ++c) {
+    const double t = (X1[i * m.d + c] - X2[j * m.d + c]) / m.ls[c];
+    r2 = fma(t, t, r2);
   }
-  const double s = 2.23606797749979 * r;
-  return -(5.0 / 6.0) * variance * (1.0 + s) * exp(-s);
+  out[i * P2 + j] = kernel_rt(m.kind, r2, m.variance) - S[i * lds + j];
+}
+
+void launch_cov_tail(hipStream_t s, const ModelDev& m, const double* X1, int64_t P1, const double* X2,
+                     int64_t P2, const double* S, int64_t lds, double* out) {
+  dim3 grid((unsigned)((P2 + 63) / 64), (unsigned)((P1 + 3) / 4));
+  hipLaunchKernelGGL(cov_tail_kernel, grid, dim3(256), 0, s, m, X1, P1, X2, P2, S, lds, out);
 }
 
 constexpr int GT_THREADS = 256;
@@ -99,12 +107,19 @@ __global__ __launch_bounds__(GT_THREADS) void grad_tail_kernel(ModelDev m, const
     const double var = clipped ? VAR_FLOOR : var_raw;
     const double sd = sqrt(var);
     double v, dv_dmu, dv_dvar;
-    if (acq == ACQ_EI) {
+    if (acq == ACQ_EI || acq == ACQ_AEI) {
       const double z = (param - mu) / sd;
       const double cdf = normal_cdf(z), pdf = normal_pdf(z);
       v = (param - mu) * cdf + sd * pdf;
       dv_dmu = -cdf;
       dv_dvar = pdf / (2.0 * sd);
+      if (acq == ACQ_AEI) {  // v = EI * aug(var), aug = 1 - sqrt(noise) / sqrt(noise + var)
+        const double sn = sqrt(m.noise), st = sqrt(m.noise + var);
+        const double aug = 1.0 - sn / st;
+        dv_dvar = dv_dvar * aug + v * (0.5 * sn / (st * (m.noise + var)));
+        dv_dmu *= aug;
+        v *= aug;
+      }
     } else if (acq == ACQ_PI) {
       const double z = (param - mu) / sd;
       const double pdf = normal_pdf(z);

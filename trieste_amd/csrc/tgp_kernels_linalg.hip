@@ -275,6 +275,23 @@ __global__ void transpose_mask_kernel(const double* __restrict__ W, double* __re
   for (int r = ty; r < 32; r += 8) Wt[(k0 + r) * Npad + i0 + tx] = tile[tx][r];
 }
 
+// dst[c][r] = src[r][c], rows x cols both multiples of 32.
+__global__ void transpose_kernel(const double* __restrict__ src, int64_t lds, double* __restrict__ dst,
+                                 int64_t ldd) {
+  __shared__ double tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int64_t r0 = (int64_t)blockIdx.y * 32, c0 = (int64_t)blockIdx.x * 32;
+  for (int r = ty; r < 32; r += 8) tile[r][tx] = src[(r0 + r) * lds + c0 + tx];
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) dst[(c0 + r) * ldd + r0 + tx] = tile[tx][r];
+}
+
+void launch_transpose(hipStream_t s, const double* src, int64_t rows, int64_t cols, int64_t lds, double* dst,
+                      int64_t ldd) {
+  dim3 grid((unsigned)(cols / 32), (unsigned)(rows / 32));
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, src, lds, dst, ldd);
+}
+
 void launch_transpose_mask(hipStream_t s, const double* W, double* Wt, int64_t N, int64_t Npad) {
   dim3 grid((unsigned)(Npad / 32), (unsigned)(Npad / 32));
   hipLaunchKernelGGL(transpose_mask_kernel, grid, dim3(256), 0, s, W, Wt, N, Npad);

@@ -159,6 +159,79 @@ void launch_traj_eval(hipStream_t s, const TrajDev& t, const double* Xq, int64_t
   launch_traj_any(s, t, Xq, M, per_traj, 0, out, blk_val, blk_idx, index_base);
 }
 
+// Value and gradient of trajectory b at its own point x[p][b][:] -- the pair the L-BFGS-B
+// refinement of Greedy/ParallelContinuousThompsonSampling needs (reference
+// continuous_thompson_sampling.py:30-245 via acquisition/optimizer.py:628-629, where TF autodiff
+// produces it).  One workgroup per (point, trajectory); threads stride over the F features and
+// the N training rows; d phi_f / dx = -sin(arg) W_f / ls,  d k(x, X_k) / dx = 2 k'(r2) (x - X_k) / ls^2
+// in scaled coordinates.  A few hundred items per L-BFGS-B iteration: latency, not throughput.
+template <int DP>
+__global__ __launch_bounds__(256) void traj_grad_kernel(TrajDev t, const double* __restrict__ Xq,
+                                                        int64_t nitems, double* __restrict__ val,
+                                                        double* __restrict__ grad) {
+  __shared__ double red[4][DP + 1];
+  const int64_t item = blockIdx.x;
+  const int B = t.B, d = t.m.d, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int b = (int)(item % B);
+  double xq[DP], g[DP];
+#pragma unroll
+  for (int c = 0; c < DP; ++c) {
+    xq[c] = (c < d) ? Xq[item * d + c] / t.m.ls[c] : 0.0;
+    g[c] = 0.0;
+  }
+  double acc = 0.0;
+  for (int f = tid; f < t.F; f += 256) {
+    double arg = t.rffb[f];
+#pragma unroll
+    for (int c = 0; c < DP; ++c) arg = fma(xq[c], t.rffW[(int64_t)f * DP + c], arg);
+    const double wv = t.ws[(int64_t)f * B + b];
+    acc = fma(cos(arg), wv, acc);
+    const double sw = -sin(arg) * wv;
+#pragma unroll
+    for (int c = 0; c < DP; ++c) g[c] = fma(sw, t.rffW[(int64_t)f * DP + c], g[c]);
+  }
+  for (int64_t k = tid; k < t.m.N; k += 256) {
+    double r2 = 0.0, df[DP];
+#pragma unroll
+    for (int c = 0; c < DP; ++c) {
+      df[c] = xq[c] - t.m.Xs[k * DP + c];
+      r2 = fma(df[c], df[c], r2);
+    }
+    const double vk = t.v[k * B + b];
+    acc = fma(kernel_rt(t.m.kind, r2, t.m.variance), vk, acc);
+    const double f1 = 2.0 * kernel_dr2(t.m.kind, r2, t.m.variance) * vk;
+#pragma unroll
+    for (int c = 0; c < DP; ++c) g[c] = fma(f1, df[c], g[c]);
+  }
+  acc = wave_sum(acc);
+#pragma unroll
+  for (int c = 0; c < DP; ++c) g[c] = wave_sum(g[c]);
+  if (lane == 0) {
+    red[w][0] = acc;
+#pragma unroll
+    for (int c = 0; c < DP; ++c) red[w][1 + c] = g[c];
+  }
+  __syncthreads();
+  if (tid <= d) {
+    const double s = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    if (tid == 0) val[item] = s + t.m.mean_const;
+    else grad[item * d + (tid - 1)] = s / t.m.ls[tid - 1];  // back to raw coordinates
+  }
+}
+
+void launch_traj_grad(hipStream_t s, const TrajDev& t, const double* Xq, int64_t nitems, double* val,
+                      double* grad) {
+  dim3 g((unsigned)nitems), b(256);
+  switch (t.m.dp) {
+    case 2: hipLaunchKernelGGL(traj_grad_kernel<2>, g, b, 0, s, t, Xq, nitems, val, grad); break;
+    case 4: hipLaunchKernelGGL(traj_grad_kernel<4>, g, b, 0, s, t, Xq, nitems, val, grad); break;
+    case 6: hipLaunchKernelGGL(traj_grad_kernel<6>, g, b, 0, s, t, Xq, nitems, val, grad); break;
+    case 8: hipLaunchKernelGGL(traj_grad_kernel<8>, g, b, 0, s, t, Xq, nitems, val, grad); break;
+    case 16: hipLaunchKernelGGL(traj_grad_kernel<16>, g, b, 0, s, t, Xq, nitems, val, grad); break;
+    default: hipLaunchKernelGGL(traj_grad_kernel<32>, g, b, 0, s, t, Xq, nitems, val, grad); break;
+  }
+}
+
 // Phi_Z w at a set of RAW points (the training inputs): out [npts][B] = sum_f phi_f(x) ws[f][b]
 // (sampler.py:726 `phi_Z @ prior_weights`).
 void launch_rff_project(hipStream_t s, const TrajDev& t, const double* X_raw, int64_t npts, double* out) {

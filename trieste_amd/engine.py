@@ -153,6 +153,17 @@ class GPEngine:
         self._chk(self._lib.tgp_predict_joint(self._h, a.ptr, G, q, pm, pc, a.where))
         return mean, cov
 
+    def cov_between(self, X1, X2):
+        """X1 [P1, d], X2 [P2, d] -> posterior cross-covariance [P1, P2] (unclipped)."""
+        a1, a2 = _Arg(X1), _Arg(X2)
+        if len(a1.shape) != 2 or len(a2.shape) != 2 or a1.shape[1] != self.d or a2.shape[1] != self.d:
+            raise ValueError(f"query points must be [P, {self.d}], got {a1.shape} and {a2.shape}")
+        if a1.where != a2.where:
+            raise ValueError("X1 and X2 must both be host arrays or both be CUDA tensors")
+        out, po = self._out(a1, (a1.shape[0], a2.shape[0]))
+        self._chk(self._lib.tgp_cov_between(self._h, a1.ptr, a1.shape[0], a2.ptr, a2.shape[0], po, a1.where))
+        return out
+
     def eta(self) -> float:
         v = C.c_double()
         self._chk(self._lib.tgp_eta(self._h, C.byref(v)))
@@ -292,6 +303,18 @@ class Trajectory:
         out, po = GPEngine._out(a, (M, self.B))
         self._eng._chk(self._eng._lib.tgp_traj_eval(self._t, a.ptr, M, per, po, a.where))
         return out
+
+    def value_and_gradient(self, Xq):
+        """Xq [P, B, d] (trajectory b at its own point) -> (values [P, B], gradients [P, B, d])."""
+        a = _Arg(Xq)
+        d = self._eng.d
+        if len(a.shape) != 3 or a.shape[1] != self.B or a.shape[2] != d:
+            raise ValueError(f"trajectory inputs must be [P, {self.B}, {d}], got {a.shape}")
+        P = a.shape[0]
+        val, pv = GPEngine._out(a, (P, self.B))
+        grad, pg = GPEngine._out(a, (P, self.B, d))
+        self._eng._chk(self._eng._lib.tgp_traj_value_grad(self._t, a.ptr, P, pv, pg, a.where))
+        return val, grad
 
     def argmin(self, Xq, index_base: int = 0):
         a = _Arg(Xq)

@@ -177,9 +177,100 @@ class GaussianProcessRegression:
         return m[..., None], v[..., None]
 
     def predict_joint(self, query_points):
-        """[..., B, D] -> (mean [..., B, 1], cov [..., 1, B, B]) (interface.py:126-133)."""
-        m, c = self._engine.predict_joint(query_points)
-        return m[..., None], c[..., None, :, :]
+        """[..., B, D] -> (mean [..., B, 1], cov [..., 1, B, B]) (interface.py:126-133).  B <= 64 runs
+        in the fused joint kernel; wider blocks are assembled from the mean and cross-covariance
+        kernels (same formula, diagonal clipped to >= 1e-12)."""
+        q = query_points if type(query_points).__module__.startswith("torch") else np.asarray(query_points, np.float64)
+        if q.shape[-2] <= 64:
+            m, c = self._engine.predict_joint(q)
+            return m[..., None], c[..., None, :, :]
+        q = np.asarray(q.cpu() if hasattr(q, "cpu") else q, dtype=np.float64)
+        lead, B = q.shape[:-2], q.shape[-2]
+        flat = q.reshape((-1, B, q.shape[-1]))
+        means = np.empty((flat.shape[0], B))
+        covs = np.empty((flat.shape[0], B, B))
+        for g in range(flat.shape[0]):
+            means[g] = self._engine.predict_mean(flat[g])
+            cov = np.array(self._engine.cov_between(flat[g], flat[g]))
+            cov = 0.5 * (cov + cov.T)
+            idx = np.diag_indices(B)
+            cov[idx] = np.maximum(cov[idx], 1e-12)
+            covs[g] = cov
+        return means.reshape(lead + (B, 1)), covs.reshape(lead + (1, B, B))
+
+    # -- SupportsCovarianceBetweenPoints / FantasizableModel (models.py:188-254, 355-526) ------------
+    def covariance_between_points(self, query_points_1, query_points_2):
+        r"""Sigma_12 = K_12 - K_x1 (K_xx + sigma^2 I)^-1 K_x2 for query_points_1 [..., N, D] and
+        query_points_2 [M, D] -> [..., 1, N, M] (one latent GP)."""
+        q1 = np.asarray(query_points_1, dtype=np.float64)
+        q2 = np.asarray(query_points_2, dtype=np.float64)
+        if q1.ndim < 2 or q2.ndim != 2 or q1.shape[-1] != q2.shape[-1]:
+            raise ValueError(f"query_points_1 must be [..., N, D] and query_points_2 [M, D], got {q1.shape} and {q2.shape}")
+        lead, N = q1.shape[:-2], q1.shape[-2]
+        cov = np.asarray(self._engine.cov_between(q1.reshape(-1, q1.shape[-1]), q2))  # [prod(lead) N, M]
+        return cov.reshape(lead + (1, N, q2.shape[0]))
+
+    def _conditional_terms(self, query_points, additional_data: Dataset, joint: bool):
+        """Shared algebra of conditional_predict_f / _joint (models.py:355-484): the posterior blocks
+        come from the engine (predict / predict_joint / cov_between); the n x n factorisation over the
+        n additional points (a pending batch: tens of points) and the two triangular solves against
+        it are host-side numpy, as they are per-leading-dimension TF ops in the reference."""
+        qp = np.asarray(query_points, dtype=np.float64)
+        xa = np.asarray(additional_data.query_points, dtype=np.float64)
+        ya = np.asarray(additional_data.observations, dtype=np.float64)
+        if qp.ndim != 2 or xa.ndim < 2 or ya.shape[:-1] != xa.shape[:-1] or ya.shape[-1] != 1:
+            raise ValueError("additional_data must have query_points with shape [..., N, D] and observations with "
+                             "shape [..., N, 1], and query_points should have shape [M, D]")
+        import scipy.linalg as sl
+
+        lead, n, M = xa.shape[:-2], xa.shape[-2], qp.shape[0]
+        xa_f, ya_f = xa.reshape((-1, n, xa.shape[-1])), ya.reshape((-1, n))
+        noise = self.get_observation_noise()
+        means = np.empty((xa_f.shape[0], M))
+        seconds = np.empty((xa_f.shape[0], M, M) if joint else (xa_f.shape[0], M))
+        if not joint:
+            mean_qp, var_qp = (np.asarray(a)[..., 0] for a in self.predict(qp))
+        for g in range(xa_f.shape[0]):
+            if joint:  # joint posterior at [additional; query] (models.py:438-452)
+                mean, cov = self.predict_joint(np.concatenate([xa_f[g], qp], axis=0))
+                mean, cov = np.asarray(mean)[:, 0], np.asarray(cov)[0]
+                mean_add, mean_q = mean[:n], mean[n:]
+                cov_add, cov_q, cov_cross = cov[:n, :n], cov[n:, n:], cov[:n, n:]
+            else:  # marginal form (models.py:381-389)
+                ma, ca = self.predict_joint(xa_f[g])
+                mean_add, cov_add = np.asarray(ma)[:, 0], np.asarray(ca)[0]
+                mean_q = mean_qp
+                cov_cross = self.covariance_between_points(xa_f[g], qp)[0]  # [n, M]
+            L_add = np.linalg.cholesky(cov_add + noise * np.eye(n))
+            A = sl.solve_triangular(L_add, cov_cross, lower=True)           # [n, M]
+            AM = sl.solve_triangular(L_add, ya_f[g] - mean_add, lower=True)  # [n]
+            means[g] = mean_q + A.T @ AM
+            seconds[g] = cov_q - A.T @ A if joint else var_qp - np.sum(A * A, axis=0)
+        return lead, means, seconds
+
+    def conditional_predict_f(self, query_points, additional_data: Dataset):
+        """Marginal posterior at query_points [M, D] conditioned also on ``additional_data``
+        ([..., N, D], [..., N, 1]) -> (mean [..., M, 1], var [..., M, 1]) (models.py:355-416)."""
+        lead, means, var = self._conditional_terms(query_points, additional_data, joint=False)
+        return means.reshape(lead + means.shape[1:] + (1,)), var.reshape(lead + var.shape[1:] + (1,))
+
+    def conditional_predict_joint(self, query_points, additional_data: Dataset):
+        """-> (mean [..., M, 1], cov [..., 1, M, M]) (models.py:418-484)."""
+        lead, means, cov = self._conditional_terms(query_points, additional_data, joint=True)
+        return means.reshape(lead + means.shape[1:] + (1,)), cov.reshape(lead + (1,) + cov.shape[1:])
+
+    def conditional_predict_f_sample(self, query_points, additional_data: Dataset, num_samples: int):
+        """Samples of f at query_points given the additional data -> [..., S, M, 1] (models.py:486-506)."""
+        mean, cov = self.conditional_predict_joint(query_points, additional_data)
+        M = mean.shape[-2]
+        Lc = np.linalg.cholesky(cov[..., 0, :, :] + 1e-6 * np.eye(M))  # sample_mvn's default jitter
+        eps = np.random.default_rng().standard_normal(mean.shape[:-2] + (int(num_samples), M))
+        return (mean[..., None, :, 0] + np.einsum("...ij,...sj->...si", Lc, eps))[..., None]
+
+    def conditional_predict_y(self, query_points, additional_data: Dataset):
+        """Observation-space version of :meth:`conditional_predict_f` (models.py:508-522)."""
+        m, v = self.conditional_predict_f(query_points, additional_data)
+        return m, v + self._model.likelihood_variance
 
     def predict_y(self, query_points):
         """Observation-space prediction: adds the Gaussian likelihood variance (models.py:167-169)."""

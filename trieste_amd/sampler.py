@@ -68,6 +68,39 @@ class BatchReparametrizationSampler:
         return self._model.engine.reparam_samples(at, eps, jitter)[..., None]
 
 
+class IndependentReparametrizationSampler:
+    r"""x -> mu(x) + sqrt(var(x)) eps with one fixed eps [S] (reference sampler.py:82-164): samples of
+    the MARGINAL posteriors, continuous in x.  On the engine this is the reparametrised sample
+    kernel at batch size one with zero jitter (the Cholesky factor of a 1 x 1 covariance is sqrt(var))."""
+
+    def __init__(self, sample_size: int, model, qmc: bool = False, seed: Optional[int] = None):
+        if sample_size <= 0:
+            raise ValueError(f"sample_size must be positive, got {sample_size}")
+        if qmc:
+            raise NotImplementedError("QMC (Sobol) draws are not implemented; the reference default is qmc=False")
+        self._sample_size = sample_size
+        self._model = model
+        self._rng = np.random.default_rng(seed)
+        self._eps: Optional[np.ndarray] = None  # [1, S]
+        self._initialized = False
+
+    def __repr__(self) -> str:
+        return f"IndependentReparametrizationSampler({self._sample_size!r}, {self._model!r})"
+
+    def reset_sampler(self) -> None:
+        self._initialized = False
+
+    def sample(self, at, *, jitter: float = JITTER):
+        """at [..., 1, D] -> samples [..., S, 1, 1] (``jitter`` is unused, as in the reference)."""
+        at = np.asarray(at, dtype=np.float64)
+        if at.ndim < 2 or at.shape[-2] != 1:
+            raise ValueError(f"at must be [..., 1, D], got shape {at.shape}")
+        if not self._initialized or self._eps is None:
+            self._eps = self._rng.standard_normal((1, self._sample_size))
+            self._initialized = True
+        return self._model.engine.reparam_samples(at, self._eps, 0.0)[..., None]
+
+
 # ---- decoupled trajectories -------------------------------------------------------------------
 _MATERN_DOF = {"matern12": 1, "matern32": 3, "matern52": 5}
 
@@ -123,6 +156,18 @@ class decoupled_trajectory:
         if x.shape[1] == 1:
             return self._traj(x[:, 0, :])[..., None]
         return self._traj(x)[..., None]
+
+    def value_and_gradient(self, x):
+        """x [P, B, D] -> (values [P, B], d f_b / d x_b [P, B, D]): what the L-BFGS-B refinement of the
+        continuous Thompson-sampling builders consumes (there is no autodiff on this engine)."""
+        x = x if type(x).__module__.startswith("torch") else np.asarray(x, dtype=np.float64)
+        if len(x.shape) == 2:  # batch-size-one optimizers pass [P, D]: a single trajectory
+            val, grad = self.value_and_gradient(x[:, None, :])
+            return val[:, 0], grad[:, 0, :]
+        if len(x.shape) != 3:
+            raise ValueError(f"trajectory inputs must be [P, B, D], got shape {tuple(x.shape)}")
+        self._ensure(int(x.shape[1]))
+        return self._traj.value_and_gradient(x)
 
     def argmin_over(self, at):
         """Fused evaluate + arg-min over shared candidates at [N, D] for every trajectory of the
