@@ -163,6 +163,16 @@ int tgp_reparam_samples(tgp_handle h, const double* Xq, int64_t G, int q, const 
 int tgp_cov_between(tgp_handle h, const double* X1, int64_t P1, const double* X2, int64_t P2, double* out,
                     int where);
 
+/* == GPflowPredictor.sample_encoded (models/gpflow/interface.py:135-137 -> gpflow
+ * predict_f_samples: predict_f(full_cov=True) then sample_mvn): exact joint posterior samples at
+ * Xq [n,d] given the standard-normal draws eps [n,S]:  out [S,n] = mean + chol(cov + jitter I) eps,
+ * cov unclipped (gpflow applies no clip here), jitter = gpflow default_jitter = 1e-6.  Any n (the
+ * n x n factorisation runs on the device); what ExactThompsonSampler.sample
+ * (acquisition/sampler.py:88-123) -- the DEFAULT sampler of DiscreteThompsonSampling
+ * (rule.py:935-938) -- draws its minimisers from. */
+int tgp_sample_joint(tgp_handle h, const double* Xq, int64_t n, const double* eps, int S, double jitter,
+                     double* out, int where);
+
 /* ---- decoupled Thompson trajectories ------------------------------------------------------ */
 /* == DecoupledTrajectorySampler._prepare_weight_sampler + weight_sampler(B)
  * (sampler.py:661-738) given the draws: rff_W [F,d], rff_b [F] (the RFF basis, gpflux

@@ -332,6 +332,18 @@ def batch_mc_ei(state: GPRState, Xq: np.ndarray, eps: np.ndarray, eta: float,
     return np.mean(np.maximum(eta - np.min(s, axis=-1), 0.0), axis=-1)
 
 
+def joint_samples(state: GPRState, Xq: np.ndarray, eps: np.ndarray, jitter: float = JITTER) -> np.ndarray:
+    """GPflowPredictor.sample_encoded (interface.py:135-137) -> gpflow predict_f_samples: mean, cov =
+    predict_f(full_cov=True) (NO clipping), samples = mean + chol(cov + jitter I) eps (sample_mvn).
+    Xq [n, d], eps [n, S] -> [S, n]."""
+    Xq = np.asarray(Xq, dtype=np.float64)
+    m, _ = predict(state, Xq)
+    cov = covariance_between_points(state, Xq, Xq)
+    cov = 0.5 * (cov + cov.T)
+    Lc = _cholesky(cov + jitter * np.eye(Xq.shape[0]), lower=True)
+    return (m[:, None] + Lc @ np.asarray(eps, dtype=np.float64)).T
+
+
 def independent_reparam_samples(state: GPRState, Xq: np.ndarray, eps: np.ndarray) -> np.ndarray:
     """IndependentReparametrizationSampler.sample (sampler.py:117-164): Xq [M, d], eps [S] ->
     samples [M, S] = mean + sqrt(var) * eps (marginal posteriors, no cross-covariance)."""

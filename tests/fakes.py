@@ -111,6 +111,9 @@ class FakeEngine:
             raise ValueError("q must be in 1..64")
         return O.predict_joint(self._st(), Xq)
 
+    def sample_joint(self, Xq, eps, jitter=1e-6):
+        return O.joint_samples(self._st(), np.asarray(Xq, float), np.asarray(eps, float), jitter)
+
     def cov_between(self, X1, X2):
         return O.covariance_between_points(self._st(), np.asarray(X1, float), np.asarray(X2, float))
 

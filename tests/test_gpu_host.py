@@ -99,6 +99,10 @@ def test_discrete_thompson_sampling_on_gpu():
     m_at = O.predict(st, pts)[0]
     m_rand = O.predict(st, space.sample(2000, seed=1))[0]
     assert np.median(m_at) < np.median(m_rand)
+    # the default (exact) sampler over a few thousand candidates: n x n factorisation on the GPU
+    pts_exact = DiscreteThompsonSampling(3000, 8, seed=4).acquire_single(space, model, dataset=data)
+    assert pts_exact.shape == (8, 2)
+    assert np.median(O.predict(st, pts_exact)[0]) < np.median(m_rand)
     # a trajectory evaluated through the reference-shaped callable agrees with its fused arg-min
     sampler = model.trajectory_sampler()
     traj = sampler.get_trajectory()

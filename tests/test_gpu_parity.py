@@ -386,3 +386,29 @@ def test_trajectory_value_and_gradient_match_oracle(cfg):
     skip0 = kind == "matern12"  # d k / dx is discontinuous at r = 0 for Matern-1/2
     sl = slice(1, None) if skip0 else slice(None)
     assert_close(grad[sl], ograd[sl], rtol=1e-6, atol=1e-8 * gs, what="trajectory gradient")
+
+
+@pytest.mark.parametrize("cfg", CONFIGS[:5], ids=[c[0] for c in CONFIGS[:5]])
+def test_exact_joint_samples_match_oracle(cfg):
+    """tgp_sample_joint (interface.py:135-137 -> gpflow predict_f_samples) vs the oracle for ragged
+    point counts (1, 64, 65, 300: the n x n factorisation runs on the device), including exact
+    duplicates of training inputs (covariance ~ 0 there: the jitter carries the factorisation)."""
+    _, obj, d, kind, N, noise = cfg
+    X, Y, ls, c, st, Xq = _problem(obj, d, kind, N, noise, M=300)
+    eng = _engine(kind, d, 1.0, ls, noise, c, X, Y)
+    rng = np.random.default_rng(17)
+    floor = cancellation_floor(N, 1.0, noise)
+    for n, S in ((1, 3), (64, 5), (65, 70), (300, 9)):
+        eps = rng.standard_normal((n, S))
+        got = eng.sample_joint(Xq[:n], eps, 1e-6)
+        assert got.shape == (S, n)
+        ref = O.joint_samples(st, Xq[:n], eps, 1e-6)
+        # the factor of (cov + 1e-6 I) amplifies covariance error by at most ~1 / sqrt(jitter)
+        assert_close(got, ref, rtol=1e-5, atol=max(floor * 1e3, 1e-9) * 30, what=f"joint samples n={n}")
+    import torch
+
+    eps = rng.standard_normal((130, 4))
+    dev = eng.sample_joint(torch.from_numpy(Xq[:130]).cuda(), torch.from_numpy(eps).cuda(), 1e-6)
+    assert_close(dev.cpu().numpy(), eng.sample_joint(Xq[:130], eps, 1e-6), rtol=0, atol=0, what="device == host inputs")
+    with pytest.raises(ValueError):
+        eng.sample_joint(Xq[:5], eps[:4], 1e-6)

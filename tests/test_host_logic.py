@@ -351,9 +351,20 @@ def test_discrete_thompson_sampling_and_random_sampling():
     smin = ThompsonSamplerFromTrajectory(sample_min_value=True).sample(model, 8, box.sample(400, seed=5))
     assert smin.shape == (8, 1)
     assert RandomSampling(4).acquire_single(box, model).shape == (4, 2)
-    # exact sampler on a small candidate set
-    pts2 = DiscreteThompsonSampling(40, 3).acquire_single(box, model, dataset=data)
+    # the DEFAULT sampler is the exact one (rule.py:935-938), any number of candidates
+    pts2 = DiscreteThompsonSampling(300, 3).acquire_single(box, model, dataset=data)
     assert pts2.shape == (3, 2)
+    # exact joint samples: [..., N, D] -> [..., S, N, 1]; sample statistics track the posterior
+    # (reference tests/unit/models/gpflow/test_models.py sample tests)
+    xs = box.sample(70, seed=11)
+    smp = model.sample(xs, 4000)
+    assert smp.shape == (4000, 70, 1)
+    m, v = model.predict(xs)
+    np.testing.assert_allclose(smp.mean(0), m, atol=5 * np.sqrt(v.max() / 4000) + 1e-3)
+    np.testing.assert_allclose(smp.var(0), v, rtol=0.2, atol=2e-5)
+    assert model.sample(np.stack([xs, xs]), 3).shape == (2, 3, 70, 1)
+    with pytest.raises(ValueError):
+        model.sample(xs, 0)
 
 
 def test_trajectory_fixed_batch_size_and_resample():

@@ -52,6 +52,7 @@ SIGNATURES = {
     "tgp_traj_get_v": (C.c_int, [_vp, _vp]),
     "tgp_traj_eval": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, C.c_int]),
     "tgp_traj_value_grad": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, C.c_int]),
+    "tgp_sample_joint": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int, C.c_double, _vp, C.c_int]),
     "tgp_cov_between": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int]),
     "tgp_traj_argmin": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, _vp, _vp, C.c_int]),
     "tgp_last_kernel_ms": (C.c_int, [_vp, _dp, C.POINTER(C.c_int)]),

@@ -46,16 +46,14 @@ def _gather(at, idx):
 
 
 class ExactThompsonSampler(ThompsonSampler):
-    """Exact Thompson samples via joint posterior samples at all candidates: O(N^3) in the number
-    of candidates; the engine's joint posterior is 64 points wide, so this sampler serves small
-    candidate sets only -- use :class:`ThompsonSamplerFromTrajectory` for sweeps."""
+    """Exact Thompson samples: joint posterior samples at ALL candidates, then per-sample arg-min
+    (sampler.py:79-123).  O(N^3) in the number of candidates -- the covariance assembly and its
+    factorisation run on the GPU (``model.sample`` -> tgp_sample_joint)."""
 
     def sample(self, model, sample_size: int, at, select_output=select_nth_output):
         _check(sample_size, at)
-        if at.shape[0] > 64:
-            raise NotImplementedError("ExactThompsonSampler is limited to 64 candidates on this engine; use "
-                                      "ThompsonSamplerFromTrajectory (decoupled trajectories) for larger sets")
-        samples = select_output(np.asarray(model.sample(at, sample_size)))  # [S, N]
+        host = at.cpu().numpy() if _is_torch(at) else np.asarray(at)
+        samples = select_output(np.asarray(model.sample(host, sample_size)))  # [S, N]
         if self._sample_min_value:
             return np.min(samples, axis=1, keepdims=True)
         return _gather(at, np.argmin(samples, axis=1))

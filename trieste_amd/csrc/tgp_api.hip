@@ -226,31 +226,40 @@ hipError_t launch_sweep_timed(tgp_handle h, const SweepArgs& a, bool joint) {
 //   chol_inv(lo, hi):  leaf (64):  L_dd, W_dd from A_dd
 //     else  chol_inv(lo, mid);  L21 = A21 W11^T;  A22 -= L21 L21^T;  chol_inv(mid, hi);
 //           T = L21 W11 (into the dead A21);  W21 = -W22 T.
-void chol_inv(tgp_handle h, int64_t lo, int64_t hi) {
-  const int64_t ld = h->Npad;
-  double* A = h->d_A.as<double>();
-  double* L = h->d_L.as<double>();
-  double* W = h->d_W.as<double>();
+struct FactorWs {  // a square workspace: A (in, destroyed), L, W (out), leading dimension, info flag
+  double *A, *L, *W;
+  int64_t ld;
+  int* info;
+};
+
+void chol_inv(hipStream_t st, const FactorWs& f, int64_t lo, int64_t hi) {
+  const int64_t ld = f.ld;
+  double *A = f.A, *L = f.L, *W = f.W;
   const int64_t n = hi - lo;
   if (n <= LEAF) {
-    launch_leaf(h->stream, A, L, W, ld, lo, h->d_info.as<int>());
+    launch_leaf(st, A, L, W, ld, lo, f.info);
     return;
   }
   const int64_t nblk = n / LEAF;
   const int64_t mid = lo + (nblk / 2) * LEAF;
   const int s1 = (int)(mid - lo), s2 = (int)(hi - mid);
-  chol_inv(h, lo, mid);
+  chol_inv(st, f, lo, mid);
   double* A21 = A + mid * ld + lo;
   double* L21 = L + mid * ld + lo;
   double* W11 = W + lo * ld + lo;
   double* A22 = A + mid * ld + mid;
-  launch_gemm(h->stream, true, s2, s1, s1, 1.0, A21, ld, W11, ld, 0.0, L21, ld, false, 1);
-  launch_gemm(h->stream, true, s2, s2, s1, -1.0, L21, ld, L21, ld, 1.0, A22, ld, true);
-  chol_inv(h, mid, hi);
+  launch_gemm(st, true, s2, s1, s1, 1.0, A21, ld, W11, ld, 0.0, L21, ld, false, 1);
+  launch_gemm(st, true, s2, s2, s1, -1.0, L21, ld, L21, ld, 1.0, A22, ld, true);
+  chol_inv(st, f, mid, hi);
   double* W22 = W + mid * ld + mid;
   double* W21 = W + mid * ld + lo;
-  launch_gemm(h->stream, false, s2, s1, s1, 1.0, L21, ld, W11, ld, 0.0, A21, ld, false, 2);
-  launch_gemm(h->stream, false, s2, s1, s2, -1.0, W22, ld, A21, ld, 0.0, W21, ld, false, 3);
+  launch_gemm(st, false, s2, s1, s1, 1.0, L21, ld, W11, ld, 0.0, A21, ld, false, 2);
+  launch_gemm(st, false, s2, s1, s2, -1.0, W22, ld, A21, ld, 0.0, W21, ld, false, 3);
+}
+
+void chol_inv(tgp_handle h, int64_t lo, int64_t hi) {
+  chol_inv(h->stream, FactorWs{h->d_A.as<double>(), h->d_L.as<double>(), h->d_W.as<double>(), h->Npad,
+                               h->d_info.as<int>()}, lo, hi);
 }
 
 }  // namespace
@@ -633,6 +642,58 @@ int tgp_cov_between(tgp_handle h, const double* X1, int64_t P1, const double* X2
   if (int rc = stage_out_finish(h, dout, out, (size_t)P1 * P2, where)) return rc;
   if (int rc = sync(h)) return rc;
   HIPCHK(h, hipGetLastError());
+  return TGP_OK;
+}
+
+int tgp_sample_joint(tgp_handle h, const double* Xq, int64_t n, const double* eps, int S, double jitter,
+                     double* out, int where) {
+  if (!h) return TGP_ERR_ARG;
+  if (!h->have_data) return fail(h, TGP_ERR_STATE, "model has no data: call tgp_set_data first");
+  if (n < 1 || S < 1 || !Xq || !eps || !out) return fail(h, TGP_ERR_SHAPE, "need n >= 1 points and S >= 1 draws");
+  if (!(jitter >= 0.0)) return fail(h, TGP_ERR_ARG, "jitter must be non-negative");
+  if (int rc = set_device(h)) return rc;
+  const int64_t Pp = ((n + 63) / 64) * 64, Sp = (((int64_t)S + 63) / 64) * 64, Npad = h->Npad;
+  const double *dXq, *deps;
+  double* dout;
+  if (int rc = stage_in(h, h->s_in, Xq, (size_t)n * h->d, where, &dXq)) return rc;
+  if (int rc = stage_in(h, h->s_in2, eps, (size_t)n * S, where, &deps)) return rc;
+  if (int rc = stage_out_prepare(h, h->s_out1, out, (size_t)S * n, where, &dout)) return rc;
+  const size_t need = (size_t)Npad * Pp * 3 + (size_t)Pp * Pp * 3 + (size_t)Pp * Sp * 2 + (size_t)Pp + 64;
+  HIPCHK(h, h->s_grad.reserve(need * sizeof(double)));
+  double* B1 = h->s_grad.as<double>();
+  double* C1 = B1 + (size_t)Npad * Pp;
+  double* C1t = C1 + (size_t)Npad * Pp;
+  double* A = C1t + (size_t)Npad * Pp;  // [Pp, Pp] covariance, then scratch of the factorisation
+  double* L = A + (size_t)Pp * Pp;
+  double* W = L + (size_t)Pp * Pp;
+  double* E = W + (size_t)Pp * Pp;      // [Pp, Sp] padded draws
+  double* R = E + (size_t)Pp * Sp;      // [Pp, Sp] L E
+  double* mean = R + (size_t)Pp * Sp;   // [Pp]
+  int* info = (int*)(mean + Pp);
+  const ModelDev m = model_dev(h);
+  hipStream_t s = h->stream;
+  HIPCHK(h, hipMemsetAsync(info, 0, sizeof(int), s));
+  launch_predict_mean(s, m, dXq, n, mean);
+  // cov = k(Xq, Xq) - (W k(X, Xq))^T (W k(X, Xq)) + jitter I   (gpflow predict_f(full_cov) + sample_mvn)
+  launch_kstar_t(s, m, dXq, n, Pp, B1);
+  launch_gemm(s, false, (int)Npad, (int)Pp, (int)Npad, 1.0, h->d_W.as<double>(), Npad, B1, Pp, 0.0, C1, Pp, false, 3);
+  launch_transpose(s, C1, Npad, Pp, Pp, C1t, Npad);
+  launch_gemm(s, false, (int)Pp, (int)Pp, (int)Npad, 1.0, C1t, Npad, C1, Pp, 0.0, L, Pp, true, 0);  // S (lower) in L
+  launch_cov_sym_tail(s, m, dXq, n, Pp, L, jitter, A);
+  HIPCHK(h, hipMemsetAsync(L, 0, (size_t)Pp * Pp * sizeof(double), s));
+  HIPCHK(h, hipMemsetAsync(W, 0, (size_t)Pp * Pp * sizeof(double), s));
+  chol_inv(s, FactorWs{A, L, W, Pp, info}, 0, Pp);
+  launch_pad_copy(s, deps, n, S, E, Pp, Sp);
+  launch_gemm(s, false, (int)Pp, (int)Sp, (int)Pp, 1.0, L, Pp, E, Sp, 0.0, R, Sp, false, 3);
+  launch_sample_tail(s, mean, R, n, S, Sp, dout);
+  int hinfo = 0;
+  HIPCHK(h, hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, s));
+  if (int rc = stage_out_finish(h, dout, out, (size_t)S * n, where)) return rc;
+  if (int rc = sync(h)) return rc;
+  HIPCHK(h, hipGetLastError());
+  if (hinfo != 0)
+    return fail(h, TGP_ERR_NOT_PD, "Cholesky of the joint posterior covariance failed at point %d: increase the jitter",
+                hinfo - 1);
   return TGP_OK;
 }
 

@@ -72,6 +72,10 @@ void launch_transpose(hipStream_t s, const double* src, int64_t rows, int64_t co
                       int64_t ldd);
 void launch_cov_tail(hipStream_t s, const ModelDev& m, const double* X1, int64_t P1, const double* X2,
                      int64_t P2, const double* S, int64_t lds, double* out);
+void launch_cov_sym_tail(hipStream_t s, const ModelDev& m, const double* X, int64_t n, int64_t Pp, const double* S,
+                         double jitter, double* A);
+void launch_pad_copy(hipStream_t s, const double* src, int64_t r, int64_t c, double* dst, int64_t rp, int64_t cp);
+void launch_sample_tail(hipStream_t s, const double* mean, const double* R, int64_t n, int S, int64_t Sp, double* out);
 void launch_row_norms(hipStream_t s, const double* Xs, double* xn, int64_t Npad, int dp);
 // y[i] = sum_k M[i][k] x[k] over k in [klo(i), khi(i)] ; lower: k<=i ; upper: k>=i
 void launch_trmv(hipStream_t s, const double* Mx, int64_t ld, int64_t n, const double* x, double* y,

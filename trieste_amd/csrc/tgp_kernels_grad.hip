@@ -49,6 +49,61 @@ void launch_cov_tail(hipStream_t s, const ModelDev& m, const double* X1, int64_t
   hipLaunchKernelGGL(cov_tail_kernel, grid, dim3(256), 0, s, m, X1, P1, X2, P2, S, lds, out);
 }
 
+// A[i][j] (lower triangle incl. diagonal, mirrored to the upper) = k(x_i, x_j) - S[i][j] + jitter [i == j]
+// for i, j < n; the padding carries the identity so the padded matrix stays positive definite.
+__global__ void cov_sym_tail_kernel(ModelDev m, const double* __restrict__ X, int64_t n, int64_t Pp,
+                                    const double* __restrict__ S, double jitter, double* __restrict__ A) {
+  const int64_t j = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int64_t i = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (i >= Pp || j >= Pp) return;
+  double v;
+  if (i < n && j < n) {
+    double r2 = 0.0;
+    for (int c = 0; c < m.d; ++c) {
+      const double t = (X[i * m.d + c] - X[j * m.d + c]) / m.ls[c];
+      r2 = fma(t, t, r2);
+    }
+    const int64_t a = i > j ? i : j, b = i > j ? j : i;  // S holds the lower triangle
+    v = kernel_rt(m.kind, r2, m.variance) - S[a * Pp + b] + (i == j ? jitter : 0.0);
+  } else {
+    v = (i == j) ? 1.0 : 0.0;
+  }
+  A[i * Pp + j] = v;
+}
+
+void launch_cov_sym_tail(hipStream_t s, const ModelDev& m, const double* X, int64_t n, int64_t Pp, const double* S,
+                         double jitter, double* A) {
+  dim3 grid((unsigned)(Pp / 64), (unsigned)(Pp / 4));
+  hipLaunchKernelGGL(cov_sym_tail_kernel, grid, dim3(256), 0, s, m, X, n, Pp, S, jitter, A);
+}
+
+// E [rp, cp] = src [r, c] zero padded
+__global__ void pad_copy_kernel(const double* __restrict__ src, int64_t r, int64_t c, double* __restrict__ dst,
+                                int64_t rp, int64_t cp) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= rp * cp) return;
+  const int64_t i = e / cp, j = e % cp;
+  dst[e] = (i < r && j < c) ? src[i * c + j] : 0.0;
+}
+
+void launch_pad_copy(hipStream_t s, const double* src, int64_t r, int64_t c, double* dst, int64_t rp, int64_t cp) {
+  hipLaunchKernelGGL(pad_copy_kernel, dim3((unsigned)((rp * cp + 255) / 256)), dim3(256), 0, s, src, r, c, dst, rp, cp);
+}
+
+// out [S, n]: out[s][j] = mean[j] + R[j][s]
+__global__ void sample_tail_kernel(const double* __restrict__ mean, const double* __restrict__ R, int64_t n, int S,
+                                   int64_t Sp, double* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)S * n) return;
+  const int64_t sidx = e / n, j = e % n;
+  out[e] = mean[j] + R[j * Sp + sidx];
+}
+
+void launch_sample_tail(hipStream_t s, const double* mean, const double* R, int64_t n, int S, int64_t Sp, double* out) {
+  hipLaunchKernelGGL(sample_tail_kernel, dim3((unsigned)(((int64_t)S * n + 255) / 256)), dim3(256), 0, s, mean, R, n,
+                     S, Sp, out);
+}
+
 constexpr int GT_THREADS = 256;
 
 // one workgroup per query point

@@ -153,6 +153,19 @@ class GPEngine:
         self._chk(self._lib.tgp_predict_joint(self._h, a.ptr, G, q, pm, pc, a.where))
         return mean, cov
 
+    def sample_joint(self, Xq, eps, jitter: float = 1e-6):
+        """Exact joint posterior samples: Xq [n, d], eps [n, S] standard normal -> [S, n]."""
+        a, e = _Arg(Xq), _Arg(eps)
+        if len(a.shape) != 2 or a.shape[1] != self.d:
+            raise ValueError(f"query points must be [n, {self.d}], got {a.shape}")
+        if len(e.shape) != 2 or e.shape[0] != a.shape[0]:
+            raise ValueError(f"eps must be [n={a.shape[0]}, S], got {e.shape}")
+        if a.where != e.where:
+            raise ValueError("Xq and eps must both be host arrays or both be CUDA tensors")
+        out, po = self._out(a, (e.shape[1], a.shape[0]))
+        self._chk(self._lib.tgp_sample_joint(self._h, a.ptr, a.shape[0], e.ptr, e.shape[1], float(jitter), po, a.where))
+        return out
+
     def cov_between(self, X1, X2):
         """X1 [P1, d], X2 [P2, d] -> posterior cross-covariance [P1, P2] (unclipped)."""
         a1, a2 = _Arg(X1), _Arg(X2)

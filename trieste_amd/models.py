@@ -278,15 +278,22 @@ class GaussianProcessRegression:
         return m, v + self._model.likelihood_variance
 
     def sample(self, query_points, num_samples: int):
-        """Exact joint samples (gpflow predict_f_samples): [..., N, D] -> [..., S, N, 1] = mean +
-        chol(cov + jitter I) eps for N <= 64 query points (the engine's joint-posterior width);
-        larger exact samples need the cross-covariance kernels SURVEY.md section 8f ranks as
-        follow-up work.  The draws eps come from numpy's generator."""
+        """Exact joint samples (interface.py:135-137 -> gpflow predict_f_samples): [..., N, D] ->
+        [..., S, N, 1] = mean + chol(cov + 1e-6 I) eps, any N: covariance assembly, the N x N
+        factorisation and the product with the draws run on the GPU (tgp_sample_joint).  The draws
+        eps come from numpy's generator."""
         q = np.asarray(query_points, dtype=np.float64)
-        if q.ndim < 2 or q.shape[-2] > 64:
-            raise NotImplementedError("exact joint sampling is limited to [..., N <= 64, D] query points")
-        eps = np.random.default_rng().normal(size=(q.shape[-2], int(num_samples)))
-        return self._engine.reparam_samples(q, eps, 1e-6)[..., None]
+        if q.ndim < 2:
+            raise ValueError(f"query_points must be [..., N, D], got shape {q.shape}")
+        if num_samples <= 0:
+            raise ValueError(f"num_samples must be positive, got {num_samples}")
+        lead, N = q.shape[:-2], q.shape[-2]
+        flat = q.reshape((-1, N, q.shape[-1]))
+        rng = np.random.default_rng()
+        out = np.empty((flat.shape[0], int(num_samples), N))
+        for g in range(flat.shape[0]):
+            out[g] = self._engine.sample_joint(flat[g], rng.standard_normal((N, int(num_samples))), 1e-6)
+        return out.reshape(lead + (int(num_samples), N, 1))
 
     def log(self, dataset: Optional[Dataset] = None) -> None:
         """TensorBoard summaries are out of scope."""
