@@ -11,6 +11,7 @@
 #include <limits>
 #include <new>
 #include <string>
+#include <algorithm>
 #include <chrono>
 #include <vector>
 
@@ -694,6 +695,28 @@ int tgp_sample_joint(tgp_handle h, const double* Xq, int64_t n, const double* ep
   if (hinfo != 0)
     return fail(h, TGP_ERR_NOT_PD, "Cholesky of the joint posterior covariance failed at point %d: increase the jitter",
                 hinfo - 1);
+  return TGP_OK;
+}
+
+// Development aid (not part of include/tgp.h): time `reps` launches of the factor GEMM on scratch buffers.
+int tgp_debug_gemm(tgp_handle h, int m, int n, int k, int tb, int tri, int lower_only, int reps, double* ms) {
+  if (!h || !ms) return TGP_ERR_ARG;
+  if (int rc = set_device(h)) return rc;
+  const size_t ld = (size_t)std::max(std::max(m, n), k);
+  HIPCHK(h, h->s_grad.reserve(3 * ld * ld * sizeof(double)));
+  double* A = h->s_grad.as<double>();
+  double* B = A + ld * ld;
+  double* Cc = B + ld * ld;
+  HIPCHK(h, hipMemsetAsync(A, 0, 3 * ld * ld * sizeof(double), h->stream));
+  launch_gemm(h->stream, tb != 0, m, n, k, 1.0, A, ld, B, ld, 0.0, Cc, ld, lower_only != 0, tri);
+  (void)hipEventRecord(h->ev0, h->stream);
+  for (int r = 0; r < reps; ++r)
+    launch_gemm(h->stream, tb != 0, m, n, k, 1.0, A, ld, B, ld, 0.0, Cc, ld, lower_only != 0, tri);
+  (void)hipEventRecord(h->ev1, h->stream);
+  HIPCHK(h, hipEventSynchronize(h->ev1));
+  float f = 0.f;
+  HIPCHK(h, hipEventElapsedTime(&f, h->ev0, h->ev1));
+  *ms = (double)f / reps;
   return TGP_OK;
 }
 

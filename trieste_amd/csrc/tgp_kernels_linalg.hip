@@ -143,6 +143,36 @@ void launch_leaf(hipStream_t s, const double* A, double* L, double* W, int64_t l
 constexpr int GB = 64, GLD = GB + 16;
 
 
+// Workgroup -> output tile.  The launch is a 1-D grid over the LIVE tiles only, ordered so that tiles
+// with the longest k range start first and equal-length tiles are adjacent (the dispatcher hands
+// workgroups out in order: a short..long pattern repeating every tile row, or a grid whose dead half
+// exits at once, left the makespan at the unpruned launch's -- measured 2110 vs 2126 us at 4096^3):
+//   lower_only: the nt (nt + 1) / 2 tiles with tn <= tm, row by row (all the same length);
+//   tri 1 (k < (tn+1) T): column-major, last column first;   tri 2 (k >= tn T): column-major, first column first;
+//   tri 3 (k < (tm+1) T): row-major, last row first;          tri 5 (k >= tm T): row-major, first row first;
+//   tri 4 (k >= max(tm, tn) T) and unpruned: row-major with the column rotated by the row.
+__device__ __forceinline__ void tile_of_block(int lower_only, int tri, int nt_m, int nt_n, int& tm, int& tn) {
+  const int id = blockIdx.x;
+  if (lower_only) {
+    int r = (int)((sqrt(8.0 * id + 1.0) - 1.0) * 0.5);
+    while ((r + 1) * (r + 2) / 2 <= id) ++r;
+    while (r * (r + 1) / 2 > id) --r;
+    tm = r;
+    tn = id - r * (r + 1) / 2;
+  } else if (tri == 1 || tri == 2) {
+    const int c = id / nt_m;
+    tm = id % nt_m;
+    tn = (tri == 1) ? nt_n - 1 - c : c;
+  } else if (tri == 3 || tri == 5) {
+    const int r = id / nt_n;
+    tn = id % nt_n;
+    tm = (tri == 3) ? nt_m - 1 - r : r;
+  } else {
+    tm = id / nt_n;
+    tn = (id % nt_n + tm) % nt_n;
+  }
+}
+
 // `tri` prunes the k range per output tile when one operand is lower triangular (the factor
 // recursion of tgp_api.hip):  1: B^T with B lower (k < (tn+1) 64);  2: B lower, not transposed
 // (k >= tn 64);  3: A lower (k < (tm+1) 64);  4: A upper and B lower (k >= max(tm, tn) 64);
@@ -154,8 +184,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(int m, int n, int k, double a
                                                    const double* __restrict__ B, int64_t ldb,
                                                    double beta, double* __restrict__ C, int64_t ldc,
                                                    int lower_only, int tri) {
-  const int tn = blockIdx.x, tm = blockIdx.y;
-  if (lower_only && tn > tm) return;
+  int tm, tn;
+  tile_of_block(lower_only, tri, m / GB, n / GB, tm, tn);
   __shared__ double As[GKT][GLD];
   __shared__ double Bs[GKT][GLD];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -239,6 +269,100 @@ __global__ __launch_bounds__(256) void gemm_kernel(int m, int n, int k, double a
       }
 }
 
+// Large-grid variant: 128 x 128 tile, 8 waves (2 x 4), wave tile 64 x 32 (the sweep kernel's wave tile:
+// 6 LDS fragment reads per 8 MFMAs), 16-deep k steps, double-buffered LDS (one barrier per step), register
+// prefetch one step ahead.  16 flop per byte of operand traffic instead of 8: the 64 x 64 kernel above
+// is L2/MALL-bandwidth bound on the large nodes of the recursion (24-39 TFLOP/s measured).
+constexpr int HB = 128, HK = 16, HLD = HB + 16;
+template <bool TB>
+__global__ __launch_bounds__(512, 2) void gemm_big_kernel(int m, int n, int k, double alpha,
+                                                          const double* __restrict__ A, int64_t lda,
+                                                          const double* __restrict__ B, int64_t ldb,
+                                                          double beta, double* __restrict__ C, int64_t ldc,
+                                                          int lower_only, int tri) {
+  int tm, tn;
+  tile_of_block(lower_only, tri, m / HB, n / HB, tm, tn);
+  __shared__ __attribute__((aligned(16))) double sm[2][2][HK][HLD];  // [stage][A|B][k][row/col]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w >> 2, wn = w & 3;
+  v4d acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+  int klo = 0, khi = k;
+  if (tri == 1) khi = min(k, (tn + 1) * HB);
+  else if (tri == 2) klo = min(k, tn * HB);
+  else if (tri == 3) khi = min(k, (tm + 1) * HB);
+  else if (tri == 4) klo = min(k, max(tm, tn) * HB);
+  else if (tri == 5) klo = min(k, tm * HB);
+
+  const double* Ab = A + (int64_t)tm * HB * lda;
+  const double* Bb = TB ? B + (int64_t)tn * HB * ldb : B + (int64_t)tn * HB;
+  const int lr = tid >> 2, lk = (tid & 3) * 4;   // [row][k..k+3] loader (A, and B when TB)
+  const int br = tid >> 5, bc = (tid & 31) * 4;  // [k][n..n+3] loader (B when !TB)
+  v2d a0, a1, b0, b1;
+  auto fetch = [&](int k0) {
+    const double* sa = Ab + (int64_t)lr * lda + k0 + lk;
+    a0 = *(const v2d*)sa;
+    a1 = *(const v2d*)(sa + 2);
+    const double* sb = TB ? Bb + (int64_t)lr * ldb + k0 + lk : Bb + (int64_t)(k0 + br) * ldb + bc;
+    b0 = *(const v2d*)sb;
+    b1 = *(const v2d*)(sb + 2);
+  };
+  auto stage = [&](int st) {
+    double(*As)[HLD] = sm[st][0];
+    double(*Bs)[HLD] = sm[st][1];
+    As[lk + 0][lr] = a0.x; As[lk + 1][lr] = a0.y; As[lk + 2][lr] = a1.x; As[lk + 3][lr] = a1.y;
+    if (TB) {
+      Bs[lk + 0][lr] = b0.x; Bs[lk + 1][lr] = b0.y; Bs[lk + 2][lr] = b1.x; Bs[lk + 3][lr] = b1.y;
+    } else {
+      *(v2d*)&Bs[br][bc] = b0;
+      *(v2d*)&Bs[br][bc + 2] = b1;
+    }
+  };
+  if (klo < khi) {
+    fetch(klo);
+    stage(0);
+  }
+  __syncthreads();
+  int st = 0;
+  for (int k0 = klo; k0 < khi; k0 += HK) {
+    const bool more = k0 + HK < khi;
+    if (more) fetch(k0 + HK);
+    const double* ab = &sm[st][0][lane >> 4][wm * 64 + (lane & 15)];
+    const double* bb = &sm[st][1][lane >> 4][wn * 32 + (lane & 15)];
+#pragma unroll
+    for (int k4 = 0; k4 < HK / 4; ++k4) {
+      double av[4], bv[2];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) av[f] = ab[k4 * 4 * HLD + f * 16];
+#pragma unroll
+      for (int f = 0; f < 2; ++f) bv[f] = bb[k4 * 4 * HLD + f * 16];
+#pragma unroll
+      for (int fm = 0; fm < 4; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < 2; ++fn) acc[fm][fn] = mfma_f64(av[fm], bv[fn], acc[fm][fn]);
+    }
+    if (more) stage(st ^ 1);
+    __syncthreads();
+    st ^= 1;
+  }
+#pragma unroll
+  for (int fm = 0; fm < 4; ++fm)
+#pragma unroll
+    for (int fn = 0; fn < 2; ++fn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = (int64_t)tm * HB + wm * 64 + fm * 16 + (lane >> 4) + 4 * r;
+        const int64_t col = (int64_t)tn * HB + wn * 32 + fn * 16 + (lane & 15);
+        double* dst = C + row * ldc + col;
+        const double v = alpha * acc[fm][fn][r];
+        *dst = (beta == 0.0) ? v : fma(beta, *dst, v);
+      }
+}
+
 // k must be a multiple of 32 (all call sites pass multiples of 64).
 // Measured (profiles/r01_update_breakdown.txt): a dependent kernel costs ~5 us on this part however
 // small it is, and the 64x64-tile kernel is L2/MALL-bandwidth bound (8 flop per byte) on the large
@@ -246,11 +370,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(int m, int n, int k, double a
 void launch_gemm(hipStream_t s, bool tb, int m, int n, int k, double alpha, const double* A,
                  int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc,
                  bool lower_only, int tri) {
-  dim3 grid((unsigned)(n / GB), (unsigned)(m / GB));
   const int lo = lower_only ? 1 : 0;
+  static const int64_t big_min = getenv("TGP_GEMM_BIG") ? atoll(getenv("TGP_GEMM_BIG")) : 512;  // tuning aid
+  auto live_tiles = [&](int T) {  // 1-D grid over the live tiles (see tile_of_block)
+    const int64_t ntm = m / T, ntn = n / T;
+    return (unsigned)(lower_only ? ntm * (ntm + 1) / 2 : ntm * ntn);
+  };
+  if (m % HB == 0 && n % HB == 0 && (int64_t)(m / HB) * (n / HB) >= big_min) {
+    dim3 gb(live_tiles(HB));
+    if (tb) hipLaunchKernelGGL(gemm_big_kernel<true>, gb, dim3(512), 0, s, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lo, tri);
+    else hipLaunchKernelGGL(gemm_big_kernel<false>, gb, dim3(512), 0, s, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lo, tri);
+    return;
+  }
+  dim3 grid(live_tiles(GB));
   // few workgroups: the k loop of one workgroup is the critical path -> deeper steps (fewer barriers,
   // more loads in flight); many workgroups: 16-deep steps keep 4 workgroups resident per CU.
-  const bool deep = (int64_t)grid.x * grid.y <= 512 && k % 32 == 0;
+  const bool deep = (int64_t)(m / GB) * (n / GB) <= 512 && k % 32 == 0;
   if (tb) {
     if (deep) hipLaunchKernelGGL((gemm_kernel<true, 32>), grid, dim3(256), 0, s, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lo, tri);
     else hipLaunchKernelGGL((gemm_kernel<true, 16>), grid, dim3(256), 0, s, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lo, tri);
