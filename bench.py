@@ -72,6 +72,33 @@ def cpu_baseline(obj_name, d, kernel, N, noise, budget_s=20.0):
                       f"reference algorithm (K* [N,{chunk}], 2 triangular solves, EI, arg-max), {el:.1f} s"}
 
 
+def end_to_end_acquire_ms(X, Y, d, kernel, noise):
+    """Informational (outside the timed region, SURVEY 8d "end-to-end acquire time"): one
+    EfficientGlobalOptimization().acquire on the same model through the reference-shaped host API --
+    eta, max(5000, 1000 d) random candidates swept + top-k on the device, 10 d greenlet-batched
+    L-BFGS-B runs on the analytic EI gradient (the reference's default for a Box)."""
+    try:
+        import trieste_amd.models as M
+        from oracle import gp_oracle as O
+        from trieste_amd.acquisition import EfficientGlobalOptimization
+        from trieste_amd.data import Dataset
+        from trieste_amd.space import Box
+
+        kern = M.Kernel(variance=1.0, lengthscales=O.default_lengthscales(d), kind=kernel)
+        model = M.GaussianProcessRegression(M.GPR(data=(X, Y[:, None]), kernel=kern,
+                                                  mean_function=M.Constant(float(Y.mean())),
+                                                  likelihood_variance=noise))
+        data = Dataset(X, Y[:, None])
+        rule = EfficientGlobalOptimization()
+        space = Box([0.0] * d, [1.0] * d)
+        rule.acquire_single(space, model, dataset=data)  # warm-up (allocations)
+        t0 = time.perf_counter()
+        rule.acquire_single(space, model, dataset=data)
+        return (time.perf_counter() - t0) * 1e3
+    except Exception as e:  # never let the informational figure break the bench line
+        return f"failed: {type(e).__name__}: {e}"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,6 +107,7 @@ def main():
     ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
     ap.add_argument("--m-per-gpu", type=int, default=0, help="override candidates per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-acquire", action="store_true", help="skip the informational end-to-end acquire timing")
     ap.add_argument("--variant", type=int, default=0)
     args = ap.parse_args()
 
@@ -187,6 +215,8 @@ def main():
                 "kernel_ms": k_ms, "flops_per_candidate": algorithmic_flops_per_candidate(N, d, kernel),
             },
         }
+        if world == 1 and not args.no_acquire:
+            out["config"]["acquire_ms"] = end_to_end_acquire_ms(X, Y, d, kernel, noise)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(obj_name, d, kernel, N, noise)
         print(json.dumps(out), flush=True)
