@@ -181,6 +181,16 @@ int tgp_sample_joint(tgp_handle h, const double* Xq, int64_t n, const double* ep
  * (the reference re-factorises per trajectory, sampler.py:730).  All inputs HOST. */
 int tgp_traj_create(tgp_handle h, const double* rff_W, const double* rff_b, int F, const double* w,
                     const double* xi, int B, tgp_traj* out);
+/* == RandomFourierFeatureTrajectorySampler._prepare_weight_sampler + theta_posterior.sample(B)
+ * (sampler.py:518-591) given the standard-normal draws eps [F,B]: the weights theta of the F scaled
+ * Fourier features are Gaussian given the data -- "design space" (F < N: an F x F factorisation,
+ * sampler.py:529-556) or "gram space" (N <= F: N x N, sampler.py:558-591) -- and
+ * theta = mean + chol(cov) eps.  The resulting trajectory is f_b(x) = phi(x) . theta_b + c (no
+ * canonical part); it is evaluated / minimised / differentiated by the same tgp_traj_* calls. */
+int tgp_traj_create_rff(tgp_handle h, const double* rff_W, const double* rff_b, int F, const double* eps,
+                        int B, tgp_traj* out);
+/* theta [F,B] (host), for tests. */
+int tgp_traj_get_theta(tgp_traj t, double* theta);
 int tgp_traj_destroy(tgp_traj t);
 /* canonical weights v [N,B] (host), for tests. */
 int tgp_traj_get_v(tgp_traj t, double* v);

@@ -402,6 +402,41 @@ def decoupled_weights(state: GPRState, W, b, w, xi) -> np.ndarray:
     return _solve_triangular(state.L.T, t, lower=False)
 
 
+def rff_theta(state: GPRState, W, b, eps) -> np.ndarray:
+    """RandomFourierFeatureTrajectorySampler (sampler.py:518-591): weights theta [F, B] of the scaled
+    features = posterior mean + chol(posterior cov) eps, eps [F, B].
+    F < N ("design space", 529-556): D = Phi^T Phi + noise I, D^-1 by cholesky_solve,
+    mean = D^-1 Phi^T r, cov = noise D^-1.   N <= F ("gram space", 558-591): G = Phi Phi^T + noise I,
+    A = L_G^-1 Phi, mean = A^T L_G^-1 r, cov = I - A^T A."""
+    F = W.shape[0]
+    eps = np.asarray(eps, dtype=np.float64).reshape(F, -1)
+    phi = rff_features(state, state.X, W, b)  # [N, F]
+    r = state.err
+    if F < state.N:
+        Ld = _cholesky(phi.T @ phi + state.noise * np.eye(F), lower=True)
+        Dinv = _solve_triangular(Ld.T, _solve_triangular(Ld, np.eye(F), lower=True), lower=False)
+        mean = Dinv @ (phi.T @ r)
+        cov = state.noise * Dinv
+    else:
+        Lg = _cholesky(phi @ phi.T + state.noise * np.eye(state.N), lower=True)
+        A = _solve_triangular(Lg, phi, lower=True)
+        mean = A.T @ _solve_triangular(Lg, r, lower=True)
+        cov = np.eye(F) - A.T @ A
+    Lc = _cholesky(0.5 * (cov + cov.T), lower=True)
+    return mean[:, None] + Lc @ eps
+
+
+def rff_trajectory_eval(state: GPRState, W, b, theta, Xq: np.ndarray) -> np.ndarray:
+    """f_b(x) = phi(x) . theta_b + c (feature_decomposition_trajectory.__call__, sampler.py:923-936, with
+    the RFF-only feature functions); Xq [M, d] shared or [M, B, d] -> [M, B]."""
+    theta = np.asarray(theta, dtype=np.float64).reshape(W.shape[0], -1)
+    Xq = np.asarray(Xq, dtype=np.float64)
+    if Xq.ndim == 2:
+        return rff_features(state, Xq, W, b) @ theta + state.mean_const
+    return np.stack([rff_features(state, Xq[:, bb, :], W, b) @ theta[:, bb] for bb in range(theta.shape[1])],
+                    axis=1) + state.mean_const
+
+
 def trajectory_eval(state: GPRState, W, b, w, v, Xq: np.ndarray) -> np.ndarray:
     """sampler.py:923-936: f(x)_b = phi(x).w_b + k(x, X).v_b + c.   Xq [M, d] (shared by all
     B trajectories) or [M, B, d] -> [M, B]."""

@@ -38,6 +38,35 @@ class FakeTrajectory:
         return vals[idx, np.arange(self.B)], idx + index_base
 
 
+class FakeRffTrajectory:
+    def __init__(self, eng, W, b, eps):
+        self._eng = eng
+        self.W, self.b = np.asarray(W, float), np.asarray(b, float)
+        self._theta = O.rff_theta(eng.state, self.W, self.b, np.asarray(eps, float))
+        self.F, self.B = self._theta.shape
+
+    def close(self):
+        pass
+
+    def theta(self):
+        return self._theta
+
+    def __call__(self, Xq):
+        return O.rff_trajectory_eval(self._eng.state, self.W, self.b, self._theta, np.asarray(Xq, float))
+
+    def value_and_gradient(self, Xq):
+        Xq = np.asarray(Xq, float)
+        zero_v = np.zeros((self._eng.N, self.B))
+        scale = np.sqrt(2.0 * self._eng.state.variance / self.F)
+        # the decoupled oracle with no canonical part: w = theta (its features carry the scale themselves)
+        return O.trajectory_value_and_grad(self._eng.state, self.W, self.b, self._theta, zero_v, Xq)
+
+    def argmin(self, Xq, index_base=0):
+        vals = self(np.asarray(Xq, float))
+        idx = np.argmin(vals, axis=0)
+        return vals[idx, np.arange(self.B)], idx + index_base
+
+
 class FakeEngine:
     """Same constructor and methods as GPEngine; arithmetic by oracle/gp_oracle.py."""
 
@@ -168,6 +197,9 @@ class FakeEngine:
 
     def last_kernel_ms(self):
         return 0.0, 0
+
+    def trajectory_rff(self, rff_W, rff_b, eps):
+        return FakeRffTrajectory(self, rff_W, rff_b, eps)
 
     def trajectory(self, rff_W, rff_b, w, xi):
         return FakeTrajectory(self, rff_W, rff_b, w, xi)

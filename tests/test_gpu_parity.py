@@ -412,3 +412,38 @@ def test_exact_joint_samples_match_oracle(cfg):
     assert_close(dev.cpu().numpy(), eng.sample_joint(Xq[:130], eps, 1e-6), rtol=0, atol=0, what="device == host inputs")
     with pytest.raises(ValueError):
         eng.sample_joint(Xq[:5], eps[:4], 1e-6)
+
+
+@pytest.mark.parametrize("cfg", CONFIGS[:5], ids=[c[0] for c in CONFIGS[:5]])
+def test_rff_weight_posterior_trajectories_match_oracle(cfg):
+    """tgp_traj_create_rff (sampler.py:518-591) vs the oracle in design space (F < N) and gram space
+    (N <= F): weights theta, trajectory values (shared and per-trajectory inputs), fused arg-min and
+    gradients."""
+    _, obj, d, kind, N, noise = cfg
+    X, Y, ls, c, st, Xq = _problem(obj, d, kind, N, noise, M=150)
+    eng = _engine(kind, d, 1.0, ls, noise, c, X, Y)
+    from trieste_amd.sampler import sample_rff_basis
+
+    for F in (max(8, N // 3), N + 37):
+        rng = np.random.default_rng(F)
+        W, b = sample_rff_basis(kind, F, d, rng)
+        B = 3
+        eps = rng.standard_normal((F, B))
+        traj = eng.trajectory_rff(W, b, eps)
+        oth = O.rff_theta(st, W, b, eps)
+        tscale = max(1.0, np.abs(oth).max())
+        # both factorisations amplify rounding by cond ~ |Phi|^2 / noise
+        assert_close(traj.theta(), oth, rtol=1e-6, atol=1e-9 * tscale / min(noise, 1.0), what=f"theta F={F}")
+        ref = O.rff_trajectory_eval(st, W, b, traj.theta(), Xq)
+        assert_close(traj(Xq), ref, rtol=1e-9, atol=1e-9 * tscale, what="rff trajectory (shared inputs)")
+        Xp = rng.uniform(size=(21, B, d))
+        assert_close(traj(Xp), O.rff_trajectory_eval(st, W, b, traj.theta(), Xp), rtol=1e-9, atol=1e-9 * tscale,
+                     what="rff trajectory (per-trajectory inputs)")
+        v, i = traj.argmin(Xq)
+        np.testing.assert_array_equal(i, np.argmin(ref, axis=0))
+        val, grad = traj.value_and_gradient(Xp)
+        oval, ograd = O.trajectory_value_and_grad(st, W, b, traj.theta(), np.zeros((N, B)), Xp)
+        assert_close(val, oval, rtol=1e-9, atol=1e-9 * tscale, what="rff value")
+        assert_close(grad, ograd, rtol=1e-7, atol=1e-8 * np.abs(ograd).max(), what="rff gradient")
+        with pytest.raises(RuntimeError):
+            traj.v()

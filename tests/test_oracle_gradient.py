@@ -76,3 +76,33 @@ def test_conditional_predict_equals_refit_on_augmented_data():
     mf, vf = O.conditional_predict_f(st, Xq, Xa, Ya)
     np.testing.assert_allclose(mf, m_ref, rtol=1e-9, atol=1e-10)
     np.testing.assert_allclose(vf, np.diag(c_ref), rtol=1e-8, atol=1e-10)
+
+
+def test_rff_weight_posterior_design_and_gram_space_agree():
+    """sampler.py:529-591: the two computation strategies describe the same Gaussian over theta -- equal
+    posterior means, and equal covariances (compared through many draws mapped with the same eps is not
+    possible: the Cholesky factors differ; compare mean and covariance directly)."""
+    rng = np.random.default_rng(4)
+    d, N, F = 3, 25, 40
+    X, Y = O.synthetic_problem(O.ackley, d, N)
+    st = O.gpr_update("rbf", 1.2, O.default_lengthscales(d), 5e-2, 0.1, X, Y)
+    W, b = rng.standard_normal((F, d)), rng.uniform(0, 2 * np.pi, F)
+    phi = O.rff_features(st, X, W, b)
+    # design-space moments
+    D = phi.T @ phi + st.noise * np.eye(F)
+    mean_d = np.linalg.solve(D, phi.T @ st.err)
+    cov_d = st.noise * np.linalg.inv(D)
+    # gram-space moments
+    G = phi @ phi.T + st.noise * np.eye(N)
+    mean_g = phi.T @ np.linalg.solve(G, st.err)
+    cov_g = np.eye(F) - phi.T @ np.linalg.solve(G, phi)
+    np.testing.assert_allclose(mean_d, mean_g, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(cov_d, cov_g, rtol=1e-7, atol=1e-10)
+    # the oracle picks gram space here (N <= F) and design space with fewer features; zero draws give the mean
+    np.testing.assert_allclose(O.rff_theta(st, W, b, np.zeros((F, 1)))[:, 0], mean_g, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(O.rff_theta(st, W[:10], b[:10], np.zeros((10, 1)))[:, 0],
+                               np.linalg.solve(phi[:, :10].T @ phi[:, :10] * (F / 10) + st.noise * np.eye(10),
+                                               np.sqrt(F / 10) * phi[:, :10].T @ st.err), rtol=1e-8, atol=1e-10)
+    # sample covariance of theta over many draws matches the analytic covariance
+    th = O.rff_theta(st, W, b, rng.standard_normal((F, 20000)))
+    np.testing.assert_allclose(np.cov(th), cov_g, atol=0.03)

@@ -48,6 +48,8 @@ SIGNATURES = {
                           C.c_int]),
     "tgp_reparam_samples": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, C.c_int, C.c_double, _vp, C.c_int]),
     "tgp_traj_create": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, C.POINTER(_vp)]),
+    "tgp_traj_create_rff": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, C.c_int, C.POINTER(_vp)]),
+    "tgp_traj_get_theta": (C.c_int, [_vp, _vp]),
     "tgp_traj_destroy": (C.c_int, [_vp]),
     "tgp_traj_get_v": (C.c_int, [_vp, _vp]),
     "tgp_traj_eval": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, C.c_int]),

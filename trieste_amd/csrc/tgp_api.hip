@@ -84,7 +84,8 @@ struct tgp_handle_s {
 struct tgp_traj_s {
   tgp_handle h = nullptr;
   int F = 0, B = 0;
-  DevBuf d_W, d_b, d_ws, d_v;
+  DevBuf d_W, d_b, d_ws, d_v, d_theta;
+  int canonical = 1;
 };
 
 namespace {
@@ -914,6 +915,7 @@ static TrajDev traj_dev(tgp_traj t) {
   td.rffb = t->d_b.as<double>();
   td.ws = t->d_ws.as<double>();
   td.v = t->d_v.as<double>();
+  td.canonical = t->canonical;
   return td;
 }
 
@@ -978,6 +980,124 @@ int tgp_traj_create(tgp_handle h, const double* rff_W, const double* rff_b, int 
   return TGP_OK;
 }
 
+// == RandomFourierFeatureTrajectorySampler (sampler.py:452-591): posterior over the weights theta of the
+// F scaled Fourier features given the data, in design space (F < N: F x F) or gram space (N <= F: N x N),
+// theta = mean + chol(cov) eps; all matrices are built, factorised and applied on the device.
+int tgp_traj_create_rff(tgp_handle h, const double* rff_W, const double* rff_b, int F, const double* eps, int B,
+                        tgp_traj* out) {
+  if (!h || !out) return TGP_ERR_ARG;
+  *out = nullptr;
+  if (!h->have_data) return fail(h, TGP_ERR_STATE, "model has no data: call tgp_set_data first");
+  if (F < 1 || B < 1 || !rff_W || !rff_b || !eps) return fail(h, TGP_ERR_ARG, "bad arguments");
+  if (int rc = set_device(h)) return rc;
+  tgp_traj t = new (std::nothrow) tgp_traj_s();
+  if (!t) return fail(h, TGP_ERR_ALLOC, "host allocation failed");
+  t->h = h;
+  t->F = F;
+  t->B = B;
+  t->canonical = 0;
+  const int d = h->d, dp = h->dp;
+  const int64_t N = h->N, Npad = h->Npad;
+  const int64_t Fp = (((int64_t)F + 63) / 64) * 64, Bp = (((int64_t)B + 63) / 64) * 64;
+  std::vector<double> Wp((size_t)F * dp, 0.0);
+  for (int f = 0; f < F; ++f)
+    for (int c = 0; c < d; ++c) Wp[(size_t)f * dp + c] = rff_W[(size_t)f * d + c];
+  const double scale = std::sqrt(2.0 * h->variance / (double)F);
+  hipError_t e;
+#define TCHK(expr)                                                            \
+  if ((e = (expr)) != hipSuccess) {                                           \
+    tgp_traj_destroy(t);                                                      \
+    return fail(h, e == hipErrorOutOfMemory ? TGP_ERR_ALLOC : TGP_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e)); \
+  }
+  TCHK(t->d_W.reserve(Wp.size() * sizeof(double)));
+  TCHK(t->d_b.reserve((size_t)F * sizeof(double)));
+  TCHK(t->d_ws.reserve((size_t)F * B * sizeof(double)));
+  TCHK(t->d_theta.reserve((size_t)F * B * sizeof(double)));
+  TCHK(t->d_v.reserve(64));
+  TCHK(hipMemcpy(t->d_W.p, Wp.data(), Wp.size() * sizeof(double), hipMemcpyHostToDevice));
+  TCHK(hipMemcpy(t->d_b.p, rff_b, (size_t)F * sizeof(double), hipMemcpyHostToDevice));
+  const bool design = (int64_t)F < N;
+  const int64_t Q = design ? Fp : Npad;  // side of the first factorisation
+  // workspace: Phi, Phit [Npad Fp]; R0 [Npad 64]; X1, X2 [max 64]; E, RE [Fp Bp]; squares S1..S3 [Q Q]; C1..C3 [Fp Fp]
+  const size_t nphi = (size_t)Npad * Fp, nsq = (size_t)Q * Q, nc = (size_t)Fp * Fp;
+  const size_t need = 3 * nphi + (size_t)Npad * 64 * 2 + (size_t)Fp * 64 * 2 + 2 * (size_t)Fp * Bp + 3 * nsq + 3 * nc + 64;
+  TCHK(h->s_grad.reserve(need * sizeof(double)));
+  double* Phi = h->s_grad.as<double>();
+  double* Phit = Phi + nphi;
+  double* Aw = Phit + nphi;                 // gram space: A = W_G Phi, then its transpose reuses Phit
+  double* R0 = Aw + nphi;                    // [Npad][64]: column 0 = Y - c
+  double* Y1 = R0 + (size_t)Npad * 64;       // [Npad][64]
+  double* M0 = Y1 + (size_t)Npad * 64;       // [Fp][64]
+  double* M1 = M0 + (size_t)Fp * 64;         // [Fp][64]: column 0 = posterior mean
+  double* E = M1 + (size_t)Fp * 64;          // [Fp][Bp]
+  double* RE = E + (size_t)Fp * Bp;
+  double* S1 = RE + (size_t)Fp * Bp;         // first factorisation: matrix / L / W
+  double* S2 = S1 + nsq;
+  double* S3 = S2 + nsq;
+  double* C1 = S3 + nsq;                     // weight covariance: matrix / L / W
+  double* C2 = C1 + nc;
+  double* C3 = C2 + nc;
+  int* info = (int*)(C3 + nc);
+  hipStream_t s = h->stream;
+  TrajDev td = traj_dev(t);
+  TCHK(hipMemsetAsync(info, 0, 2 * sizeof(int), s));
+  launch_rff_features(s, td, scale, Fp, Phi);
+  launch_transpose(s, Phi, Npad, Fp, Fp, Phit, Npad);
+  launch_pad_copy(s, h->d_err.as<double>(), N, 1, R0, Npad, 64);
+  TCHK(h->s_in.reserve((size_t)F * B * sizeof(double)));
+  TCHK(hipMemcpyAsync(h->s_in.p, eps, (size_t)F * B * sizeof(double), hipMemcpyHostToDevice, s));
+  launch_pad_copy(s, h->s_in.as<double>(), F, B, E, Fp, Bp);
+  TCHK(hipMemsetAsync(S2, 0, 2 * nsq * sizeof(double), s));
+  TCHK(hipMemsetAsync(C2, 0, 2 * nc * sizeof(double), s));
+  if (design) {
+    // D = Phi^T Phi + noise I;  D^-1 = W_D^T W_D;  mean = D^-1 Phi^T r;  cov = noise D^-1   (sampler.py:529-556)
+    launch_gemm(s, true, (int)Fp, (int)Fp, (int)Npad, 1.0, Phit, Npad, Phit, Npad, 0.0, S1, Fp, true, 0);
+    launch_sym_finish(s, S1, F, Fp, 1.0, h->noise, 0);
+    chol_inv(s, FactorWs{S1, S2, S3, Fp, info}, 0, Fp);
+    launch_transpose(s, S3, Fp, Fp, Fp, S1, Fp);                                                   // W_D^T (S1 is dead)
+    launch_gemm(s, false, (int)Fp, (int)Fp, (int)Fp, 1.0, S1, Fp, S3, Fp, 0.0, C1, Fp, false, 4);  // D^-1
+    launch_gemm(s, false, (int)Fp, 64, (int)Npad, 1.0, Phit, Npad, R0, 64, 0.0, M0, 64, false, 0);  // Phi^T r
+    launch_gemm(s, false, (int)Fp, 64, (int)Fp, 1.0, C1, Fp, M0, 64, 0.0, M1, 64, false, 0);        // mean
+    launch_sym_finish(s, C1, F, Fp, h->noise, 0.0, 0);
+  } else {
+    // G = Phi Phi^T + noise I;  A = L_G^-1 Phi;  mean = A^T L_G^-1 r;  cov = I - A^T A            (sampler.py:558-591)
+    launch_gemm(s, true, (int)Npad, (int)Npad, (int)Fp, 1.0, Phi, Fp, Phi, Fp, 0.0, S1, Npad, true, 0);
+    launch_sym_finish(s, S1, N, Npad, 1.0, h->noise, 0);
+    chol_inv(s, FactorWs{S1, S2, S3, Npad, info}, 0, Npad);
+    launch_gemm(s, false, (int)Npad, (int)Fp, (int)Npad, 1.0, S3, Npad, Phi, Fp, 0.0, Aw, Fp, false, 3);
+    launch_gemm(s, false, (int)Npad, 64, (int)Npad, 1.0, S3, Npad, R0, 64, 0.0, Y1, 64, false, 3);
+    launch_transpose(s, Aw, Npad, Fp, Fp, Phit, Npad);                                              // A^T
+    launch_gemm(s, false, (int)Fp, 64, (int)Npad, 1.0, Phit, Npad, Y1, 64, 0.0, M1, 64, false, 0);  // mean
+    launch_gemm(s, true, (int)Fp, (int)Fp, (int)Npad, 1.0, Phit, Npad, Phit, Npad, 0.0, C1, Fp, true, 0);
+    launch_sym_finish(s, C1, F, Fp, 1.0, 1.0, 1);
+  }
+  chol_inv(s, FactorWs{C1, C2, C3, Fp, info + 1}, 0, Fp);
+  launch_gemm(s, false, (int)Fp, (int)Bp, (int)Fp, 1.0, C2, Fp, E, Bp, 0.0, RE, Bp, false, 3);
+  launch_theta_tail(s, M1, 64, RE, Bp, F, B, scale, t->d_theta.as<double>(), t->d_ws.as<double>());
+  int hinfo[2] = {0, 0};
+  TCHK(hipMemcpyAsync(hinfo, info, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+  TCHK(hipStreamSynchronize(s));
+  TCHK(hipGetLastError());
+#undef TCHK
+  if (hinfo[0] != 0 || hinfo[1] != 0) {
+    tgp_traj_destroy(t);
+    return fail(h, TGP_ERR_NOT_PD, "Cholesky failed in the RFF weight posterior (%s, pivot %d)",
+                hinfo[0] ? (design ? "design matrix" : "gram matrix") : "weight covariance",
+                (hinfo[0] ? hinfo[0] : hinfo[1]) - 1);
+  }
+  *out = t;
+  return TGP_OK;
+}
+
+int tgp_traj_get_theta(tgp_traj t, double* theta) {
+  if (!t || !theta) return TGP_ERR_ARG;
+  tgp_handle h = t->h;
+  if (t->canonical) return fail(h, TGP_ERR_STATE, "not an RFF-weight trajectory");
+  if (int rc = set_device(h)) return rc;
+  HIPCHK(h, hipMemcpy(theta, t->d_theta.p, (size_t)t->F * t->B * sizeof(double), hipMemcpyDeviceToHost));
+  return TGP_OK;
+}
+
 int tgp_traj_destroy(tgp_traj t) {
   if (!t) return TGP_OK;
   if (t->h) (void)hipSetDevice(t->h->device);
@@ -985,6 +1105,7 @@ int tgp_traj_destroy(tgp_traj t) {
   t->d_b.release();
   t->d_ws.release();
   t->d_v.release();
+  t->d_theta.release();
   delete t;
   return TGP_OK;
 }
@@ -992,6 +1113,7 @@ int tgp_traj_destroy(tgp_traj t) {
 int tgp_traj_get_v(tgp_traj t, double* v) {
   if (!t || !v) return TGP_ERR_ARG;
   tgp_handle h = t->h;
+  if (!t->canonical) return fail(h, TGP_ERR_STATE, "an RFF-weight trajectory has no canonical weights");
   if (int rc = set_device(h)) return rc;
   HIPCHK(h, hipMemcpy(v, t->d_v.p, (size_t)h->N * t->B * sizeof(double), hipMemcpyDeviceToHost));
   return TGP_OK;

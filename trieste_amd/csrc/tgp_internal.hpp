@@ -116,12 +116,17 @@ struct TrajDev {
   const double* rffb;  // [F]
   const double* ws;    // [F][B]  sqrt(2 variance / F) * w
   const double* v;     // [Npad][B] canonical weights, zero padded
+  int canonical;       // 1: decoupled trajectory (features + k(x, X) v); 0: RFF-only trajectory (features + mean)
 };
 void launch_rff_project(hipStream_t s, const TrajDev& t, const double* Xs_pts, int64_t npts,
                         double* out /*[npts][B]*/);
 void launch_traj_eval(hipStream_t s, const TrajDev& t, const double* Xq, int64_t M, int per_traj,
                       double* out, double* blk_val, int64_t* blk_idx, int64_t index_base);
 int64_t traj_grid(int64_t M);
+void launch_rff_features(hipStream_t s, const TrajDev& t, double scale, int64_t Fp, double* Phi);
+void launch_sym_finish(hipStream_t s, double* A, int64_t n, int64_t np, double scale, double shift, int negate);
+void launch_theta_tail(hipStream_t s, const double* mean, int64_t ldm, const double* R, int64_t ldr, int F, int B,
+                       double scale, double* theta, double* ws);
 void launch_traj_grad(hipStream_t s, const TrajDev& t, const double* Xq, int64_t nitems, double* val,
                       double* grad);
 void launch_argmin_final_multi(hipStream_t s, const double* blk_val, const int64_t* blk_idx,

@@ -104,6 +104,49 @@ void launch_sample_tail(hipStream_t s, const double* mean, const double* R, int6
                      S, Sp, out);
 }
 
+// A[i][j] <- (negate ? -1 : 1) * scale * A[i][j] + shift [i == j]  for i, j < n (lower triangle is the
+// input, the result is mirrored);  padding rows/cols: identity.  Finishes D = Phi^T Phi + noise I,
+// G = Phi Phi^T + noise I, noise * D^-1 and I - A^T A of the RFF weight posterior.
+__global__ void sym_finish_kernel(double* __restrict__ A, int64_t n, int64_t np, double scale, double shift,
+                                  int negate) {
+  const int64_t j = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int64_t i = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (i >= np || j > i) return;
+  double v;
+  if (i < n) {
+    v = scale * A[i * np + j];
+    if (negate) v = -v;
+    if (i == j) v += shift;
+  } else {
+    v = (i == j) ? 1.0 : 0.0;
+  }
+  A[i * np + j] = v;
+  A[j * np + i] = v;
+}
+
+void launch_sym_finish(hipStream_t s, double* A, int64_t n, int64_t np, double scale, double shift, int negate) {
+  dim3 grid((unsigned)(np / 64), (unsigned)(np / 4));
+  hipLaunchKernelGGL(sym_finish_kernel, grid, dim3(256), 0, s, A, n, np, scale, shift, negate);
+}
+
+// theta[f][b] = mean[f] + R[f][b];  ws[f][b] = feature scale * theta  (what the trajectory kernels consume)
+__global__ void theta_tail_kernel(const double* __restrict__ mean, int64_t ldm, const double* __restrict__ R,
+                                  int64_t ldr, int F, int B, double scale, double* __restrict__ theta,
+                                  double* __restrict__ ws) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)F * B) return;
+  const int64_t f = e / B, b = e % B;
+  const double th = mean[f * ldm] + R[f * ldr + b];
+  theta[e] = th;
+  ws[e] = scale * th;
+}
+
+void launch_theta_tail(hipStream_t s, const double* mean, int64_t ldm, const double* R, int64_t ldr, int F, int B,
+                       double scale, double* theta, double* ws) {
+  hipLaunchKernelGGL(theta_tail_kernel, dim3((unsigned)(((int64_t)F * B + 255) / 256)), dim3(256), 0, s, mean, ldm, R,
+                     ldr, F, B, scale, theta, ws);
+}
+
 constexpr int GT_THREADS = 256;
 
 // one workgroup per query point

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void traj_eval_kernel(TrajDev t, const double*
       }
     }
   }
-  const double c0 = rff_only ? 0.0 : t.m.mean_const;
+  const double c0 = (rff_only == 1) ? 0.0 : t.m.mean_const;  // 1: bare projection Phi w; 2: RFF trajectory (+ mean)
   if (out && valid) {
     if (per_traj) out[item] = acc[0] + c0;
     else {
@@ -156,7 +156,7 @@ int64_t traj_grid(int64_t M) { return (M + 255) / 256; }
 
 void launch_traj_eval(hipStream_t s, const TrajDev& t, const double* Xq, int64_t M, int per_traj,
                       double* out, double* blk_val, int64_t* blk_idx, int64_t index_base) {
-  launch_traj_any(s, t, Xq, M, per_traj, 0, out, blk_val, blk_idx, index_base);
+  launch_traj_any(s, t, Xq, M, per_traj, t.canonical ? 0 : 2, out, blk_val, blk_idx, index_base);
 }
 
 // Value and gradient of trajectory b at its own point x[p][b][:] -- the pair the L-BFGS-B
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void traj_grad_kernel(TrajDev t, const double*
 #pragma unroll
     for (int c = 0; c < DP; ++c) g[c] = fma(sw, t.rffW[(int64_t)f * DP + c], g[c]);
   }
-  for (int64_t k = tid; k < t.m.N; k += 256) {
+  for (int64_t k = tid; k < (t.canonical ? t.m.N : 0); k += 256) {
     double r2 = 0.0, df[DP];
 #pragma unroll
     for (int c = 0; c < DP; ++c) {
@@ -230,6 +230,26 @@ void launch_traj_grad(hipStream_t s, const TrajDev& t, const double* Xq, int64_t
     case 16: hipLaunchKernelGGL(traj_grad_kernel<16>, g, b, 0, s, t, Xq, nitems, val, grad); break;
     default: hipLaunchKernelGGL(traj_grad_kernel<32>, g, b, 0, s, t, Xq, nitems, val, grad); break;
   }
+}
+
+// Phi[i][f] = sqrt(2 variance / F) cos(Xs_i . W_f + b_f) for the N training rows, [Npad][Fp] zero padded
+// (the scaled feature matrix of RandomFourierFeatureTrajectorySampler, sampler.py:541-546 / 570-573).
+__global__ void rff_features_kernel(TrajDev t, double scale, int64_t Fp, double* __restrict__ Phi) {
+  const int64_t f = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int64_t i = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (f >= Fp || i >= t.m.Npad) return;
+  double v = 0.0;
+  if (f < t.F && i < t.m.N) {
+    double arg = t.rffb[f];
+    for (int c = 0; c < t.m.dp; ++c) arg = fma(t.m.Xs[i * t.m.dp + c], t.rffW[f * t.m.dp + c], arg);
+    v = scale * cos(arg);
+  }
+  Phi[i * Fp + f] = v;
+}
+
+void launch_rff_features(hipStream_t s, const TrajDev& t, double scale, int64_t Fp, double* Phi) {
+  dim3 grid((unsigned)(Fp / 64), (unsigned)(t.m.Npad / 4));
+  hipLaunchKernelGGL(rff_features_kernel, grid, dim3(256), 0, s, t, scale, Fp, Phi);
 }
 
 // Phi_Z w at a set of RAW points (the training inputs): out [npts][B] = sum_f phi_f(x) ws[f][b]

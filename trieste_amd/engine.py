@@ -262,6 +262,11 @@ class GPEngine:
         return ms.value, n.value
 
     # -- trajectories ----------------------------------------------------------------------------
+    def trajectory_rff(self, rff_W, rff_b, eps) -> "Trajectory":
+        """B trajectories f_b(x) = phi(x) . theta_b + c with theta ~ the posterior of the RFF weights given
+        the data (reference RandomFourierFeatureTrajectorySampler), theta = mean + chol(cov) eps[:, b]."""
+        return Trajectory(self, rff_W, rff_b, eps, None)
+
     def trajectory(self, rff_W, rff_b, w, xi) -> "Trajectory":
         return Trajectory(self, rff_W, rff_b, w, xi)
 
@@ -269,7 +274,10 @@ class GPEngine:
 class Trajectory:
     """B decoupled trajectories sharing one RFF basis (tgp_traj_*)."""
 
-    def __init__(self, eng: GPEngine, rff_W, rff_b, w, xi):
+    def __init__(self, eng: GPEngine, rff_W, rff_b, w, xi=None):
+        """Decoupled trajectories from prior weights w [F, B] and noise draws xi [N, B]; with
+        ``xi=None`` ``w`` holds standard-normal draws eps [F, B] for the RFF weight posterior
+        (tgp_traj_create_rff: no canonical part)."""
         self._eng = eng
         Wf = np.ascontiguousarray(rff_W, dtype=_NP)
         bf = np.ascontiguousarray(rff_b, dtype=_NP).reshape(-1)
@@ -278,14 +286,23 @@ class Trajectory:
             raise ValueError("rff_W must be [F, d] and rff_b [F]")
         w = np.ascontiguousarray(np.asarray(w, dtype=_NP).reshape(F, -1))
         B = w.shape[1]
-        xi = np.ascontiguousarray(np.asarray(xi, dtype=_NP).reshape(eng.N, -1))
-        if xi.shape[1] != B:
-            raise ValueError(f"xi must be [N, B={B}], got {xi.shape}")
         t = C.c_void_p()
-        rc = eng._lib.tgp_traj_create(eng._h, Wf.ctypes.data, bf.ctypes.data, F, w.ctypes.data,
-                                      xi.ctypes.data, B, C.byref(t))
+        if xi is None:
+            rc = eng._lib.tgp_traj_create_rff(eng._h, Wf.ctypes.data, bf.ctypes.data, F, w.ctypes.data, B, C.byref(t))
+        else:
+            xi = np.ascontiguousarray(np.asarray(xi, dtype=_NP).reshape(eng.N, -1))
+            if xi.shape[1] != B:
+                raise ValueError(f"xi must be [N, B={B}], got {xi.shape}")
+            rc = eng._lib.tgp_traj_create(eng._h, Wf.ctypes.data, bf.ctypes.data, F, w.ctypes.data,
+                                          xi.ctypes.data, B, C.byref(t))
         eng._chk(rc)
         self._t, self.F, self.B = t, F, B
+
+    def theta(self):
+        """Feature weights [F, B] of an RFF-weight trajectory."""
+        out = np.empty((self.F, self.B))
+        self._eng._chk(self._eng._lib.tgp_traj_get_theta(self._t, out.ctypes.data))
+        return out
 
     def close(self):
         if getattr(self, "_t", None):

@@ -140,8 +140,6 @@ class GaussianProcessRegression:
             raise ValueError(f"num_kernel_samples must be greater or equal to zero but got {num_kernel_samples}.")
         if num_rff_features <= 0:
             raise ValueError(f"num_rff_features must be greater than zero but got {num_rff_features}.")
-        if not use_decoupled_sampler:
-            raise NotImplementedError("only the decoupled trajectory sampler is on the engine's path")
         self._model = model
         self._num_kernel_samples = num_kernel_samples
         self._num_rff_features = num_rff_features
@@ -442,7 +440,9 @@ class GaussianProcessRegression:
         return BatchReparametrizationSampler(num_samples, self)
 
     def trajectory_sampler(self):
-        """models.py:323-345 (decoupled branch)."""
-        from .sampler import DecoupledTrajectorySampler
+        """models.py:323-345: decoupled sampler by default, the RFF weight-posterior sampler otherwise."""
+        from .sampler import DecoupledTrajectorySampler, RandomFourierFeatureTrajectorySampler
 
-        return DecoupledTrajectorySampler(self, self._num_rff_features)
+        if self._use_decoupled_sampler:
+            return DecoupledTrajectorySampler(self, self._num_rff_features)
+        return RandomFourierFeatureTrajectorySampler(self, self._num_rff_features)

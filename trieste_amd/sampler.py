@@ -141,11 +141,9 @@ class decoupled_trajectory:
         s = self._sampler
         if self._batch_size == 0:
             raise ValueError("the trajectory has not been evaluated yet: its batch size is unknown")
-        w = s._rng.standard_normal((s._num_features, self._batch_size))
-        xi = s._rng.standard_normal((s._model.engine.N, self._batch_size))
         if self._traj is not None:
             self._traj.close()
-        self._traj = s._model.engine.trajectory(s._W, s._b, w, xi)
+        self._traj = s._new_engine_trajectory(self._batch_size)
 
     def __call__(self, x):
         """x [N, B, D] -> [N, B, 1]."""
@@ -202,6 +200,13 @@ class DecoupledTrajectorySampler:
         k = self._model.get_kernel()
         self._W, self._b = sample_rff_basis(k.kind, self._num_features, self._model.engine.d, self._rng)
 
+    def _new_engine_trajectory(self, batch_size: int):
+        """Fresh weights: prior weights w [F, B] and noise draws xi [N, B]; the canonical weights v are solved
+        on the GPU from the cached factor."""
+        w = self._rng.standard_normal((self._num_features, batch_size))
+        xi = self._rng.standard_normal((self._model.engine.N, batch_size))
+        return self._model.engine.trajectory(self._W, self._b, w, xi)
+
     def get_trajectory(self) -> decoupled_trajectory:
         return decoupled_trajectory(self)
 
@@ -213,3 +218,18 @@ class DecoupledTrajectorySampler:
         self._resample_basis()
         trajectory.resample()
         return trajectory
+
+
+class RandomFourierFeatureTrajectorySampler(DecoupledTrajectorySampler):
+    """Trajectories f(x) = phi(x) . theta + m(x) with theta drawn from the posterior of a Bayesian linear
+    model over the F Fourier features (reference sampler.py:452-591): "design space" (an F x F
+    factorisation) when F < N, "gram space" (N x N) otherwise -- built, factorised and sampled on the
+    GPU (tgp_traj_create_rff).  Same trajectory object / resample / update protocol as the decoupled
+    sampler; selected by ``GaussianProcessRegression(..., use_decoupled_sampler=False)``."""
+
+    def __repr__(self) -> str:
+        return f"RandomFourierFeatureTrajectorySampler({self._model!r}, {self._num_features!r})"
+
+    def _new_engine_trajectory(self, batch_size: int):
+        eps = self._rng.standard_normal((self._num_features, batch_size))
+        return self._model.engine.trajectory_rff(self._W, self._b, eps)
