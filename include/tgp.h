@@ -82,6 +82,14 @@ int tgp_set_hyper(tgp_handle h, double variance, const double* lengthscales, dou
  * err = Y - c.  Additionally caches W = L^-1 and alpha = K^-1 err.  TGP_ERR_NOT_PD on failure. */
 int tgp_set_data(tgp_handle h, const double* X, const double* Y, int64_t N, int where);
 
+/* Rank-k fast path of `update` for the BO loop's usual case -- the new data set is the old one plus k
+ * rows, hyper-parameters unchanged (models/gpflow/models.py:171-186 re-assigns the whole data set and
+ * gpflow refactorises it; the result is the same posterior): Xnew [k,d], Ynew [k] are appended to the
+ * handle's copy of the data and only the trailing block of the factor is recomputed
+ * (L21 = A21 W11^T, the Schur complement, its factor, W21): O(k N^2) instead of O(N^3).  When the padded
+ * size (N rounded up to 256) changes, the call refactorises everything. */
+int tgp_append_data(tgp_handle h, const double* Xnew, const double* Ynew, int64_t k, int where);
+
 int tgp_get_sizes(tgp_handle h, int64_t* N, int* d);
 /* Negative log marginal likelihood of the current (hyper-parameters, data) and its gradient:
  * value (host scalar); grad (host [d + 3], may be NULL) = d/d lengthscales[d], d/d variance,

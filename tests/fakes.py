@@ -71,6 +71,7 @@ class FakeEngine:
     """Same constructor and methods as GPEngine; arithmetic by oracle/gp_oracle.py."""
 
     created = 0
+    appended = 0
 
     def __init__(self, d, kernel="matern52", device=0):
         if kernel not in O.KERNEL_KINDS:
@@ -114,6 +115,15 @@ class FakeEngine:
             self.state = None
             raise NotPositiveDefiniteError(str(e))
         self.N = X.shape[0]
+
+    def append_data(self, Xnew, Ynew):
+        st = self._st()
+        Xnew = np.asarray(Xnew, float)
+        Ynew = np.asarray(Ynew, float).reshape(-1)
+        if Xnew.ndim != 2 or Xnew.shape[1] != self.d or Ynew.shape[0] != Xnew.shape[0]:
+            raise ValueError("Xnew must be [k, d] and Ynew hold k observations")
+        FakeEngine.appended += 1
+        self.set_data(np.concatenate([st.X, Xnew]), np.concatenate([st.Y, Ynew]))
 
     def _st(self):
         if self.state is None:

@@ -447,3 +447,41 @@ def test_rff_weight_posterior_trajectories_match_oracle(cfg):
         assert_close(grad, ograd, rtol=1e-7, atol=1e-8 * np.abs(ograd).max(), what="rff gradient")
         with pytest.raises(RuntimeError):
             traj.v()
+
+
+@pytest.mark.parametrize("cfg", CONFIGS[:5], ids=[c[0] for c in CONFIGS[:5]])
+def test_append_data_equals_full_refactorisation(cfg):
+    """tgp_append_data (rank-k fast path of `update`) vs tgp_set_data on the concatenated data and vs the
+    oracle: factor, alpha, eta, posterior; k = 1, 7 and 70 appended rows, chained appends, crossing a
+    64-row block boundary and (ackley N=257 -> 512 padding stays, N=1000 + 70 crosses 1024) the padded size."""
+    _, obj, d, kind, N, noise = cfg
+    X, Y, ls, c, st, Xq = _problem(obj, d, kind, N, noise, M=120)
+    rng = np.random.default_rng(23)
+    floor = cancellation_floor(N + 80, 1.0, noise)
+    eng = _engine(kind, d, 1.0, ls, noise, c, X, Y)
+    Xall, Yall = X, Y
+    for k in (1, 7, 70):
+        Xn = rng.uniform(size=(k, d))
+        Yn = rng.standard_normal(k) * 0.3 + c
+        eng.append_data(Xn, Yn)
+        Xall, Yall = np.concatenate([Xall, Xn]), np.concatenate([Yall, Yn])
+        assert eng.N == Xall.shape[0]
+        full = _engine(kind, d, 1.0, ls, noise, c, Xall, Yall)
+        sto = O.gpr_update(kind, 1.0, ls, noise, c, Xall, Yall)
+        La, Wa, aa = eng.get_factor()
+        Lf, Wf, af = full.get_factor()
+        assert_close(La, sto.L, atol=floor, what=f"L after append k={k}")
+        assert_close(La, Lf, rtol=1e-9, atol=floor, what="L append == full")
+        ascale = max(1.0, np.abs(af).max())
+        assert_close(aa, af, rtol=1e-7, atol=floor * ascale / min(noise, 1.0), what="alpha append == full")
+        ma, va = eng.predict(Xq)
+        mo, vo = O.predict(sto, Xq)
+        assert_close(ma, mo, atol=floor * 10, what="mean after append")
+        assert_close(va, vo, atol=floor, what="var after append")
+        assert_close(eng.eta(), O.eta_min_mean(sto), atol=floor * 10, what="eta after append")
+    # a hyper-parameter change invalidates the factor: append must refuse until set_data is called again
+    eng.set_hyper(1.1, ls, noise, c)
+    with pytest.raises(RuntimeError):
+        eng.append_data(Xq[:2], np.zeros(2))
+    with pytest.raises(ValueError):
+        full.append_data(Xq[:2], np.zeros(3))

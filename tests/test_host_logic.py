@@ -664,3 +664,26 @@ def test_rff_weight_posterior_sampler_in_both_spaces():
     pts = DiscreteThompsonSampling(200, 3, ThompsonSamplerFromTrajectory(), seed=1).acquire_single(
         Box([0.0, 0.0], [1.0, 1.0]), m2, dataset=m2.get_internal_data())
     assert pts.shape == (3, 2)
+
+
+def test_update_with_appended_rows_takes_the_rank_k_path():
+    """models.py:171-186 semantics are unchanged (update == a fresh model on the new data, the identity
+    of reference test_models.py:117-139); old data + new rows goes through engine.append_data, anything
+    else (changed rows, fewer rows, changed hyper-parameters) through the full refactorisation."""
+    model, data = _model(n=20, noise=1e-2)
+    rng = np.random.default_rng(2)
+    extra = Dataset(rng.uniform(size=(3, 2)), rng.standard_normal((3, 1)))
+    before = FakeEngine.appended
+    model.update(data + extra)
+    assert FakeEngine.appended == before + 1 and model.engine.N == 23
+    fresh = M.GaussianProcessRegression(M.GPR(data=((data + extra).query_points, (data + extra).observations),
+                                              kernel=model.get_kernel(), mean_function=model.get_mean_function(),
+                                              likelihood_variance=model.get_observation_noise()))
+    xs = rng.uniform(size=(9, 2))
+    for a, b in zip(model.predict(xs), fresh.predict(xs)):
+        np.testing.assert_allclose(a, b, rtol=1e-10, atol=1e-12)
+    changed = Dataset((data + extra).query_points[::-1].copy(), (data + extra).observations[::-1].copy())
+    model.update(changed)  # same size, different rows: full path
+    assert FakeEngine.appended == before + 1
+    model.update(data)  # fewer rows: full path
+    assert FakeEngine.appended == before + 1 and model.engine.N == 20

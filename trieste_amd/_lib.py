@@ -30,6 +30,7 @@ SIGNATURES = {
     "tgp_set_stream": (C.c_int, [_vp, _vp]),
     "tgp_set_hyper": (C.c_int, [_vp, C.c_double, _vp, C.c_double, C.c_double]),
     "tgp_set_data": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int]),
+    "tgp_append_data": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int]),
     "tgp_get_sizes": (C.c_int, [_vp, _ip, C.POINTER(C.c_int)]),
     "tgp_nlml": (C.c_int, [_vp, _dp, _vp]),
     "tgp_get_factor": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int]),

@@ -50,6 +50,24 @@ struct DevBuf {  // grow-only device buffer
     if (e == hipSuccess) cap = bytes;
     return e;
   }
+  hipError_t grow_keep(size_t bytes, size_t keep, hipStream_t st) {  // like reserve, but keeps the first `keep` bytes
+    if (bytes <= cap) return hipSuccess;
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) return e;
+    if (p && keep) {
+      e = hipMemcpyAsync(q, p, keep, hipMemcpyDeviceToDevice, st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
+      if (e != hipSuccess) {
+        (void)hipFree(q);
+        return e;
+      }
+    }
+    if (p) (void)hipFree(p);
+    p = q;
+    cap = bytes;
+    return hipSuccess;
+  }
   void release() {
     if (p) (void)hipFree(p);
     p = nullptr;
@@ -361,31 +379,27 @@ int tgp_set_hyper(tgp_handle h, double variance, const double* lengthscales, dou
   return TGP_OK;
 }
 
-int tgp_set_data(tgp_handle h, const double* X, const double* Y, int64_t N, int where) {
-  if (!h) return TGP_ERR_ARG;
-  if (!h->have_hyper) return fail(h, TGP_ERR_STATE, "tgp_set_hyper must be called before tgp_set_data");
-  if (!X || !Y) return fail(h, TGP_ERR_ARG, "X / Y is NULL");
-  if (N < 1) return fail(h, TGP_ERR_SHAPE, "N must be >= 1, got %lld", (long long)N);
-  if (int rc = set_device(h)) return rc;
-  h->have_data = false;
+// (Re)build everything that depends on (X, Y, hyper-parameters) from the device copies d_X [N,d], d_Y [N]:
+// scaled inputs, K + noise I, L, W = L^-1, Wt, alpha.  `keep_rows` > 0 (a multiple of 64, Npad unchanged):
+// rows/columns [0, keep_rows) of L and W are still valid (same inputs, same hyper-parameters) and only
+// the tail block is refactorised -- one node step of the recursion with the split at keep_rows:
+// L21 = A21 W11^T, A22 -= L21 L21^T, factor A22, W21 = -W22 (L21 W11): O((N - keep) N^2) instead of O(N^3).
+static int factorise(tgp_handle h, int64_t N, int64_t keep_rows) {
   const int64_t Npad = ((N + NPAD_MULT - 1) / NPAD_MULT) * NPAD_MULT;
   const size_t nn = (size_t)Npad * Npad * sizeof(double);
   const int d = h->d, dp = h->dp;
-  HIPCHK(h, h->d_X.reserve((size_t)N * d * sizeof(double)));
-  HIPCHK(h, h->d_Y.reserve((size_t)N * sizeof(double)));
   HIPCHK(h, h->d_Xs.reserve((size_t)Npad * dp * sizeof(double)));
   HIPCHK(h, h->d_xn.reserve((size_t)Npad * sizeof(double)));
-  HIPCHK(h, h->d_A.reserve(nn));
-  HIPCHK(h, h->d_L.reserve(nn));
-  HIPCHK(h, h->d_W.reserve(nn));
+  if (keep_rows == 0) {
+    HIPCHK(h, h->d_A.reserve(nn));
+    HIPCHK(h, h->d_L.reserve(nn));
+    HIPCHK(h, h->d_W.reserve(nn));
+  }
   HIPCHK(h, h->d_alpha.reserve(Npad * sizeof(double)));
   HIPCHK(h, h->d_err.reserve(Npad * sizeof(double)));
   HIPCHK(h, h->d_tmp1.reserve(Npad * sizeof(double)));
   HIPCHK(h, h->d_tmp2.reserve(Npad * sizeof(double)));
   HIPCHK(h, h->d_info.reserve(sizeof(int)));
-  const hipMemcpyKind kindcp = where == TGP_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-  HIPCHK(h, hipMemcpyAsync(h->d_X.p, X, (size_t)N * d * sizeof(double), kindcp, h->stream));
-  HIPCHK(h, hipMemcpyAsync(h->d_Y.p, Y, (size_t)N * sizeof(double), kindcp, h->stream));
   HIPCHK(h, hipMemsetAsync(h->d_info.p, 0, sizeof(int), h->stream));
   h->N = N;
   h->Npad = Npad;
@@ -395,20 +409,40 @@ int tgp_set_data(tgp_handle h, const double* X, const double* Y, int64_t N, int 
   double* W = h->d_W.as<double>();
   launch_scale_inputs(s, h->d_X.as<double>(), h->d_ls.as<double>(), h->d_Xs.as<double>(), N, Npad, d, dp);
   launch_row_norms(s, h->d_Xs.as<double>(), h->d_xn.as<double>(), Npad, dp);
-  launch_assemble_K(s, h->d_Xs.as<double>(), A, N, Npad, dp, h->kind, h->variance, h->noise);
-  HIPCHK(h, hipMemsetAsync(L, 0, nn, s));
-  HIPCHK(h, hipMemsetAsync(W, 0, nn, s));
-  static const bool timing = getenv("TGP_TIMING") != nullptr;  // development aid: enqueue vs execution time
-  std::chrono::steady_clock::time_point tq0;
-  if (timing) { (void)hipStreamSynchronize(s); tq0 = std::chrono::steady_clock::now(); }
-  chol_inv(h, 0, Npad);
-  if (timing) {
-    const auto tq1 = std::chrono::steady_clock::now();
-    (void)hipStreamSynchronize(s);
-    const auto tq2 = std::chrono::steady_clock::now();
-    fprintf(stderr, "[tgp] chol_inv N=%lld: enqueue %.3f ms, total %.3f ms\n", (long long)Npad,
-            std::chrono::duration<double, std::milli>(tq1 - tq0).count(),
-            std::chrono::duration<double, std::milli>(tq2 - tq0).count());
+  if (keep_rows == 0) {
+    launch_assemble_K(s, h->d_Xs.as<double>(), A, N, Npad, dp, h->kind, h->variance, h->noise);
+    HIPCHK(h, hipMemsetAsync(L, 0, nn, s));
+    HIPCHK(h, hipMemsetAsync(W, 0, nn, s));
+    static const bool timing = getenv("TGP_TIMING") != nullptr;  // development aid: enqueue vs execution time
+    std::chrono::steady_clock::time_point tq0;
+    if (timing) { (void)hipStreamSynchronize(s); tq0 = std::chrono::steady_clock::now(); }
+    chol_inv(h, 0, Npad);
+    if (timing) {
+      const auto tq1 = std::chrono::steady_clock::now();
+      (void)hipStreamSynchronize(s);
+      const auto tq2 = std::chrono::steady_clock::now();
+      fprintf(stderr, "[tgp] chol_inv N=%lld: enqueue %.3f ms, total %.3f ms\n", (long long)Npad,
+              std::chrono::duration<double, std::milli>(tq1 - tq0).count(),
+              std::chrono::duration<double, std::milli>(tq2 - tq0).count());
+    }
+  } else {
+    const int64_t lo = keep_rows, s2 = Npad - lo;
+    // rows [lo, Npad) of K + noise I in a scratch strip addressed with global row indices (d_A holds Wt)
+    HIPCHK(h, h->s_grad.reserve((size_t)s2 * Npad * sizeof(double)));
+    double* As = h->s_grad.as<double>() - (size_t)lo * Npad;
+    launch_assemble_K(s, h->d_Xs.as<double>(), As, N, Npad, dp, h->kind, h->variance, h->noise, lo);
+    HIPCHK(h, hipMemsetAsync(L + (size_t)lo * Npad, 0, (size_t)s2 * Npad * sizeof(double), s));
+    HIPCHK(h, hipMemsetAsync(W + (size_t)lo * Npad, 0, (size_t)s2 * Npad * sizeof(double), s));
+    double* A21 = As + (size_t)lo * Npad;
+    double* L21 = L + (size_t)lo * Npad;
+    double* A22 = As + (size_t)lo * Npad + lo;
+    launch_gemm(s, true, (int)s2, (int)lo, (int)lo, 1.0, A21, Npad, W, Npad, 0.0, L21, Npad, false, 1);
+    launch_gemm(s, true, (int)s2, (int)s2, (int)lo, -1.0, L21, Npad, L21, Npad, 1.0, A22, Npad, true);
+    chol_inv(s, FactorWs{As, L, W, Npad, h->d_info.as<int>()}, lo, Npad);
+    double* W22 = W + (size_t)lo * Npad + lo;
+    double* W21 = W + (size_t)lo * Npad;
+    launch_gemm(s, false, (int)s2, (int)lo, (int)lo, 1.0, L21, Npad, W, Npad, 0.0, A21, Npad, false, 2);
+    launch_gemm(s, false, (int)s2, (int)lo, (int)s2, -1.0, W22, Npad, A21, Npad, 0.0, W21, Npad, false, 3);
   }
   // err = Y - c (zero padded)  -- gpflow GPRPosterior._precompute: err = Y - mean_function(X)
   launch_center(s, h->d_Y.as<double>(), h->mean_const, h->d_err.as<double>(), N, Npad);
@@ -426,6 +460,42 @@ int tgp_set_data(tgp_handle h, const double* X, const double* Y, int64_t N, int 
                 info - 1);
   h->have_data = true;
   return TGP_OK;
+}
+
+int tgp_set_data(tgp_handle h, const double* X, const double* Y, int64_t N, int where) {
+  if (!h) return TGP_ERR_ARG;
+  if (!h->have_hyper) return fail(h, TGP_ERR_STATE, "tgp_set_hyper must be called before tgp_set_data");
+  if (!X || !Y) return fail(h, TGP_ERR_ARG, "X / Y is NULL");
+  if (N < 1) return fail(h, TGP_ERR_SHAPE, "N must be >= 1, got %lld", (long long)N);
+  if (int rc = set_device(h)) return rc;
+  h->have_data = false;
+  const int d = h->d;
+  HIPCHK(h, h->d_X.reserve((size_t)N * d * sizeof(double)));
+  HIPCHK(h, h->d_Y.reserve((size_t)N * sizeof(double)));
+  const hipMemcpyKind kindcp = where == TGP_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  HIPCHK(h, hipMemcpyAsync(h->d_X.p, X, (size_t)N * d * sizeof(double), kindcp, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->d_Y.p, Y, (size_t)N * sizeof(double), kindcp, h->stream));
+  return factorise(h, N, 0);
+}
+
+int tgp_append_data(tgp_handle h, const double* Xnew, const double* Ynew, int64_t k, int where) {
+  if (!h) return TGP_ERR_ARG;
+  if (!h->have_data) return fail(h, TGP_ERR_STATE, "no factorisation to extend: call tgp_set_data first");
+  if (!Xnew || !Ynew) return fail(h, TGP_ERR_ARG, "Xnew / Ynew is NULL");
+  if (k < 1) return fail(h, TGP_ERR_SHAPE, "k must be >= 1, got %lld", (long long)k);
+  if (int rc = set_device(h)) return rc;
+  const int d = h->d;
+  const int64_t N0 = h->N, N = N0 + k, Npad0 = h->Npad;
+  h->have_data = false;
+  HIPCHK(h, h->d_X.grow_keep((size_t)N * d * sizeof(double), (size_t)N0 * d * sizeof(double), h->stream));
+  HIPCHK(h, h->d_Y.grow_keep((size_t)N * sizeof(double), (size_t)N0 * sizeof(double), h->stream));
+  const hipMemcpyKind kindcp = where == TGP_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  HIPCHK(h, hipMemcpyAsync(h->d_X.as<double>() + (size_t)N0 * d, Xnew, (size_t)k * d * sizeof(double), kindcp, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->d_Y.as<double>() + N0, Ynew, (size_t)k * sizeof(double), kindcp, h->stream));
+  const int64_t Npad = ((N + NPAD_MULT - 1) / NPAD_MULT) * NPAD_MULT;
+  // the factor of the first floor(N0 / 64) * 64 rows survives when the padded size does not change
+  const int64_t keep = (Npad == Npad0) ? (N0 / LEAF) * LEAF : 0;
+  return factorise(h, N, keep);
 }
 
 int tgp_nlml(tgp_handle h, double* value, double* grad) {

@@ -59,7 +59,7 @@ struct SweepArgs {
 void launch_scale_inputs(hipStream_t s, const double* X, const double* ls, double* Xs, int64_t N,
                          int64_t Npad, int d, int dp);
 void launch_assemble_K(hipStream_t s, const double* Xs, double* A, int64_t N, int64_t Npad, int dp,
-                       int kind, double variance, double noise);
+                       int kind, double variance, double noise, int64_t row0 = 0);
 void launch_leaf(hipStream_t s, const double* A, double* L, double* W, int64_t ld, int64_t off,
                  int* info);
 // C[m x n] = alpha * A[m x k] * op(B) + beta * C ;  TB: B stored [n x k] (row-major), else [k x n]

@@ -31,9 +31,9 @@ void launch_scale_inputs(hipStream_t s, const double* X, const double* ls, doubl
 // K[i][j] = k(x_i, x_j) + noise * (i == j) on the N x N part; identity on the padding so that the
 // padded matrix stays SPD and factorises to blockdiag(L, I).
 __global__ void assemble_K_kernel(const double* __restrict__ Xs, double* __restrict__ A, int64_t N,
-                                  int64_t Npad, int dp, int kind, double variance, double noise) {
+                                  int64_t Npad, int dp, int kind, double variance, double noise, int64_t row0) {
   const int64_t j = (int64_t)blockIdx.x * 16 + (threadIdx.x & 15);
-  const int64_t i = (int64_t)blockIdx.y * 16 + (threadIdx.x >> 4);
+  const int64_t i = row0 + (int64_t)blockIdx.y * 16 + (threadIdx.x >> 4);  // rows [row0, Npad) only
   if (i >= Npad || j >= Npad) return;
   double v;
   if (i < N && j < N) {
@@ -51,10 +51,11 @@ __global__ void assemble_K_kernel(const double* __restrict__ Xs, double* __restr
 }
 
 void launch_assemble_K(hipStream_t s, const double* Xs, double* A, int64_t N, int64_t Npad, int dp,
-                       int kind, double variance, double noise) {
-  dim3 grid((unsigned)(Npad / 16), (unsigned)(Npad / 16));
+                       int kind, double variance, double noise, int64_t row0) {
+  // A is addressed with GLOBAL row indices: for row0 > 0 the caller passes (scratch - row0 * Npad)
+  dim3 grid((unsigned)(Npad / 16), (unsigned)((Npad - row0) / 16));
   hipLaunchKernelGGL(assemble_K_kernel, grid, dim3(256), 0, s, Xs, A, N, Npad, dp, kind, variance,
-                     noise);
+                     noise, row0);
 }
 
 // ---------------------------------------------------------------------------------------------

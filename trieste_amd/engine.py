@@ -97,6 +97,21 @@ class GPEngine:
         self._chk(self._lib.tgp_set_data(self._h, ax.ptr, ay.ptr, n, ax.where))
         self.N = n
 
+    def append_data(self, Xnew, Ynew):
+        """Extend the data set by k rows with unchanged hyper-parameters: only the trailing block of the
+        factor is recomputed (tgp_append_data)."""
+        ax = _Arg(Xnew)
+        ay = _Arg(Ynew)
+        if len(ax.shape) != 2 or ax.shape[1] != self.d:
+            raise ValueError(f"Xnew must be [k, {self.d}], got {ax.shape}")
+        k = ax.shape[0]
+        if int(np.prod(ay.shape)) != k:
+            raise ValueError(f"Ynew must hold k={k} observations, got shape {ay.shape}")
+        if ax.where != ay.where:
+            raise ValueError("Xnew and Ynew must both be host arrays or both device tensors")
+        self._chk(self._lib.tgp_append_data(self._h, ax.ptr, ay.ptr, k, ax.where))
+        self.N += k
+
     def nlml(self):
         """(negative log marginal likelihood, gradient [d + 3] w.r.t. lengthscales, variance, noise, mean)."""
         v = C.c_double()

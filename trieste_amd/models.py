@@ -307,8 +307,14 @@ class GaussianProcessRegression:
             raise ValueError(f"query points have dimension {qp.shape[-1]}, the model has {x.shape[-1]}")
         if obs.shape[-1] != y.shape[-1]:
             raise ValueError(f"observations have dimension {obs.shape[-1]}, the model has {y.shape[-1]}")
+        n0 = x.shape[0]
+        appended = (self._engine.N == n0 and qp.shape[0] > n0 and np.array_equal(qp[:n0], x)
+                    and np.array_equal(obs[:n0], y))
         self._model.data = (qp, obs)
-        self._engine.set_data(qp, obs[:, 0])
+        if appended:  # the BO loop's usual update: old data + new rows, same hyper-parameters -> rank-k path
+            self._engine.append_data(qp[n0:], obs[n0:, 0])
+        else:
+            self._engine.set_data(qp, obs[:, 0])
 
     def optimize(self, dataset: Dataset):
         """MAP / maximum-likelihood fit of (lengthscales, variance, constant mean[, noise variance])
