@@ -87,9 +87,15 @@ def _problem(obj, d, kind, N, noise, M=1500, seed=5678):
     return X, Y, ls, c, st, Xq
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2], ids=["u16", "v1", "ws"])
+@pytest.mark.parametrize("variant", [0, 3, 1, 2], ids=["u16-rowsplit", "u16", "v1", "ws"])
 @pytest.mark.parametrize("cfg", CONFIGS, ids=[c[0] for c in CONFIGS])
-def test_sweep_matches_oracle(cfg, variant):
+def test_sweep_matches_oracle(cfg, variant, monkeypatch):
+    """Every sweep kernel: the default u16 kernel in its row-group-split form (what a launch with few
+    candidate blocks uses) and in its fused form (forced here with TGP_NO_SPLIT; large launches use
+    it), the first-generation kernel and the wave-specialised one."""
+    if variant == 3:
+        monkeypatch.setenv("TGP_NO_SPLIT", "1")
+        variant = 0
     _, obj, d, kind, N, noise = cfg
     X, Y, ls, c, st, Xq = _problem(obj, d, kind, N, noise)
     floor = cancellation_floor(N, 1.0, noise)

@@ -92,7 +92,7 @@ struct tgp_handle_s {
   // model state on device
   DevBuf d_xn, d_ls, d_X, d_Y, d_Xs, d_A, d_L, d_W, d_alpha, d_err, d_tmp1, d_tmp2, d_info;
   // scratch
-  DevBuf s_in, s_in2, s_out1, s_out2, s_out3, s_blkv, s_blki, s_small, s_kcache, s_ssq, s_aslab, s_grad;
+  DevBuf s_in, s_in2, s_out1, s_out2, s_out3, s_blkv, s_blki, s_small, s_kcache, s_ssq, s_aslab, s_grad, s_ks, s_part;
   // timing of the dominant kernel
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double last_ms = 0.0;
@@ -199,8 +199,36 @@ hipError_t launch_sweep_timed(tgp_handle h, const SweepArgs& a, bool joint) {
   SweepArgs& am = const_cast<SweepArgs&>(a);
   am.dbg = h->variant >> 8;
   int64_t wgrid = grid;
+  am.split_g = 0;
+  const bool u16 = ws && (h->variant & 0xff) != 2;
+  if (u16 && !joint && grid < 4 * (int64_t)h->num_cu && !getenv("TGP_NO_SPLIT")) {
+    // Few candidate blocks (EGO's default sweep is max(5000, 1000 d) candidates = 63 blocks at d = 8): one
+    // workgroup per block walks all of W alone (7.5 ms at N = 4096) on a quarter of the CUs.  Split every
+    // block's row blocks of W into up to 8 groups of roughly equal triangular work.
+    const int nb = (int)(h->Npad / 256);
+    int g = (int)std::min<int64_t>(std::min(8, nb), (8 * (int64_t)h->num_cu + grid - 1) / grid);
+    if (g > 1) {
+      const int total = nb * (nb + 1) / 2;
+      am.split_ib[0] = 0;
+      int ib = 0;
+      for (int k = 1; k < g; ++k) {
+        while (ib < nb && ib * (ib + 1) / 2 < (int64_t)total * k / g) ++ib;
+        am.split_ib[k] = std::max(ib, am.split_ib[k - 1] + 1);
+      }
+      am.split_ib[g] = nb;
+      bool ok = true;
+      for (int k = 0; k < g; ++k) ok = ok && am.split_ib[k] < am.split_ib[k + 1];
+      if (ok) {
+        am.split_g = g;
+        hipError_t ep = h->s_part.reserve((size_t)grid * g * 256 * sizeof(double));
+        if (ep != hipSuccess) return ep;
+        am.part = h->s_part.as<double>();
+      }
+    }
+  }
   if (ws) {
-    wgrid = grid < h->num_cu ? grid : h->num_cu;  // persistent: one workgroup per CU
+    wgrid = grid * std::max(1, am.split_g);
+    wgrid = wgrid < h->num_cu ? wgrid : h->num_cu;  // persistent: one workgroup per CU
     hipError_t ea = h->s_kcache.reserve((size_t)wgrid * (size_t)h->Npad * SW_BN * sizeof(double));
     if (ea != hipSuccess) return ea;
     am.kcache = h->s_kcache.as<double>();
@@ -236,6 +264,7 @@ hipError_t launch_sweep_timed(tgp_handle h, const SweepArgs& a, bool joint) {
       default: e = launch_sweep_kind3(h->stream, a, joint, grid); break;
     }
   }
+  if (e == hipSuccess && am.split_g > 1) launch_sweep_combine(h->stream, a, grid);
   (void)hipEventRecord(h->ev1, h->stream);
   h->last_launches = 1;
   h->last_ms = -1.0;  // resolved lazily in tgp_last_kernel_ms
@@ -280,6 +309,21 @@ void chol_inv(hipStream_t st, const FactorWs& f, int64_t lo, int64_t hi) {
 void chol_inv(tgp_handle h, int64_t lo, int64_t hi) {
   chol_inv(h->stream, FactorWs{h->d_A.as<double>(), h->d_L.as<double>(), h->d_W.as<double>(), h->Npad,
                                h->d_info.as<int>()}, lo, hi);
+}
+
+// Products with few output tiles and a long k (N x P x N, P <= 128: gradients, cross-covariances): split k.
+int gemm_tall(tgp_handle h, bool tb, int m, int n, int k, double alpha, const double* A, int64_t lda,
+              const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int tri) {
+  const int64_t tiles = (int64_t)(m / 64) * (n / 64);
+  int nz = 1;
+  if (tiles < 256 && k >= 1024) nz = (int)std::min<int64_t>(8, std::max<int64_t>(1, 512 / tiles));
+  if (nz > 1) {
+    HIPCHK(h, h->s_ks.reserve((size_t)nz * m * n * sizeof(double)));
+    launch_gemm_ksplit(h->stream, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, nz, h->s_ks.as<double>());
+  } else {
+    launch_gemm(h->stream, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, false, tri);
+  }
+  return TGP_OK;
 }
 
 }  // namespace
@@ -337,7 +381,7 @@ int tgp_destroy(tgp_handle h) {
   (void)hipStreamSynchronize(h->stream);
   for (DevBuf* b : {&h->d_xn, &h->d_ls, &h->d_X, &h->d_Y, &h->d_Xs, &h->d_A, &h->d_L, &h->d_W, &h->d_alpha,
                     &h->d_err, &h->d_tmp1, &h->d_tmp2, &h->d_info, &h->s_in, &h->s_in2, &h->s_out1,
-                    &h->s_out2, &h->s_out3, &h->s_blkv, &h->s_blki, &h->s_small, &h->s_kcache, &h->s_ssq, &h->s_aslab, &h->s_grad})
+                    &h->s_out2, &h->s_out3, &h->s_blkv, &h->s_blki, &h->s_small, &h->s_kcache, &h->s_ssq, &h->s_aslab, &h->s_grad, &h->s_ks, &h->s_part})
     b->release();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -669,10 +713,10 @@ int tgp_acq_value_grad(tgp_handle h, int acq_kind, double param, const double* X
   const ModelDev m = model_dev(h);
   launch_kstar_t(h->stream, m, dXq, P, Ppad, B);
   // C1 = W B (W = L^-1, lower triangular incl. explicit zeros), Z = W^T C1 = K^-1 k*
-  launch_gemm(h->stream, false, (int)Npad, (int)Ppad, (int)Npad, 1.0, h->d_W.as<double>(), Npad, B, Ppad, 0.0, C1,
-              Ppad, false, 3);
-  launch_gemm(h->stream, false, (int)Npad, (int)Ppad, (int)Npad, 1.0, h->d_A.as<double>(), Npad, C1, Ppad, 0.0, Z,
-              Ppad, false, 5);
+  if (int rc = gemm_tall(h, false, (int)Npad, (int)Ppad, (int)Npad, 1.0, h->d_W.as<double>(), Npad, B, Ppad, 0.0, C1,
+                         Ppad, 3)) return rc;
+  if (int rc = gemm_tall(h, false, (int)Npad, (int)Ppad, (int)Npad, 1.0, h->d_A.as<double>(), Npad, C1, Ppad, 0.0, Z,
+                         Ppad, 5)) return rc;
   launch_grad_tail(h->stream, m, dXq, P, Ppad, B, C1, Z, acq_kind, param, dval, dgrad);
   if (int rc = stage_out_finish(h, dval, val, P, where)) return rc;
   if (int rc = stage_out_finish(h, dgrad, grad, (size_t)P * h->d, where)) return rc;
@@ -705,11 +749,11 @@ int tgp_cov_between(tgp_handle h, const double* X1, int64_t P1, const double* X2
   hipStream_t s = h->stream;
   // A_i = L^-1 K(X, X_i) = W B_i;  S = A_1^T A_2  (the reference's two triangular solves + einsum)
   launch_kstar_t(s, m, d1, P1, P1p, B1);
-  launch_gemm(s, false, (int)Npad, (int)P1p, (int)Npad, 1.0, h->d_W.as<double>(), Npad, B1, P1p, 0.0, C1, P1p, false, 3);
+  if (int rc = gemm_tall(h, false, (int)Npad, (int)P1p, (int)Npad, 1.0, h->d_W.as<double>(), Npad, B1, P1p, 0.0, C1, P1p, 3)) return rc;
   launch_kstar_t(s, m, d2, P2, P2p, B2);
-  launch_gemm(s, false, (int)Npad, (int)P2p, (int)Npad, 1.0, h->d_W.as<double>(), Npad, B2, P2p, 0.0, C2, P2p, false, 3);
+  if (int rc = gemm_tall(h, false, (int)Npad, (int)P2p, (int)Npad, 1.0, h->d_W.as<double>(), Npad, B2, P2p, 0.0, C2, P2p, 3)) return rc;
   launch_transpose(s, C1, Npad, P1p, P1p, C1t, Npad);
-  launch_gemm(s, false, (int)P1p, (int)P2p, (int)Npad, 1.0, C1t, Npad, C2, P2p, 0.0, S, P2p, false, 0);
+  if (int rc = gemm_tall(h, false, (int)P1p, (int)P2p, (int)Npad, 1.0, C1t, Npad, C2, P2p, 0.0, S, P2p, 0)) return rc;
   launch_cov_tail(s, m, d1, P1, d2, P2, S, P2p, dout);
   if (int rc = stage_out_finish(h, dout, out, (size_t)P1 * P2, where)) return rc;
   if (int rc = sync(h)) return rc;
@@ -823,20 +867,19 @@ int tgp_acq_topk(tgp_handle h, int acq_kind, double param, const double* Xq, int
   }
   HIPCHK(h, h->s_blkv.reserve(512 * sizeof(double)));
   HIPCHK(h, h->s_blki.reserve(512 * sizeof(int64_t)));
-  HIPCHK(h, h->s_small.reserve(64));
-  double* fv = h->s_small.as<double>();
-  int64_t* fi = (int64_t*)(fv + 1);
-  double pv = 0.0;
-  int64_t pi = 0;
-  for (int t = 0; t < k; ++t) {
-    launch_topk_pass(h->stream, dvals, M, index_base, pv, pi, t == 0, h->s_blkv.as<double>(),
-                     h->s_blki.as<int64_t>(), fv, fi);
-    HIPCHK(h, hipMemcpyAsync(&pv, fv, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(&pi, fi, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-    if (int rc = sync(h)) return rc;
-    vals[t] = pv;
-    idx[t] = pi;
+  HIPCHK(h, h->s_small.reserve((size_t)k * 16 + 64));
+  double* fv = h->s_small.as<double>();       // [k] winners' values
+  int64_t* fi = (int64_t*)(fv + k);           // [k] winners' indices
+  if (M <= topk_small_max()) {
+    launch_topk_small(h->stream, dvals, M, index_base, k, fv, fi);
+  } else {
+    for (int t = 0; t < k; ++t)  // thresholds stay on the device: no host round trip per pass
+      launch_topk_pass(h->stream, dvals, M, index_base, t ? fv + t - 1 : nullptr, t ? fi + t - 1 : nullptr,
+                       h->s_blkv.as<double>(), h->s_blki.as<int64_t>(), fv + t, fi + t);
   }
+  HIPCHK(h, hipMemcpyAsync(vals, fv, (size_t)k * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(idx, fi, (size_t)k * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+  if (int rc = sync(h)) return rc;
   HIPCHK(h, hipGetLastError());
   return TGP_OK;
 }

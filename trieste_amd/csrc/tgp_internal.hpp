@@ -53,7 +53,13 @@ struct SweepArgs {
   double* aslab;      // [grid][Npad][128] C = W K* slabs of joint mode (device scratch)
   double* ssq_scratch; // [grid][8 waves][4][64] column-norm partials of the flag-synchronised sweep
   int dbg;            // development only: bit0 skip K* generation, bit1 skip W loads, bit2 skip MFMA
+  // row-group split of small sweeps (u16 SPLIT instantiation): group g of a candidate block owns the row
+  // blocks [split_ib[g], split_ib[g+1]) of W and leaves partial (mean, sum c^2) in `part`
+  int split_g;            // 0/1: off
+  int split_ib[9];
+  double* part;           // [blocks][split_g][2][128]
 };
+void launch_sweep_combine(hipStream_t s, const SweepArgs& a, int64_t nblk);
 
 // ---- linalg (tgp_kernels_linalg.hip) ----
 void launch_scale_inputs(hipStream_t s, const double* X, const double* ls, double* Xs, int64_t N,
@@ -65,6 +71,9 @@ void launch_leaf(hipStream_t s, const double* A, double* L, double* W, int64_t l
 // C[m x n] = alpha * A[m x k] * op(B) + beta * C ;  TB: B stored [n x k] (row-major), else [k x n]
 void launch_gemm(hipStream_t s, bool tb, int m, int n, int k, double alpha, const double* A, int64_t lda,
                  const double* B, int64_t ldb, double beta, double* C, int64_t ldc, bool lower_only, int tri = 0);
+void launch_gemm_ksplit(hipStream_t s, bool tb, int m, int n, int k, double alpha, const double* A, int64_t lda,
+                        const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int tri, int nz,
+                        double* scratch);
 void launch_transpose_mask(hipStream_t s, const double* W, double* Wt, int64_t N, int64_t Npad);
 void launch_zero(hipStream_t s, double* p, int64_t n);
 void launch_center(hipStream_t s, const double* Y, double c, double* err, int64_t N, int64_t Npad);
@@ -92,9 +101,12 @@ void launch_predict_mean(hipStream_t s, const ModelDev& m, const double* Xq, int
 void launch_argmax_final(hipStream_t s, const double* blk_val, const int64_t* blk_idx, int64_t n,
                          double* out_val, int64_t* out_idx);
 void launch_min_value(hipStream_t s, const double* v, int64_t n, double* out);
-void launch_topk_pass(hipStream_t s, const double* vals, int64_t M, int64_t index_base, double pv,
-                      int64_t pi, int first, double* scratch_val, int64_t* scratch_idx,
-                      double* out_val, int64_t* out_idx);
+void launch_topk_pass(hipStream_t s, const double* vals, int64_t M, int64_t index_base, const double* prev_val,
+                      const int64_t* prev_idx, double* scratch_val, int64_t* scratch_idx, double* out_val,
+                      int64_t* out_idx);
+void launch_topk_small(hipStream_t s, const double* vals, int64_t M, int64_t index_base, int k, double* out_val,
+                       int64_t* out_idx);
+int64_t topk_small_max();
 void launch_sample_box(hipStream_t s, uint64_t seed, int64_t first, int64_t M, int d,
                        const double* lower, const double* upper, double* out);
 void launch_qei_tail(hipStream_t s, const double* mean, const double* cov, int64_t G, int q,

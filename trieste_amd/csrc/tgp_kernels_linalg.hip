@@ -203,6 +203,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(int m, int n, int k, double a
   else if (tri == 3) khi = min(k, (tm + 1) * GB);
   else if (tri == 4) klo = min(k, max(tm, tn) * GB);
   else if (tri == 5) klo = min(k, tm * GB);
+  if (gridDim.y > 1) {  // k-split: slice blockIdx.y of the (pruned) k range, partial result to C + slice * m * ldc
+    const int steps = (khi - klo + GKT - 1) / GKT, per = (steps + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int lo2 = klo + (int)blockIdx.y * per * GKT;
+    khi = min(khi, lo2 + per * GKT);
+    klo = min(lo2, khi);
+    C += (int64_t)blockIdx.y * m * ldc;
+  }
 
   const double* Ab = A + (int64_t)tm * GB * lda;
   const double* Bb = TB ? B + (int64_t)tn * GB * ldb : B + (int64_t)tn * GB;
@@ -362,6 +369,31 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(int m, int n, int k, d
         const double v = alpha * acc[fm][fn][r];
         *dst = (beta == 0.0) ? v : fma(beta, *dst, v);
       }
+}
+
+// C = beta C + alpha sum_z P[z]  (fixed order: deterministic) for the k-split launches below.
+__global__ void ksplit_reduce_kernel(const double* __restrict__ P, int nz, int64_t m, int64_t n, int64_t ldp,
+                                     double alpha, double beta, double* __restrict__ C, int64_t ldc) {
+  const int64_t j = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int64_t i = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (i >= m || j >= n) return;
+  double acc = 0.0;
+  for (int z = 0; z < nz; ++z) acc += P[((int64_t)z * m + i) * ldp + j];
+  double* dst = C + i * ldc + j;
+  *dst = (beta == 0.0) ? alpha * acc : fma(beta, *dst, alpha * acc);
+}
+
+// Few output tiles but a long k (the gradient / cross-covariance products: N x P x N with P <= 128): one
+// 4-wave workgroup per tile walks k serially at ~1.7 us per 32-deep step (exposed load latency).  Split k
+// over `nz` workgroups per tile (partials in `scratch` [nz][m][n]) and reduce in a fixed order.
+void launch_gemm_ksplit(hipStream_t s, bool tb, int m, int n, int k, double alpha, const double* A, int64_t lda,
+                        const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int tri, int nz,
+                        double* scratch) {
+  dim3 grid((unsigned)((m / GB) * (n / GB)), (unsigned)nz);
+  if (tb) hipLaunchKernelGGL((gemm_kernel<true, 32>), grid, dim3(256), 0, s, m, n, k, 1.0, A, lda, B, ldb, 0.0, scratch, (int64_t)n, 0, tri);
+  else hipLaunchKernelGGL((gemm_kernel<false, 32>), grid, dim3(256), 0, s, m, n, k, 1.0, A, lda, B, ldb, 0.0, scratch, (int64_t)n, 0, tri);
+  dim3 rg((unsigned)((n + 63) / 64), (unsigned)((m + 3) / 4));
+  hipLaunchKernelGGL(ksplit_reduce_kernel, rg, dim3(256), 0, s, scratch, nz, (int64_t)m, (int64_t)n, (int64_t)n, alpha, beta, C, ldc);
 }
 
 // k must be a multiple of 32 (all call sites pass multiples of 64).

@@ -86,6 +86,61 @@ void launch_predict_mean(hipStream_t s, const ModelDev& m, const double* Xq, int
 }
 
 // ---------------------------------------------------------------------------------------------
+// Second half of a row-group-split sweep (tgp_kernels_sweep_u16.inc, SPLIT): sum the groups' partial
+// (k*.alpha, sum c^2) in a fixed order, then the same tail as the fused epilogue -- clip, acquisition value,
+// outputs, per-block (max value, min index).  One 128-thread workgroup per candidate block.
+__global__ __launch_bounds__(128) void sweep_combine_kernel(SweepArgs a) {
+  __shared__ double bvs[2];
+  __shared__ int64_t bis[2];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int64_t blk = blockIdx.x, cj = blk * 128 + tid;
+  double val = -INFINITY;
+  int64_t gidx = INT64_MAX;
+  if (cj < a.M) {
+    double m = 0.0, sq = 0.0;
+    for (int g = 0; g < a.split_g; ++g) {
+      const double* pp = a.part + ((size_t)blk * a.split_g + g) * 256;
+      m += pp[tid];
+      sq += pp[128 + tid];
+    }
+    const double mean = m + a.m.mean_const;
+    const double var = fmax(a.m.variance - sq, VAR_FLOOR);
+    if (a.mean_out) a.mean_out[cj] = mean;
+    if (a.var_out) a.var_out[cj] = var;
+    if (a.acq_kind >= 0) {
+      const double v = acq_tail(a.acq_kind, a.acq_param, mean, var, a.m.noise);
+      if (a.acq_out) a.acq_out[cj] = v;
+      if (!(v != v)) {
+        val = v;
+        gidx = a.index_base + cj;
+      }
+    }
+  }
+  if (a.blk_val) {
+    wave_argmax(val, gidx);
+    if (lane == 0) {
+      bvs[w] = val;
+      bis[w] = gidx;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double v0 = bvs[0];
+      int64_t i0 = bis[0];
+      if (better(bvs[1], bis[1], v0, i0)) {
+        v0 = bvs[1];
+        i0 = bis[1];
+      }
+      a.blk_val[blk] = v0;
+      a.blk_idx[blk] = i0;
+    }
+  }
+}
+
+void launch_sweep_combine(hipStream_t s, const SweepArgs& a, int64_t nblk) {
+  hipLaunchKernelGGL(sweep_combine_kernel, dim3((unsigned)nblk), dim3(128), 0, s, a);
+}
+
+// ---------------------------------------------------------------------------------------------
 // final (max value, min index) over per-workgroup partials: one workgroup.
 __global__ __launch_bounds__(256) void argmax_final_kernel(const double* __restrict__ bv,
                                                            const int64_t* __restrict__ bi, int64_t n,
@@ -140,13 +195,18 @@ void launch_min_value(hipStream_t s, const double* v, int64_t n, double* out) {
 // ---------------------------------------------------------------------------------------------
 // One top-k pass: best element strictly after (pv, pi) in the order (value desc, index asc).
 // == one extraction step of tf.math.top_k in generate_initial_points (optimizer.py:326-335).
+// The threshold (previous winner) lives on the device (out_val/out_idx[t-1]): the k passes are enqueued
+// back to back and the host reads all k results once.
 constexpr int TOPK_BLOCKS = 512;
 __global__ __launch_bounds__(256) void topk_pass_kernel(const double* __restrict__ vals, int64_t M,
-                                                        int64_t index_base, double pv, int64_t pi,
-                                                        int first, double* __restrict__ sv,
-                                                        int64_t* __restrict__ si) {
+                                                        int64_t index_base, const double* __restrict__ prev_val,
+                                                        const int64_t* __restrict__ prev_idx,
+                                                        double* __restrict__ sv, int64_t* __restrict__ si) {
   __shared__ double wv[4];
   __shared__ int64_t wi[4];
+  const bool first = prev_val == nullptr;
+  const double pv = first ? 0.0 : *prev_val;
+  const int64_t pi = first ? 0 : *prev_idx;
   double v = -INFINITY;
   int64_t i = INT64_MAX;
   for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < M; t += (int64_t)TOPK_BLOCKS * 256) {
@@ -175,13 +235,68 @@ __global__ __launch_bounds__(256) void topk_pass_kernel(const double* __restrict
     si[blockIdx.x] = i;
   }
 }
-void launch_topk_pass(hipStream_t s, const double* vals, int64_t M, int64_t index_base, double pv,
-                      int64_t pi, int first, double* scratch_val, int64_t* scratch_idx,
-                      double* out_val, int64_t* out_idx) {
-  hipLaunchKernelGGL(topk_pass_kernel, dim3(TOPK_BLOCKS), dim3(256), 0, s, vals, M, index_base, pv, pi,
-                     first, scratch_val, scratch_idx);
+void launch_topk_pass(hipStream_t s, const double* vals, int64_t M, int64_t index_base, const double* prev_val,
+                      const int64_t* prev_idx, double* scratch_val, int64_t* scratch_idx, double* out_val,
+                      int64_t* out_idx) {
+  hipLaunchKernelGGL(topk_pass_kernel, dim3(TOPK_BLOCKS), dim3(256), 0, s, vals, M, index_base, prev_val,
+                     prev_idx, scratch_val, scratch_idx);
   launch_argmax_final(s, scratch_val, scratch_idx, TOPK_BLOCKS, out_val, out_idx);
 }
+
+// Small candidate sets (EGO's default initial sweep: max(5000, 1000 d) values): all k extraction steps in
+// ONE workgroup / ONE launch, the values stay in L2 (<= 512 KiB), each step is a block arg-max with the
+// previous winner as threshold.
+constexpr int64_t TOPK_SMALL_MAX = 65536;
+__global__ __launch_bounds__(1024) void topk_small_kernel(const double* __restrict__ vals, int64_t M,
+                                                          int64_t index_base, int k, double* __restrict__ out_val,
+                                                          int64_t* __restrict__ out_idx) {
+  __shared__ double wv[16];
+  __shared__ int64_t wi[16];
+  __shared__ double bv;
+  __shared__ int64_t bi;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  double pv = 0.0;
+  int64_t pi = 0;
+  for (int t = 0; t < k; ++t) {
+    double v = -INFINITY;
+    int64_t i = INT64_MAX;
+    for (int64_t e = tid; e < M; e += 1024) {
+      const double x = vals[e];
+      const int64_t xi = index_base + e;
+      if (x != x) continue;
+      const bool after = t == 0 || (x < pv) || (x == pv && xi > pi);
+      if (after && better(x, xi, v, i)) {
+        v = x;
+        i = xi;
+      }
+    }
+    wave_argmax(v, i);
+    if (lane == 0) {
+      wv[w] = v;
+      wi[w] = i;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      for (int ww = 1; ww < 16; ++ww)
+        if (better(wv[ww], wi[ww], v, i)) {
+          v = wv[ww];
+          i = wi[ww];
+        }
+      bv = v;
+      bi = i;
+      out_val[t] = v;
+      out_idx[t] = i;
+    }
+    __syncthreads();
+    pv = bv;
+    pi = bi;
+  }
+}
+void launch_topk_small(hipStream_t s, const double* vals, int64_t M, int64_t index_base, int k, double* out_val,
+                       int64_t* out_idx) {
+  hipLaunchKernelGGL(topk_small_kernel, dim3(1), dim3(1024), 0, s, vals, M, index_base, k, out_val, out_idx);
+}
+int64_t topk_small_max() { return TOPK_SMALL_MAX; }
 
 // ---------------------------------------------------------------------------------------------
 // Box.sample (reference space.py:843-867) on device: uniform in [lower, upper).
