@@ -92,7 +92,8 @@ int tgp_append_data(tgp_handle h, const double* Xnew, const double* Ynew, int64_
 
 int tgp_get_sizes(tgp_handle h, int64_t* N, int* d);
 /* Negative log marginal likelihood of the current (hyper-parameters, data) and its gradient:
- * value (host scalar); grad (host [d + 3], may be NULL) = d/d lengthscales[d], d/d variance,
+ * value (host scalar); grad (host [d + 3]; NULL = value only, which skips the K^-1 product and the
+ * pair reduction) = d/d lengthscales[d], d/d variance,
  * d/d noise_variance, d/d mean_const, all in the natural (constrained) parameters.  This is the
  * likelihood part of the loss gpflow's Scipy optimizer minimises in
  * GaussianProcessRegression.optimize_encoded (models/gpflow/models.py:256-292); priors and

@@ -130,8 +130,9 @@ class FakeEngine:
             raise RuntimeError("model has no data: call tgp_set_data first")
         return self.state
 
-    def nlml(self):
-        return O.nlml_and_grad(self._st())
+    def nlml(self, with_gradient=True):
+        v, g = O.nlml_and_grad(self._st())
+        return (v, g) if with_gradient else (v, None)
 
     def get_factor(self):
         st = self._st()

@@ -342,6 +342,8 @@ def test_nlml_value_and_gradient_match_oracle(cfg):
     val, grad = eng.nlml()
     oval, ograd = O.nlml_and_grad(st)
     assert_close(val, oval, rtol=1e-9, atol=1e-7, what="nlml")
+    vonly, gnone = eng.nlml(with_gradient=False)
+    assert gnone is None and vonly == val  # value-only path: same reduction, no K^-1 product
     assert_close(grad, ograd, rtol=1e-5, atol=1e-7 * np.abs(ograd).max() + 1e-6 / noise * 1e-6, what="nlml gradient")
 
 

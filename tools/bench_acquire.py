@@ -26,3 +26,22 @@ for M in (8000, 16000, 100000):
     print(f"acq_argmax M={M}: {(time.perf_counter()-t0)/5*1e3:.3f} ms", flush=True)
 X1, X2 = rng.uniform(size=(50, d)), rng.uniform(size=(2000, d))
 eng.cov_between(X1, X2); t0 = time.perf_counter(); eng.cov_between(X1, X2); print(f"cov_between 50 x 2000: {(time.perf_counter()-t0)*1e3:.3f} ms")
+
+# one full BO step through the host API: model.update (append) + model.optimize (MAP fit) + rule.acquire
+import trieste_amd.models as M
+from trieste_amd.acquisition import EfficientGlobalOptimization
+from trieste_amd.data import Dataset
+from trieste_amd.space import Box
+for n in (1000, N):
+    Xn, Yn = X[:n], Y[:n, None] if Y.ndim == 1 else Y[:n]
+    space = Box([0.0] * d, [1.0] * d)
+    data = Dataset(Xn, Yn)
+    model = M.GaussianProcessRegression(M.build_gpr(data, space, likelihood_variance=1e-2))
+    rule = EfficientGlobalOptimization()
+    rule.acquire_single(space, model, dataset=data)
+    newx = rng.uniform(size=(1, d)); newd = data + Dataset(newx, np.array([[0.1]]))
+    t0 = time.perf_counter(); model.update(newd); t1 = time.perf_counter()
+    res = model.optimize(newd); t2 = time.perf_counter()
+    rule.acquire_single(space, model, dataset=newd); t3 = time.perf_counter()
+    nfev = getattr(res, "nfev", None)
+    print(f"BO step at N={n}: update {1e3*(t1-t0):.1f} ms, optimize {1e3*(t2-t1):.0f} ms (nfev={nfev}), acquire {1e3*(t3-t2):.1f} ms", flush=True)

@@ -549,14 +549,18 @@ int tgp_nlml(tgp_handle h, double* value, double* grad) {
   const int64_t Npad = h->Npad;
   const int np = h->d + 4;
   HIPCHK(h, h->s_small.reserve(64 + (MAX_D + 8) * sizeof(double)));
-  HIPCHK(h, h->s_blkv.reserve((size_t)nlml_blocks(Npad) * (MAX_D + 2) * sizeof(double)));
-  HIPCHK(h, h->s_grad.reserve((size_t)Npad * Npad * sizeof(double)));
-  double* Kinv = h->s_grad.as<double>();
   double* out = h->s_small.as<double>() + 8;
-  // Kinv = W^T W  (Wt is in d_A, W in d_W; both carry explicit zeros outside their triangles)
-  launch_gemm(h->stream, false, (int)Npad, (int)Npad, (int)Npad, 1.0, h->d_A.as<double>(), Npad, h->d_W.as<double>(),
-              Npad, 0.0, Kinv, Npad, false, 4);
-  launch_nlml(h->stream, model_dev(h), Kinv, h->d_L.as<double>(), h->d_err.as<double>(), h->s_blkv.as<double>(), out);
+  if (grad) {
+    HIPCHK(h, h->s_blkv.reserve((size_t)nlml_blocks(Npad) * (MAX_D + 2) * sizeof(double)));
+    HIPCHK(h, h->s_grad.reserve((size_t)Npad * Npad * sizeof(double)));
+    double* Kinv = h->s_grad.as<double>();
+    // Kinv = W^T W  (Wt is in d_A, W in d_W; both carry explicit zeros outside their triangles)
+    launch_gemm(h->stream, false, (int)Npad, (int)Npad, (int)Npad, 1.0, h->d_A.as<double>(), Npad, h->d_W.as<double>(),
+                Npad, 0.0, Kinv, Npad, false, 4);
+    launch_nlml(h->stream, model_dev(h), Kinv, h->d_L.as<double>(), h->d_err.as<double>(), h->s_blkv.as<double>(), out);
+  } else {  // value only: 1/2 err^T alpha + sum log L_ii + N/2 log(2 pi)
+    launch_nlml_value(h->stream, model_dev(h), h->d_L.as<double>(), h->d_err.as<double>(), out);
+  }
   std::vector<double> host((size_t)np);
   HIPCHK(h, hipMemcpyAsync(host.data(), out, (size_t)np * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   if (int rc = sync(h)) return rc;

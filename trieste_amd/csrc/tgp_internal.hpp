@@ -120,6 +120,7 @@ void launch_grad_tail(hipStream_t s, const ModelDev& m, const double* Xq, int64_
 int64_t nlml_blocks(int64_t Npad);
 void launch_nlml(hipStream_t s, const ModelDev& m, const double* Kinv, const double* L, const double* err,
                  double* partial, double* out);
+void launch_nlml_value(hipStream_t s, const ModelDev& m, const double* L, const double* err, double* out);
 // trajectories
 struct TrajDev {
   ModelDev m;

@@ -350,6 +350,11 @@ __global__ __launch_bounds__(256) void nlml_final_kernel(ModelDev m, const doubl
   }
 }
 
+// value only (find_best_model_initialization compares losses, no gradient): no K^-1, no pair reduction
+void launch_nlml_value(hipStream_t s, const ModelDev& m, const double* L, const double* err, double* out) {
+  hipLaunchKernelGGL(nlml_final_kernel, dim3(1), dim3(256), 0, s, m, L, err, (const double*)nullptr, (int64_t)0, out);
+}
+
 int64_t nlml_blocks(int64_t Npad) { return (Npad / 64) * (Npad / 64); }
 
 void launch_nlml(hipStream_t s, const ModelDev& m, const double* Kinv, const double* L, const double* err,

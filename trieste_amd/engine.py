@@ -112,9 +112,13 @@ class GPEngine:
         self._chk(self._lib.tgp_append_data(self._h, ax.ptr, ay.ptr, k, ax.where))
         self.N += k
 
-    def nlml(self):
-        """(negative log marginal likelihood, gradient [d + 3] w.r.t. lengthscales, variance, noise, mean)."""
+    def nlml(self, with_gradient: bool = True):
+        """(negative log marginal likelihood, gradient [d + 3] w.r.t. lengthscales, variance, noise, mean);
+        ``with_gradient=False`` returns (value, None) and skips the K^-1 product."""
         v = C.c_double()
+        if not with_gradient:
+            self._chk(self._lib.tgp_nlml(self._h, C.byref(v), None))
+            return v.value, None
         g = np.empty(self.d + 3)
         self._chk(self._lib.tgp_nlml(self._h, C.byref(v), g.ctypes.data))
         return v.value, g

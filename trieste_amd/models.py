@@ -362,32 +362,36 @@ class GaussianProcessRegression:
                                  likelihood_variance=math.exp(best[d + 2]) if train_noise else None)
         return res
 
-    def _loss_at(self, ls, var, noise, c):
+    def _loss_at(self, ls, var, noise, c, with_gradient: bool = True):
         """-log p(y | theta) - log p(theta) and its gradient [d + 3] w.r.t. (ls, var, noise, mean) at the
-        given hyper-parameters (the engine is left at those hyper-parameters)."""
+        given hyper-parameters (the engine is left at those hyper-parameters).  ``with_gradient=False``
+        (comparing prior draws) returns (value, None)."""
         x, y = self._model.data
         self._engine.set_hyper(var, ls, noise, c)
         self._engine.set_data(x, y[:, 0])
-        value, g = self._engine.nlml()
-        g = np.array(g, dtype=np.float64)
+        value, g = self._engine.nlml(with_gradient)
+        g = np.array(g, dtype=np.float64) if with_gradient else None
         k = self._model.kernel
         if k.lengthscales_prior is not None:
             loc, s = k.lengthscales_prior
             z = (np.log(ls) - loc) / s
             value += float(np.sum(np.log(ls) + math.log(s * math.sqrt(2 * math.pi)) + 0.5 * z * z))
-            g[: len(ls)] += (1.0 + z / s) / ls
+            if with_gradient:
+                g[: len(ls)] += (1.0 + z / s) / ls
         if k.variance_prior is not None:
             loc, s = k.variance_prior
             z = (math.log(var) - loc) / s
             value += math.log(var) + math.log(s * math.sqrt(2 * math.pi)) + 0.5 * z * z
-            g[len(ls)] += (1.0 + z / s) / var
+            if with_gradient:
+                g[len(ls)] += (1.0 + z / s) / var
         return value, g
 
     def training_loss(self) -> float:
         """The loss of the current hyper-parameters (gpflow ``GPR.training_loss``)."""
         k = self._model.kernel
         ls = np.broadcast_to(k.lengthscales, (self._engine.d,))
-        return self._loss_at(ls, k.variance, self._model.likelihood_variance, self._model.mean_function.c)[0]
+        return self._loss_at(ls, k.variance, self._model.likelihood_variance, self._model.mean_function.c,
+                             with_gradient=False)[0]
 
     def find_best_model_initialization(self, num_kernel_samples: int, seed: Optional[int] = None) -> None:
         """Evaluate ``num_kernel_samples`` hyper-parameter draws from the priors and keep the best
@@ -397,7 +401,7 @@ class GaussianProcessRegression:
         rng = np.random.default_rng(seed)
         noise, c = self._model.likelihood_variance, self._model.mean_function.c
         best_ls, best_var = np.array(np.broadcast_to(k.lengthscales, (d,))), k.variance
-        best = self._loss_at(best_ls, best_var, noise, c)[0]
+        best = self._loss_at(best_ls, best_var, noise, c, with_gradient=False)[0]
         for _ in range(num_kernel_samples):
             ls = np.exp(rng.normal(k.lengthscales_prior[0], k.lengthscales_prior[1])) \
                 if k.lengthscales_prior is not None else best_ls
@@ -405,7 +409,7 @@ class GaussianProcessRegression:
             var = math.exp(rng.normal(k.variance_prior[0], k.variance_prior[1])) \
                 if k.variance_prior is not None else best_var
             try:
-                loss = self._loss_at(ls, var, noise, c)[0]
+                loss = self._loss_at(ls, var, noise, c, with_gradient=False)[0]
             except ArithmeticError:
                 loss = 1e100
             if loss < best:
