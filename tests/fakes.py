@@ -87,6 +87,9 @@ class FakeEngine:
     def use_torch_stream(self):
         pass
 
+    def use_private_stream(self):
+        pass
+
     def set_variant(self, v):
         pass
 

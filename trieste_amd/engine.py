@@ -74,6 +74,15 @@ class GPEngine:
         self._chk(self._lib.tgp_set_stream(self._h, C.c_void_p(
             torch.cuda.current_stream(self.device).cuda_stream)))
 
+    def use_private_stream(self):
+        """Give this engine its own (non-blocking) stream, so that several engines driven from several
+        host threads overlap on the GPU -- the latency-bound factorisation chain of one model leaves most
+        of the chip idle (used by ``GaussianProcessRegression.find_best_model_initialization``)."""
+        import torch
+
+        self._stream = torch.cuda.Stream(device=self.device)  # kept alive with the engine
+        self._chk(self._lib.tgp_set_stream(self._h, C.c_void_p(self._stream.cuda_stream)))
+
     def set_variant(self, v: int):
         self._chk(self._lib.tgp_set_variant(self._h, int(v)))
 

@@ -371,19 +371,28 @@ class GaussianProcessRegression:
         self._engine.set_data(x, y[:, 0])
         value, g = self._engine.nlml(with_gradient)
         g = np.array(g, dtype=np.float64) if with_gradient else None
+        pv, pg = self._log_prior(ls, var)
+        value += pv
+        if with_gradient:
+            g[: len(pg)] += pg
+        return value, g
+
+    def _log_prior(self, ls, var):
+        """-log p(theta) of the LogNormal priors build_gpr sets (builders.py:401-408) and its gradient
+        w.r.t. (lengthscales[d], variance)."""
         k = self._model.kernel
+        ls = np.asarray(ls, dtype=np.float64)
+        value, g = 0.0, np.zeros(len(ls) + 1)
         if k.lengthscales_prior is not None:
             loc, s = k.lengthscales_prior
             z = (np.log(ls) - loc) / s
             value += float(np.sum(np.log(ls) + math.log(s * math.sqrt(2 * math.pi)) + 0.5 * z * z))
-            if with_gradient:
-                g[: len(ls)] += (1.0 + z / s) / ls
+            g[: len(ls)] += (1.0 + z / s) / ls
         if k.variance_prior is not None:
             loc, s = k.variance_prior
             z = (math.log(var) - loc) / s
             value += math.log(var) + math.log(s * math.sqrt(2 * math.pi)) + 0.5 * z * z
-            if with_gradient:
-                g[len(ls)] += (1.0 + z / s) / var
+            g[len(ls)] += (1.0 + z / s) / var
         return value, g
 
     def training_loss(self) -> float:
@@ -393,27 +402,67 @@ class GaussianProcessRegression:
         return self._loss_at(ls, k.variance, self._model.likelihood_variance, self._model.mean_function.c,
                              with_gradient=False)[0]
 
+    MAX_PARALLEL_EVALUATIONS = 8
+
+    def _evaluation_engines(self, count: int):
+        """Worker engines (own device buffers, own HIP stream) for concurrent loss evaluations."""
+        pool = getattr(self, "_eval_engines", None)
+        if pool is None:
+            pool = self._eval_engines = []
+        while len(pool) < count:
+            eng = type(self._engine)(self._engine.d, self._model.kernel.kind, device=self._engine.device)
+            eng.use_private_stream()
+            pool.append(eng)
+        return pool[:count]
+
     def find_best_model_initialization(self, num_kernel_samples: int, seed: Optional[int] = None) -> None:
         """Evaluate ``num_kernel_samples`` hyper-parameter draws from the priors and keep the best
-        (reference models.py:294-321); a failed Cholesky counts as loss 1e100."""
+        (reference models.py:294-321); a failed Cholesky counts as loss 1e100.  The draws are independent
+        (different kernel matrices), and one factorisation is a latency-bound chain of small kernels that
+        leaves most of the GPU idle: up to MAX_PARALLEL_EVALUATIONS of them run concurrently, each on its
+        own engine / HIP stream from its own host thread (ctypes releases the GIL inside the C-ABI)."""
+        from concurrent.futures import ThreadPoolExecutor
+
         k = self._model.kernel
         d = self._engine.d
         rng = np.random.default_rng(seed)
         noise, c = self._model.likelihood_variance, self._model.mean_function.c
         best_ls, best_var = np.array(np.broadcast_to(k.lengthscales, (d,))), k.variance
         best = self._loss_at(best_ls, best_var, noise, c, with_gradient=False)[0]
+        draws = []
         for _ in range(num_kernel_samples):
             ls = np.exp(rng.normal(k.lengthscales_prior[0], k.lengthscales_prior[1])) \
                 if k.lengthscales_prior is not None else best_ls
-            ls = np.broadcast_to(ls, (d,))
             var = math.exp(rng.normal(k.variance_prior[0], k.variance_prior[1])) \
                 if k.variance_prior is not None else best_var
-            try:
-                loss = self._loss_at(ls, var, noise, c, with_gradient=False)[0]
-            except ArithmeticError:
-                loss = 1e100
-            if loss < best:
-                best, best_ls, best_var = loss, np.array(ls), var
+            draws.append((np.array(np.broadcast_to(ls, (d,))), var))
+        if not draws:
+            return
+        workers = min(self.MAX_PARALLEL_EVALUATIONS, len(draws))
+        engines = self._evaluation_engines(workers)
+        x, y = self._model.data
+        y0 = np.ascontiguousarray(y[:, 0])
+
+        def evaluate(w):  # worker w takes draws w, w + workers, ...
+            out = []
+            for ls, var in draws[w::workers]:
+                try:
+                    engines[w].set_hyper(var, ls, noise, c)
+                    engines[w].set_data(x, y0)
+                    out.append(engines[w].nlml(False)[0] + self._log_prior(ls, var)[0])
+                except ArithmeticError:
+                    out.append(1e100)
+            return out
+
+        if workers == 1:
+            results = [evaluate(0)]
+        else:
+            with ThreadPoolExecutor(max_workers=workers) as pool:
+                results = list(pool.map(evaluate, range(workers)))
+        for w in range(workers):
+            for (ls, var), loss in zip(draws[w::workers], results[w]):
+                if loss < best:
+                    best, best_ls, best_var = loss, ls, var
         self.set_hyperparameters(variance=best_var, lengthscales=best_ls)
 
     def set_hyperparameters(self, variance=None, lengthscales=None, likelihood_variance=None, mean=None) -> None:
