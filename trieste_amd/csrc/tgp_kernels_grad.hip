@@ -272,6 +272,13 @@ __global__ __launch_bounds__(256) void nlml_grad_kernel(ModelDev m, const double
                                                         double* __restrict__ partial) {
   __shared__ double red[4][DP + 2];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  // G_ij dK_ij is symmetric: only the tiles on and below the diagonal are visited (K^-1 is produced for
+  // those tiles only), off-diagonal ones count twice
+  if (blockIdx.x > blockIdx.y) {
+    if (tid < m.d + 2) partial[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * NG_MAXP + tid] = 0.0;
+    return;
+  }
+  const double sym = (blockIdx.x == blockIdx.y) ? 1.0 : 2.0;
   const int64_t j = (int64_t)blockIdx.x * 64 + lane;
   const int64_t i0 = (int64_t)blockIdx.y * 64 + w * 16;
   const int d = m.d;
@@ -311,7 +318,7 @@ __global__ __launch_bounds__(256) void nlml_grad_kernel(ModelDev m, const double
   if (tid < d + 2) {
     // slot order of `partial`: d lengthscale terms, variance, noise
     const int src = tid < d ? tid : DP + (tid - d);
-    double v = (red[0][src] + red[1][src]) + (red[2][src] + red[3][src]);
+    double v = sym * ((red[0][src] + red[1][src]) + (red[2][src] + red[3][src]));
     if (tid < d) v *= -2.0 / m.ls[tid];
     else if (tid == d) v /= m.variance;
     const int64_t b = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
