@@ -42,7 +42,7 @@ def algorithmic_flops_per_candidate(N: int, d: int, kernel: str) -> float:
     return float(N) * N + N * (3 * d + KERNEL_FLOPS[kernel]) + 2.0 * N + 60.0
 
 
-def cpu_baseline(obj_name, d, kernel, N, noise, budget_s=20.0):
+def cpu_baseline(obj_name, d, kernel, N, noise, budget_s=15.0):
     """The oracle's reference-shaped sweep (materialise K*, two triangular solves, column norms,
     EI, arg-max per chunk) on the host cores.  kind = "port": trieste's own GPflow/TF path cannot
     be installed here."""
@@ -65,7 +65,7 @@ def cpu_baseline(obj_name, d, kernel, N, noise, budget_s=20.0):
         O.ei_sweep_reference_shape(st, Xq, eta, chunk=chunk)
         done += chunk
         el = time.perf_counter() - t0
-        if el > budget_s or done >= 20 * chunk:
+        if el > budget_s or done >= 60 * chunk:
             break
     return {"value": done / el, "unit": "candidates/s", "cores": int(threads), "kind": "port",
             "sample": f"{done} candidates at N={N}, d={d}, {kernel}: numpy/scipy fp64 restatement of the "
