@@ -344,11 +344,12 @@ def joint_samples(state: GPRState, Xq: np.ndarray, eps: np.ndarray, jitter: floa
     return (m[:, None] + Lc @ np.asarray(eps, dtype=np.float64)).T
 
 
-def independent_reparam_samples(state: GPRState, Xq: np.ndarray, eps: np.ndarray) -> np.ndarray:
+def independent_reparam_samples(state: GPRState, Xq: np.ndarray, eps: np.ndarray,
+                                jitter: float = JITTER) -> np.ndarray:
     """IndependentReparametrizationSampler.sample (sampler.py:117-164): Xq [M, d], eps [S] ->
-    samples [M, S] = mean + sqrt(var) * eps (marginal posteriors, no cross-covariance)."""
+    samples [M, S] = mean + sqrt(var + jitter) * eps (marginal posteriors, no cross-covariance)."""
     m, v = predict(state, Xq)
-    return m[:, None] + np.sqrt(v)[:, None] * np.asarray(eps, dtype=np.float64)[None, :]
+    return m[:, None] + np.sqrt(v + jitter)[:, None] * np.asarray(eps, dtype=np.float64)[None, :]
 
 
 def conditional_predict_joint(state: GPRState, Xq: np.ndarray, X_add: np.ndarray, Y_add: np.ndarray):

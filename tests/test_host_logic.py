@@ -687,3 +687,33 @@ def test_update_with_appended_rows_takes_the_rank_k_path():
     assert FakeEngine.appended == before + 1
     model.update(data)  # fewer rows: full path
     assert FakeEngine.appended == before + 1 and model.engine.N == 20
+
+
+def test_qmc_draws_are_sobol_normal_quantiles_with_a_shared_skip_counter():
+    """reference sampler.py:53-79, 95-96, 241-256: Sobol points through the normal quantile; the class-wide
+    skip counter makes a reset produce NEW points; qmc_skip=False always restarts the sequence."""
+    from trieste_amd import sampler as S
+
+    z = S.qmc_normal_samples(4, 2, skip=0)
+    # first unscrambled Sobol points after the origin: (.5,.5), (.75,.25), (.25,.75), (.375,.375)
+    from scipy.special import ndtri
+
+    np.testing.assert_allclose(z, ndtri(np.array([[0.5, 0.5], [0.75, 0.25], [0.25, 0.75], [0.375, 0.375]])), atol=1e-12)
+    assert S.qmc_normal_samples(0, 3).shape == (0, 3)
+    np.testing.assert_allclose(S.qmc_normal_samples(2, 2, skip=2), z[2:], atol=1e-12)
+    model, _ = _model(n=12)
+    x = np.random.default_rng(0).uniform(size=(5, 3, 2))
+    s = S.BatchReparametrizationSampler(64, model, qmc=True)
+    a = s.sample(x)
+    np.testing.assert_array_equal(a, s.sample(x))
+    s.reset_sampler()
+    assert not np.array_equal(a, s.sample(x))  # skip counter advanced
+    s0 = S.BatchReparametrizationSampler(64, model, qmc=True, qmc_skip=False)
+    b = s0.sample(x)
+    s0.reset_sampler()
+    np.testing.assert_array_equal(b, s0.sample(x))  # no skipping: the same points again
+    # QMC means are closer to the posterior mean than 64 random draws would typically be
+    m, _ = model.predict_joint(x)
+    assert np.abs(b.mean(axis=-3) - m).max() < 0.5 * np.sqrt(np.asarray(model.predict(x.reshape(-1, 2))[1]).max())
+    si = S.IndependentReparametrizationSampler(128, model, qmc=True)
+    assert si.sample(x[:, :1, :]).shape == (5, 128, 1, 1)

@@ -16,18 +16,45 @@ import numpy as np
 JITTER = 1e-6  # reference utils/misc.py:180-183
 
 
+def qmc_normal_samples(num_samples: int, n_sample_dim: int, skip: int = 0) -> np.ndarray:
+    """``num_samples`` Sobol points of dimension ``n_sample_dim`` (the first ``skip`` skipped) pushed through
+    the normal quantile function -> [num_samples, n_sample_dim] (reference sampler.py:53-79:
+    ``tf.math.sobol_sample`` + ``Normal.quantile``).  scipy's unscrambled Sobol generator is the same
+    direction-number sequence; TF's stream starts after the all-zero point, hence the ``+ 1``."""
+    if num_samples == 0 or n_sample_dim == 0:
+        return np.zeros((num_samples, n_sample_dim))
+    from scipy.special import ndtri
+    from scipy.stats import qmc
+
+    gen = qmc.Sobol(d=n_sample_dim, scramble=False)
+    gen.fast_forward(int(skip) + 1)
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # scipy warns when num_samples is not a power of two
+        pts = gen.random(num_samples)
+    return ndtri(pts)
+
+
+class _QmcSkip:
+    """The class-wide Sobol skip counter shared by the reparametrization samplers (reference
+    ``IndependentReparametrizationSampler.skip``, sampler.py:95-96, incremented per (re)draw)."""
+
+    skip = 0
+
+
 class BatchReparametrizationSampler:
     r"""x -> mu(x) + L(x) eps with eps ~ N(0, 1) fixed until :meth:`reset_sampler`, so samples form
     a continuous surface (reference sampler.py:167-287)."""
 
-    def __init__(self, sample_size: int, model, qmc: bool = False, seed: Optional[int] = None):
+    def __init__(self, sample_size: int, model, qmc: bool = False, qmc_skip: bool = True,
+                 seed: Optional[int] = None):
         if sample_size <= 0:
             raise ValueError(f"sample_size must be positive, got {sample_size}")
         if not hasattr(model, "predict_joint"):
             raise NotImplementedError(
                 f"BatchReparametrizationSampler only works with models that support predict_joint; received {model!r}")
-        if qmc:
-            raise NotImplementedError("QMC (Sobol) draws are not implemented; the reference default is qmc=False")
+        self._qmc, self._qmc_skip = qmc, qmc_skip
         self._sample_size = sample_size
         self._model = model
         self._rng = np.random.default_rng(seed)
@@ -50,7 +77,13 @@ class BatchReparametrizationSampler:
         if batch_size <= 0:
             raise ValueError(f"batch size must be positive, got {batch_size}")
         if not self._initialized or self._eps is None:
-            self._eps = self._rng.standard_normal((batch_size, self._sample_size))
+            if self._qmc:  # Sobol points [S, B] -> [B, S] (sampler.py:241-256)
+                skip = _QmcSkip.skip if self._qmc_skip else 0
+                if self._qmc_skip:
+                    _QmcSkip.skip += self._sample_size
+                self._eps = np.ascontiguousarray(qmc_normal_samples(self._sample_size, batch_size, skip).T)
+            else:
+                self._eps = self._rng.standard_normal((batch_size, self._sample_size))
             self._initialized = True
         elif self._eps.shape[0] != batch_size:
             raise ValueError(f"{type(self).__name__} requires a fixed batch size. Got batch size {batch_size} "
@@ -69,15 +102,15 @@ class BatchReparametrizationSampler:
 
 
 class IndependentReparametrizationSampler:
-    r"""x -> mu(x) + sqrt(var(x)) eps with one fixed eps [S] (reference sampler.py:82-164): samples of
-    the MARGINAL posteriors, continuous in x.  On the engine this is the reparametrised sample
-    kernel at batch size one with zero jitter (the Cholesky factor of a 1 x 1 covariance is sqrt(var))."""
+    r"""x -> mu(x) + sqrt(var(x) + jitter) eps with one fixed eps [S] (reference sampler.py:82-164):
+    samples of the MARGINAL posteriors, continuous in x.  On the engine this is the reparametrised
+    sample kernel at batch size one (the Cholesky factor of the 1 x 1 matrix var + jitter)."""
 
-    def __init__(self, sample_size: int, model, qmc: bool = False, seed: Optional[int] = None):
+    def __init__(self, sample_size: int, model, qmc: bool = False, qmc_skip: bool = True,
+                 seed: Optional[int] = None):
         if sample_size <= 0:
             raise ValueError(f"sample_size must be positive, got {sample_size}")
-        if qmc:
-            raise NotImplementedError("QMC (Sobol) draws are not implemented; the reference default is qmc=False")
+        self._qmc, self._qmc_skip = qmc, qmc_skip
         self._sample_size = sample_size
         self._model = model
         self._rng = np.random.default_rng(seed)
@@ -91,14 +124,22 @@ class IndependentReparametrizationSampler:
         self._initialized = False
 
     def sample(self, at, *, jitter: float = JITTER):
-        """at [..., 1, D] -> samples [..., S, 1, 1] (``jitter`` is unused, as in the reference)."""
+        """at [..., 1, D] -> samples [..., S, 1, 1] = mean + sqrt(var + jitter) eps (sampler.py:137-164)."""
         at = np.asarray(at, dtype=np.float64)
         if at.ndim < 2 or at.shape[-2] != 1:
             raise ValueError(f"at must be [..., 1, D], got shape {at.shape}")
+        if jitter < 0:
+            raise ValueError(f"jitter must be non-negative, got {jitter}")
         if not self._initialized or self._eps is None:
-            self._eps = self._rng.standard_normal((1, self._sample_size))
+            if self._qmc:
+                skip = _QmcSkip.skip if self._qmc_skip else 0
+                if self._qmc_skip:
+                    _QmcSkip.skip += self._sample_size
+                self._eps = np.ascontiguousarray(qmc_normal_samples(self._sample_size, 1, skip).T)
+            else:
+                self._eps = self._rng.standard_normal((1, self._sample_size))
             self._initialized = True
-        return self._model.engine.reparam_samples(at, self._eps, 0.0)[..., None]
+        return self._model.engine.reparam_samples(at, self._eps, jitter)[..., None]
 
 
 # ---- decoupled trajectories -------------------------------------------------------------------
