@@ -70,6 +70,10 @@ const char* tgp_last_error(tgp_handle h); /* h may be NULL: message of the last 
 const char* tgp_version(void);
 /* Use the caller's HIP stream (e.g. torch.cuda.current_stream().cuda_stream); NULL = default. */
 int tgp_set_stream(tgp_handle h, void* hip_stream);
+/* Give the handle its own non-blocking HIP stream (owned and destroyed by the handle).  Several handles
+ * driven from several host threads then overlap on the GPU -- used for the concurrent loss evaluations
+ * of find_best_model_initialization (models/gpflow/models.py:294-321). */
+int tgp_use_private_stream(tgp_handle h);
 
 /* ---- model state ------------------------------------------------------------------------ */
 /* Hyper-parameters of kernel + Gaussian likelihood + Constant mean (builders.py:399-443).

@@ -493,3 +493,26 @@ def test_append_data_equals_full_refactorisation(cfg):
         eng.append_data(Xq[:2], np.zeros(2))
     with pytest.raises(ValueError):
         full.append_data(Xq[:2], np.zeros(3))
+
+
+def test_destruction_order_and_sticky_errors_do_not_leak_into_later_calls():
+    """A garbage collector may destroy a model handle before its trajectories (finalisers of a reference
+    cycle run in arbitrary order): trajectory destruction must not touch the dead handle, and no cleanup
+    error may surface from a later, unrelated launch check (hipGetLastError is sticky per host thread)."""
+    _, obj, d, kind, N, noise = CONFIGS[0]
+    X, Y, ls, c, st, Xq = _problem(obj, d, kind, N, noise, M=300)
+    rng = np.random.default_rng(3)
+    for _ in range(5):
+        eng = _engine(kind, d, 1.0, ls, noise, c, X, Y)
+        eng.use_private_stream()
+        traj = eng.trajectory(rng.standard_normal((32, d)), rng.uniform(0, 6.28, 32), rng.standard_normal((32, 2)),
+                              rng.standard_normal((N, 2)))
+        assert traj(Xq).shape == (300, 2)
+        eng.close()  # handle first ...
+        with pytest.raises(RuntimeError):
+            traj(Xq)
+        traj.close()  # ... its trajectory afterwards
+        other = _engine(kind, d, 1.0, ls, noise, c, X, Y)
+        v, i = other.acq_topk("ei", other.eta(), Xq, 5)  # would report a stale "invalid device ordinal"
+        assert len(i) == 5
+        other.close()

@@ -28,6 +28,7 @@ SIGNATURES = {
     "tgp_last_error": (C.c_char_p, [_vp]),
     "tgp_version": (C.c_char_p, []),
     "tgp_set_stream": (C.c_int, [_vp, _vp]),
+    "tgp_use_private_stream": (C.c_int, [_vp]),
     "tgp_set_hyper": (C.c_int, [_vp, C.c_double, _vp, C.c_double, C.c_double]),
     "tgp_set_data": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int]),
     "tgp_append_data": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int]),

@@ -47,7 +47,13 @@ struct DevBuf {  // grow-only device buffer
     p = nullptr;
     cap = 0;
     hipError_t e = hipMalloc(&p, bytes);
-    if (e == hipSuccess) cap = bytes;
+    if (e == hipSuccess) {
+      cap = bytes;
+      // TGP_POISON=1 (tests): fill fresh allocations with NaNs so that any read of memory the engine did
+      // not write shows up deterministically instead of depending on what the allocator recycled
+      static const bool poison = getenv("TGP_POISON") != nullptr;
+      if (poison) e = hipMemset(p, 0xFF, bytes);
+    }
     return e;
   }
   hipError_t grow_keep(size_t bytes, size_t keep, hipStream_t st) {  // like reserve, but keeps the first `keep` bytes
@@ -81,7 +87,8 @@ struct DevBuf {  // grow-only device buffer
 
 struct tgp_handle_s {
   int device = 0, d = 0, dp = 0, kind = 0, num_cu = 256;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;      // where the kernels go (default stream, a caller's, or own_stream)
+  hipStream_t own_stream = nullptr;  // created by tgp_use_private_stream, destroyed with the handle
   std::string err;
   // hyper-parameters
   bool have_hyper = false, have_data = false;
@@ -104,6 +111,7 @@ struct tgp_traj_s {
   int F = 0, B = 0;
   DevBuf d_W, d_b, d_ws, d_v, d_theta;
   int canonical = 1;
+  int device = 0;  // copied from the handle: destruction must not dereference `h` (it may be gone already)
 };
 
 namespace {
@@ -186,6 +194,10 @@ int sync(tgp_handle h) {
 
 int set_device(tgp_handle h) {
   HIPCHK(h, hipSetDevice(h->device));
+  // hipGetLastError is per host thread and sticky: an error left behind by ANY earlier runtime call on
+  // this thread (another library's, or a failed cleanup call of a garbage-collected handle) would be
+  // reported by the next launch check of this call.  Every entry point starts from a clean slate.
+  (void)hipGetLastError();
   return TGP_OK;
 }
 
@@ -378,7 +390,15 @@ int tgp_create(int device_id, int d, int kernel_kind, tgp_handle* out) {
 int tgp_destroy(tgp_handle h) {
   if (!h) return TGP_OK;
   (void)hipSetDevice(h->device);
-  (void)hipStreamSynchronize(h->stream);
+  // a caller-provided stream (tgp_set_stream) may already be gone when a garbage collector destroys the
+  // handle: only the handle's own stream is synchronised / destroyed here; hipFree below synchronises the
+  // device before releasing memory in any case
+  if (h->own_stream) {
+    (void)hipStreamSynchronize(h->own_stream);
+    (void)hipStreamDestroy(h->own_stream);
+  } else if (h->stream == nullptr) {
+    (void)hipStreamSynchronize(nullptr);
+  }
   for (DevBuf* b : {&h->d_xn, &h->d_ls, &h->d_X, &h->d_Y, &h->d_Xs, &h->d_A, &h->d_L, &h->d_W, &h->d_alpha,
                     &h->d_err, &h->d_tmp1, &h->d_tmp2, &h->d_info, &h->s_in, &h->s_in2, &h->s_out1,
                     &h->s_out2, &h->s_out3, &h->s_blkv, &h->s_blki, &h->s_small, &h->s_kcache, &h->s_ssq, &h->s_aslab, &h->s_grad, &h->s_ks, &h->s_part})
@@ -386,12 +406,21 @@ int tgp_destroy(tgp_handle h) {
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   delete h;
+  (void)hipGetLastError();  // do not leave a cleanup error behind for the thread's next launch check
   return TGP_OK;
 }
 
 int tgp_set_stream(tgp_handle h, void* hip_stream) {
   if (!h) return TGP_ERR_ARG;
   h->stream = (hipStream_t)hip_stream;
+  return TGP_OK;
+}
+
+int tgp_use_private_stream(tgp_handle h) {
+  if (!h) return TGP_ERR_ARG;
+  if (int rc = set_device(h)) return rc;
+  if (!h->own_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+  h->stream = h->own_stream;
   return TGP_OK;
 }
 
@@ -1048,6 +1077,7 @@ int tgp_traj_create(tgp_handle h, const double* rff_W, const double* rff_b, int 
   tgp_traj t = new (std::nothrow) tgp_traj_s();
   if (!t) return fail(h, TGP_ERR_ALLOC, "host allocation failed");
   t->h = h;
+  t->device = h->device;
   t->F = F;
   t->B = B;
   const int d = h->d, dp = h->dp;
@@ -1112,6 +1142,7 @@ int tgp_traj_create_rff(tgp_handle h, const double* rff_W, const double* rff_b, 
   tgp_traj t = new (std::nothrow) tgp_traj_s();
   if (!t) return fail(h, TGP_ERR_ALLOC, "host allocation failed");
   t->h = h;
+  t->device = h->device;
   t->F = F;
   t->B = B;
   t->canonical = 0;
@@ -1219,13 +1250,15 @@ int tgp_traj_get_theta(tgp_traj t, double* theta) {
 
 int tgp_traj_destroy(tgp_traj t) {
   if (!t) return TGP_OK;
-  if (t->h) (void)hipSetDevice(t->h->device);
+  // a garbage collector may destroy the model handle before its trajectories: `t->h` is not touched here
+  (void)hipSetDevice(t->device);
   t->d_W.release();
   t->d_b.release();
   t->d_ws.release();
   t->d_v.release();
   t->d_theta.release();
   delete t;
+  (void)hipGetLastError();
   return TGP_OK;
 }
 

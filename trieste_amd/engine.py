@@ -78,10 +78,7 @@ class GPEngine:
         """Give this engine its own (non-blocking) stream, so that several engines driven from several
         host threads overlap on the GPU -- the latency-bound factorisation chain of one model leaves most
         of the chip idle (used by ``GaussianProcessRegression.find_best_model_initialization``)."""
-        import torch
-
-        self._stream = torch.cuda.Stream(device=self.device)  # kept alive with the engine
-        self._chk(self._lib.tgp_set_stream(self._h, C.c_void_p(self._stream.cuda_stream)))
+        self._chk(self._lib.tgp_use_private_stream(self._h))
 
     def set_variant(self, v: int):
         self._chk(self._lib.tgp_set_variant(self._h, int(v)))
@@ -328,6 +325,7 @@ class Trajectory:
 
     def theta(self):
         """Feature weights [F, B] of an RFF-weight trajectory."""
+        self._live()
         out = np.empty((self.F, self.B))
         self._eng._chk(self._eng._lib.tgp_traj_get_theta(self._t, out.ctypes.data))
         return out
@@ -337,6 +335,11 @@ class Trajectory:
             self._eng._lib.tgp_traj_destroy(self._t)
             self._t = None
 
+    def _live(self):
+        """The C trajectory keeps a pointer to its model handle: refuse to run once either is closed."""
+        if not getattr(self, "_t", None) or not getattr(self._eng, "_h", None):
+            raise RuntimeError("the trajectory (or the engine it belongs to) has been closed")
+
     def __del__(self):
         try:
             self.close()
@@ -344,12 +347,14 @@ class Trajectory:
             pass
 
     def v(self):
+        self._live()
         out = np.empty((self._eng.N, self.B))
         self._eng._chk(self._eng._lib.tgp_traj_get_v(self._t, out.ctypes.data))
         return out
 
     def __call__(self, Xq):
         """Xq [M, d] (shared) or [M, B, d] (per-trajectory inputs) -> [M, B]."""
+        self._live()
         a = _Arg(Xq)
         d = self._eng.d
         if len(a.shape) == 2 and a.shape[1] == d:
@@ -364,6 +369,7 @@ class Trajectory:
 
     def value_and_gradient(self, Xq):
         """Xq [P, B, d] (trajectory b at its own point) -> (values [P, B], gradients [P, B, d])."""
+        self._live()
         a = _Arg(Xq)
         d = self._eng.d
         if len(a.shape) != 3 or a.shape[1] != self.B or a.shape[2] != d:
@@ -375,6 +381,7 @@ class Trajectory:
         return val, grad
 
     def argmin(self, Xq, index_base: int = 0):
+        self._live()
         a = _Arg(Xq)
         if len(a.shape) != 2 or a.shape[1] != self._eng.d:
             raise ValueError("arg-min candidates must be [M, d]")
