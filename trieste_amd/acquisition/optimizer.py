@@ -17,7 +17,7 @@ TensorFlow autodiff (optimizer.py:628-629), the engine computes the same derivat
 """
 from __future__ import annotations
 
-from typing import Any, Callable, Dict, Iterator, Optional, Tuple, Union
+from typing import Any, Callable, Dict, Iterator, Optional, Tuple
 
 import numpy as np
 import scipy.optimize as spo

@@ -4,7 +4,6 @@ Only what the loop needs is restated; checkpoint records and TensorBoard logging
 (SURVEY.md section 2 rows 15-16)."""
 from __future__ import annotations
 
-import copy
 from typing import Mapping, Optional, Union
 
 from .acquisition.rule import AcquisitionRule, EfficientGlobalOptimization

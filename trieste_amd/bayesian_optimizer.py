@@ -4,7 +4,6 @@ wrapped so a failure (e.g. a non-positive-definite Cholesky) is returned as ``Er
 the history so far (855-875) instead of propagating."""
 from __future__ import annotations
 
-import copy
 import traceback
 from dataclasses import dataclass, field
 from typing import Callable, List, Mapping, Optional, Union

@@ -9,7 +9,7 @@ Model state is replicated: every rank runs the same deterministic `update`.
 """
 from __future__ import annotations
 
-from typing import Optional, Sequence, Tuple
+from typing import Tuple
 
 import numpy as np
 
