@@ -155,6 +155,9 @@ def main():
         gv, gi = all_gather_best(val, idx, device=f"cuda:{local_rank}", force=use_dist)
         return float(gv[0]), int(gi[0])
 
+    if use_dist:  # communicator set-up (lazy in RCCL) must not land in the timed region even with --warmup 0
+        all_gather_best(0.0, rank * M, device=f"cuda:{local_rank}", force=True)
+    best = (float("nan"), -1)
     for _ in range(args.warmup):
         best = step()
     kernel_ms = []
