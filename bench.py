@@ -185,7 +185,7 @@ def main():
         achieved = flops / (k_ms * 1e-3) * 1e-12
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tfile):
+        if os.path.exists(tfile) and not args.m_per_gpu:  # measured for the workload's own candidate count
             try:
                 traffic = json.load(open(tfile)).get(args.workload)
             except Exception:
