@@ -131,9 +131,166 @@ __global__ __launch_bounds__(256) void leaf_kernel(const double* __restrict__ A,
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Blocked form of the same leaf: 16-wide panels, the 64 x 64 block resident in LDS.
+//   per panel:  (1) wave 0 factors the 16 x 16 diagonal block AND inverts it with the register-resident
+//                   rank-1 scheme above at 1/4 scale (64 lanes, 4 + 4 entries each) -- a single wave, so its
+//                   16 pivot steps need no workgroup barrier (the 64-step form pays LDS round trip + barrier
+//                   per pivot: 0.34 us with the arithmetic removed);
+//               (2) panel  L_p = A_p W_d^T  (VALU, <= 48 x 16 outputs);
+//               (3) trailing update  A_22 -= L_p L_p^T  by MFMA (<= 6 tiles of 16 x 16, k = 16);
+//   then the blocked triangular inverse  W[bi][bk] = -W_d[bi] sum_j L[bi][j] W[j][bk]  by MFMA (the
+//   accumulator layout of the first product is the B-operand layout of the second: no LDS round trip).
+constexpr int LS = LEAF + 4;  // LDS row stride (16-byte aligned rows)
+__global__ __launch_bounds__(256) void leaf_blocked_kernel(const double* __restrict__ A, double* __restrict__ L,
+                                                           double* __restrict__ W, int64_t ld, int64_t off,
+                                                           int* __restrict__ info) {
+  __shared__ __attribute__((aligned(16))) double S[LEAF][LS];
+  __shared__ __attribute__((aligned(16))) double T[LEAF][LS];
+  __shared__ __attribute__((aligned(16))) double colb[2][16];
+  __shared__ __attribute__((aligned(16))) double rowb[2][16];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int e = tid; e < LEAF * LEAF; e += 256) {  // rows of the lower triangle: coalesced
+    const int i = e >> 6, j = e & 63;
+    S[i][j] = (j <= i) ? A[(off + i) * ld + off + j] : 0.0;
+    T[i][j] = 0.0;
+  }
+  __syncthreads();
+  {  // only the diagonal 16 x 16 tiles are read as full symmetric tiles: mirror them inside LDS
+    const int bt = tid >> 6, i = (tid >> 2) & 15, p = tid & 3;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int k = p + 4 * m;
+      if (k > i) S[16 * bt + i][16 * bt + k] = S[16 * bt + k][16 * bt + i];
+    }
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int kb = 0; kb < 4; ++kb) {
+    const int r0 = 16 * kb, r1 = r0 + 16;
+    if (w == 0) {  // (1) diagonal block: factor + inverse, one wave, no workgroup barrier
+      const int i = lane >> 2, p = lane & 3;
+      double a[4], t[4], myrs = 1.0;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        a[m] = S[r0 + i][r0 + p + 4 * m];
+        t[m] = (p + 4 * m == i) ? 1.0 : 0.0;
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int jm = j >> 2, jp = j & 3, bsel = j & 1;
+        if (p == jp) colb[bsel][i] = a[jm];
+        if (i == j) {
+#pragma unroll
+          for (int m = 0; m <= jm; ++m) rowb[bsel][p + 4 * m] = t[m];
+        }
+        __builtin_amdgcn_wave_barrier();  // LDS executes a wave's accesses in order: the reads below see the writes
+        double dj = colb[bsel][j];
+        if (!(dj > 0.0)) {
+          if (lane == 0) atomicCAS(info, 0, (int)(off + r0 + j) + 1);
+          dj = 1.0;
+        }
+        double sd, rs;
+        sqrt_and_rsqrt(dj, sd, rs);
+        const double lij = colb[bsel][i];
+        const double f = lij * (rs * rs);
+#pragma unroll
+        for (int m = jm; m < 4; ++m) {
+          const double upd = fma(-f, colb[bsel][p + 4 * m], a[m]);
+          a[m] = (m > jm || p > jp) ? upd : a[m];
+        }
+        if (p == jp) a[jm] = (i == j) ? sd : lij * rs;
+        const double ft = (i > j) ? f : 0.0;
+        myrs = (i == j) ? rs : myrs;
+#pragma unroll
+        for (int m = 0; m <= jm; ++m) t[m] = fma(-ft, rowb[bsel][p + 4 * m], t[m]);
+        __builtin_amdgcn_wave_barrier();
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int k = p + 4 * m;
+        S[r0 + i][r0 + k] = (k <= i) ? a[m] : 0.0;
+        T[r0 + i][r0 + k] = (k <= i) ? t[m] * myrs : 0.0;
+      }
+    }
+    __syncthreads();
+    if (r1 < LEAF) {
+      {  // (2) panel: L_p[row][c] = sum_{k <= c} A_p[row][k] W_d[c][k]
+        const int row = tid >> 2, part = tid & 3;
+        double out[4] = {0.0, 0.0, 0.0, 0.0};
+        if (row >= r1) {
+          double in[16];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) in[k] = S[row][r0 + k];
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) {
+            const int c = part * 4 + cc;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) out[cc] = fma(in[k], (k <= c) ? T[r0 + c][r0 + k] : 0.0, out[cc]);
+          }
+        }
+        __syncthreads();
+        if (row >= r1) {
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) S[row][r0 + part * 4 + cc] = out[cc];
+        }
+        __syncthreads();
+      }
+      // (3) trailing update on the lower 16 x 16 tiles (bi >= bj > kb), MFMA, k = 16
+      int tix = 0;
+      for (int bi = kb + 1; bi < 4; ++bi)
+        for (int bj = kb + 1; bj <= bi; ++bj, ++tix) {
+          if ((tix & 3) != w) continue;
+          v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int k4 = 0; k4 < 4; ++k4) {
+            const double av = S[16 * bi + (lane & 15)][r0 + 4 * k4 + (lane >> 4)];
+            const double bv = S[16 * bj + (lane & 15)][r0 + 4 * k4 + (lane >> 4)];
+            acc = mfma_f64(av, bv, acc);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) S[16 * bi + (lane >> 4) + 4 * r][16 * bj + (lane & 15)] -= acc[r];
+        }
+      __syncthreads();
+    }
+  }
+  // blocked triangular inverse: block row bi, block column bk = wave index
+#pragma unroll 1
+  for (int bi = 1; bi < 4; ++bi) {
+    if (w < bi) {
+      const int bk = w;
+      v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+      for (int j = bk; j < bi; ++j) {
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+          const double av = S[16 * bi + (lane & 15)][16 * j + 4 * k4 + (lane >> 4)];   // L[bi][j]
+          const double bv = T[16 * j + 4 * k4 + (lane >> 4)][16 * bk + (lane & 15)];   // W[j][bk]
+          acc = mfma_f64(av, bv, acc);
+        }
+      }
+      v4d out = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        const double av = T[16 * bi + (lane & 15)][16 * bi + 4 * k4 + (lane >> 4)];     // W_d[bi]
+        out = mfma_f64(av, acc[k4], out);  // acc[k4] holds rows 4 k4 .. 4 k4 + 3: the B operand of this k group
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) T[16 * bi + (lane >> 4) + 4 * r][16 * bk + (lane & 15)] = -out[r];
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < LEAF * LEAF; e += 256) {
+    const int i = e >> 6, j = e & 63;
+    L[(off + i) * ld + off + j] = (j <= i) ? S[i][j] : 0.0;
+    W[(off + i) * ld + off + j] = (j <= i) ? T[i][j] : 0.0;
+  }
+}
+
 void launch_leaf(hipStream_t s, const double* A, double* L, double* W, int64_t ld, int64_t off,
                  int* info) {
-  hipLaunchKernelGGL(leaf_kernel, dim3(1), dim3(256), 0, s, A, L, W, ld, off, info);
+  static const bool rank1 = getenv("TGP_LEAF_RANK1") != nullptr;  // A/B aid: the 64-step form (31 us; blocked: 25 us)
+  if (rank1) hipLaunchKernelGGL(leaf_kernel, dim3(1), dim3(256), 0, s, A, L, W, ld, off, info);
+  else hipLaunchKernelGGL(leaf_blocked_kernel, dim3(1), dim3(256), 0, s, A, L, W, ld, off, info);
 }
 
 // ---------------------------------------------------------------------------------------------
