@@ -215,6 +215,9 @@ def main():
                 "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                 "kernel": {0: "sweep_u16_kernel", 1: "sweep_kernel", 2: "sweep_ws_kernel"}.get(args.variant & 0xff, "?"),
                 "kernel_ms": k_ms, "flops_per_candidate": algorithmic_flops_per_candidate(N, d, kernel),
+                # the other roofline (SURVEY 8d asks for both): PMC traffic / kernel time against 8 TB/s HBM3E
+                "hbm_GBps": (traffic / (k_ms * 1e-3) * 1e-9) if traffic else None,
+                "hbm_frac": (traffic / (k_ms * 1e-3) / 8.0e12) if traffic else None,
             },
         }
         if world == 1 and not args.no_acquire:
