@@ -6,3 +6,5 @@ candidate sweep + arg-max of EfficientGlobalOptimization / DiscreteThompsonSampl
 hand-written HIP for gfx950 behind a C-ABI (include/tgp.h).  No CPU fallback.
 """
 __version__ = "0.1.0"
+
+from .rng import set_seed  # noqa: E402,F401  (the analogue of tf.random.set_seed for the host-side draws)

@@ -14,6 +14,8 @@ from typing import Optional, Tuple
 
 import numpy as np
 
+from .rng import make_rng
+
 from .data import Dataset
 from .engine import GPEngine
 from .space import SearchSpace
@@ -262,7 +264,7 @@ class GaussianProcessRegression:
         mean, cov = self.conditional_predict_joint(query_points, additional_data)
         M = mean.shape[-2]
         Lc = np.linalg.cholesky(cov[..., 0, :, :] + 1e-6 * np.eye(M))  # sample_mvn's default jitter
-        eps = np.random.default_rng().standard_normal(mean.shape[:-2] + (int(num_samples), M))
+        eps = make_rng().standard_normal(mean.shape[:-2] + (int(num_samples), M))
         return (mean[..., None, :, 0] + np.einsum("...ij,...sj->...si", Lc, eps))[..., None]
 
     def conditional_predict_y(self, query_points, additional_data: Dataset):
@@ -287,7 +289,7 @@ class GaussianProcessRegression:
             raise ValueError(f"num_samples must be positive, got {num_samples}")
         lead, N = q.shape[:-2], q.shape[-2]
         flat = q.reshape((-1, N, q.shape[-1]))
-        rng = np.random.default_rng()
+        rng = make_rng()
         out = np.empty((flat.shape[0], int(num_samples), N))
         for g in range(flat.shape[0]):
             out[g] = self._engine.sample_joint(flat[g], rng.standard_normal((N, int(num_samples))), 1e-6)
@@ -425,7 +427,7 @@ class GaussianProcessRegression:
 
         k = self._model.kernel
         d = self._engine.d
-        rng = np.random.default_rng(seed)
+        rng = make_rng(seed)
         noise, c = self._model.likelihood_variance, self._model.mean_function.c
         best_ls, best_var = np.array(np.broadcast_to(k.lengthscales, (d,))), k.variance
         best = self._loss_at(best_ls, best_var, noise, c, with_gradient=False)[0]

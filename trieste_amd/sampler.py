@@ -13,6 +13,8 @@ from typing import Optional
 
 import numpy as np
 
+from .rng import make_rng
+
 JITTER = 1e-6  # reference utils/misc.py:180-183
 
 
@@ -57,7 +59,7 @@ class BatchReparametrizationSampler:
         self._qmc, self._qmc_skip = qmc, qmc_skip
         self._sample_size = sample_size
         self._model = model
-        self._rng = np.random.default_rng(seed)
+        self._rng = make_rng(seed)
         self._eps: Optional[np.ndarray] = None  # [B, S]
         self._initialized = False
 
@@ -113,7 +115,7 @@ class IndependentReparametrizationSampler:
         self._qmc, self._qmc_skip = qmc, qmc_skip
         self._sample_size = sample_size
         self._model = model
-        self._rng = np.random.default_rng(seed)
+        self._rng = make_rng(seed)
         self._eps: Optional[np.ndarray] = None  # [1, S]
         self._initialized = False
 
@@ -231,7 +233,7 @@ class DecoupledTrajectorySampler:
             raise ValueError(f"num_features must be positive, got {num_features}")
         self._model = model
         self._num_features = num_features
-        self._rng = np.random.default_rng(seed)
+        self._rng = make_rng(seed)
         self._resample_basis()
 
     def __repr__(self) -> str:

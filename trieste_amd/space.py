@@ -7,6 +7,8 @@ from typing import Optional, Sequence
 
 import numpy as np
 
+from .rng import make_rng
+
 
 class SearchSpace:
     has_constraints = False
@@ -57,7 +59,7 @@ class Box(SearchSpace):
         reproduced outside TF; the distribution and the seed-reproducibility contract are kept.)"""
         if num_samples < 0:
             raise ValueError(f"num_samples must be non-negative, got {num_samples}")
-        rng = np.random.default_rng(seed)
+        rng = make_rng(seed)
         return rng.uniform(self._lower, self._upper, size=(num_samples, self.dimension))
 
     def sample_device(self, engine, num_samples: int, seed: int = 0, first: int = 0):
@@ -113,7 +115,7 @@ class DiscreteSearchSpace(SearchSpace):
             raise ValueError(f"num_samples must be non-negative, got {num_samples}")
         if num_samples == 0:
             return self._points[:0]
-        rng = np.random.default_rng(seed)
+        rng = make_rng(seed)
         n = self._points.shape[0]
         idx = rng.permutation(n)[: min(num_samples, n)]
         return self._points[idx]
