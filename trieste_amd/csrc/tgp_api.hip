@@ -587,7 +587,7 @@ int tgp_nlml(tgp_handle h, double* value, double* grad) {
     // lower tiles only (the reduction uses the symmetry); within the lower triangle the k range
     // [tm T, N) shrinks with the tile row, so the row-by-row order of the live-tile grid is longest-first
     launch_gemm(h->stream, false, (int)Npad, (int)Npad, (int)Npad, 1.0, h->d_A.as<double>(), Npad, h->d_W.as<double>(),
-                Npad, 0.0, Kinv, Npad, true, 4);
+                Npad, 0.0, Kinv, Npad, true, 4, Npad <= 4096 ? 1 : 0);
     launch_nlml(h->stream, model_dev(h), Kinv, h->d_L.as<double>(), h->d_err.as<double>(), h->s_blkv.as<double>(), out);
   } else {  // value only: 1/2 err^T alpha + sum log L_ii + N/2 log(2 pi)
     launch_nlml_value(h->stream, model_dev(h), h->d_L.as<double>(), h->d_err.as<double>(), out);

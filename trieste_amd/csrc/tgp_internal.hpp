@@ -70,7 +70,8 @@ void launch_leaf(hipStream_t s, const double* A, double* L, double* W, int64_t l
                  int* info);
 // C[m x n] = alpha * A[m x k] * op(B) + beta * C ;  TB: B stored [n x k] (row-major), else [k x n]
 void launch_gemm(hipStream_t s, bool tb, int m, int n, int k, double alpha, const double* A, int64_t lda,
-                 const double* B, int64_t ldb, double beta, double* C, int64_t ldc, bool lower_only, int tri = 0);
+                 const double* B, int64_t ldb, double beta, double* C, int64_t ldc, bool lower_only, int tri = 0,
+                 int small_tiles = 0);
 void launch_gemm_ksplit(hipStream_t s, bool tb, int m, int n, int k, double alpha, const double* A, int64_t lda,
                         const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int tri, int nz,
                         double* scratch);

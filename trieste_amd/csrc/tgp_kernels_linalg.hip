@@ -559,14 +559,16 @@ void launch_gemm_ksplit(hipStream_t s, bool tb, int m, int n, int k, double alph
 // nodes of the recursion; splitting k over more waves did not change either and was dropped.
 void launch_gemm(hipStream_t s, bool tb, int m, int n, int k, double alpha, const double* A,
                  int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc,
-                 bool lower_only, int tri) {
+                 bool lower_only, int tri, int small_tiles) {
   const int lo = lower_only ? 1 : 0;
   static const int64_t big_min = getenv("TGP_GEMM_BIG") ? atoll(getenv("TGP_GEMM_BIG")) : 512;  // tuning aid
   auto live_tiles = [&](int T) {  // 1-D grid over the live tiles (see tile_of_block)
     const int64_t ntm = m / T, ntn = n / T;
     return (unsigned)(lower_only ? ntm * (ntm + 1) / 2 : ntm * ntn);
   };
-  if (m % HB == 0 && n % HB == 0 && (int64_t)(m / HB) * (n / HB) >= big_min) {
+  // small_tiles: the caller knows a few tiles carry a very long k range (K^-1 = W^T W: the first tile
+  // rows sum over all of N) -- one 128 x 128 workgroup walking k = 4096 alone on its CU is the makespan
+  if (!small_tiles && m % HB == 0 && n % HB == 0 && (int64_t)(m / HB) * (n / HB) >= big_min) {
     dim3 gb(live_tiles(HB));
     if (tb) hipLaunchKernelGGL(gemm_big_kernel<true>, gb, dim3(512), 0, s, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lo, tri);
     else hipLaunchKernelGGL(gemm_big_kernel<false>, gb, dim3(512), 0, s, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lo, tri);
