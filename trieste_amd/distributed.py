@@ -66,3 +66,32 @@ def all_gather_best(val, idx, minimize: bool = False, group=None, device=None, f
     vals = out[:, 0, :].numpy()
     idxs = out[:, 1, :].contiguous().view(torch.int64).numpy()
     return merge_best(vals, idxs, minimize)
+
+
+def generate_sharded_discrete_optimizer(group=None, device=None):
+    """An ``AcquisitionOptimizer`` (reference acquisition/optimizer.py:73-87) for one process per GPU: every
+    rank holds the same model and the same ``DiscreteSearchSpace``; rank r sweeps the contiguous shard
+    ``shard_range(M, r, world)`` of its points with the function's fused device arg-max (``index_base`` =
+    shard offset, so global indices and the first-index tie-break survive), the (value, index) winners are
+    all-gathered and merged, and every rank returns the same point [1, D].  Single process: identical to
+    :func:`~trieste_amd.acquisition.optimizer.optimize_discrete`."""
+    import torch.distributed as dist
+
+    def optimizer(space, target_func):
+        if isinstance(target_func, tuple):
+            raise ValueError("the sharded optimizer takes batch-size-one acquisition functions")
+        if not hasattr(target_func, "argmax"):
+            raise TypeError("the sharded optimizer needs an engine-backed acquisition function (fused arg-max)")
+        points = np.asarray(space.points, dtype=np.float64)
+        active = dist.is_available() and dist.is_initialized()
+        rank = dist.get_rank(group) if active else 0
+        world = dist.get_world_size(group) if active else 1
+        lo, hi = shard_range(points.shape[0], rank, world)
+        if hi > lo:
+            val, idx, _ = target_func.argmax(points[lo:hi], index_base=lo)
+        else:  # more ranks than points: an empty shard never wins
+            val, idx = float("nan"), -1
+        _, gi = all_gather_best(val, idx, group=group, device=device)
+        return points[int(gi[0])][None, :]
+
+    return optimizer
