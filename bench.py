@@ -78,7 +78,7 @@ def end_to_end_acquire_ms(X, Y, d, kernel, noise):
     L-BFGS-B runs on the analytic EI gradient (the reference's default for a Box)."""
     try:
         import trieste_amd.models as M
-        from oracle import gp_oracle as O
+        from trieste_amd import objectives as O
         from trieste_amd.acquisition import EfficientGlobalOptimization
         from trieste_amd.data import Dataset
         from trieste_amd.space import Box
@@ -127,7 +127,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
-    from oracle import gp_oracle as O  # synthetic objective only (inputs), never the measured path
+    from trieste_amd import objectives as O  # the seeded synthetic problem (inputs)
     from trieste_amd.distributed import all_gather_best
     from trieste_amd.engine import GPEngine
 

@@ -2,7 +2,7 @@
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from oracle import gp_oracle as O
+from trieste_amd import objectives as O  # seeded synthetic problems (product side)
 from trieste_amd.engine import GPEngine
 N, d = int(sys.argv[1]) if len(sys.argv) > 1 else 4096, 8
 X, Y = O.synthetic_problem(O.ackley, d, N)

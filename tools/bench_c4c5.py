@@ -2,7 +2,7 @@
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from oracle import gp_oracle as O
+from trieste_amd import objectives as O  # seeded synthetic problems (product side)
 from trieste_amd.engine import GPEngine
 
 def c4(G=20000, q=50, S=512, N=2048, d=6):

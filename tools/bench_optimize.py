@@ -1,7 +1,7 @@
 import sys, os, time
 sys.path.insert(0, "/root/repo")
 import numpy as np
-from oracle import gp_oracle as O
+from trieste_amd import objectives as O  # seeded synthetic problems (product side)
 import trieste_amd.models as M
 from trieste_amd.data import Dataset
 from trieste_amd.space import Box

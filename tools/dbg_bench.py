@@ -1,7 +1,7 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from oracle import gp_oracle as O
+from trieste_amd import objectives as O  # seeded synthetic problems (product side)
 from trieste_amd.engine import GPEngine
 d, N, M = 8, 4096, 1 << 18
 X, Y = O.synthetic_problem(O.ackley, d, N)

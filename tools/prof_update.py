@@ -2,7 +2,7 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from oracle import gp_oracle as O
+from trieste_amd import objectives as O  # seeded synthetic problems (product side)
 from trieste_amd.engine import GPEngine
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 X, Y = O.synthetic_problem(O.ackley, 8, N)

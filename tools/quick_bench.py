@@ -3,7 +3,7 @@ import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
-from oracle import gp_oracle as O
+from trieste_amd import objectives as O  # seeded synthetic problems (product side)
 from trieste_amd.engine import GPEngine
 
 def run(kind, d, N, M, noise=1e-2, variant=0, reps=3):

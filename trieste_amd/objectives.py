@@ -68,6 +68,21 @@ def ackley_5(x):
     return ackley(x)
 
 
+def synthetic_problem(objective, d: int, N: int, seed: int = 1234):
+    """The seeded synthetic regression problem of the benchmarks (SURVEY.md section 8d): X ~ U[0,1]^{N x d}
+    (numpy PCG64), Y = objective(X) standardised to zero mean / unit variance -> (X [N, d], Y [N])."""
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(size=(N, d))
+    Yraw = np.asarray(objective(X), dtype=np.float64).reshape(N)
+    return X, (Yraw - Yraw.mean()) / Yraw.std()
+
+
+def default_lengthscales(d: int) -> np.ndarray:
+    """build_gpr's initial lengthscales on the unit cube: 0.2 * (upper - lower) * sqrt(d)
+    (reference models/gpflow/builders.py:41, 413-423)."""
+    return np.full(d, 0.2 * math.sqrt(d))
+
+
 def mk_observer(objective, key=OBJECTIVE):
     """Observer returning {key: Dataset(x, objective(x))} (or a bare Dataset when key is None)."""
     if key is None:
