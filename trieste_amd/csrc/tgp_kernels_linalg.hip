@@ -392,11 +392,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(int m, int n, int k, double a
 #pragma unroll
     for (int q = 0; q < NS; ++q) {
       const int kq = q * 16;
-      As[kq + lk + 0][lr] = a0[q].x; As[kq + lk + 1][lr] = a0[q].y;
-      As[kq + lk + 2][lr] = a1[q].x; As[kq + lk + 3][lr] = a1[q].y;
+      // transposing stores: the k rows lk, lk+4, ... of the lanes sharing a tile row are 4 LDS rows apart =
+      // the same bank with the +16 pad (an 8-way conflict on every store); element (k, col) therefore lives
+      // at column (col + 8 (k >> 2)) & 63 -- a rotation that is uniform inside a 4-row k group, so the
+      // fragment reads stay conflict-free
+      const int sc = (lr + 2 * (kq + lk)) & 63;
+      As[kq + lk + 0][sc] = a0[q].x; As[kq + lk + 1][sc] = a0[q].y;
+      As[kq + lk + 2][sc] = a1[q].x; As[kq + lk + 3][sc] = a1[q].y;
       if (TB) {
-        Bs[kq + lk + 0][lr] = b0[q].x; Bs[kq + lk + 1][lr] = b0[q].y;
-        Bs[kq + lk + 2][lr] = b1[q].x; Bs[kq + lk + 3][lr] = b1[q].y;
+        Bs[kq + lk + 0][sc] = b0[q].x; Bs[kq + lk + 1][sc] = b0[q].y;
+        Bs[kq + lk + 2][sc] = b1[q].x; Bs[kq + lk + 3][sc] = b1[q].y;
       } else {
         *(v2d*)&Bs[kq + br][bc] = b0[q];
         *(v2d*)&Bs[kq + br][bc + 2] = b1[q];
@@ -410,8 +415,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(int m, int n, int k, double a
       double a[2], b[2];
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
-        a[f] = As[kr][wm * 32 + f * 16 + (lane & 15)];
-        b[f] = Bs[kr][wn * 32 + f * 16 + (lane & 15)];
+        a[f] = As[kr][(wm * 32 + f * 16 + (lane & 15) + 8 * k4) & 63];
+        b[f] = Bs[kr][TB ? (wn * 32 + f * 16 + (lane & 15) + 8 * k4) & 63 : wn * 32 + f * 16 + (lane & 15)];
       }
 #pragma unroll
       for (int fa = 0; fa < 2; ++fa)
@@ -432,6 +437,79 @@ __global__ __launch_bounds__(256) void gemm_kernel(int m, int n, int k, double a
         const double v = alpha * acc[fa][fb][r];
         *dst = (beta == 0.0) ? v : fma(beta, *dst, v);
       }
+}
+
+// Few-tile variant (<= one workgroup per CU): the same 64 x 64 tile on EIGHT waves (2 x 4, wave tile
+// 32 x 16).  A lone 4-wave workgroup leaves one MFMA-issuing wave per SIMD, and one wave issues an f64 MFMA
+// only every 128 cycles (half the pipe rate): 512^3 on 64 CUs took 16 steps x 32 MFMAs x 128 cycles =
+// 27.6 us, exactly what was measured.  Two waves per SIMD halve that.
+template <bool TB>
+__global__ __launch_bounds__(512) void gemm_kernel8(int m, int n, int k, double alpha,
+                                                    const double* __restrict__ A, int64_t lda,
+                                                    const double* __restrict__ B, int64_t ldb,
+                                                    double beta, double* __restrict__ C, int64_t ldc,
+                                                    int lower_only, int tri) {
+  constexpr int GKT = 32;
+  int tm, tn;
+  tile_of_block(lower_only, tri, m / GB, n / GB, tm, tn);
+  __shared__ double As[GKT][GLD];
+  __shared__ double Bs[GKT][GLD];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w >> 2, wn = w & 3;
+  v4d acc[2];
+  acc[0] = (v4d){0.0, 0.0, 0.0, 0.0};
+  acc[1] = (v4d){0.0, 0.0, 0.0, 0.0};
+  int klo = 0, khi = k;
+  if (tri == 1) khi = min(k, (tn + 1) * GB);
+  else if (tri == 2) klo = min(k, tn * GB);
+  else if (tri == 3) khi = min(k, (tm + 1) * GB);
+  else if (tri == 4) klo = min(k, max(tm, tn) * GB);
+  else if (tri == 5) klo = min(k, tm * GB);
+  const double* Ab = A + (int64_t)tm * GB * lda;
+  const double* Bb = TB ? B + (int64_t)tn * GB * ldb : B + (int64_t)tn * GB;
+  const int lr = tid >> 3, lk = (tid & 7) * 4;   // [row][k..k+3] loader: 64 rows x 32 k
+  const int br = tid >> 4, bc = (tid & 15) * 4;  // [k][n..n+3] loader: 32 k x 64 n
+  v2d a0, a1, b0, b1;
+  auto fetch = [&](int k0) {
+    const double* sa = Ab + (int64_t)lr * lda + k0 + lk;
+    a0 = *(const v2d*)sa;
+    a1 = *(const v2d*)(sa + 2);
+    const double* sb = TB ? Bb + (int64_t)lr * ldb + k0 + lk : Bb + (int64_t)(k0 + br) * ldb + bc;
+    b0 = *(const v2d*)sb;
+    b1 = *(const v2d*)(sb + 2);
+  };
+  if (klo < khi) fetch(klo);
+  for (int k0 = klo; k0 < khi; k0 += GKT) {
+    const int sc = (lr + 2 * lk) & 63;  // column rotation by 8 (k >> 2): see gemm_kernel
+    As[lk + 0][sc] = a0.x; As[lk + 1][sc] = a0.y; As[lk + 2][sc] = a1.x; As[lk + 3][sc] = a1.y;
+    if (TB) {
+      Bs[lk + 0][sc] = b0.x; Bs[lk + 1][sc] = b0.y; Bs[lk + 2][sc] = b1.x; Bs[lk + 3][sc] = b1.y;
+    } else {
+      *(v2d*)&Bs[br][bc] = b0;
+      *(v2d*)&Bs[br][bc + 2] = b1;
+    }
+    __syncthreads();
+    if (k0 + GKT < khi) fetch(k0 + GKT);
+#pragma unroll
+    for (int k4 = 0; k4 < GKT / 4; ++k4) {
+      const int kr = k4 * 4 + (lane >> 4);
+      const double bv = Bs[kr][TB ? (wn * 16 + (lane & 15) + 8 * k4) & 63 : wn * 16 + (lane & 15)];
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+        acc[f] = mfma_f64(As[kr][(wm * 32 + f * 16 + (lane & 15) + 8 * k4) & 63], bv, acc[f]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t row = (int64_t)tm * GB + wm * 32 + f * 16 + (lane >> 4) + 4 * r;
+      const int64_t col = (int64_t)tn * GB + wn * 16 + (lane & 15);
+      double* dst = C + row * ldc + col;
+      const double v = alpha * acc[f][r];
+      *dst = (beta == 0.0) ? v : fma(beta, *dst, v);
+    }
 }
 
 // Large-grid variant: 128 x 128 tile, 8 waves (2 x 4), wave tile 64 x 32 (the sweep kernel's wave tile:
@@ -479,9 +557,10 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(int m, int n, int k, d
   auto stage = [&](int st) {
     double(*As)[HLD] = sm[st][0];
     double(*Bs)[HLD] = sm[st][1];
-    As[lk + 0][lr] = a0.x; As[lk + 1][lr] = a0.y; As[lk + 2][lr] = a1.x; As[lk + 3][lr] = a1.y;
+    const int sc = (lr + 2 * lk) & (HB - 1);  // column rotation by 8 (k >> 2): see gemm_kernel
+    As[lk + 0][sc] = a0.x; As[lk + 1][sc] = a0.y; As[lk + 2][sc] = a1.x; As[lk + 3][sc] = a1.y;
     if (TB) {
-      Bs[lk + 0][lr] = b0.x; Bs[lk + 1][lr] = b0.y; Bs[lk + 2][lr] = b1.x; Bs[lk + 3][lr] = b1.y;
+      Bs[lk + 0][sc] = b0.x; Bs[lk + 1][sc] = b0.y; Bs[lk + 2][sc] = b1.x; Bs[lk + 3][sc] = b1.y;
     } else {
       *(v2d*)&Bs[br][bc] = b0;
       *(v2d*)&Bs[br][bc + 2] = b1;
@@ -496,15 +575,15 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(int m, int n, int k, d
   for (int k0 = klo; k0 < khi; k0 += HK) {
     const bool more = k0 + HK < khi;
     if (more) fetch(k0 + HK);
-    const double* ab = &sm[st][0][lane >> 4][wm * 64 + (lane & 15)];
-    const double* bb = &sm[st][1][lane >> 4][wn * 32 + (lane & 15)];
 #pragma unroll
     for (int k4 = 0; k4 < HK / 4; ++k4) {
+      const int kr = k4 * 4 + (lane >> 4);
       double av[4], bv[2];
 #pragma unroll
-      for (int f = 0; f < 4; ++f) av[f] = ab[k4 * 4 * HLD + f * 16];
+      for (int f = 0; f < 4; ++f) av[f] = sm[st][0][kr][(wm * 64 + f * 16 + (lane & 15) + 8 * k4) & (HB - 1)];
 #pragma unroll
-      for (int f = 0; f < 2; ++f) bv[f] = bb[k4 * 4 * HLD + f * 16];
+      for (int f = 0; f < 2; ++f)
+        bv[f] = sm[st][1][kr][TB ? (wn * 32 + f * 16 + (lane & 15) + 8 * k4) & (HB - 1) : wn * 32 + f * 16 + (lane & 15)];
 #pragma unroll
       for (int fm = 0; fm < 4; ++fm)
 #pragma unroll
@@ -575,6 +654,12 @@ void launch_gemm(hipStream_t s, bool tb, int m, int n, int k, double alpha, cons
     return;
   }
   dim3 grid(live_tiles(GB));
+  static const int64_t w8_max = getenv("TGP_GEMM_W8") ? atoll(getenv("TGP_GEMM_W8")) : 256;  // tuning aid
+  if ((int64_t)(m / GB) * (n / GB) <= w8_max && k % 32 == 0) {  // at most one workgroup per CU: eight waves per tile
+    if (tb) hipLaunchKernelGGL(gemm_kernel8<true>, grid, dim3(512), 0, s, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lo, tri);
+    else hipLaunchKernelGGL(gemm_kernel8<false>, grid, dim3(512), 0, s, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lo, tri);
+    return;
+  }
   // few workgroups: the k loop of one workgroup is the critical path -> deeper steps (fewer barriers,
   // more loads in flight); many workgroups: 16-deep steps keep 4 workgroups resident per CU.
   const bool deep = (int64_t)(m / GB) * (n / GB) <= 512 && k % 32 == 0;
