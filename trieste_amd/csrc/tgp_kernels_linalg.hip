@@ -294,10 +294,9 @@ void launch_leaf(hipStream_t s, const double* A, double* L, double* W, int64_t l
 }
 
 // ---------------------------------------------------------------------------------------------
-// f64 MFMA GEMM, 64x64 tile per workgroup, 4 waves (2x2), each wave 32x32 = 2x2 fragments of
-// v_mfma_f64_16x16x4_f64.  m, n multiples of 64; k multiple of 16.  Operand tiles are staged in
-// LDS k-major ([k][m] / [k][n]) with a +16-double row pad so that the 4 k-rows a fragment read
-// touches fall on disjoint bank halves.
+// f64 MFMA GEMMs of the factor recursion (v_mfma_f64_16x16x4_f64).  m, n multiples of 64; k multiple of 32.
+// Operand tiles are staged in LDS k-major ([k][m] / [k][n]) with a +16-double row pad so that the 4 k-rows
+// a fragment read touches fall on disjoint bank halves.
 constexpr int GB = 64, GLD = GB + 16;
 
 
@@ -336,113 +335,18 @@ __device__ __forceinline__ void tile_of_block(int lower_only, int tri, int nt_m,
 // (k >= tn 64);  3: A lower (k < (tm+1) 64);  4: A upper and B lower (k >= max(tm, tn) 64);
 // 5: A upper (k >= tm 64).  Global loads of step k0+16 are in flight while the
 // MFMAs of step k0 run (register prefetch), so a step costs max(load, math) instead of the sum.
-template <bool TB, int GKT>
-__global__ __launch_bounds__(256) void gemm_kernel(int m, int n, int k, double alpha,
-                                                   const double* __restrict__ A, int64_t lda,
-                                                   const double* __restrict__ B, int64_t ldb,
-                                                   double beta, double* __restrict__ C, int64_t ldc,
-                                                   int lower_only, int tri) {
-  int tm, tn;
-  tile_of_block(lower_only, tri, m / GB, n / GB, tm, tn);
-  __shared__ double As[GKT][GLD];
-  __shared__ double Bs[GKT][GLD];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int wm = w >> 1, wn = w & 1;
-  v4d acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
-
-  int klo = 0, khi = k;
-  if (tri == 1) khi = min(k, (tn + 1) * GB);
-  else if (tri == 2) klo = min(k, tn * GB);
-  else if (tri == 3) khi = min(k, (tm + 1) * GB);
-  else if (tri == 4) klo = min(k, max(tm, tn) * GB);
-  else if (tri == 5) klo = min(k, tm * GB);
-  if (gridDim.y > 1) {  // k-split: slice blockIdx.y of the (pruned) k range, partial result to C + slice * m * ldc
-    const int steps = (khi - klo + GKT - 1) / GKT, per = (steps + (int)gridDim.y - 1) / (int)gridDim.y;
-    const int lo2 = klo + (int)blockIdx.y * per * GKT;
-    khi = min(khi, lo2 + per * GKT);
-    klo = min(lo2, khi);
-    C += (int64_t)blockIdx.y * m * ldc;
-  }
-
-  const double* Ab = A + (int64_t)tm * GB * lda;
-  const double* Bb = TB ? B + (int64_t)tn * GB * ldb : B + (int64_t)tn * GB;
-  const int lr = tid >> 2, lk = (tid & 3) * 4;       // [row][k..k+3] loader (A, and B when TB)
-  const int br = tid >> 4, bc = (tid & 15) * 4;      // [k][n..n+3] loader (B when !TB)
-  constexpr int NS = GKT / 16;                       // 16-deep k slices per step
-
-  v2d a0[NS], a1[NS], b0[NS], b1[NS];
-  auto fetch = [&](int k0) {
-#pragma unroll
-    for (int q = 0; q < NS; ++q) {
-      const double* sa = Ab + (int64_t)lr * lda + k0 + q * 16 + lk;
-      a0[q] = *(const v2d*)sa;
-      a1[q] = *(const v2d*)(sa + 2);
-      const double* sb = TB ? Bb + (int64_t)lr * ldb + k0 + q * 16 + lk
-                            : Bb + (int64_t)(k0 + q * 16 + br) * ldb + bc;
-      b0[q] = *(const v2d*)sb;
-      b1[q] = *(const v2d*)(sb + 2);
-    }
-  };
-  if (klo < khi) fetch(klo);
-  for (int k0 = klo; k0 < khi; k0 += GKT) {
-#pragma unroll
-    for (int q = 0; q < NS; ++q) {
-      const int kq = q * 16;
-      // transposing stores: the k rows lk, lk+4, ... of the lanes sharing a tile row are 4 LDS rows apart =
-      // the same bank with the +16 pad (an 8-way conflict on every store); element (k, col) therefore lives
-      // at column (col + 8 (k >> 2)) & 63 -- a rotation that is uniform inside a 4-row k group, so the
-      // fragment reads stay conflict-free
-      const int sc = (lr + 2 * (kq + lk)) & 63;
-      As[kq + lk + 0][sc] = a0[q].x; As[kq + lk + 1][sc] = a0[q].y;
-      As[kq + lk + 2][sc] = a1[q].x; As[kq + lk + 3][sc] = a1[q].y;
-      if (TB) {
-        Bs[kq + lk + 0][sc] = b0[q].x; Bs[kq + lk + 1][sc] = b0[q].y;
-        Bs[kq + lk + 2][sc] = b1[q].x; Bs[kq + lk + 3][sc] = b1[q].y;
-      } else {
-        *(v2d*)&Bs[kq + br][bc] = b0[q];
-        *(v2d*)&Bs[kq + br][bc + 2] = b1[q];
-      }
-    }
-    __syncthreads();
-    if (k0 + GKT < khi) fetch(k0 + GKT);
-#pragma unroll
-    for (int k4 = 0; k4 < GKT / 4; ++k4) {
-      const int kr = k4 * 4 + (lane >> 4);
-      double a[2], b[2];
-#pragma unroll
-      for (int f = 0; f < 2; ++f) {
-        a[f] = As[kr][(wm * 32 + f * 16 + (lane & 15) + 8 * k4) & 63];
-        b[f] = Bs[kr][TB ? (wn * 32 + f * 16 + (lane & 15) + 8 * k4) & 63 : wn * 32 + f * 16 + (lane & 15)];
-      }
-#pragma unroll
-      for (int fa = 0; fa < 2; ++fa)
-#pragma unroll
-        for (int fb = 0; fb < 2; ++fb) acc[fa][fb] = mfma_f64(a[fa], b[fb], acc[fa][fb]);
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int fa = 0; fa < 2; ++fa)
-#pragma unroll
-    for (int fb = 0; fb < 2; ++fb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int64_t row = (int64_t)tm * GB + wm * 32 + fa * 16 + (lane >> 4) + 4 * r;
-        const int64_t col = (int64_t)tn * GB + wn * 32 + fb * 16 + (lane & 15);
-        double* dst = C + row * ldc + col;
-        const double v = alpha * acc[fa][fb][r];
-        *dst = (beta == 0.0) ? v : fma(beta, *dst, v);
-      }
-}
-
-// Few-tile variant (<= one workgroup per CU): the same 64 x 64 tile on EIGHT waves (2 x 4, wave tile
-// 32 x 16).  A lone 4-wave workgroup leaves one MFMA-issuing wave per SIMD, and one wave issues an f64 MFMA
-// only every 128 cycles (half the pipe rate): 512^3 on 64 CUs took 16 steps x 32 MFMAs x 128 cycles =
-// 27.6 us, exactly what was measured.  Two waves per SIMD halve that.
+// 64 x 64 tile on EIGHT waves (2 x 4, wave tile 32 x 16), 32-deep k steps, register prefetch of the next
+// step's global loads.  Eight rather than four waves: with at most one workgroup per CU (every node of the
+// recursion below 2048) a 4-wave workgroup leaves one MFMA-issuing wave per SIMD, and one wave issues an
+// f64 MFMA only every 128 cycles -- half the pipe rate; measured, the 8-wave form wins at every size.
+//
+// Transposing stores into LDS: the k rows lk, lk+4, ... of the lanes that share a tile row are 4 LDS rows
+// apart = the same bank with the +16 pad that keeps the fragment READS conflict-free (an 8-way conflict on
+// every store; it capped every small product at 1.7 us per 32-deep step whatever the wave count).  Element
+// (k, col) therefore lives at column (col + 8 (k >> 2)) & 63: a rotation that is uniform inside a 4-row k
+// group, so the reads stay conflict-free.
+//
+// gridDim.y > 1: k-split -- slice blockIdx.y of the (pruned) k range, partial result to C + slice * m * ldc.
 template <bool TB>
 __global__ __launch_bounds__(512) void gemm_kernel8(int m, int n, int k, double alpha,
                                                     const double* __restrict__ A, int64_t lda,
@@ -465,6 +369,13 @@ __global__ __launch_bounds__(512) void gemm_kernel8(int m, int n, int k, double 
   else if (tri == 3) khi = min(k, (tm + 1) * GB);
   else if (tri == 4) klo = min(k, max(tm, tn) * GB);
   else if (tri == 5) klo = min(k, tm * GB);
+  if (gridDim.y > 1) {
+    const int steps = (khi - klo + GKT - 1) / GKT, per = (steps + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int lo2 = klo + (int)blockIdx.y * per * GKT;
+    khi = min(khi, lo2 + per * GKT);
+    klo = min(lo2, khi);
+    C += (int64_t)blockIdx.y * m * ldc;
+  }
   const double* Ab = A + (int64_t)tm * GB * lda;
   const double* Bb = TB ? B + (int64_t)tn * GB * ldb : B + (int64_t)tn * GB;
   const int lr = tid >> 3, lk = (tid & 7) * 4;   // [row][k..k+3] loader: 64 rows x 32 k
@@ -480,7 +391,7 @@ __global__ __launch_bounds__(512) void gemm_kernel8(int m, int n, int k, double 
   };
   if (klo < khi) fetch(klo);
   for (int k0 = klo; k0 < khi; k0 += GKT) {
-    const int sc = (lr + 2 * lk) & 63;  // column rotation by 8 (k >> 2): see gemm_kernel
+    const int sc = (lr + 2 * lk) & 63;  // the column rotation by 8 (k >> 2)
     As[lk + 0][sc] = a0.x; As[lk + 1][sc] = a0.y; As[lk + 2][sc] = a1.x; As[lk + 3][sc] = a1.y;
     if (TB) {
       Bs[lk + 0][sc] = b0.x; Bs[lk + 1][sc] = b0.y; Bs[lk + 2][sc] = b1.x; Bs[lk + 3][sc] = b1.y;
@@ -557,7 +468,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(int m, int n, int k, d
   auto stage = [&](int st) {
     double(*As)[HLD] = sm[st][0];
     double(*Bs)[HLD] = sm[st][1];
-    const int sc = (lr + 2 * lk) & (HB - 1);  // column rotation by 8 (k >> 2): see gemm_kernel
+    const int sc = (lr + 2 * lk) & (HB - 1);  // column rotation by 8 (k >> 2): see gemm_kernel8
     As[lk + 0][sc] = a0.x; As[lk + 1][sc] = a0.y; As[lk + 2][sc] = a1.x; As[lk + 3][sc] = a1.y;
     if (TB) {
       Bs[lk + 0][sc] = b0.x; Bs[lk + 1][sc] = b0.y; Bs[lk + 2][sc] = b1.x; Bs[lk + 3][sc] = b1.y;
@@ -620,14 +531,14 @@ __global__ void ksplit_reduce_kernel(const double* __restrict__ P, int nz, int64
 }
 
 // Few output tiles but a long k (the gradient / cross-covariance products: N x P x N with P <= 128): one
-// 4-wave workgroup per tile walks k serially at ~1.7 us per 32-deep step (exposed load latency).  Split k
+// workgroup per tile walks a long k range alone.  Split k
 // over `nz` workgroups per tile (partials in `scratch` [nz][m][n]) and reduce in a fixed order.
 void launch_gemm_ksplit(hipStream_t s, bool tb, int m, int n, int k, double alpha, const double* A, int64_t lda,
                         const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int tri, int nz,
                         double* scratch) {
   dim3 grid((unsigned)((m / GB) * (n / GB)), (unsigned)nz);
-  if (tb) hipLaunchKernelGGL((gemm_kernel<true, 32>), grid, dim3(256), 0, s, m, n, k, 1.0, A, lda, B, ldb, 0.0, scratch, (int64_t)n, 0, tri);
-  else hipLaunchKernelGGL((gemm_kernel<false, 32>), grid, dim3(256), 0, s, m, n, k, 1.0, A, lda, B, ldb, 0.0, scratch, (int64_t)n, 0, tri);
+  if (tb) hipLaunchKernelGGL(gemm_kernel8<true>, grid, dim3(512), 0, s, m, n, k, 1.0, A, lda, B, ldb, 0.0, scratch, (int64_t)n, 0, tri);
+  else hipLaunchKernelGGL(gemm_kernel8<false>, grid, dim3(512), 0, s, m, n, k, 1.0, A, lda, B, ldb, 0.0, scratch, (int64_t)n, 0, tri);
   dim3 rg((unsigned)((n + 63) / 64), (unsigned)((m + 3) / 4));
   hipLaunchKernelGGL(ksplit_reduce_kernel, rg, dim3(256), 0, s, scratch, nz, (int64_t)m, (int64_t)n, (int64_t)n, alpha, beta, C, ldc);
 }
@@ -654,22 +565,8 @@ void launch_gemm(hipStream_t s, bool tb, int m, int n, int k, double alpha, cons
     return;
   }
   dim3 grid(live_tiles(GB));
-  static const int64_t w8_max = getenv("TGP_GEMM_W8") ? atoll(getenv("TGP_GEMM_W8")) : 256;  // tuning aid
-  if ((int64_t)(m / GB) * (n / GB) <= w8_max && k % 32 == 0) {  // at most one workgroup per CU: eight waves per tile
-    if (tb) hipLaunchKernelGGL(gemm_kernel8<true>, grid, dim3(512), 0, s, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lo, tri);
-    else hipLaunchKernelGGL(gemm_kernel8<false>, grid, dim3(512), 0, s, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lo, tri);
-    return;
-  }
-  // few workgroups: the k loop of one workgroup is the critical path -> deeper steps (fewer barriers,
-  // more loads in flight); many workgroups: 16-deep steps keep 4 workgroups resident per CU.
-  const bool deep = (int64_t)(m / GB) * (n / GB) <= 512 && k % 32 == 0;
-  if (tb) {
-    if (deep) hipLaunchKernelGGL((gemm_kernel<true, 32>), grid, dim3(256), 0, s, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lo, tri);
-    else hipLaunchKernelGGL((gemm_kernel<true, 16>), grid, dim3(256), 0, s, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lo, tri);
-  } else {
-    if (deep) hipLaunchKernelGGL((gemm_kernel<false, 32>), grid, dim3(256), 0, s, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lo, tri);
-    else hipLaunchKernelGGL((gemm_kernel<false, 16>), grid, dim3(256), 0, s, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lo, tri);
-  }
+  if (tb) hipLaunchKernelGGL(gemm_kernel8<true>, grid, dim3(512), 0, s, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lo, tri);
+  else hipLaunchKernelGGL(gemm_kernel8<false>, grid, dim3(512), 0, s, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lo, tri);
 }
 
 // ---------------------------------------------------------------------------------------------
