@@ -20,8 +20,12 @@
  *     handle's GPU, e.g. torch tensors' data_ptr()).  Scalars/small outputs documented as "host"
  *     are always host pointers.
  *   - the handle owns all internal device memory; the caller owns every buffer it passes.
- *   - one host thread per handle; calls are synchronous on return (work is queued on the
- *     handle's HIP stream -- tgp_set_stream -- and the stream is synchronised before returning).
+ *   - one host thread per handle at a time; different handles may be driven from different threads
+ *     concurrently (tgp_use_private_stream).  Calls are synchronous on return (work is queued on the
+ *     handle's HIP stream -- tgp_set_stream / tgp_use_private_stream -- and the stream is
+ *     synchronised before returning).  Every call clears the calling thread's sticky HIP error first.
+ *   - a trajectory (tgp_traj) must not be used after its model handle is destroyed; destroying it
+ *     afterwards is allowed (garbage collectors finalise in arbitrary order).
  *   - no torch types, no C++ types: plain pointers and sizes only.
  */
 #ifndef TGP_H
