@@ -63,6 +63,20 @@ __device__ __forceinline__ void sqrt_and_rsqrt(double x, double& g_out, double& 
   rs_out = h + h;
 }
 
+// The same pair with ONE coupled iteration (the pivot chain of the factor leaf is a serial dependency of the
+// whole wave: every dependent fp64 op costs ~10 cycles x 64 pivots x 64 leaves).  v_rsq_f64 delivers ~2^-26;
+// one Goldschmidt step squares that, the residual step on g brings sqrt(x) to ~1 ulp, 1/sqrt(x) to ~2 ulp.
+__device__ __forceinline__ void sqrt_and_rsqrt_short(double x, double& g_out, double& rs_out) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  const double dd = fma(-g, g, x);
+  g_out = fma(dd, h, g);
+  rs_out = h + h;
+}
+
 // exp(x) for x <= 0.  n = rint(x / ln2), r = x - n ln2 (two-term Cody-Waite), degree-11
 // Chebyshev-fitted polynomial on |r| <= ln2/2 (relative error 4.2e-18), ldexp.
 __device__ __forceinline__ double fast_exp_nonpos(double x) {

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void leaf_blocked_kernel(const double* __restr
           dj = 1.0;
         }
         double sd, rs;
-        sqrt_and_rsqrt(dj, sd, rs);
+        sqrt_and_rsqrt_short(dj, sd, rs);
         const double lij = colb[bsel][i];
         const double f = lij * (rs * rs);
 #pragma unroll
