@@ -29,33 +29,66 @@ void launch_scale_inputs(hipStream_t s, const double* X, const double* ls, doubl
 }
 
 // K[i][j] = k(x_i, x_j) + noise * (i == j) on the N x N part; identity on the padding so that the
-// padded matrix stays SPD and factorises to blockdiag(L, I).
-__global__ void assemble_K_kernel(const double* __restrict__ Xs, double* __restrict__ A, int64_t N,
-                                  int64_t Npad, int dp, int kind, double variance, double noise, int64_t row0) {
-  const int64_t j = (int64_t)blockIdx.x * 16 + (threadIdx.x & 15);
-  const int64_t i = row0 + (int64_t)blockIdx.y * 16 + (threadIdx.x >> 4);  // rows [row0, Npad) only
-  if (i >= Npad || j >= Npad) return;
-  double v;
-  if (i < N && j < N) {
-    double r2 = 0.0;
-    for (int c = 0; c < dp; ++c) {
-      const double t = Xs[i * dp + c] - Xs[j * dp + c];
-      r2 = fma(t, t, r2);
+// padded matrix stays SPD and factorises to blockdiag(L, I).  Only the 64 x 64 tiles on and below the
+// diagonal are written: nothing downstream reads the upper triangle (the leaf mirrors its diagonal tiles
+// inside LDS, the node products read A21 / the lower tiles of A22).  One workgroup per tile: lane -> column
+// (coalesced stores, x_j in registers), wave -> 16 rows (wave-uniform: x_i through scalar loads); the same
+// branch-free kernel_from_r2<KIND> as the sweep, so K and K* are the same function bit for bit.
+template <int KIND, int DP>
+__global__ __launch_bounds__(256) void assemble_K_kernel(const double* __restrict__ Xs, double* __restrict__ A,
+                                                         int64_t N, int64_t Npad, double variance, double noise,
+                                                         int64_t row0) {
+  const int64_t tj = blockIdx.x, ti = row0 / 64 + blockIdx.y;
+  if (tj > ti) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t j = tj * 64 + lane;
+  double xj[DP];
+#pragma unroll
+  for (int c = 0; c < DP; ++c) xj[c] = Xs[j * DP + c];
+  const cptr xs = as_const(Xs);
+#pragma unroll 4
+  for (int r = 0; r < 16; ++r) {
+    const int64_t i = ti * 64 + w * 16 + r;
+    double v;
+    if (i < N && j < N) {
+      double r2 = 0.0;
+#pragma unroll
+      for (int c = 0; c < DP; ++c) {
+        const double t = xs[i * DP + c] - xj[c];
+        r2 = fma(t, t, r2);
+      }
+      v = kernel_from_r2<KIND>(r2, variance);
+      if (i == j) v += noise;
+    } else {
+      v = (i == j) ? 1.0 : 0.0;
     }
-    v = kernel_rt(kind, r2, variance);
-    if (i == j) v += noise;
-  } else {
-    v = (i == j) ? 1.0 : 0.0;
+    A[i * Npad + j] = v;
   }
-  A[i * Npad + j] = v;
+}
+
+template <int KIND>
+static void launch_assemble_K_dp(hipStream_t s, const double* Xs, double* A, int64_t N, int64_t Npad, int dp,
+                                 double variance, double noise, int64_t row0) {
+  // A is addressed with GLOBAL row indices: for row0 > 0 the caller passes (scratch - row0 * Npad)
+  dim3 g((unsigned)(Npad / 64), (unsigned)((Npad - row0) / 64)), b(256);
+  switch (dp) {
+    case 2: hipLaunchKernelGGL((assemble_K_kernel<KIND, 2>), g, b, 0, s, Xs, A, N, Npad, variance, noise, row0); break;
+    case 4: hipLaunchKernelGGL((assemble_K_kernel<KIND, 4>), g, b, 0, s, Xs, A, N, Npad, variance, noise, row0); break;
+    case 6: hipLaunchKernelGGL((assemble_K_kernel<KIND, 6>), g, b, 0, s, Xs, A, N, Npad, variance, noise, row0); break;
+    case 8: hipLaunchKernelGGL((assemble_K_kernel<KIND, 8>), g, b, 0, s, Xs, A, N, Npad, variance, noise, row0); break;
+    case 16: hipLaunchKernelGGL((assemble_K_kernel<KIND, 16>), g, b, 0, s, Xs, A, N, Npad, variance, noise, row0); break;
+    default: hipLaunchKernelGGL((assemble_K_kernel<KIND, 32>), g, b, 0, s, Xs, A, N, Npad, variance, noise, row0); break;
+  }
 }
 
 void launch_assemble_K(hipStream_t s, const double* Xs, double* A, int64_t N, int64_t Npad, int dp,
                        int kind, double variance, double noise, int64_t row0) {
-  // A is addressed with GLOBAL row indices: for row0 > 0 the caller passes (scratch - row0 * Npad)
-  dim3 grid((unsigned)(Npad / 16), (unsigned)((Npad - row0) / 16));
-  hipLaunchKernelGGL(assemble_K_kernel, grid, dim3(256), 0, s, Xs, A, N, Npad, dp, kind, variance,
-                     noise, row0);
+  switch (kind) {
+    case KIND_RBF: launch_assemble_K_dp<KIND_RBF>(s, Xs, A, N, Npad, dp, variance, noise, row0); break;
+    case KIND_M12: launch_assemble_K_dp<KIND_M12>(s, Xs, A, N, Npad, dp, variance, noise, row0); break;
+    case KIND_M32: launch_assemble_K_dp<KIND_M32>(s, Xs, A, N, Npad, dp, variance, noise, row0); break;
+    default: launch_assemble_K_dp<KIND_M52>(s, Xs, A, N, Npad, dp, variance, noise, row0); break;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
