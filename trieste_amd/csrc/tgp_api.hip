@@ -310,11 +310,19 @@ void chol_inv(hipStream_t st, const FactorWs& f, int64_t lo, int64_t hi) {
   double* W11 = W + lo * ld + lo;
   double* A22 = A + mid * ld + mid;
   launch_gemm(st, true, s2, s1, s1, 1.0, A21, ld, W11, ld, 0.0, L21, ld, false, 1);
-  launch_gemm(st, true, s2, s2, s1, -1.0, L21, ld, L21, ld, 1.0, A22, ld, true);
+  // A22 -= L21 L21^T and T = L21 W11 (into the dead A21) are independent: below the big-tile sizes they
+  // share one launch instead of queueing behind each other
+  static const bool pair = getenv("TGP_NO_PAIR") == nullptr;  // A/B aid
+  const bool fused = pair && (int64_t)(s2 / 64) * (s1 / 64) < 512 && (int64_t)(s2 / 64) * (s2 / 64) < 512;
+  if (fused) {
+    launch_node_pair(st, s2, s1, L21, A22, W11, A21, ld);
+  } else {
+    launch_gemm(st, true, s2, s2, s1, -1.0, L21, ld, L21, ld, 1.0, A22, ld, true);
+  }
   chol_inv(st, f, mid, hi);
   double* W22 = W + mid * ld + mid;
   double* W21 = W + mid * ld + lo;
-  launch_gemm(st, false, s2, s1, s1, 1.0, L21, ld, W11, ld, 0.0, A21, ld, false, 2);
+  if (!fused) launch_gemm(st, false, s2, s1, s1, 1.0, L21, ld, W11, ld, 0.0, A21, ld, false, 2);
   launch_gemm(st, false, s2, s1, s2, -1.0, W22, ld, A21, ld, 0.0, W21, ld, false, 3);
 }
 

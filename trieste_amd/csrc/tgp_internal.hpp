@@ -72,6 +72,8 @@ void launch_leaf(hipStream_t s, const double* A, double* L, double* W, int64_t l
 void launch_gemm(hipStream_t s, bool tb, int m, int n, int k, double alpha, const double* A, int64_t lda,
                  const double* B, int64_t ldb, double beta, double* C, int64_t ldc, bool lower_only, int tri = 0,
                  int small_tiles = 0);
+void launch_node_pair(hipStream_t s, int s2, int s1, const double* L21, double* A22, const double* W11, double* T,
+                      int64_t ld);
 void launch_gemm_ksplit(hipStream_t s, bool tb, int m, int n, int k, double alpha, const double* A, int64_t lda,
                         const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int tri, int nz,
                         double* scratch);

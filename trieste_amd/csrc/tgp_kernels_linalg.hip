@@ -341,8 +341,9 @@ constexpr int GB = 64, GLD = GB + 16;
 //   tri 1 (k < (tn+1) T): column-major, last column first;   tri 2 (k >= tn T): column-major, first column first;
 //   tri 3 (k < (tm+1) T): row-major, last row first;          tri 5 (k >= tm T): row-major, first row first;
 //   tri 4 (k >= max(tm, tn) T) and unpruned: row-major with the column rotated by the row.
-__device__ __forceinline__ void tile_of_block(int lower_only, int tri, int nt_m, int nt_n, int& tm, int& tn) {
-  const int id = blockIdx.x;
+__device__ __forceinline__ void tile_of_block(int lower_only, int tri, int nt_m, int nt_n, int& tm, int& tn,
+                                              int id = -1) {
+  if (id < 0) id = blockIdx.x;
   if (lower_only) {
     int r = (int)((sqrt(8.0 * id + 1.0) - 1.0) * 0.5);
     while ((r + 1) * (r + 2) / 2 <= id) ++r;
@@ -380,17 +381,14 @@ __device__ __forceinline__ void tile_of_block(int lower_only, int tri, int nt_m,
 // group, so the reads stay conflict-free.
 //
 // gridDim.y > 1: k-split -- slice blockIdx.y of the (pruned) k range, partial result to C + slice * m * ldc.
+constexpr int GKT = 32;
 template <bool TB>
-__global__ __launch_bounds__(512) void gemm_kernel8(int m, int n, int k, double alpha,
-                                                    const double* __restrict__ A, int64_t lda,
-                                                    const double* __restrict__ B, int64_t ldb,
-                                                    double beta, double* __restrict__ C, int64_t ldc,
-                                                    int lower_only, int tri) {
-  constexpr int GKT = 32;
+__device__ __forceinline__ void gemm8_body(int m, int n, int k, double alpha, const double* __restrict__ A,
+                                           int64_t lda, const double* __restrict__ B, int64_t ldb, double beta,
+                                           double* __restrict__ C, int64_t ldc, int lower_only, int tri,
+                                           int block_id, double (*As)[GLD], double (*Bs)[GLD]) {
   int tm, tn;
-  tile_of_block(lower_only, tri, m / GB, n / GB, tm, tn);
-  __shared__ double As[GKT][GLD];
-  __shared__ double Bs[GKT][GLD];
+  tile_of_block(lower_only, tri, m / GB, n / GB, tm, tn, block_id);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = w >> 2, wn = w & 3;
   v4d acc[2];
@@ -454,6 +452,53 @@ __global__ __launch_bounds__(512) void gemm_kernel8(int m, int n, int k, double 
       const double v = alpha * acc[f][r];
       *dst = (beta == 0.0) ? v : fma(beta, *dst, v);
     }
+}
+
+template <bool TB>
+__global__ __launch_bounds__(512) void gemm_kernel8(int m, int n, int k, double alpha,
+                                                    const double* __restrict__ A, int64_t lda,
+                                                    const double* __restrict__ B, int64_t ldb,
+                                                    double beta, double* __restrict__ C, int64_t ldc,
+                                                    int lower_only, int tri) {
+  __shared__ double As[GKT][GLD];
+  __shared__ double Bs[GKT][GLD];
+  gemm8_body<TB>(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lower_only, tri, (int)blockIdx.x, As, Bs);
+}
+
+// Two INDEPENDENT products of a recursion node in one launch: A22 -= L21 L21^T (lower tiles) and
+// T = L21 W11 both need only L21; as two dependent launches the second waited for the first although each is
+// a latency-bound chain on a handful of CUs.  Workgroups [0, nt1) run the first problem, the rest the second.
+struct Gemm8Args {
+  int m, n, k;
+  double alpha;
+  const double* A;
+  int64_t lda;
+  const double* B;
+  int64_t ldb;
+  double beta;
+  double* C;
+  int64_t ldc;
+  int lower_only, tri;
+};
+__global__ __launch_bounds__(512) void gemm_dual_kernel(Gemm8Args p1 /* A B^T */, int nt1, Gemm8Args p2 /* A B */) {
+  __shared__ double As[GKT][GLD];
+  __shared__ double Bs[GKT][GLD];
+  if ((int)blockIdx.x < nt1)
+    gemm8_body<true>(p1.m, p1.n, p1.k, p1.alpha, p1.A, p1.lda, p1.B, p1.ldb, p1.beta, p1.C, p1.ldc, p1.lower_only,
+                     p1.tri, (int)blockIdx.x, As, Bs);
+  else
+    gemm8_body<false>(p2.m, p2.n, p2.k, p2.alpha, p2.A, p2.lda, p2.B, p2.ldb, p2.beta, p2.C, p2.ldc, p2.lower_only,
+                      p2.tri, (int)blockIdx.x - nt1, As, Bs);
+}
+
+// node step 2 + 3:  A22 -= L21 L21^T (lower)  and  T = L21 W11 (W11 lower triangular: tri 2)
+void launch_node_pair(hipStream_t s, int s2, int s1, const double* L21, double* A22, const double* W11, double* T,
+                      int64_t ld) {
+  Gemm8Args p1{s2, s2, s1, -1.0, L21, ld, L21, ld, 1.0, A22, ld, 1, 0};
+  Gemm8Args p2{s2, s1, s1, 1.0, L21, ld, W11, ld, 0.0, T, ld, 0, 2};
+  const int t2 = s2 / GB, t1 = s1 / GB;
+  const int nt1 = t2 * (t2 + 1) / 2, nt2 = t2 * t1;
+  hipLaunchKernelGGL(gemm_dual_kernel, dim3((unsigned)(nt1 + nt2)), dim3(512), 0, s, p1, nt1, p2);
 }
 
 // Large-grid variant: 128 x 128 tile, 8 waves (2 x 4), wave tile 64 x 32 (the sweep kernel's wave tile:
