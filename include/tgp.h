@@ -98,6 +98,32 @@ int tgp_set_data(tgp_handle h, const double* X, const double* Y, int64_t N, int 
  * size (N rounded up to 256) changes, the call refactorises everything. */
 int tgp_append_data(tgp_handle h, const double* Xnew, const double* Ynew, int64_t k, int where);
 
+/* Make `dst` (same device, input dimension and kernel family) a copy of `src`: hyper-parameters, data and
+ * the cached factorisation (device-to-device copies: 3 Npad^2 doubles, ~0.2 ms at N = 4096).  Together with
+ * tgp_append_data this is the engine's form of the reference's fantasised model (_fantasized_model,
+ * acquisition/function/greedy_batch.py:630-773, built on FastUpdateModel.conditional_predict_f/_joint/_y,
+ * models/gpflow/models.py:355-526): instead of re-deriving the conditional posterior of every query batch from
+ * the base model, a clone conditioned on the pending points IS an exact GPR on (data + fantasised data) and
+ * every sweep on it runs at full speed.  `src` is not modified. */
+int tgp_clone_from(tgp_handle dst, tgp_handle src);
+
+/* Local penalization for greedy batches (LocalPenalization / PenalizedAcquisition, greedy_batch.py:54-269):
+ * while set, every tgp_acq_values / tgp_acq_argmax / tgp_acq_topk / tgp_acq_value_grad result is
+ * acquisition(x) * prod_p phi_p(x) over the P pending points, with dist_p = |x - pending_p|_2:
+ *   kind 1 (soft_local_penalizer.__call__, greedy_batch.py:341-354): phi_p = Phi((dist_p - radius_p) / scale_p)
+ *   kind 2 (hard_local_penalizer.__call__, greedy_batch.py:376-389): phi_p = ((dist_p / (radius_p + scale_p))^-5 + 1)^(-1/5)
+ *   kind 0 or P == 0: clears it.
+ * pending host [P,d], radius / scale host [P] (local_penalizer.__init__, greedy_batch.py:287-300:
+ * radius = (mean(pending) - eta) / L, scale = sqrt(var(pending)) / L), P <= 1024.  The gradient is the
+ * analytic one of the product (the reference differentiates exp(log a + log phi) by autodiff); at dist_p = 0
+ * that pending point contributes no gradient. */
+int tgp_set_penalization(tgp_handle h, int kind, const double* pending, const double* radius, const double* scale,
+                         int64_t P);
+
+/* The penalization alone, prod_p phi_p(x) at Xq [M,d] -> out [M] (the penalizer objects are callables in the
+ * reference: local_penalizer.__call__, greedy_batch.py:341-354, 376-389).  TGP_ERR_STATE if none is set. */
+int tgp_penalization_values(tgp_handle h, const double* Xq, int64_t M, double* out, int where);
+
 int tgp_get_sizes(tgp_handle h, int64_t* N, int* d);
 /* Negative log marginal likelihood of the current (hyper-parameters, data) and its gradient:
  * value (host scalar); grad (host [d + 3]; NULL = value only, which skips the K^-1 product and the

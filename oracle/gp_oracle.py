@@ -381,6 +381,90 @@ def conditional_predict_f(state: GPRState, Xq: np.ndarray, X_add: np.ndarray, Y_
 
 
 # --------------------------------------------------------------------------------------
+# Greedy batches on the same posterior (acquisition/function/greedy_batch.py)
+# --------------------------------------------------------------------------------------
+def lipschitz_estimate(state: GPRState, points: np.ndarray) -> Tuple[float, float]:
+    """LocalPenalization._get_lipschitz_estimate (greedy_batch.py:206-217): (max_i |d mean / d x_i|_2,
+    min_i mean(x_i)) over the sampled points; the gradient (autodiff there) in analytic form."""
+    val, g = acq_value_and_grad(state, "nlcb", 0.0, points)  # -(mean - 0 * sd) = -mean
+    return float(np.max(np.linalg.norm(g, axis=1))), float(np.min(-val))
+
+
+def local_penalizer_parameters(state: GPRState, pending: np.ndarray, lipschitz: float, eta: float):
+    """local_penalizer.__init__ (greedy_batch.py:287-300): radius = (mean(pending) - eta) / L,
+    scale = sqrt(var(pending)) / L (predict's clipped variance)."""
+    mean, var = predict(state, pending)
+    return (mean - eta) / lipschitz, np.sqrt(var) / lipschitz
+
+
+def _pairwise_distances(x: np.ndarray, pending: np.ndarray) -> np.ndarray:
+    x, pending = np.asarray(x, dtype=np.float64), np.asarray(pending, dtype=np.float64)
+    return np.linalg.norm(x[:, None, :] - pending[None, :, :], axis=-1)  # [M, P]
+
+
+def soft_local_penalizer(x, pending, radius, scale) -> np.ndarray:
+    """soft_local_penalizer.__call__ (greedy_batch.py:341-354): prod_p Phi((|x - x_p| - r_p) / s_p); x [M, d]."""
+    z = (_pairwise_distances(x, pending) - np.asarray(radius)[None, :]) / np.asarray(scale)[None, :]
+    return np.prod(normal_cdf(z), axis=-1)
+
+
+def hard_local_penalizer(x, pending, radius, scale) -> np.ndarray:
+    """hard_local_penalizer.__call__ (greedy_batch.py:376-389): prod_p ((|x - x_p| / (r_p + s_p))^p + 1)^(1/p),
+    p = -5."""
+    p = -5.0
+    with np.errstate(divide="ignore"):
+        pen = ((_pairwise_distances(x, pending) / (np.asarray(radius) + np.asarray(scale))[None, :]) ** p + 1.0) ** (1.0 / p)
+    return np.prod(pen, axis=-1)
+
+
+PENALIZERS = {"soft": soft_local_penalizer, "hard": hard_local_penalizer}
+
+
+def penalized_acquisition(base_values: np.ndarray, penalization: np.ndarray) -> np.ndarray:
+    """PenalizedAcquisition.__call__ (greedy_batch.py:265-269): exp(log a + log phi)."""
+    with np.errstate(divide="ignore"):
+        return np.exp(np.log(base_values) + np.log(penalization))
+
+
+def penalized_value_and_grad(state: GPRState, acq: str, param: float, kind: str, pending, radius, scale, Xq):
+    """Value [P'] and gradient [P', d] of a(x) prod_p phi_p(x) -- what autodiff through PenalizedAcquisition gives
+    the L-BFGS-B refinement -- analytically: phi a' + a sum_p phi_p' prod_{q != p} phi_q, with
+    d Phi(z_p) / dx = pdf(z_p) / s_p * (x - x_p) / dist_p (soft) and
+    d ((u^-5 + 1)^(-1/5)) / dx = u^-6 (u^-5 + 1)^(-6/5) / (r_p + s_p) * (x - x_p) / dist_p (hard, u = dist_p / (r_p + s_p))."""
+    Xq = np.asarray(Xq, dtype=np.float64)
+    pending = np.asarray(pending, dtype=np.float64)
+    radius, scale = np.asarray(radius, dtype=np.float64), np.asarray(scale, dtype=np.float64)
+    a, da = acq_value_and_grad(state, acq, param, Xq)
+    diff = Xq[:, None, :] - pending[None, :, :]             # [P', P, d]
+    dist = np.linalg.norm(diff, axis=-1)                      # [P', P]
+    if kind == "soft":
+        z = (dist - radius) / scale
+        phi = normal_cdf(z)
+        slope = normal_pdf(z) / scale
+    else:
+        u = dist / (radius + scale)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            phi = (u ** -5.0 + 1.0) ** -0.2
+            slope = u ** -6.0 * (u ** -5.0 + 1.0) ** -1.2 / (radius + scale)
+    P = pending.shape[0]
+    others = np.stack([np.prod(np.delete(phi, p, axis=1), axis=1) for p in range(P)], axis=1)  # [P', P]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        w = np.where(dist > 0.0, slope * others / dist, 0.0)
+    dphi = np.einsum("mp,mpd->md", w, diff)
+    prod = np.prod(phi, axis=1)
+    return a * prod, prod[:, None] * da + a[:, None] * dphi
+
+
+def fantasized_state(state: GPRState, X_add: np.ndarray, Y_add: np.ndarray) -> GPRState:
+    """The posterior _fantasized_model represents (greedy_batch.py:630-773: the base model's
+    conditional_predict_* with the fantasised data): for an exact GPR with Gaussian noise this IS the GPR on
+    (data + fantasised data) with the same hyper-parameters."""
+    X = np.concatenate([state.X, np.asarray(X_add, dtype=np.float64)], axis=0)
+    Y = np.concatenate([state.Y, np.asarray(Y_add, dtype=np.float64).reshape(-1)])
+    return gpr_update(state.kind, state.variance, state.lengthscales, state.noise, state.mean_const, X, Y)
+
+
+# --------------------------------------------------------------------------------------
 # A.6 decoupled trajectories (sampler.py:661-738, 801-806, 841-855, 901-936;
 # gpflux RandomFourierFeaturesCosine, gpflux.math.compute_A_inv_b); draws passed in.
 # --------------------------------------------------------------------------------------

@@ -189,7 +189,43 @@ def make_case(name, kind, d, N, variance, ls, noise, mean_const, seed, M=6, q=3,
                          + sum(ks[i] * vmat[bb][i] for i in range(N)) + mpf(mean_const))
                      for bb in range(B)])
 
+    # greedy batches (acquisition/function/greedy_batch.py): local penalizers around the q points of group 1
+    # with given radius / scale (soft :341-354, hard :376-389), and the posterior conditioned additionally on
+    # fantasised observations there (what _fantasized_model predicts, :630-773) = a refit on N + q points
+    pend = [Xg[1, a] for a in range(q)]
+    pen_r = rng.uniform(0.05, 0.4, size=q)
+    pen_s = rng.uniform(0.05, 0.3, size=q)
+    yf = rng.normal(size=q)
+    pen_soft, pen_hard = [], []
+    for x in Xq:
+        ps, ph_ = mp.mpf(1), mp.mpf(1)
+        for a in range(q):
+            dist = mp.sqrt(sum((mpf(x[k]) - mpf(pend[a][k])) ** 2 for k in range(d)))
+            ps *= mp.ncdf((dist - mpf(pen_r[a])) / mpf(pen_s[a]))
+            u = dist / (mpf(pen_r[a]) + mpf(pen_s[a]))
+            ph_ *= (u ** -5 + 1) ** (mp.mpf(-1) / 5) if dist > 0 else mp.mpf(0)
+        pen_soft.append(f64(ps))
+        pen_hard.append(f64(ph_))
+    Xf = [X[i] for i in range(N)] + pend
+    Nf = N + q
+    Kf = mp.zeros(Nf, Nf)
+    for i in range(Nf):
+        for j in range(Nf):
+            Kf[i, j] = kern(kind, variance, ls, Xf[i], Xf[j])
+        Kf[i, i] += mpf(noise)
+    Lf = chol(Kf)
+    errf = err + [mpf(yf[a]) - mpf(mean_const) for a in range(q)]
+    alphaf = bsub(Lf, fsub(Lf, errf))
+    fant_mean, fant_var = [], []
+    for x in Xq:
+        ks = [kern(kind, variance, ls, Xf[i], x) for i in range(Nf)]
+        A_ = fsub(Lf, ks)
+        fant_mean.append(f64(sum(ks[i] * alphaf[i] for i in range(Nf)) + mpf(mean_const)))
+        fant_var.append(f64(kern(kind, variance, ls, x, x) - sum(a_ * a_ for a_ in A_)))
+
     return {
+        "pen_radius": pen_r.tolist(), "pen_scale": pen_s.tolist(), "pen_soft": pen_soft, "pen_hard": pen_hard,
+        "fant_y": yf.tolist(), "fant_mean": fant_mean, "fant_var_raw": fant_var,
         "name": name, "kind": kind, "d": d, "N": N, "variance": variance, "lengthscales": ls,
         "noise": noise, "mean_const": mean_const,
         "X": X.tolist(), "Y": Y.tolist(), "Xq": Xq.tolist(),

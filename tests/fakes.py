@@ -72,6 +72,7 @@ class FakeEngine:
 
     created = 0
     appended = 0
+    cloned = 0
 
     def __init__(self, d, kernel="matern52", device=0):
         if kernel not in O.KERNEL_KINDS:
@@ -79,6 +80,7 @@ class FakeEngine:
         self.d, self.kernel, self.device, self.N = int(d), kernel, device, 0
         self._hyper = None
         self.state = None
+        self._pen = None
         FakeEngine.created += 1
 
     def close(self):
@@ -92,6 +94,53 @@ class FakeEngine:
 
     def set_variant(self, v):
         pass
+
+    def clone_from(self, other):
+        if not isinstance(other, FakeEngine):
+            raise TypeError(f"can only clone from an engine, got {other!r}")
+        if other.d != self.d or other.kernel != self.kernel:
+            raise ValueError("clone needs equal input dimension and kernel")
+        self._hyper, self.state, self.N = other._hyper, other.state, other.N
+        FakeEngine.cloned += 1
+
+    def clone(self):
+        twin = FakeEngine(self.d, self.kernel, self.device)
+        twin.clone_from(self)
+        return twin
+
+    def set_penalization(self, kind, pending=None, radius=None, scale=None):
+        if kind not in ("none", "soft", "hard"):
+            raise ValueError(f"unknown penalizer {kind!r}")
+        if kind == "none" or pending is None or len(pending) == 0:
+            self._pen = None
+            return
+        pts = np.asarray(pending, float)
+        if pts.ndim != 2 or pts.shape[1] != self.d:
+            raise ValueError(f"pending points must be [P, {self.d}], got {pts.shape}")
+        r, sc = np.asarray(radius, float).reshape(-1), np.asarray(scale, float).reshape(-1)
+        if r.shape[0] != pts.shape[0] or sc.shape[0] != pts.shape[0]:
+            raise ValueError("radius and scale must hold P values")
+        self._pen = (kind, pts, r, sc)
+
+    def penalized(self, kind, pending, radius, scale):
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            self.set_penalization(kind, pending, radius, scale)
+            try:
+                yield self
+            finally:
+                self.set_penalization("none")
+
+        return scope()
+
+    def penalization_values(self, Xq):
+        if self._pen is None:
+            raise RuntimeError("no penalization set: call tgp_set_penalization first")
+        Xq = np.asarray(Xq, float)
+        kind, pts, r, sc = self._pen
+        return O.PENALIZERS[kind](Xq.reshape(-1, self.d), pts, r, sc).reshape(Xq.shape[:-1])
 
     def set_hyper(self, variance, lengthscales, noise_variance, mean_const=0.0):
         if not (variance > 0 and noise_variance > 0):
@@ -166,16 +215,23 @@ class FakeEngine:
     def acq_values(self, acq, param, Xq):
         m, v = self.predict(Xq)
         if acq == "ei":
-            return O.expected_improvement(m, v, param)
-        if acq == "pi":
-            return O.probability_of_improvement(m, v, param)
-        if acq == "nlcb":
-            return O.negative_lower_confidence_bound(m, v, param)
-        if acq == "aei":
-            return O.augmented_expected_improvement(m, v, param, self.state.noise)
-        raise KeyError(acq)
+            vals = O.expected_improvement(m, v, param)
+        elif acq == "pi":
+            vals = O.probability_of_improvement(m, v, param)
+        elif acq == "nlcb":
+            vals = O.negative_lower_confidence_bound(m, v, param)
+        elif acq == "aei":
+            vals = O.augmented_expected_improvement(m, v, param, self.state.noise)
+        else:
+            raise KeyError(acq)
+        if self._pen is not None:
+            vals = vals * self.penalization_values(Xq)
+        return vals
 
     def acq_value_grad(self, acq, param, Xq):
+        if self._pen is not None:
+            kind, pts, r, sc = self._pen
+            return O.penalized_value_and_grad(self._st(), acq, param, kind, pts, r, sc, np.asarray(Xq, float))
         return O.acq_value_and_grad(self._st(), acq, param, np.asarray(Xq, float))
 
     def acq_argmax(self, acq, param, Xq, index_base=0):

@@ -228,3 +228,79 @@ def test_fantasising_surfaces_on_gpu_equal_refit():
     rm, rv = refit.predict(xq)
     assert_close(m, rm, atol=1e-8, what="conditional == refit mean")
     assert_close(v, rv, atol=1e-9, what="conditional == refit var")
+
+
+@pytest.mark.parametrize("penalizer", ["soft", "hard"])
+def test_local_penalization_batches_on_gpu(penalizer):
+    """EGO + LocalPenalization (rule.py:384-397, greedy_batch.py:54-247) on the real engine: every batch element
+    is the maximiser of the penalised EI the oracle computes from the builder's own constants."""
+    import trieste_amd.acquisition as A
+
+    space, data, model, st = _setup(n=60, noise=1e-2)
+    pen_cls = A.soft_local_penalizer if penalizer == "soft" else A.hard_local_penalizer
+    builder = A.LocalPenalization(space, num_samples=300, penalizer=pen_cls)
+    rule = A.EfficientGlobalOptimization(builder, optimizer=A.generate_random_search_optimizer(20000, seed=4),
+                                         num_query_points=4)
+    pts = rule.acquire_single(space, model, data)
+    assert pts.shape == (4, 2)
+    lip, eta = builder._lipschitz_constant, builder._eta
+    olip, oeta = O.lipschitz_estimate(st, data.query_points)
+    assert lip >= olip * (1 - 1e-6) and eta <= oeta + 1e-9
+    cand = np.asarray(space.sample_device(model.engine, 20000, seed=4).cpu())
+    om, ov = O.predict(st, cand)
+    base = O.expected_improvement(om, ov, eta)
+    for j in range(4):
+        vals = base
+        if j:
+            r, s = O.local_penalizer_parameters(st, pts[:j], lip, eta)
+            vals = base * O.PENALIZERS[penalizer](cand, pts[:j], r, s)
+        best = cand[int(np.argmax(vals))]
+        got = float(vals[np.argmin(np.linalg.norm(cand - pts[j], axis=1))])
+        assert_close(got, vals.max(), rtol=1e-6, atol=1e-12, what=f"batch element {j} maximises the penalised EI")
+        if got == vals.max():
+            np.testing.assert_allclose(pts[j], best, atol=1e-12)
+    # continuous optimizer on the penalised function: gradient path
+    rule2 = A.EfficientGlobalOptimization(A.LocalPenalization(space, num_samples=300, penalizer=pen_cls),
+                                          num_query_points=3)
+    pts2 = rule2.acquire_single(space, model, data)
+    assert pts2.shape == (3, 2) and np.all((pts2 >= 0) & (pts2 <= 1))
+    dist = np.linalg.norm(pts2[:, None, :] - pts2[None, :, :], axis=-1) + np.eye(3)
+    assert dist.min() > 1e-3
+
+
+@pytest.mark.parametrize("method", ["KB", "sample"])
+def test_fantasizer_batches_on_gpu(method):
+    """EGO + Fantasizer (greedy_batch.py:415-585) on the real engine: the fantasized model is a clone with appended
+    rows and equals the reference's conditional posterior (oracle restatement)."""
+    import trieste_amd.acquisition as A
+    from trieste_amd.data import OBJECTIVE
+
+    space, data, model, st = _setup(n=60, noise=1e-2)
+    builder = A.Fantasizer(fantasize_method=method)
+    rule = A.EfficientGlobalOptimization(builder, optimizer=A.generate_random_search_optimizer(20000, seed=4),
+                                         num_query_points=3)
+    pts = rule.acquire_single(space, model, data)
+    assert pts.shape == (3, 2)
+    fm = builder._fantasized_models[OBJECTIVE]
+    assert fm.engine.N == 62 and model.engine.N == 60
+    fx, fy = fm.get_internal_data().astuple()
+    np.testing.assert_array_equal(fx[60:], pts[:2])
+    xs = np.random.default_rng(2).uniform(size=(300, 2))
+    m, v = fm.predict(xs)
+    om, ov = O.conditional_predict_f(st, xs, fx[60:], fy[60:, 0])
+    assert_close(m[:, 0], om, atol=1e-8, what="fantasized mean == conditional_predict_f")
+    assert_close(v[:, 0], np.maximum(ov, 1e-12), atol=1e-9, what="fantasized var == conditional_predict_f")
+    if method == "KB":
+        assert_close(fy[60:, 0], O.predict(st, pts[:2])[0], atol=1e-9, what="believer observations")
+        # the third point maximises EI of the fantasized posterior over the same candidates
+        cand = np.asarray(space.sample_device(model.engine, 20000, seed=4).cpu())
+        sto = O.fantasized_state(st, fx[60:], fy[60:, 0])
+        fmean, fvar = O.predict(sto, cand)
+        vals = O.expected_improvement(fmean, fvar, O.eta_min_mean(sto))
+        got = float(vals[np.argmin(np.linalg.norm(cand - pts[2], axis=1))])
+        assert_close(got, vals.max(), rtol=1e-5, atol=1e-12, what="third element maximises fantasized EI")
+    if method == "KB":  # EI at a believed point is ~0; a posterior *sample* there may well invite a repeat
+        dist = np.linalg.norm(pts[:, None, :] - pts[None, :, :], axis=-1) + np.eye(3)
+        assert dist.min() > 1e-4
+    pts2 = rule.acquire_single(space, model, data)  # next BO step reuses the objects
+    assert pts2.shape == (3, 2)

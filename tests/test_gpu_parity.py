@@ -516,3 +516,126 @@ def test_destruction_order_and_sticky_errors_do_not_leak_into_later_calls():
         v, i = other.acq_topk("ei", other.eta(), Xq, 5)  # would report a stale "invalid device ordinal"
         assert len(i) == 5
         other.close()
+
+
+@pytest.mark.parametrize("c", [c for c in CASES if c["noise"] >= 1e-3],
+                         ids=[c["name"] for c in CASES if c["noise"] >= 1e-3])
+def test_greedy_batch_pieces_match_mpmath_goldens(c):
+    """tgp_set_penalization / tgp_penalization_values and tgp_clone_from + tgp_append_data (the engine's
+    fantasized model) against the 50-digit vectors."""
+    N, var0, noise = c["N"], c["variance"], c["noise"]
+    floor = cancellation_floor(N + 3, var0, noise)
+    X, Y = np.array(c["X"]), np.array(c["Y"])
+    eng = _engine(c["kind"], c["d"], var0, c["lengthscales"], noise, c["mean_const"], X, Y)
+    Xq, pend = np.array(c["Xq"]), np.array(c["Xg"])[1]
+    r, sc = np.array(c["pen_radius"]), np.array(c["pen_scale"])
+    for kind in ("soft", "hard"):
+        with eng.penalized(kind, pend, r, sc):
+            assert_close(eng.penalization_values(Xq), c["pen_" + kind], rtol=1e-12, atol=1e-300, what=kind)
+            pei = eng.acq_values("ei", c["eta"], Xq)
+        assert_close(pei, np.array(c["ei"]) * np.array(c["pen_" + kind]), atol=floor, what=f"{kind}-penalized ei")
+    assert_close(eng.acq_values("ei", c["eta"], Xq), c["ei"], atol=floor, what="penalization cleared")
+    twin = eng.clone()
+    twin.append_data(pend, np.array(c["fant_y"]))
+    fm, fv = twin.predict(Xq)
+    assert_close(fm, c["fant_mean"], atol=floor * 10 / min(noise, 1.0) ** 0.5, what="fantasized mean")
+    assert_close(fv, np.maximum(np.array(c["fant_var_raw"]), 1e-12), atol=floor, what="fantasized var")
+    mean, var = eng.predict(Xq)  # the source is untouched
+    assert_close(mean, c["mean"], atol=floor * 10, what="base mean after clone")
+    assert_close(var, c["var"], atol=floor, what="base var after clone")
+    assert eng.N == N and twin.N == N + pend.shape[0]
+
+
+@pytest.mark.parametrize("kind", ["soft", "hard"])
+@pytest.mark.parametrize("cfg", CONFIGS[:5], ids=[c[0] for c in CONFIGS[:5]])
+def test_penalized_sweeps_match_oracle(cfg, kind):
+    """Local penalization on every sweep entry point: values, fused arg-max (routed through the value array),
+    top-k, value-and-gradient (greedy_batch.py:250-389), with the LocalPenalization parameter recipe."""
+    _, obj, d, kname, N, noise = cfg
+    X, Y, ls, c, st, Xq = _problem(obj, d, kname, N, noise, M=3000)
+    floor = cancellation_floor(N, 1.0, noise)
+    eng = _engine(kname, d, 1.0, ls, noise, c, X, Y)
+    rng = np.random.default_rng(11)
+    pending = np.concatenate([rng.uniform(size=(4, d)), Xq[7:8]])  # one pending point IS a candidate
+    lip, eta = O.lipschitz_estimate(st, np.concatenate([X, rng.uniform(size=(100, d))]))
+    nm, ng = eng.acq_value_grad("nlcb", 0.0, np.concatenate([X, Xq[:50]]))  # the engine's own estimate inputs
+    om, og = O.acq_value_and_grad(st, "nlcb", 0.0, np.concatenate([X, Xq[:50]]))
+    assert_close(np.linalg.norm(ng, axis=1).max(), np.linalg.norm(og, axis=1).max(), rtol=1e-6, what="lipschitz")
+    radius, scale = O.local_penalizer_parameters(st, pending, lip, eta)
+    base = eng.acq_values("ei", eta, Xq)
+    open_ = O.PENALIZERS[kind](Xq, pending, radius, scale)
+    with eng.penalized(kind, pending, radius, scale):
+        assert_close(eng.penalization_values(Xq), open_, rtol=1e-11, atol=1e-300, what="penalization")
+        vals = eng.acq_values("ei", eta, Xq)
+        val, idx, x = eng.acq_argmax("ei", eta, Xq, index_base=1000)
+        tv, ti = eng.acq_topk("ei", eta, Xq, 9)
+        gv, gg = eng.acq_value_grad("ei", eta, Xq[:64])
+    assert_close(vals, base * open_, rtol=1e-11, atol=1e-300, what="penalized = base * phi")
+    assert vals[7] <= base[7] * 0.5 + 1e-300  # at a pending point: Phi(-r/s) <= 1/2 (soft), 0 (hard)
+    assert idx - 1000 == int(np.argmax(vals)) and val == vals[idx - 1000]
+    np.testing.assert_array_equal(x, Xq[idx - 1000])
+    ov_, oi_ = O.top_k(vals, 9)
+    np.testing.assert_array_equal(ti, oi_)
+    np.testing.assert_array_equal(tv, ov_)
+    oval, ograd = O.penalized_value_and_grad(st, "ei", eta, kind, pending, radius, scale, Xq[:64])
+    assert_close(gv, oval, atol=floor * 100, what="penalized value")
+    gscale = np.abs(ograd).max() + 1e-300
+    assert_close(gg, ograd, rtol=1e-5, atol=max(floor * 1e3, 1e-9 * gscale), what="penalized gradient")
+    assert np.all(np.isfinite(gg))
+    # cleared on exit; an un-set penalization is an error for the stand-alone values
+    assert_close(eng.acq_values("ei", eta, Xq), base, rtol=0, atol=0, what="cleared")
+    with pytest.raises(RuntimeError):
+        eng.penalization_values(Xq)
+    with pytest.raises(ValueError):
+        eng.set_penalization("soft", pending[:, :-1] if d > 1 else np.zeros((2, 3)), radius, scale)
+    with pytest.raises(ValueError):
+        eng.set_penalization("cubic", pending, radius, scale)
+
+
+@pytest.mark.parametrize("cfg", CONFIGS[:5], ids=[c[0] for c in CONFIGS[:5]])
+def test_clone_then_append_is_the_fantasized_posterior(cfg):
+    """tgp_clone_from: an independent copy (factor, data, hyper-parameters); conditioning the copy on pending
+    points by tgp_append_data gives the posterior the reference's _fantasized_model computes through
+    conditional_predict_f (greedy_batch.py:669-691, models.py:355-416); clone_from into an existing engine
+    resets it; the source never changes."""
+    _, obj, d, kind, N, noise = cfg
+    X, Y, ls, c, st, Xq = _problem(obj, d, kind, N, noise, M=200)
+    floor = cancellation_floor(N + 8, 1.0, noise)
+    eng = _engine(kind, d, 1.0, ls, noise, c, X, Y)
+    m0, v0 = eng.predict(Xq)
+    twin = eng.clone()
+    np.testing.assert_array_equal(twin.predict(Xq)[0], m0)
+    np.testing.assert_array_equal(twin.predict(Xq)[1], v0)
+    for a, b in zip(twin.get_factor(), eng.get_factor()):
+        np.testing.assert_array_equal(a, b)
+    rng = np.random.default_rng(31)
+    pend = rng.uniform(size=(6, d))
+    kb = eng.predict_mean(pend)  # kriging believer
+    twin.append_data(pend[:1], kb[:1])
+    twin.append_data(pend[1:], kb[1:])  # the greedy loop's growth
+    sto = O.fantasized_state(st, pend, O.predict(st, pend)[0])
+    fm, fv = twin.predict(Xq)
+    om, ov = O.predict(sto, Xq)
+    assert_close(fm, om, atol=floor * 100, what="fantasized mean")
+    assert_close(fv, ov, atol=floor, what="fantasized var")
+    if noise >= 1e-3:
+        cm, cv = O.conditional_predict_f(st, Xq, pend, O.predict(st, pend)[0])
+        assert_close(fm, cm, atol=floor * 1000, what="== conditional_predict_f mean")
+        assert_close(fv, np.maximum(cv, 1e-12), atol=floor * 10, what="== conditional_predict_f var")
+    assert_close(fm, m0, atol=max(floor * 1e4, 1e-6), what="kriging believer keeps the mean")  # test_greedy_batch.py:233-257
+    assert np.all(fv <= v0 + floor)  # :260-296
+    assert_close(twin.eta(), O.eta_min_mean(sto), atol=floor * 100, what="fantasized eta")
+    np.testing.assert_array_equal(eng.predict(Xq)[0], m0)
+    assert eng.N == N and twin.N == N + 6
+    twin.clone_from(eng)  # reset
+    assert twin.N == N
+    np.testing.assert_array_equal(twin.predict(Xq)[1], v0)
+    from trieste_amd.engine import GPEngine
+
+    other = GPEngine(d + 1, kind)
+    with pytest.raises(ValueError):
+        other.clone_from(eng)
+    fresh = GPEngine(d, kind)
+    with pytest.raises(RuntimeError):
+        eng.clone_from(fresh)  # the source has no hyper-parameters
+    np.testing.assert_array_equal(eng.predict(Xq)[0], m0)

@@ -60,3 +60,28 @@ def test_oracle_ei_and_qei_end_to_end(c):
     assert_close(ei, c["ei"], atol=floor, what="ei")
     qei = O.batch_mc_ei(st, np.array(c["Xg"]), np.array(c["eps"]), c["eta"], c["jitter"])
     assert_close(qei, c["qei"], atol=floor * 10, what="qei")
+
+
+@pytest.mark.parametrize("c", CASES, ids=[c["name"] for c in CASES])
+def test_oracle_greedy_batch_pieces_match_mpmath(c):
+    """Local penalizers (greedy_batch.py:341-354, 376-389) and the posterior a fantasized model represents
+    (greedy_batch.py:630-773 through models.py:355-416) against the mpmath vectors; the reference's
+    conditional formula and the refit on data + fantasized data must be the same posterior."""
+    st = _state(c)
+    floor = cancellation_floor(c["N"] + 3, c["variance"], c["noise"])
+    Xq, pend = np.array(c["Xq"]), np.array(c["Xg"])[1]
+    r, sc = np.array(c["pen_radius"]), np.array(c["pen_scale"])
+    assert_close(O.soft_local_penalizer(Xq, pend, r, sc), c["pen_soft"], atol=1e-300, what="soft penalizer")
+    assert_close(O.hard_local_penalizer(Xq, pend, r, sc), c["pen_hard"], atol=1e-300, what="hard penalizer")
+    base = np.array(c["ei"])
+    assert_close(O.penalized_acquisition(base, np.array(c["pen_soft"])), base * np.array(c["pen_soft"]), atol=1e-300,
+                 what="exp(log a + log phi) = a phi")
+    yf = np.array(c["fant_y"])
+    fm, fv = O.predict(O.fantasized_state(st, pend, yf), Xq, clip=False)
+    assert_close(fm, c["fant_mean"], atol=floor * 10 / min(c["noise"], 1.0) ** 0.5, what="fantasized mean")
+    assert_close(fv, c["fant_var_raw"], atol=floor, what="fantasized var")
+    if c["noise"] >= 1e-3:  # the reference's conditional form subtracts two nearly equal terms at tiny noise
+        cm, cv = O.conditional_predict_f(st, Xq, pend, yf)
+        assert_close(cm, c["fant_mean"], atol=floor * 100, what="conditional mean")
+        assert_close(np.maximum(cv, 1e-12), np.maximum(np.array(c["fant_var_raw"]), 1e-12), atol=floor * 10,
+                     what="conditional var")

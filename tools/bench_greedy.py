@@ -1,0 +1,56 @@
+"""Greedy-batch acquisition latency on the engine (development aid): LocalPenalization and Fantasizer batches
+through EfficientGlobalOptimization at N training points, d = 8, plus the raw engine operations behind them."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from trieste_amd import objectives as OBJ  # seeded synthetic problems (product side)
+import trieste_amd.models as M
+import trieste_amd.acquisition as A
+from trieste_amd.data import Dataset
+from trieste_amd.space import Box
+
+N, d = int(sys.argv[1]) if len(sys.argv) > 1 else 4000, 8
+X, Y = OBJ.synthetic_problem(OBJ.ackley, d, N)
+Y = Y[:, None] if Y.ndim == 1 else Y
+space = Box([0.0] * d, [1.0] * d)
+data = Dataset(X, Y)
+model = M.GaussianProcessRegression(M.build_gpr(data, space, likelihood_variance=1e-2))
+eng = model.engine
+rng = np.random.default_rng(0)
+
+def timed(f, reps=3):
+    f()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = f()
+    return (time.perf_counter() - t0) / reps * 1e3, out
+
+ms, twin = timed(lambda: eng.clone())
+print(f"N={N}: clone {ms:.2f} ms", flush=True)
+pend = rng.uniform(size=(10, d))
+kb = eng.predict_mean(pend)
+def refant():
+    twin.clone_from(eng)
+    twin.append_data(pend, kb)
+ms, _ = timed(refant)
+print(f"clone_from + append 10 rows {ms:.2f} ms", flush=True)
+Mc = 1 << 20
+cand = space.sample_device(eng, Mc, seed=1)
+eta = eng.eta()
+ms0, _ = timed(lambda: eng.acq_argmax("ei", eta, cand), 2)
+r, s = rng.uniform(0.05, 0.3, 10), rng.uniform(0.05, 0.3, 10)
+with eng.penalized("soft", pend, r, s):
+    ms1, _ = timed(lambda: eng.acq_argmax("ei", eta, cand), 2)
+print(f"EI arg-max over 2^20 candidates: fused {ms0:.1f} ms, locally penalized (10 pending) {ms1:.1f} ms", flush=True)
+for name, builder in (("LocalPenalization(soft)", lambda: A.LocalPenalization(space)),
+                      ("LocalPenalization(hard)", lambda: A.LocalPenalization(space, penalizer=A.hard_local_penalizer)),
+                      ("Fantasizer(KB)", lambda: A.Fantasizer()),
+                      ("Fantasizer(sample)", lambda: A.Fantasizer(fantasize_method="sample"))):
+    for q in (5, 10):
+        rule = A.EfficientGlobalOptimization(builder(), num_query_points=q)
+        rule.acquire_single(space, model, data)
+        t0 = time.perf_counter()
+        pts = rule.acquire_single(space, model, data)
+        ms = (time.perf_counter() - t0) * 1e3
+        dmin = (np.linalg.norm(pts[:, None] - pts[None], axis=-1) + np.eye(q) * 9).min()
+        print(f"EGO {name} q={q}: acquire {ms:.0f} ms ({ms / q:.0f} ms per element), min pairwise distance {dmin:.3f}", flush=True)

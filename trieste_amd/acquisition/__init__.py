@@ -6,6 +6,8 @@ from .function import (AugmentedExpectedImprovement, BatchMonteCarloExpectedImpr
                        augmented_expected_improvement, batch_monte_carlo_expected_improvement, expected_improvement,
                        monte_carlo_expected_improvement, negative_lower_confidence_bound,
                        probability_below_threshold)
+from .greedy_batch import (Fantasizer, LocalPenalization, PenalizedAcquisition, hard_local_penalizer,
+                           local_penalizer, soft_local_penalizer)
 from .interface import (AcquisitionFunctionBuilder, AcquisitionFunctionClass, GreedyAcquisitionFunctionBuilder,
                         SingleModelAcquisitionBuilder, SingleModelGreedyAcquisitionBuilder,
                         SingleModelVectorizedAcquisitionBuilder, VectorizedAcquisitionFunctionBuilder)

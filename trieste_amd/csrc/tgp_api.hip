@@ -98,6 +98,9 @@ struct tgp_handle_s {
   int variant = 0;
   // model state on device
   DevBuf d_xn, d_ls, d_X, d_Y, d_Xs, d_A, d_L, d_W, d_alpha, d_err, d_tmp1, d_tmp2, d_info;
+  // local penalization applied to every tgp_acq_* result while pen_kind != 0 (tgp_set_penalization)
+  int pen_kind = 0, pen_P = 0;
+  DevBuf d_pen;  // [P, d] pending points, [P] radius, [P] scale
   // scratch
   DevBuf s_in, s_in2, s_out1, s_out2, s_out3, s_blkv, s_blki, s_small, s_kcache, s_ssq, s_aslab, s_grad, s_ks, s_part;
   // timing of the dominant kernel
@@ -199,6 +202,14 @@ int set_device(tgp_handle h) {
   // reported by the next launch check of this call.  Every entry point starts from a clean slate.
   (void)hipGetLastError();
   return TGP_OK;
+}
+
+// multiply acquisition values (device, [M]) by the handle's local penalization, if one is set
+void apply_penalization(tgp_handle h, double* dvals, const double* dXq, int64_t M) {
+  if (h->pen_kind == 0 || h->pen_P == 0 || !dvals) return;
+  const double* pend = h->d_pen.as<double>();
+  launch_penalize(h->stream, dvals, dXq, M, h->d, h->pen_kind, h->pen_P, pend, pend + (size_t)h->pen_P * h->d,
+                  pend + (size_t)h->pen_P * (h->d + 1));
 }
 
 hipError_t launch_sweep_timed(tgp_handle h, const SweepArgs& a, bool joint) {
@@ -408,7 +419,7 @@ int tgp_destroy(tgp_handle h) {
     (void)hipStreamSynchronize(nullptr);
   }
   for (DevBuf* b : {&h->d_xn, &h->d_ls, &h->d_X, &h->d_Y, &h->d_Xs, &h->d_A, &h->d_L, &h->d_W, &h->d_alpha,
-                    &h->d_err, &h->d_tmp1, &h->d_tmp2, &h->d_info, &h->s_in, &h->s_in2, &h->s_out1,
+                    &h->d_err, &h->d_tmp1, &h->d_tmp2, &h->d_info, &h->d_pen, &h->s_in, &h->s_in2, &h->s_out1,
                     &h->s_out2, &h->s_out3, &h->s_blkv, &h->s_blki, &h->s_small, &h->s_kcache, &h->s_ssq, &h->s_aslab, &h->s_grad, &h->s_ks, &h->s_part})
     b->release();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -579,6 +590,93 @@ int tgp_append_data(tgp_handle h, const double* Xnew, const double* Ynew, int64_
   return factorise(h, N, keep);
 }
 
+int tgp_clone_from(tgp_handle dst, tgp_handle src) {
+  if (!dst || !src) return TGP_ERR_ARG;
+  if (dst == src) return TGP_OK;
+  if (dst->d != src->d || dst->kind != src->kind)
+    return fail(dst, TGP_ERR_SHAPE, "clone needs equal input dimension and kernel (dst d=%d kind=%d, src d=%d kind=%d)",
+                dst->d, dst->kind, src->d, src->kind);
+  if (dst->device != src->device) return fail(dst, TGP_ERR_ARG, "clone across devices is not supported");
+  if (!src->have_hyper) return fail(dst, TGP_ERR_STATE, "source has no hyper-parameters");
+  if (int rc = set_device(dst)) return rc;
+  dst->have_data = false;
+  dst->variance = src->variance;
+  dst->noise = src->noise;
+  dst->mean_const = src->mean_const;
+  dst->ls = src->ls;
+  dst->have_hyper = true;
+  hipStream_t s = dst->stream;
+  auto copy = [&](DevBuf& to, const DevBuf& from, size_t bytes) -> hipError_t {
+    if (bytes == 0) return hipSuccess;
+    hipError_t e = to.reserve(bytes);
+    if (e != hipSuccess) return e;
+    return hipMemcpyAsync(to.p, from.p, bytes, hipMemcpyDeviceToDevice, s);
+  };
+  HIPCHK(dst, copy(dst->d_ls, src->d_ls, (size_t)src->d * sizeof(double)));
+  if (src->have_data) {
+    // every entry point of the source synchronises its stream before returning: its state is complete
+    const size_t N = (size_t)src->N, Npad = (size_t)src->Npad, nn = Npad * Npad * sizeof(double);
+    HIPCHK(dst, copy(dst->d_X, src->d_X, N * src->d * sizeof(double)));
+    HIPCHK(dst, copy(dst->d_Y, src->d_Y, N * sizeof(double)));
+    HIPCHK(dst, copy(dst->d_Xs, src->d_Xs, Npad * src->dp * sizeof(double)));
+    HIPCHK(dst, copy(dst->d_xn, src->d_xn, Npad * sizeof(double)));
+    HIPCHK(dst, copy(dst->d_A, src->d_A, nn));
+    HIPCHK(dst, copy(dst->d_L, src->d_L, nn));
+    HIPCHK(dst, copy(dst->d_W, src->d_W, nn));
+    HIPCHK(dst, copy(dst->d_alpha, src->d_alpha, Npad * sizeof(double)));
+    HIPCHK(dst, copy(dst->d_err, src->d_err, Npad * sizeof(double)));
+    dst->N = src->N;
+    dst->Npad = src->Npad;
+    HIPCHK(dst, hipStreamSynchronize(s));
+    dst->have_data = true;
+  }
+  return TGP_OK;
+}
+
+int tgp_set_penalization(tgp_handle h, int kind, const double* pending, const double* radius, const double* scale,
+                         int64_t P) {
+  if (!h) return TGP_ERR_ARG;
+  if (kind < 0 || kind > 2) return fail(h, TGP_ERR_ARG, "unknown penalizer kind %d", kind);
+  if (kind == 0 || P == 0) {
+    h->pen_kind = 0;
+    h->pen_P = 0;
+    return TGP_OK;
+  }
+  if (P < 0 || P > 1024) return fail(h, TGP_ERR_SHAPE, "number of pending points must be in 0..1024, got %lld", (long long)P);
+  if (!pending || !radius || !scale) return fail(h, TGP_ERR_ARG, "pending / radius / scale is NULL");
+  if (int rc = set_device(h)) return rc;
+  h->pen_kind = 0;
+  const size_t np = (size_t)P * h->d;
+  HIPCHK(h, h->d_pen.reserve((np + 2 * (size_t)P) * sizeof(double)));
+  double* dp = h->d_pen.as<double>();
+  HIPCHK(h, hipMemcpyAsync(dp, pending, np * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(dp + np, radius, (size_t)P * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(dp + np + P, scale, (size_t)P * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));  // the host arrays may be released on return
+  h->pen_kind = kind;
+  h->pen_P = (int)P;
+  return TGP_OK;
+}
+
+int tgp_penalization_values(tgp_handle h, const double* Xq, int64_t M, double* out, int where) {
+  if (!h) return TGP_ERR_ARG;
+  if (h->pen_kind == 0 || h->pen_P == 0) return fail(h, TGP_ERR_STATE, "no penalization set: call tgp_set_penalization first");
+  if (M < 0 || (M > 0 && (!Xq || !out))) return fail(h, TGP_ERR_ARG, "bad arguments");
+  if (M == 0) return TGP_OK;
+  if (int rc = set_device(h)) return rc;
+  const double* dXq;
+  double* dout;
+  if (int rc = stage_in(h, h->s_in, Xq, (size_t)M * h->d, where, &dXq)) return rc;
+  if (int rc = stage_out_prepare(h, h->s_out1, out, M, where, &dout)) return rc;
+  const double* pend = h->d_pen.as<double>();
+  launch_penalize(h->stream, dout, dXq, M, h->d, h->pen_kind, h->pen_P, pend, pend + (size_t)h->pen_P * h->d,
+                  pend + (size_t)h->pen_P * (h->d + 1), true);
+  if (int rc = stage_out_finish(h, dout, out, M, where)) return rc;
+  if (int rc = sync(h)) return rc;
+  HIPCHK(h, hipGetLastError());
+  return TGP_OK;
+}
+
 int tgp_nlml(tgp_handle h, double* value, double* grad) {
   if (!h || !value) return TGP_ERR_ARG;
   if (!h->have_data) return fail(h, TGP_ERR_STATE, "no factorisation: call tgp_set_data first");
@@ -664,6 +762,7 @@ static int sweep_common(tgp_handle h, const double* Xq, int64_t M, double* mean,
     a.blk_idx = h->s_blki.as<int64_t>();
   }
   HIPCHK(h, launch_sweep_timed(h, a, false));
+  if (acq_kind >= 0 && !want_best) apply_penalization(h, a.acq_out, dXq, M);
   if (want_best) {
     double* fv = h->s_small.as<double>();
     int64_t* fi = (int64_t*)(fv + 1);
@@ -761,6 +860,11 @@ int tgp_acq_value_grad(tgp_handle h, int acq_kind, double param, const double* X
   if (int rc = gemm_tall(h, false, (int)Npad, (int)Ppad, (int)Npad, 1.0, h->d_A.as<double>(), Npad, C1, Ppad, 0.0, Z,
                          Ppad, 5)) return rc;
   launch_grad_tail(h->stream, m, dXq, P, Ppad, B, C1, Z, acq_kind, param, dval, dgrad);
+  if (h->pen_kind != 0 && h->pen_P > 0) {
+    const double* pend = h->d_pen.as<double>();
+    launch_penalize_grad(h->stream, dval, dgrad, dXq, P, h->d, h->pen_kind, h->pen_P, pend,
+                         pend + (size_t)h->pen_P * h->d, pend + (size_t)h->pen_P * (h->d + 1));
+  }
   if (int rc = stage_out_finish(h, dval, val, P, where)) return rc;
   if (int rc = stage_out_finish(h, dgrad, grad, (size_t)P * h->d, where)) return rc;
   if (int rc = sync(h)) return rc;
@@ -878,9 +982,30 @@ int tgp_debug_gemm(tgp_handle h, int m, int n, int k, int tb, int tri, int lower
   return TGP_OK;
 }
 
+int tgp_acq_topk(tgp_handle h, int acq_kind, double param, const double* Xq, int64_t M, int64_t index_base, int k,
+                 double* vals, int64_t* idx, int where);
+
 int tgp_acq_argmax(tgp_handle h, int acq_kind, double param, const double* Xq, int64_t M,
                    int64_t index_base, double* best_val, int64_t* best_idx, double* best_x, int where) {
   if (acq_kind < 0 || acq_kind > 3) return fail(h, TGP_ERR_ARG, "unknown acquisition kind %d", acq_kind);
+  if (h && h->pen_kind != 0 && h->pen_P > 0) {
+    // penalised: the values take one trip through HBM (8 B per candidate) between the sweep and the arg-max
+    if (M < 1) return fail(h, TGP_ERR_SHAPE, "arg-max over an empty candidate set");
+    double v;
+    int64_t i;
+    if (int rc = tgp_acq_topk(h, acq_kind, param, Xq, M, index_base, 1, &v, &i, where)) return rc;
+    if (best_val) *best_val = v;
+    if (best_idx) *best_idx = i;
+    if (best_x) {
+      const int64_t local = i - index_base;
+      if (local < 0 || local >= M) return fail(h, TGP_ERR_HIP, "arg-max produced no valid index (all NaN?)");
+      if (where == TGP_DEVICE)
+        HIPCHK(h, hipMemcpy(best_x, Xq + local * h->d, h->d * sizeof(double), hipMemcpyDeviceToHost));
+      else
+        memcpy(best_x, Xq + local * h->d, h->d * sizeof(double));
+    }
+    return TGP_OK;
+  }
   return sweep_common(h, Xq, M, nullptr, nullptr, nullptr, acq_kind, param, where, true, index_base,
                       best_val, best_idx, best_x);
 }
@@ -907,6 +1032,7 @@ int tgp_acq_topk(tgp_handle h, int acq_kind, double param, const double* Xq, int
     a.acq_kind = acq_kind;
     a.acq_param = param;
     HIPCHK(h, launch_sweep_timed(h, a, false));
+    apply_penalization(h, dvals, dXq, M);
   }
   HIPCHK(h, h->s_blkv.reserve(512 * sizeof(double)));
   HIPCHK(h, h->s_blki.reserve(512 * sizeof(int64_t)));

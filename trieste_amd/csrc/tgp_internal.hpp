@@ -103,6 +103,10 @@ constexpr int WS_MAX_GRID = 256;  // persistent workgroups of the wave-specialis
 void launch_predict_mean(hipStream_t s, const ModelDev& m, const double* Xq, int64_t M, double* mean);
 void launch_argmax_final(hipStream_t s, const double* blk_val, const int64_t* blk_idx, int64_t n,
                          double* out_val, int64_t* out_idx);
+void launch_penalize(hipStream_t s, double* vals, const double* Xq, int64_t M, int d, int kind, int P,
+                     const double* pend, const double* radius, const double* scale, bool init_one = false);
+void launch_penalize_grad(hipStream_t s, double* val, double* grad, const double* Xq, int64_t Pq, int d, int kind,
+                          int P, const double* pend, const double* radius, const double* scale);
 void launch_min_value(hipStream_t s, const double* v, int64_t n, double* out);
 void launch_topk_pass(hipStream_t s, const double* vals, int64_t M, int64_t index_base, const double* prev_val,
                       const int64_t* prev_idx, double* scratch_val, int64_t* scratch_idx, double* out_val,

@@ -84,6 +84,59 @@ class GPEngine:
         self._chk(self._lib.tgp_set_variant(self._h, int(v)))
 
     # -- model state -----------------------------------------------------------------------------
+    def clone_from(self, other: "GPEngine") -> None:
+        """Become a copy of ``other`` (hyper-parameters, data, cached factorisation): tgp_clone_from."""
+        if not isinstance(other, GPEngine):
+            raise TypeError(f"can only clone from a GPEngine, got {other!r}")
+        self._chk(self._lib.tgp_clone_from(self._h, other._h))
+        self.N = other.N
+
+    def clone(self) -> "GPEngine":
+        """A new engine on the same device holding a copy of this one's state."""
+        twin = GPEngine(self.d, self.kernel, device=self.device)
+        twin.clone_from(self)
+        return twin
+
+    def set_penalization(self, kind: str, pending=None, radius=None, scale=None) -> None:
+        """Multiply every acquisition result by prod_p phi_p(x) around the pending points until cleared with
+        ``kind="none"`` (tgp_set_penalization; greedy_batch.py:250-389)."""
+        if kind not in _lib.PENALIZERS:
+            raise ValueError(f"unknown penalizer {kind!r}; choose from {sorted(_lib.PENALIZERS)}")
+        if kind == "none" or pending is None or len(pending) == 0:
+            self._chk(self._lib.tgp_set_penalization(self._h, 0, None, None, None, 0))
+            return
+        pts = np.ascontiguousarray(np.asarray(pending, dtype=_NP))
+        if pts.ndim != 2 or pts.shape[1] != self.d:
+            raise ValueError(f"pending points must be [P, {self.d}], got {pts.shape}")
+        P = pts.shape[0]
+        r = np.ascontiguousarray(np.asarray(radius, dtype=_NP).reshape(-1))
+        sc = np.ascontiguousarray(np.asarray(scale, dtype=_NP).reshape(-1))
+        if r.shape[0] != P or sc.shape[0] != P:
+            raise ValueError(f"radius and scale must hold P={P} values, got {r.shape}, {sc.shape}")
+        self._chk(self._lib.tgp_set_penalization(self._h, _lib.PENALIZERS[kind], pts.ctypes.data, r.ctypes.data,
+                                                 sc.ctypes.data, P))
+
+    def penalization_values(self, Xq):
+        """prod_p phi_p(x) of the penalization currently set, at Xq [..., d] -> [...]."""
+        a, lead, M = self._flat(Xq)
+        out, po = self._out(a, lead)
+        self._chk(self._lib.tgp_penalization_values(self._h, a.ptr, M, po, a.where))
+        return out
+
+    def penalized(self, kind: str, pending, radius, scale):
+        """Context manager: the penalization is active inside the block only."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            self.set_penalization(kind, pending, radius, scale)
+            try:
+                yield self
+            finally:
+                self.set_penalization("none")
+
+        return scope()
+
     def set_hyper(self, variance: float, lengthscales, noise_variance: float, mean_const: float = 0.0):
         ls = np.ascontiguousarray(np.broadcast_to(np.asarray(lengthscales, dtype=_NP), (self.d,)))
         self._chk(self._lib.tgp_set_hyper(self._h, float(variance), ls.ctypes.data,

@@ -507,3 +507,83 @@ class GaussianProcessRegression:
         if self._use_decoupled_sampler:
             return DecoupledTrajectorySampler(self, self._num_rff_features)
         return RandomFourierFeatureTrajectorySampler(self, self._num_rff_features)
+
+
+class FantasizedGaussianProcessRegression(GaussianProcessRegression):
+    """The base model conditioned additionally on fantasized observations -- the reference's
+    ``_fantasized_model`` (acquisition/function/greedy_batch.py:630-773), which answers every predict
+    by calling the base model's ``conditional_predict_f/_joint/_y`` (models.py:355-526) with the
+    fantasized data.  For an exact GPR with Gaussian noise that conditional posterior IS the posterior
+    of a GPR on (data + fantasized data) with the same hyper-parameters, so here the object owns a
+    *clone* of the base engine with the fantasized rows appended to the cached factorisation
+    (``tgp_clone_from`` + ``tgp_append_data``): predict / predict_joint / sample / acquisition sweeps
+    run on it like on any model; the base model is untouched.  Batches of fantasized data sets
+    (leading dimensions) are outside the engine's path."""
+
+    def __init__(self, model: GaussianProcessRegression, fantasized_data: Dataset):
+        if not isinstance(model, GaussianProcessRegression):
+            raise NotImplementedError(f"a fantasized model needs an engine-backed GaussianProcessRegression; "
+                                      f"received {model!r}")
+        self._base = model
+        base = model.model
+        self._num_kernel_samples = model._num_kernel_samples
+        self._num_rff_features = model._num_rff_features
+        self._use_decoupled_sampler = model._use_decoupled_sampler
+        self._model = GPR(base.data, base.kernel, base.mean_function, base.likelihood_variance,
+                          base.trainable_likelihood)
+        self._engine = model.engine.clone()
+        self._fantasized = None
+        self.update_fantasized_data(fantasized_data)
+
+    def __repr__(self) -> str:
+        return f"FantasizedGaussianProcessRegression({self._base!r})"
+
+    @staticmethod
+    def _check(fantasized_data: Dataset):
+        qp, obs = fantasized_data.query_points, fantasized_data.observations
+        if qp.ndim != 2 or obs.ndim != 2 or obs.shape[-1] != 1:
+            raise NotImplementedError("fantasized data must be [N, D] query points with [N, 1] observations "
+                                      f"(no leading dimensions on this engine), got {qp.shape}, {obs.shape}")
+        return qp, obs
+
+    def update_fantasized_data(self, fantasized_data: Dataset) -> None:
+        """New additional data to condition on (greedy_batch.py:657-667).  The greedy loop's usual case --
+        the previous fantasized rows plus new ones, the base model unchanged -- appends only the new rows."""
+        qp, obs = self._check(fantasized_data)
+        base = self._base.model
+        bx, by = base.data
+        old = self._fantasized
+        n0 = bx.shape[0]
+        grown = (old is not None and self._engine.N == n0 + old[0].shape[0] and qp.shape[0] > old[0].shape[0]
+                 and np.array_equal(qp[: old[0].shape[0]], old[0])
+                 and np.allclose(obs[: old[0].shape[0]], old[1], rtol=1e-10, atol=1e-13)  # re-predicted means: same to rounding
+                 and self._synced_with_base())
+        if grown:
+            k0 = old[0].shape[0]
+            self._engine.append_data(qp[k0:], obs[k0:, 0])
+        else:
+            self._engine.clone_from(self._base.engine)
+            self._stamp = self._base_stamp()
+            if qp.shape[0]:
+                self._engine.append_data(qp, obs[:, 0])
+        if grown:  # keep the values the factor was built from
+            obs = np.concatenate([old[1], obs[old[0].shape[0]:]], axis=0)
+        self._fantasized = (qp.copy(), obs.copy())
+        self._model = GPR((np.concatenate([bx, qp], axis=0), np.concatenate([by, obs], axis=0)), base.kernel,
+                          base.mean_function, base.likelihood_variance, base.trainable_likelihood)
+
+    def _base_stamp(self):
+        m = self._base.model
+        k = m.kernel
+        return (id(m.data[0]), m.data[0].shape, float(k.variance), np.array(k.lengthscales, dtype=np.float64).tobytes(),
+                float(m.likelihood_variance), float(m.mean_function.c))
+
+    def _synced_with_base(self) -> bool:
+        return getattr(self, "_stamp", None) == self._base_stamp()
+
+    # a fantasized model is a view of its base model: training it makes no sense
+    def update(self, dataset: Dataset) -> None:
+        raise NotImplementedError("a fantasized model is conditioned through update_fantasized_data")
+
+    def optimize(self, dataset: Dataset):
+        raise NotImplementedError("a fantasized model is not trainable; optimize its base model")
