@@ -61,8 +61,12 @@ enum tgp_acq {
   TGP_ACQ_EI = 0,   /* expected_improvement.__call__            function.py:215-223; param = eta   */
   TGP_ACQ_PI = 1,   /* probability_below_threshold / PoF         function.py:509-510; param = thr  */
   TGP_ACQ_NLCB = 2, /* negative_lower_confidence_bound           function.py:415-416; param = beta */
-  TGP_ACQ_AEI = 3   /* augmented_expected_improvement.__call__  function.py:312-325; param = eta,
+  TGP_ACQ_AEI = 3,  /* augmented_expected_improvement.__call__  function.py:312-325; param = eta,
                        noise variance = the model's likelihood variance (tgp_set_hyper)        */
+  TGP_ACQ_MES = 4,  /* min_value_entropy_search.__call__        entropy.py:195-214; param unused,
+                       the min-value samples come from tgp_set_min_value_samples               */
+  TGP_ACQ_GIBBON = 5 /* gibbon_quality_term.__call__            entropy.py:479-500 (+ the repulsion
+                       term :580-619 while tgp_set_repulsion is in force); param unused         */
 };
 
 /* ---- lifetime ------------------------------------------------------------------------- */
@@ -119,6 +123,25 @@ int tgp_clone_from(tgp_handle dst, tgp_handle src);
  * that pending point contributes no gradient. */
 int tgp_set_penalization(tgp_handle h, int kind, const double* pending, const double* radius, const double* scale,
                          int64_t P);
+
+/* Entropy-search tails (acquisition/function/entropy.py).  The S samples of the objective's minimum value
+ * (MinValueEntropySearch.prepare_acquisition_function :118-139 / GIBBON._update_quality_term :405-419 draw them
+ * with a Thompson or Gumbel sampler) are handle state: samples host [S], S <= 4096; S == 0 clears.  With
+ * gamma_s = (s - mean) / max(sqrt(var), 1e-8), ratio = pdf(gamma) / Phi(-gamma):
+ *   TGP_ACQ_MES:    mean_s [ -gamma ratio / 2 - log Phi(-gamma) ]
+ *   TGP_ACQ_GIBBON: -1/2 mean_s log(1 + rho^2 ratio (gamma - ratio)),  rho^2 = var / (var + noise)
+ * log Phi as tfp's log_ndtr (asymptotic series below -20).  All tgp_acq_* entry points accept the two kinds;
+ * the gradient is analytic. */
+int tgp_set_min_value_samples(tgp_handle h, const double* samples, int S);
+
+/* GIBBON's repulsion term (gibbon_repulsion_term.__call__, entropy.py:580-619): while set, TGP_ACQ_GIBBON
+ * results are quality(x) + weight / 2 * (log(var_twin(x) + noise) - log(var(x) + noise)), where `twin` is this
+ * model conditioned additionally on the m pending points (tgp_clone_from + tgp_append_data with any
+ * observations: variances do not depend on them).  The reference forms V_det = yvar - A^T (B + noise I)^-1 A
+ * from covariance_between_points(x, pending) and predict_joint(pending); that Schur complement IS the
+ * twin's predictive variance + noise.  weight = 1 / m^2 for rescaled_repulsion, else 1.  `twin` is not owned
+ * and must outlive the setting; twin == NULL clears. */
+int tgp_set_repulsion(tgp_handle h, tgp_handle twin, double weight);
 
 /* The penalization alone, prod_p phi_p(x) at Xq [M,d] -> out [M] (the penalizer objects are callables in the
  * reference: local_penalizer.__call__, greedy_batch.py:341-354, 376-389).  TGP_ERR_STATE if none is set. */

@@ -465,6 +465,134 @@ def fantasized_state(state: GPRState, X_add: np.ndarray, Y_add: np.ndarray) -> G
 
 
 # --------------------------------------------------------------------------------------
+# Entropy search on the same posterior (acquisition/function/entropy.py, acquisition/sampler.py:126-213)
+# --------------------------------------------------------------------------------------
+CLAMP_LB = 1e-8  # entropy.py:47
+_HALF_LOG_2PI = 0.5 * math.log(2.0 * math.pi)
+
+
+def log_normal_cdf(x):
+    """tfp.distributions.Normal(0, 1).log_cdf = special_math.log_ndtr for float64 (tensorflow-probability 0.24,
+    special_math.py): x > 8: -ndtr(-x);  -20 <= x <= 8: log(ndtr(x));  x < -20: asymptotic series of order 3,
+    -x^2/2 - log(-x) - log(2 pi)/2 + log(1 - 1/x^2 + 3/x^4 - 15/x^6)."""
+    x = np.asarray(x, dtype=np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        mid = np.log(_ndtr(np.clip(x, -20.0, 8.0)))
+        hi = -_ndtr(-np.maximum(x, 8.0))
+        xl = np.minimum(x, -20.0)
+        x2 = xl * xl
+        lo = -0.5 * x2 - np.log(-xl) - _HALF_LOG_2PI + np.log(1.0 - 1.0 / x2 + 3.0 / x2 ** 2 - 15.0 / x2 ** 3)
+    return np.where(x > 8.0, hi, np.where(x >= -20.0, mid, lo))
+
+
+def _gamma_ratio(mean, var, samples):
+    fsd = np.maximum(np.sqrt(var), CLAMP_LB)                       # clip below (entropy.py:201-204)
+    gamma = (np.asarray(samples, dtype=np.float64).reshape(1, -1) - np.asarray(mean)[:, None]) / fsd[:, None]
+    log_minus_cdf = log_normal_cdf(-gamma)
+    ratio = np.exp(-0.5 * gamma * gamma - _HALF_LOG_2PI - log_minus_cdf)   # exp(log_prob(gamma) - log_cdf(-gamma))
+    return gamma, log_minus_cdf, ratio
+
+
+def min_value_entropy_search(mean, var, samples) -> np.ndarray:
+    """min_value_entropy_search.__call__ (entropy.py:195-214): mean [M], var [M] (predict's), samples [S]."""
+    gamma, log_minus_cdf, ratio = _gamma_ratio(np.asarray(mean), np.asarray(var), samples)
+    return np.mean(-gamma * ratio / 2.0 - log_minus_cdf, axis=1)
+
+
+def gibbon_quality_term(mean, var, samples, noise) -> np.ndarray:
+    """gibbon_quality_term.__call__ (entropy.py:479-500)."""
+    var = np.asarray(var, dtype=np.float64)
+    rho_squared = var / (var + noise)
+    gamma, _, ratio = _gamma_ratio(np.asarray(mean), var, samples)
+    inner_log = 1.0 + rho_squared[:, None] * ratio * (gamma - ratio)
+    return -0.5 * np.mean(np.log(inner_log), axis=1)
+
+
+def gibbon_repulsion_term(state: GPRState, x: np.ndarray, pending: np.ndarray, rescaled_repulsion: bool = True):
+    """gibbon_repulsion_term.__call__ (entropy.py:580-619): yvar = predict var + noise; B = predict_joint cov of
+    the pending points; L = chol(B + noise I); A = covariance_between_points(x, pending);
+    V_det = yvar - |L^-1 A|^2; 1/2 (log V_det - log yvar), times (1/m)^2 if rescaled."""
+    x, pending = np.asarray(x, dtype=np.float64), np.asarray(pending, dtype=np.float64)
+    _, fvar = predict(state, x)
+    yvar = fvar + state.noise
+    _, B = predict_joint(state, pending)
+    m = pending.shape[0]
+    L = _cholesky(B + state.noise * np.eye(m), lower=True)
+    A = covariance_between_points(state, x, pending)              # [M, m]
+    L_inv_A = _solve_triangular(L, A.T, lower=True)               # [m, M]
+    V_det = yvar - np.sum(L_inv_A * L_inv_A, axis=0)
+    repulsion = 0.5 * (np.log(V_det) - np.log(yvar))
+    return repulsion * ((1.0 / m) ** 2 if rescaled_repulsion else 1.0)
+
+
+def entropy_value_and_grad(state: GPRState, acq: str, samples, Xq, twin: Optional[GPRState] = None,
+                           weight: float = 0.0):
+    """Value [P] and gradient [P, d] of the MES / GIBBON acquisition at Xq -- what autodiff through
+    min_value_entropy_search / GibbonAcquisition hands L-BFGS-B -- analytically.  With u = gamma,
+    r = pdf(u) / Phi(-u): dr/du = r (r - u);  MES: f = -u r / 2 - log Phi(-u), df/du = r/2 - u r (r - u) / 2;
+    GIBBON: g = -1/2 log(1 + rho^2 h), h = r (u - r), dh/du = -r (u - r)^2 + r - r^2 (r - u);
+    du/dmean = -1/sd, du/dvar = -u / (2 var), d rho^2 / dvar = noise / (var + noise)^2.  The repulsion term (twin =
+    the state conditioned on the pending points) adds weight/2 (log(var_twin + noise) - log(var + noise))."""
+    Xq = np.asarray(Xq, dtype=np.float64)
+
+    def mean_var_grads(st):
+        negm, dnegm = acq_value_and_grad(st, "nlcb", 0.0, Xq)       # -mean, -dmean
+        v1, g1 = acq_value_and_grad(st, "nlcb", 1.0, Xq)            # -(mean - sd)
+        sd = v1 - negm
+        dsd = g1 - dnegm
+        return -negm, sd * sd, -dnegm, 2.0 * sd[:, None] * dsd
+
+    mu, var, dmu, dvar = mean_var_grads(state)
+    sd_raw = np.sqrt(var)
+    clamped = ~(sd_raw > CLAMP_LB)
+    gamma, lmc, r = _gamma_ratio(mu, var, samples)
+    if acq == "mes":
+        f = -gamma * r / 2.0 - lmc
+        fu = r / 2.0 - gamma * r * (r - gamma) / 2.0
+        frho = np.zeros_like(f)
+    else:
+        rho2 = (var / (var + state.noise))[:, None]
+        h = r * (gamma - r)
+        inner = 1.0 + rho2 * h
+        dh = -r * (gamma - r) ** 2 + r - r * r * (r - gamma)
+        f = -0.5 * np.log(inner)
+        fu = -0.5 * rho2 * dh / inner
+        frho = -0.5 * h / inner
+    sd = np.maximum(sd_raw, CLAMP_LB)
+    val = f.mean(axis=1)
+    dv_dmu = -fu.mean(axis=1) / sd
+    dv_dvar = np.where(clamped, 0.0, -(fu * gamma).mean(axis=1) / (2.0 * var))
+    if acq != "mes":
+        dv_dvar = dv_dvar + frho.mean(axis=1) * state.noise / (var + state.noise) ** 2
+    grad = dv_dmu[:, None] * dmu + dv_dvar[:, None] * dvar
+    if twin is not None and acq != "mes":
+        _, vt, _, dvt = mean_var_grads(twin)
+        val = val + 0.5 * weight * (np.log(vt + state.noise) - np.log(var + state.noise))
+        grad = grad + 0.5 * weight * (dvt / (vt + state.noise)[:, None] - dvar / (var + state.noise)[:, None])
+    return val, grad
+
+
+def gumbel_min_value_samples(mean, sd, uniform_samples) -> np.ndarray:
+    """GumbelSampler.sample (acquisition/sampler.py:156-212) given the model's (predict_y) mean / sd at the grid
+    and the uniform draws: fit a Gumbel to the quartiles of Pr(y* < y) = 1 - prod_i Phi(-(y - mean_i) / sd_i)
+    (bisection on [min(mean - 5 sd), max(mean + 5 sd)]), then y = a + b log(-log(1 - u))."""
+    from scipy.optimize import bisect
+
+    mean, sd = np.asarray(mean, dtype=np.float64).reshape(-1), np.asarray(sd, dtype=np.float64).reshape(-1)
+
+    def probf(y):
+        return 1.0 - np.exp(np.sum(log_normal_cdf(-(y - mean) / sd)))
+
+    left, right = float(np.min(mean - 5.0 * sd)), float(np.max(mean + 5.0 * sd))
+    q1, q2 = (bisect(lambda y: probf(y) - val, left, right, maxiter=10000) for val in (0.25, 0.75))
+    l1, l2 = math.log(math.log(4.0 / 3.0)), math.log(math.log(4.0))
+    b = (q1 - q2) / (l1 - l2)
+    a = (q2 * l1 - q1 * l2) / (l1 - l2)
+    u = np.asarray(uniform_samples, dtype=np.float64).reshape(-1)
+    return (np.log(-np.log(1.0 - u)) * b + a)[:, None]
+
+
+# --------------------------------------------------------------------------------------
 # A.6 decoupled trajectories (sampler.py:661-738, 801-806, 841-855, 901-936;
 # gpflux RandomFourierFeaturesCosine, gpflux.math.compute_A_inv_b); draws passed in.
 # --------------------------------------------------------------------------------------

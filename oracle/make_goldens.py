@@ -223,7 +223,42 @@ def make_case(name, kind, d, N, variance, ls, noise, mean_const, seed, M=6, q=3,
         fant_mean.append(f64(sum(ks[i] * alphaf[i] for i in range(Nf)) + mpf(mean_const)))
         fant_var.append(f64(kern(kind, variance, ls, x, x) - sum(a_ * a_ for a_ in A_)))
 
+    # entropy search (acquisition/function/entropy.py): MES (:195-214) and GIBBON's quality (:479-500) and repulsion
+    # (:580-619) terms at the candidates, from the exact posterior, with given min-value samples
+    S_ent = 4
+    ent_samples = [float(f64(eta)) - abs(float(t)) * 0.3 for t in rng.normal(size=S_ent)]
+    mes, gq, grep = [], [], []
+    for idx, (m, v) in enumerate(zip(mean, var)):
+        sd = max(mp.sqrt(v), mp.mpf("1e-8"))
+        rho2 = v / (v + mpf(noise))
+        acc_m, acc_g = mp.mpf(0), mp.mpf(0)
+        for smp in ent_samples:
+            u = (mpf(smp) - m) / sd
+            lmc = mp.log(mp.ncdf(-u))
+            r = mp.npdf(u) / mp.ncdf(-u)
+            acc_m += -u * r / 2 - lmc
+            acc_g += mp.log(1 + rho2 * r * (u - r))
+        mes.append(f64(acc_m / S_ent))
+        gq.append(f64(-acc_g / (2 * S_ent)))
+        # repulsion by the reference's block-determinant formula, from the joint posterior of [x; pending]
+        _, cj = post([Xq[idx]] + pend)
+        Bm = mp.zeros(q, q)
+        for a in range(q):
+            for b_ in range(q):
+                Bm[a, b_] = cj[1 + a, 1 + b_]
+            Bm[a, a] += mpf(noise)
+        Lb = chol(Bm)
+        Avec = [cj[0, 1 + a] for a in range(q)]
+        LiA = fsub(Lb, Avec)
+        yvar = v + mpf(noise)
+        vdet = yvar - sum(t * t for t in LiA)
+        grep.append(f64((mp.log(vdet) - mp.log(yvar)) / 2 / (q * q)))
+        # ... which is the conditioned (fantasised) variance + noise: the identity the engine's twin relies on
+        if var_raw[idx] > mp.mpf("1e-12"):
+            assert abs(vdet - (mpf(fant_var[idx]) + mpf(noise))) < mp.mpf("1e-13") * (1 + abs(vdet)), (name, idx)
+
     return {
+        "ent_samples": ent_samples, "mes": mes, "gibbon_quality": gq, "gibbon_repulsion": grep,
         "pen_radius": pen_r.tolist(), "pen_scale": pen_s.tolist(), "pen_soft": pen_soft, "pen_hard": pen_hard,
         "fant_y": yf.tolist(), "fant_mean": fant_mean, "fant_var_raw": fant_var,
         "name": name, "kind": kind, "d": d, "N": N, "variance": variance, "lengthscales": ls,

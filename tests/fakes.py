@@ -81,6 +81,8 @@ class FakeEngine:
         self._hyper = None
         self.state = None
         self._pen = None
+        self._ent = None
+        self._rep = None
         FakeEngine.created += 1
 
     def close(self):
@@ -121,6 +123,40 @@ class FakeEngine:
         if r.shape[0] != pts.shape[0] or sc.shape[0] != pts.shape[0]:
             raise ValueError("radius and scale must hold P values")
         self._pen = (kind, pts, r, sc)
+
+    def set_min_value_samples(self, samples):
+        sm = np.asarray(samples, float).reshape(-1)
+        if sm.size > 4096:
+            raise ValueError("number of min-value samples must be in 0..4096")
+        self._ent = sm if sm.size else None
+
+    def set_repulsion(self, twin=None, weight=1.0):
+        if twin is None:
+            self._rep = None
+            return
+        if not isinstance(twin, FakeEngine):
+            raise TypeError(f"the repulsion twin must be an engine, got {twin!r}")
+        if twin is self:
+            raise ValueError("the repulsion twin must be a different handle")
+        if twin.d != self.d or twin.kernel != self.kernel:
+            raise ValueError("the repulsion twin must share input dimension, kernel and device")
+        if not weight >= 0:
+            raise ValueError("repulsion weight must be >= 0")
+        twin._st()
+        self._rep = (twin, float(weight))
+
+    def _entropy_values(self, acq, Xq):
+        if self._ent is None:
+            raise RuntimeError("entropy-search acquisition needs min-value samples: call tgp_set_min_value_samples")
+        m, v = self.predict(Xq)
+        if acq == "mes":
+            return O.min_value_entropy_search(m, v, self._ent)
+        vals = O.gibbon_quality_term(m, v, self._ent, self.state.noise)
+        if self._rep is not None:
+            twin, w = self._rep
+            _, vt = twin.predict(Xq)
+            vals = vals + 0.5 * w * (np.log(vt + self.state.noise) - np.log(v + self.state.noise))
+        return vals
 
     def penalized(self, kind, pending, radius, scale):
         import contextlib
@@ -222,6 +258,8 @@ class FakeEngine:
             vals = O.negative_lower_confidence_bound(m, v, param)
         elif acq == "aei":
             vals = O.augmented_expected_improvement(m, v, param, self.state.noise)
+        elif acq in ("mes", "gibbon"):
+            vals = self._entropy_values(acq, Xq)
         else:
             raise KeyError(acq)
         if self._pen is not None:
@@ -229,6 +267,21 @@ class FakeEngine:
         return vals
 
     def acq_value_grad(self, acq, param, Xq):
+        if acq in ("mes", "gibbon"):
+            if self._ent is None:
+                raise RuntimeError("entropy-search acquisition needs min-value samples: call tgp_set_min_value_samples")
+            twin, w = self._rep if (self._rep is not None and acq == "gibbon") else (None, 0.0)
+            val, grad = O.entropy_value_and_grad(self._st(), acq, self._ent, np.asarray(Xq, float),
+                                                 None if twin is None else twin._st(), w)
+            if self._pen is not None:  # product rule with the penalization, by finite differences of phi
+                kind, pts, r, sc = self._pen
+                x = np.asarray(Xq, float)
+                phi = O.PENALIZERS[kind](x, pts, r, sc)
+                h = 1e-6
+                dphi = np.stack([(O.PENALIZERS[kind](x + h * e, pts, r, sc) - O.PENALIZERS[kind](x - h * e, pts, r, sc))
+                                 / (2 * h) for e in np.eye(self.d)], axis=1)
+                return val * phi, phi[:, None] * grad + val[:, None] * dphi
+            return val, grad
         if self._pen is not None:
             kind, pts, r, sc = self._pen
             return O.penalized_value_and_grad(self._st(), acq, param, kind, pts, r, sc, np.asarray(Xq, float))

@@ -304,3 +304,47 @@ def test_fantasizer_batches_on_gpu(method):
         assert dist.min() > 1e-4
     pts2 = rule.acquire_single(space, model, data)  # next BO step reuses the objects
     assert pts2.shape == (3, 2)
+
+
+def test_entropy_search_rules_on_gpu():
+    """EGO + MinValueEntropySearch / GIBBON (entropy.py) on the real engine: values equal the oracle's reference-form
+    acquisition built from the builder's own samples; a GIBBON batch spreads out; the Gumbel sampler's samples are
+    the restated algorithm's."""
+    import trieste_amd
+    import trieste_amd.acquisition as A
+    from trieste_amd.rng import make_rng
+
+    space, data, model, st = _setup(n=60, noise=1e-2)
+    xs = np.random.default_rng(3).uniform(size=(500, 2))
+    om, ov = O.predict(st, xs)
+    for sampler in (A.ExactThompsonSampler(True), A.GumbelSampler(True), A.ThompsonSamplerFromTrajectory(True)):
+        builder = A.MinValueEntropySearch(space, num_samples=6, grid_size=300, min_value_sampler=sampler)
+        acq = builder.prepare_acquisition_function(model, dataset=data)
+        assert acq.samples.shape == (6, 1) and np.all(acq.samples < O.eta_min_mean(st) + 0.3)
+        assert_close(acq(xs[:, None, :])[:, 0], O.min_value_entropy_search(om, ov, acq.samples[:, 0]), rtol=1e-6,
+                     atol=1e-9, what=f"MES with {sampler!r}")
+    trieste_amd.set_seed(5)
+    at = np.concatenate([data.query_points, space.sample(200, seed=2)])
+    got = A.GumbelSampler(True).sample(model, 4, at)
+    trieste_amd.set_seed(5)
+    u = make_rng().uniform(size=4)
+    ym, yv = O.predict_y(st, at)
+    assert_close(got, O.gumbel_min_value_samples(ym, np.sqrt(yv), u), rtol=1e-7, what="gumbel samples")
+    rule = A.EfficientGlobalOptimization(A.MinValueEntropySearch(space, grid_size=500))
+    pt = rule.acquire_single(space, model, data)
+    assert pt.shape == (1, 2)
+    acq = rule.acquisition_function
+    best = float(acq(pt[:, None, :])[0, 0])
+    assert best >= float(acq(xs[:, None, :]).max()) - 1e-9  # the refined point beats a random sweep
+    gb = A.GIBBON(space, grid_size=500)
+    rule = A.EfficientGlobalOptimization(gb, num_query_points=4)
+    pts = rule.acquire_single(space, model, data)
+    assert pts.shape == (4, 2) and np.all((pts >= 0) & (pts <= 1))
+    dist = np.linalg.norm(pts[:, None, :] - pts[None, :, :], axis=-1) + np.eye(4)
+    assert dist.min() > 1e-3
+    fused = rule.acquisition_function  # quality + repulsion against the first three points
+    ref = (O.gibbon_quality_term(om, ov, gb._quality_term.samples[:, 0], st.noise)
+           + O.gibbon_repulsion_term(st, xs, pts[:3], True))
+    assert_close(fused(xs[:, None, :])[:, 0], ref, rtol=1e-6, atol=1e-8, what="batch GIBBON == reference form")
+    assert float(fused(pts[3:4, None, :])[0, 0]) >= float(ref.max()) - 1e-8
+    assert model.engine.N == 60

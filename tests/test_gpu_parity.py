@@ -639,3 +639,104 @@ def test_clone_then_append_is_the_fantasized_posterior(cfg):
     with pytest.raises(RuntimeError):
         eng.clone_from(fresh)  # the source has no hyper-parameters
     np.testing.assert_array_equal(eng.predict(Xq)[0], m0)
+
+
+@pytest.mark.parametrize("c", [c for c in CASES if c["noise"] >= 1e-3],
+                         ids=[c["name"] for c in CASES if c["noise"] >= 1e-3])
+def test_entropy_tails_match_mpmath_goldens(c):
+    """TGP_ACQ_MES / TGP_ACQ_GIBBON (+ tgp_set_repulsion against a clone conditioned on the pending points) vs the
+    50-digit vectors, in the regime float64 resolves (gamma <= 30, see tests/test_oracle_golden.py)."""
+    N, var0, noise = c["N"], c["variance"], c["noise"]
+    floor = cancellation_floor(N + 3, var0, noise)
+    X, Y = np.array(c["X"]), np.array(c["Y"])
+    eng = _engine(c["kind"], c["d"], var0, c["lengthscales"], noise, c["mean_const"], X, Y)
+    Xq, pend = np.array(c["Xq"]), np.array(c["Xg"])[1]
+    smp = np.array(c["ent_samples"])
+    gm, gv = np.array(c["mean"]), np.array(c["var"])
+    gmax = np.max((smp[None, :] - gm[:, None]) / np.sqrt(gv)[:, None], axis=1)
+    ok = gmax <= 30.0
+    # sensitivity of the tails to the posterior's own rounding: d/dmean ~ gamma / sd
+    sens = floor * 100 * (1.0 + np.abs(gmax[ok])) / np.sqrt(gv[ok])
+    with pytest.raises(RuntimeError):
+        eng.acq_values("mes", 0.0, Xq)  # no samples yet
+    eng.set_min_value_samples(smp)
+    assert_close(eng.acq_values("mes", 0.0, Xq)[ok], np.array(c["mes"])[ok], rtol=1e-6, atol=sens + 1e-14, what="mes")
+    assert_close(eng.acq_values("gibbon", 0.0, Xq)[ok], np.array(c["gibbon_quality"])[ok], rtol=1e-6, atol=sens + 1e-14,
+                 what="gibbon quality")
+    twin = eng.clone()
+    twin.append_data(pend, np.zeros(len(pend)))
+    eng.set_repulsion(twin, 1.0 / len(pend) ** 2)
+    both = eng.acq_values("gibbon", 0.0, Xq)
+    eng.set_repulsion(None)
+    quality = eng.acq_values("gibbon", 0.0, Xq)
+    assert_close(both - quality, c["gibbon_repulsion"], atol=floor / noise + 1e-14, what="gibbon repulsion")
+    eng.set_min_value_samples([])
+    with pytest.raises(RuntimeError):
+        eng.acq_values("gibbon", 0.0, Xq)
+
+
+@pytest.mark.parametrize("cfg", CONFIGS[:5], ids=[c[0] for c in CONFIGS[:5]])
+def test_entropy_sweeps_and_gradients_match_oracle(cfg):
+    """MES / GIBBON on every sweep entry point (values, arg-max, top-k, value-and-gradient), GIBBON with the
+    repulsion twin, against the oracle's reference-form values (block determinant) and analytic gradients."""
+    _, obj, d, kname, N, noise = cfg
+    X, Y, ls, c, st, Xq = _problem(obj, d, kname, N, noise, M=2500)
+    floor = cancellation_floor(N, 1.0, noise)
+    eng = _engine(kname, d, 1.0, ls, noise, c, X, Y)
+    rng = np.random.default_rng(13)
+    eta = O.eta_min_mean(st)
+    samples = eta - np.array([0.01, 0.05, 0.2, 0.35, 0.6])
+    pending = rng.uniform(size=(4, d))
+    weight = 1.0 / 16.0
+    om, ov = O.predict(st, Xq)
+    eng.set_min_value_samples(samples)
+    twin = eng.clone()
+    twin.append_data(pending, np.zeros(4))
+    sto = O.fantasized_state(st, pending, np.zeros(4))
+    gmax = np.max((samples[None, :] - om[:, None]) / np.sqrt(ov)[:, None], axis=1)
+    ok = gmax <= 30.0
+    sens = floor * 100 * (1.0 + np.abs(gmax)) / np.sqrt(ov) + 1e-13
+    for acq, ref in (("mes", O.min_value_entropy_search(om, ov, samples)),
+                     ("gibbon", O.gibbon_quality_term(om, ov, samples, noise))):
+        vals = eng.acq_values(acq, 0.0, Xq)
+        assert_close(vals[ok], ref[ok], rtol=1e-6, atol=sens[ok], what=acq)
+        val, idx, x = eng.acq_argmax(acq, 0.0, Xq, index_base=7)
+        assert idx - 7 == int(np.nanargmax(vals)) and val == vals[idx - 7]
+        np.testing.assert_array_equal(x, Xq[idx - 7])
+        tv, ti = eng.acq_topk(acq, 0.0, Xq, 11)
+        ov_, oi_ = O.top_k(vals, 11)
+        np.testing.assert_array_equal(ti, oi_)
+        np.testing.assert_array_equal(tv, ov_)
+    # batch GIBBON: quality + repulsion; the reference forms the repulsion from a block determinant
+    eng.set_repulsion(twin, weight)
+    full = eng.acq_values("gibbon", 0.0, Xq)
+    ref_full = O.gibbon_quality_term(om, ov, samples, noise) + weight * 16.0 * O.gibbon_repulsion_term(st, Xq, pending, True)
+    assert_close(full[ok], ref_full[ok], rtol=1e-6, atol=sens[ok] + floor / noise, what="gibbon + repulsion")
+    # gradients at points near the best data (the regime L-BFGS-B works in), incl. one training input
+    near = np.clip(X[np.argsort(Y)[:40]] + 0.03 * rng.standard_normal((40, d)), 0.0, 1.0)
+    near[0] = X[np.argmin(Y)]
+    for acq, tw, w in (("mes", None, 0.0), ("gibbon", None, 0.0), ("gibbon", sto, weight)):
+        eng.set_repulsion(twin if tw is not None else None, w)
+        gv_, gg = eng.acq_value_grad(acq, 0.0, near)
+        oval, ograd = O.entropy_value_and_grad(st, acq, samples, near, tw, w)
+        assert_close(gv_, oval, rtol=1e-6, atol=floor * 1e3 + 1e-12, what=f"{acq} value")
+        gscale = np.abs(ograd).max() + 1e-300
+        assert_close(gg, ograd, rtol=1e-5, atol=max(floor * 1e4, 1e-8 * gscale), what=f"{acq} gradient")
+        sweep_vals = eng.acq_values(acq, 0.0, near)
+        assert_close(gv_, sweep_vals, rtol=1e-8, atol=floor * 1e3 + 1e-12, what=f"{acq} value == sweep value")
+    eng.set_repulsion(None)
+    # local penalization composes with the entropy tails (LocalPenalization's second supported base)
+    base = eng.acq_values("mes", 0.0, Xq)
+    r, s = rng.uniform(0.1, 0.3, 4), rng.uniform(0.05, 0.2, 4)
+    with eng.penalized("soft", pending, r, s):
+        pen = eng.acq_values("mes", 0.0, Xq)
+    assert_close(pen, base * O.soft_local_penalizer(Xq, pending, r, s), rtol=1e-11, atol=1e-300, what="penalized mes")
+    # argument checks
+    from trieste_amd.engine import GPEngine
+
+    with pytest.raises(ValueError):
+        eng.set_repulsion(GPEngine(d + 1, kname), 1.0)
+    with pytest.raises(RuntimeError):
+        eng.set_repulsion(GPEngine(d, kname), 1.0)  # a twin without data
+    with pytest.raises(ValueError):
+        eng.set_repulsion(twin, -1.0)

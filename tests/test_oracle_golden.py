@@ -85,3 +85,33 @@ def test_oracle_greedy_batch_pieces_match_mpmath(c):
         assert_close(cm, c["fant_mean"], atol=floor * 100, what="conditional mean")
         assert_close(np.maximum(cv, 1e-12), np.maximum(np.array(c["fant_var_raw"]), 1e-12), atol=floor * 10,
                      what="conditional var")
+
+
+@pytest.mark.parametrize("c", CASES, ids=[c["name"] for c in CASES])
+def test_oracle_entropy_tails_match_mpmath(c):
+    """MES (entropy.py:195-214), GIBBON quality (:479-500) and repulsion (:580-619) against the mpmath vectors; the
+    repulsion also through the identity the engine uses (conditioned variance + noise = the block determinant)."""
+    st = _state(c)
+    floor = cancellation_floor(c["N"] + 3, c["variance"], c["noise"])
+    Xq, pend = np.array(c["Xq"]), np.array(c["Xg"])[1]
+    gm, gv = np.array(c["mean"]), np.array(c["var"])
+    smp = np.array(c["ent_samples"])
+    # -gamma ratio / 2 - log Phi(-gamma) subtracts two terms of size gamma^2 / 2 and takes the ratio from
+    # exp(difference of two such terms) -- in float64 in the reference too: where a sample lies far ABOVE a
+    # candidate's mean (gamma >> 1; wild extrapolations of the tiny-noise cases) float64 has no digits left, so
+    # the vectors pin the regime gamma <= 30
+    gmax = np.max((smp[None, :] - gm[:, None]) / np.sqrt(gv)[:, None], axis=1)
+    ok = gmax <= 30.0
+    assert ok.sum() >= 3
+    atol = 1e-16 + 2e-16 * np.maximum(gmax[ok], 1.0) ** 4
+    assert_close(O.min_value_entropy_search(gm, gv, smp)[ok], np.array(c["mes"])[ok], rtol=1e-6, atol=atol,
+                 what="mes(golden mv)")
+    assert_close(O.gibbon_quality_term(gm, gv, smp, c["noise"])[ok], np.array(c["gibbon_quality"])[ok], rtol=1e-6,
+                 atol=atol, what="gibbon quality(golden mv)")
+    if c["noise"] >= 1e-3:
+        rel = floor / c["noise"]  # log(var + noise): absolute error of var over its magnitude
+        assert_close(O.gibbon_repulsion_term(st, Xq, pend, True), c["gibbon_repulsion"], atol=rel, what="repulsion")
+        _, v0 = O.predict(st, Xq)
+        _, vt = O.predict(O.fantasized_state(st, pend, np.zeros(len(pend))), Xq)
+        twin_form = 0.5 * (np.log(vt + c["noise"]) - np.log(v0 + c["noise"])) / len(pend) ** 2
+        assert_close(twin_form, c["gibbon_repulsion"], atol=rel, what="repulsion through the conditioned model")

@@ -138,3 +138,32 @@ def test_penalized_gradient_matches_finite_differences(kind, acq):
     # at a pending point itself the distance has no gradient: that term is dropped, the result stays finite
     _, g0 = O.penalized_value_and_grad(st, acq, eta, kind, pending, radius, scale, pending[:1])
     assert np.all(np.isfinite(g0))
+
+
+@pytest.mark.parametrize("acq", ["mes", "gibbon"])
+def test_entropy_gradient_matches_finite_differences(acq):
+    """d/dx of min_value_entropy_search / GibbonAcquisition (entropy.py:195-214, 422-436, 479-500, 580-619) in
+    analytic form vs central differences of the reference-form values, in the regime the acquisition is used in
+    (samples a little below the best mean, candidates near the data)."""
+    rng = np.random.default_rng(4)
+    d = 3
+    X, Y = O.synthetic_problem(O.hartmann_6, 6, 40)
+    X, Y = X[:, :d], Y
+    st = O.gpr_update("matern52", float(np.var(Y)), O.default_lengthscales(d), 1e-3, float(Y.mean()), X, Y)
+    samples = O.eta_min_mean(st) - np.array([0.02, 0.1, 0.25, 0.4])
+    pending = rng.uniform(size=(3, d))
+    twin = O.fantasized_state(st, pending, np.zeros(3))
+    Xq = np.clip(X[np.argsort(Y)[:6]] + 0.05 * rng.standard_normal((6, d)), 0, 1)
+
+    def f(x):
+        m, v = O.predict(st, x)
+        if acq == "mes":
+            return O.min_value_entropy_search(m, v, samples)
+        return O.gibbon_quality_term(m, v, samples, st.noise) + O.gibbon_repulsion_term(st, x, pending, True)
+
+    val, grad = O.entropy_value_and_grad(st, acq, samples, Xq, twin, 1.0 / 9.0)
+    np.testing.assert_allclose(val, f(Xq), rtol=1e-8, atol=1e-12)
+    assert np.abs(val).max() > 1e-3
+    h = 1e-6
+    num = np.stack([(f(Xq + h * e) - f(Xq - h * e)) / (2 * h) for e in np.eye(d)], axis=1)
+    np.testing.assert_allclose(grad, num, rtol=1e-5, atol=1e-6 * np.abs(num).max())

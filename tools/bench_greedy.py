@@ -42,7 +42,20 @@ r, s = rng.uniform(0.05, 0.3, 10), rng.uniform(0.05, 0.3, 10)
 with eng.penalized("soft", pend, r, s):
     ms1, _ = timed(lambda: eng.acq_argmax("ei", eta, cand), 2)
 print(f"EI arg-max over 2^20 candidates: fused {ms0:.1f} ms, locally penalized (10 pending) {ms1:.1f} ms", flush=True)
-for name, builder in (("LocalPenalization(soft)", lambda: A.LocalPenalization(space)),
+eng.set_min_value_samples(eta - np.array([0.01, 0.05, 0.1, 0.2, 0.4]))
+ms2, _ = timed(lambda: eng.acq_argmax("mes", 0.0, cand), 2)
+eng.set_repulsion(twin, 0.01)
+ms3, _ = timed(lambda: eng.acq_argmax("gibbon", 0.0, cand), 2)
+eng.set_repulsion(None)
+print(f"MES arg-max over 2^20 candidates {ms2:.1f} ms; GIBBON with repulsion twin (two sweeps) {ms3:.1f} ms", flush=True)
+for name, builder in (("MinValueEntropySearch", lambda: A.MinValueEntropySearch(space)),):
+    rule = A.EfficientGlobalOptimization(builder())
+    rule.acquire_single(space, model, data)
+    t0 = time.perf_counter()
+    rule.acquire_single(space, model, data)
+    print(f"EGO {name}: acquire {(time.perf_counter() - t0) * 1e3:.0f} ms", flush=True)
+for name, builder in (("GIBBON", lambda: A.GIBBON(space)),
+                      ("LocalPenalization(soft)", lambda: A.LocalPenalization(space)),
                       ("LocalPenalization(hard)", lambda: A.LocalPenalization(space, penalizer=A.hard_local_penalizer)),
                       ("Fantasizer(KB)", lambda: A.Fantasizer()),
                       ("Fantasizer(sample)", lambda: A.Fantasizer(fantasize_method="sample"))):

@@ -16,7 +16,7 @@ TGP_OK, TGP_ERR_SHAPE, TGP_ERR_NOT_PD, TGP_ERR_ALLOC, TGP_ERR_HIP, TGP_ERR_STATE
 HOST, DEVICE = 0, 1
 KERNELS = {"rbf": 0, "squared_exponential": 0, "matern12": 1, "matern32": 2, "matern52": 3}
 PENALIZERS = {"none": 0, "soft": 1, "hard": 2}
-ACQ = {"ei": 0, "pi": 1, "nlcb": 2, "aei": 3}
+ACQ = {"ei": 0, "pi": 1, "nlcb": 2, "aei": 3, "mes": 4, "gibbon": 5}
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int64)
@@ -35,6 +35,8 @@ SIGNATURES = {
     "tgp_append_data": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int]),
     "tgp_clone_from": (C.c_int, [_vp, _vp]),
     "tgp_set_penalization": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int64]),
+    "tgp_set_min_value_samples": (C.c_int, [_vp, _vp, C.c_int]),
+    "tgp_set_repulsion": (C.c_int, [_vp, _vp, C.c_double]),
     "tgp_penalization_values": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int]),
     "tgp_get_sizes": (C.c_int, [_vp, _ip, C.POINTER(C.c_int)]),
     "tgp_nlml": (C.c_int, [_vp, _dp, _vp]),

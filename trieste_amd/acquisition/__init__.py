@@ -1,6 +1,8 @@
 """Acquisition functions, optimizers, rules and samplers of the hot path."""
 from .continuous_thompson_sampling import (GreedyContinuousThompsonSampling, ParallelContinuousThompsonSampling,
                                            negate_trajectory_function)
+from .entropy import (GIBBON, GibbonAcquisition, MinValueEntropySearch, gibbon_quality_term,
+                      gibbon_repulsion_term, min_value_entropy_search)
 from .function import (AugmentedExpectedImprovement, BatchMonteCarloExpectedImprovement, ExpectedImprovement,
                        MonteCarloExpectedImprovement, NegativeLowerConfidenceBound, ProbabilityOfImprovement,
                        augmented_expected_improvement, batch_monte_carlo_expected_improvement, expected_improvement,
@@ -15,5 +17,5 @@ from .optimizer import (FailedOptimizationError, automatic_optimizer_selector, b
                         generate_continuous_optimizer, generate_initial_points, generate_random_search_optimizer,
                         optimize_discrete, sample_from_space)
 from .rule import AcquisitionRule, DiscreteThompsonSampling, EfficientGlobalOptimization, RandomSampling
-from .sampler import ExactThompsonSampler, ThompsonSampler, ThompsonSamplerFromTrajectory
+from .sampler import ExactThompsonSampler, GumbelSampler, ThompsonSampler, ThompsonSamplerFromTrajectory
 from .utils import select_nth_output, split_acquisition_function, split_acquisition_function_calls

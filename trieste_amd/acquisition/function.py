@@ -45,21 +45,41 @@ class _posterior_tail(AcquisitionFunctionClass):
             raise ValueError(f"This acquisition function only supports batch sizes of one, got input shape {tuple(x.shape)}")
         return x[..., 0, :]
 
-    def __call__(self, x):
+    def _prepare(self) -> None:
+        """Install per-function engine state before a call (the entropy tails' min-value samples)."""
+
+    # the engine calls proper; wrappers that install their own engine state (GibbonAcquisition) use these
+    def _evaluate(self, x):
         return self._engine.acq_values(self._acq, self._param, self._points(x))[..., None]
+
+    def _value_and_gradient(self, points):
+        return self._engine.acq_value_grad(self._acq, self._param, points)
+
+    def _argmax(self, points, index_base: int = 0):
+        return self._engine.acq_argmax(self._acq, self._param, points, index_base)
+
+    def _top_k(self, points, k: int, index_base: int = 0):
+        return self._engine.acq_topk(self._acq, self._param, points, k, index_base)
+
+    def __call__(self, x):
+        self._prepare()
+        return self._evaluate(x)
 
     def value_and_gradient(self, points):
         """points [P, D] -> (values [P], d value / d point [P, D]): the pair
         tfp.math.value_and_gradient feeds L-BFGS-B with in the reference (optimizer.py:628-629)."""
-        return self._engine.acq_value_grad(self._acq, self._param, points)
+        self._prepare()
+        return self._value_and_gradient(points)
 
-    # fused sweeps (no [M] values written to HBM / returned to the host)
+    # fused sweeps (no [M] values returned to the host)
     def argmax(self, points, index_base: int = 0):
         """points [M, D] -> (value, global index, point [D])."""
-        return self._engine.acq_argmax(self._acq, self._param, points, index_base)
+        self._prepare()
+        return self._argmax(points, index_base)
 
     def top_k(self, points, k: int, index_base: int = 0):
-        return self._engine.acq_topk(self._acq, self._param, points, k, index_base)
+        self._prepare()
+        return self._top_k(points, k, index_base)
 
 
 class expected_improvement(_posterior_tail):

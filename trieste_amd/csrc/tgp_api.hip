@@ -101,8 +101,13 @@ struct tgp_handle_s {
   // local penalization applied to every tgp_acq_* result while pen_kind != 0 (tgp_set_penalization)
   int pen_kind = 0, pen_P = 0;
   DevBuf d_pen;  // [P, d] pending points, [P] radius, [P] scale
+  // entropy-search tails (TGP_ACQ_MES / TGP_ACQ_GIBBON): min-value samples; GIBBON's repulsion twin
+  int ent_S = 0;
+  DevBuf d_ent;  // [S]
+  tgp_handle rep_twin = nullptr;  // not owned: this model conditioned additionally on the pending points
+  double rep_weight = 0.0;
   // scratch
-  DevBuf s_in, s_in2, s_out1, s_out2, s_out3, s_blkv, s_blki, s_small, s_kcache, s_ssq, s_aslab, s_grad, s_ks, s_part;
+  DevBuf s_ent, s_in, s_in2, s_out1, s_out2, s_out3, s_blkv, s_blki, s_small, s_kcache, s_ssq, s_aslab, s_grad, s_ks, s_part;
   // timing of the dominant kernel
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double last_ms = 0.0;
@@ -228,7 +233,7 @@ hipError_t launch_sweep_timed(tgp_handle h, const SweepArgs& a, bool joint) {
     // Few candidate blocks (EGO's default sweep is max(5000, 1000 d) candidates = 63 blocks at d = 8): one
     // workgroup per block walks all of W alone (7.5 ms at N = 4096) on a quarter of the CUs.  Split every
     // block's row blocks of W into up to 8 groups of roughly equal triangular work.
-    const int nb = (int)(h->Npad / 256);
+    const int nb = (int)(a.m.Npad / 256);
     int g = (int)std::min<int64_t>(std::min(8, nb), (8 * (int64_t)h->num_cu + grid - 1) / grid);
     if (g > 1) {
       const int total = nb * (nb + 1) / 2;
@@ -252,11 +257,11 @@ hipError_t launch_sweep_timed(tgp_handle h, const SweepArgs& a, bool joint) {
   if (ws) {
     wgrid = grid * std::max(1, am.split_g);
     wgrid = wgrid < h->num_cu ? wgrid : h->num_cu;  // persistent: one workgroup per CU
-    hipError_t ea = h->s_kcache.reserve((size_t)wgrid * (size_t)h->Npad * SW_BN * sizeof(double));
+    hipError_t ea = h->s_kcache.reserve((size_t)wgrid * (size_t)a.m.Npad * SW_BN * sizeof(double));
     if (ea != hipSuccess) return ea;
     am.kcache = h->s_kcache.as<double>();
     if (joint) {
-      ea = h->s_aslab.reserve((size_t)wgrid * (size_t)h->Npad * SW_BN * sizeof(double));
+      ea = h->s_aslab.reserve((size_t)wgrid * (size_t)a.m.Npad * SW_BN * sizeof(double));
       if (ea != hipSuccess) return ea;
       am.aslab = h->s_aslab.as<double>();
     }
@@ -357,6 +362,53 @@ int gemm_tall(tgp_handle h, bool tb, int m, int n, int k, double alpha, const do
   return TGP_OK;
 }
 
+constexpr int ACQ_KIND_MAX = TGP_ACQ_GIBBON;  // public kinds: EI, PI, -LCB, AEI, MES, GIBBON
+constexpr int ACQ_LOGYVAR = 6;  // internal tail log(var + noise): tgp::ACQ_LOGYVAR of tgp_dev.hpp
+
+// Acquisition values of M device-resident candidates into dvals (device, [M]): the fused sweep for the posterior
+// tails; sweep -> (mean, var) -> tail kernel for the entropy tails (their S-sample loop stays out of the MFMA
+// kernel's register budget; 16 B per candidate of extra HBM traffic against N^2 flops); then the local
+// penalization, if one is set.
+int acq_values_device(tgp_handle h, int acq_kind, double param, const double* dXq, int64_t M, double* dvals) {
+  SweepArgs a{};
+  a.m = model_dev(h);
+  a.Xq = dXq;
+  a.M = M;
+  if (acq_kind < TGP_ACQ_MES) {
+    a.acq_out = dvals;
+    a.acq_kind = acq_kind;
+    a.acq_param = param;
+    HIPCHK(h, launch_sweep_timed(h, a, false));
+  } else {
+    if (h->ent_S == 0)
+      return fail(h, TGP_ERR_STATE, "entropy-search acquisition needs min-value samples: call tgp_set_min_value_samples");
+    HIPCHK(h, h->s_ent.reserve((size_t)3 * M * sizeof(double)));
+    double* mean = h->s_ent.as<double>();
+    double* var = mean + M;
+    double* var_twin = nullptr;
+    a.mean_out = mean;
+    a.var_out = var;
+    a.acq_kind = -1;
+    HIPCHK(h, launch_sweep_timed(h, a, false));
+    if (acq_kind == TGP_ACQ_GIBBON && h->rep_twin) {
+      tgp_handle t = h->rep_twin;
+      if (!t->have_data) return fail(h, TGP_ERR_STATE, "the repulsion twin has no data");
+      SweepArgs b{};
+      b.m = model_dev(t);
+      b.Xq = dXq;
+      b.M = M;
+      var_twin = var + M;
+      b.var_out = var_twin;
+      b.acq_kind = -1;
+      HIPCHK(h, launch_sweep_timed(h, b, false));
+    }
+    launch_entropy_tail(h->stream, mean, var, var_twin, M, acq_kind, h->noise, h->d_ent.as<double>(), h->ent_S,
+                        h->rep_weight, dvals);
+  }
+  apply_penalization(h, dvals, dXq, M);
+  return TGP_OK;
+}
+
 }  // namespace
 
 namespace tgp {
@@ -419,7 +471,7 @@ int tgp_destroy(tgp_handle h) {
     (void)hipStreamSynchronize(nullptr);
   }
   for (DevBuf* b : {&h->d_xn, &h->d_ls, &h->d_X, &h->d_Y, &h->d_Xs, &h->d_A, &h->d_L, &h->d_W, &h->d_alpha,
-                    &h->d_err, &h->d_tmp1, &h->d_tmp2, &h->d_info, &h->d_pen, &h->s_in, &h->s_in2, &h->s_out1,
+                    &h->d_err, &h->d_tmp1, &h->d_tmp2, &h->d_info, &h->d_pen, &h->d_ent, &h->s_ent, &h->s_in, &h->s_in2, &h->s_out1,
                     &h->s_out2, &h->s_out3, &h->s_blkv, &h->s_blki, &h->s_small, &h->s_kcache, &h->s_ssq, &h->s_aslab, &h->s_grad, &h->s_ks, &h->s_part})
     b->release();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -658,6 +710,40 @@ int tgp_set_penalization(tgp_handle h, int kind, const double* pending, const do
   return TGP_OK;
 }
 
+int tgp_set_min_value_samples(tgp_handle h, const double* samples, int S) {
+  if (!h) return TGP_ERR_ARG;
+  if (S < 0 || S > 4096) return fail(h, TGP_ERR_SHAPE, "number of min-value samples must be in 0..4096, got %d", S);
+  if (S == 0) {
+    h->ent_S = 0;
+    return TGP_OK;
+  }
+  if (!samples) return fail(h, TGP_ERR_ARG, "samples is NULL");
+  if (int rc = set_device(h)) return rc;
+  h->ent_S = 0;
+  HIPCHK(h, h->d_ent.reserve((size_t)S * sizeof(double)));
+  HIPCHK(h, hipMemcpyAsync(h->d_ent.p, samples, (size_t)S * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->ent_S = S;
+  return TGP_OK;
+}
+
+int tgp_set_repulsion(tgp_handle h, tgp_handle twin, double weight) {
+  if (!h) return TGP_ERR_ARG;
+  if (!twin) {
+    h->rep_twin = nullptr;
+    h->rep_weight = 0.0;
+    return TGP_OK;
+  }
+  if (twin == h) return fail(h, TGP_ERR_ARG, "the repulsion twin must be a different handle");
+  if (twin->d != h->d || twin->kind != h->kind || twin->device != h->device)
+    return fail(h, TGP_ERR_SHAPE, "the repulsion twin must share input dimension, kernel and device");
+  if (!twin->have_data) return fail(h, TGP_ERR_STATE, "the repulsion twin has no data");
+  if (!(weight >= 0.0)) return fail(h, TGP_ERR_ARG, "repulsion weight must be >= 0");
+  h->rep_twin = twin;
+  h->rep_weight = weight;
+  return TGP_OK;
+}
+
 int tgp_penalization_values(tgp_handle h, const double* Xq, int64_t M, double* out, int where) {
   if (!h) return TGP_ERR_ARG;
   if (h->pen_kind == 0 || h->pen_P == 0) return fail(h, TGP_ERR_STATE, "no penalization set: call tgp_set_penalization first");
@@ -828,8 +914,24 @@ int tgp_eta(tgp_handle h, double* eta) {
 
 int tgp_acq_values(tgp_handle h, int acq_kind, double param, const double* Xq, int64_t M, double* out,
                    int where) {
-  if (acq_kind < 0 || acq_kind > 3) return fail(h, TGP_ERR_ARG, "unknown acquisition kind %d", acq_kind);
+  if (acq_kind < 0 || acq_kind > ACQ_KIND_MAX) return fail(h, TGP_ERR_ARG, "unknown acquisition kind %d", acq_kind);
   if (M > 0 && !out) return fail(h, TGP_ERR_ARG, "out is NULL");
+  if (h && acq_kind >= TGP_ACQ_MES) {  // entropy tails: sweep + tail kernel
+    if (!h->have_data) return fail(h, TGP_ERR_STATE, "model has no data: call tgp_set_data first");
+    if (M < 0) return fail(h, TGP_ERR_SHAPE, "M must be >= 0");
+    if (M == 0) return TGP_OK;
+    if (!Xq) return fail(h, TGP_ERR_ARG, "Xq is NULL");
+    if (int rc = set_device(h)) return rc;
+    const double* dXq;
+    double* dout;
+    if (int rc = stage_in(h, h->s_in, Xq, (size_t)M * h->d, where, &dXq)) return rc;
+    if (int rc = stage_out_prepare(h, h->s_out3, out, M, where, &dout)) return rc;
+    if (int rc = acq_values_device(h, acq_kind, param, dXq, M, dout)) return rc;
+    if (int rc = stage_out_finish(h, dout, out, M, where)) return rc;
+    if (int rc = sync(h)) return rc;
+    HIPCHK(h, hipGetLastError());
+    return TGP_OK;
+  }
   return sweep_common(h, Xq, M, nullptr, nullptr, out, acq_kind, param, where, false, 0, nullptr, nullptr,
                       nullptr);
 }
@@ -837,7 +939,7 @@ int tgp_acq_values(tgp_handle h, int acq_kind, double param, const double* Xq, i
 int tgp_acq_value_grad(tgp_handle h, int acq_kind, double param, const double* Xq, int64_t P, double* val,
                        double* grad, int where) {
   if (!h) return TGP_ERR_ARG;
-  if (acq_kind < 0 || acq_kind > 3) return fail(h, TGP_ERR_ARG, "unknown acquisition kind %d", acq_kind);
+  if (acq_kind < 0 || acq_kind > ACQ_KIND_MAX) return fail(h, TGP_ERR_ARG, "unknown acquisition kind %d", acq_kind);
   if (!h->have_data) return fail(h, TGP_ERR_STATE, "model has no data: call tgp_set_data first");
   if (P < 0 || (P > 0 && (!Xq || !val || !grad))) return fail(h, TGP_ERR_ARG, "bad arguments");
   if (P == 0) return TGP_OK;
@@ -848,7 +950,8 @@ int tgp_acq_value_grad(tgp_handle h, int acq_kind, double param, const double* X
   if (int rc = stage_in(h, h->s_in, Xq, (size_t)P * h->d, where, &dXq)) return rc;
   if (int rc = stage_out_prepare(h, h->s_out1, val, P, where, &dval)) return rc;
   if (int rc = stage_out_prepare(h, h->s_out2, grad, (size_t)P * h->d, where, &dgrad)) return rc;
-  HIPCHK(h, h->s_grad.reserve((size_t)3 * Npad * Ppad * sizeof(double)));
+  const int64_t Nscratch = (acq_kind == TGP_ACQ_GIBBON && h->rep_twin) ? std::max(Npad, h->rep_twin->Npad) : Npad;
+  HIPCHK(h, h->s_grad.reserve((size_t)3 * Nscratch * Ppad * sizeof(double)));
   double* B = h->s_grad.as<double>();
   double* C1 = B + (size_t)Npad * Ppad;
   double* Z = C1 + (size_t)Npad * Ppad;
@@ -859,7 +962,26 @@ int tgp_acq_value_grad(tgp_handle h, int acq_kind, double param, const double* X
                          Ppad, 3)) return rc;
   if (int rc = gemm_tall(h, false, (int)Npad, (int)Ppad, (int)Npad, 1.0, h->d_A.as<double>(), Npad, C1, Ppad, 0.0, Z,
                          Ppad, 5)) return rc;
-  launch_grad_tail(h->stream, m, dXq, P, Ppad, B, C1, Z, acq_kind, param, dval, dgrad);
+  if (acq_kind >= TGP_ACQ_MES && h->ent_S == 0)
+    return fail(h, TGP_ERR_STATE, "entropy-search acquisition needs min-value samples: call tgp_set_min_value_samples");
+  tgp_handle twin = acq_kind == TGP_ACQ_GIBBON ? h->rep_twin : nullptr;
+  launch_grad_tail(h->stream, m, dXq, P, Ppad, B, C1, Z, acq_kind, param, dval, dgrad, h->d_ent.as<double>(), h->ent_S,
+                   twin ? h->rep_weight : 0.0, 0.0);
+  if (twin) {  // + w/2 log(var_twin + noise): the same pipeline on the conditioned model, accumulated
+    if (!twin->have_data) return fail(h, TGP_ERR_STATE, "the repulsion twin has no data");
+    const int64_t Nt = twin->Npad;
+    double* Bt = h->s_grad.as<double>();
+    double* C1t = Bt + (size_t)Nt * Ppad;
+    double* Zt = C1t + (size_t)Nt * Ppad;
+    const ModelDev mt = model_dev(twin);
+    launch_kstar_t(h->stream, mt, dXq, P, Ppad, Bt);
+    if (int rc = gemm_tall(h, false, (int)Nt, (int)Ppad, (int)Nt, 1.0, twin->d_W.as<double>(), Nt, Bt, Ppad, 0.0, C1t,
+                           Ppad, 3)) return rc;
+    if (int rc = gemm_tall(h, false, (int)Nt, (int)Ppad, (int)Nt, 1.0, twin->d_A.as<double>(), Nt, C1t, Ppad, 0.0, Zt,
+                           Ppad, 5)) return rc;
+    launch_grad_tail(h->stream, mt, dXq, P, Ppad, Bt, C1t, Zt, ACQ_LOGYVAR, 0.0, dval, dgrad, nullptr, 0, 0.0,
+                     0.5 * h->rep_weight);
+  }
   if (h->pen_kind != 0 && h->pen_P > 0) {
     const double* pend = h->d_pen.as<double>();
     launch_penalize_grad(h->stream, dval, dgrad, dXq, P, h->d, h->pen_kind, h->pen_P, pend,
@@ -987,9 +1109,9 @@ int tgp_acq_topk(tgp_handle h, int acq_kind, double param, const double* Xq, int
 
 int tgp_acq_argmax(tgp_handle h, int acq_kind, double param, const double* Xq, int64_t M,
                    int64_t index_base, double* best_val, int64_t* best_idx, double* best_x, int where) {
-  if (acq_kind < 0 || acq_kind > 3) return fail(h, TGP_ERR_ARG, "unknown acquisition kind %d", acq_kind);
-  if (h && h->pen_kind != 0 && h->pen_P > 0) {
-    // penalised: the values take one trip through HBM (8 B per candidate) between the sweep and the arg-max
+  if (acq_kind < 0 || acq_kind > ACQ_KIND_MAX) return fail(h, TGP_ERR_ARG, "unknown acquisition kind %d", acq_kind);
+  if (h && ((h->pen_kind != 0 && h->pen_P > 0) || acq_kind >= TGP_ACQ_MES)) {
+    // penalised / entropy tails: the values take one trip through HBM (8 B per candidate) between the sweep and the arg-max
     if (M < 1) return fail(h, TGP_ERR_SHAPE, "arg-max over an empty candidate set");
     double v;
     int64_t i;
@@ -1015,7 +1137,7 @@ int tgp_acq_topk(tgp_handle h, int acq_kind, double param, const double* Xq, int
   if (!h) return TGP_ERR_ARG;
   if (k < 1 || k > 1024) return fail(h, TGP_ERR_ARG, "k must be in 1..1024");
   if (M < k) return fail(h, TGP_ERR_SHAPE, "top-k needs M >= k (M=%lld, k=%d)", (long long)M, k);
-  if (acq_kind < 0 || acq_kind > 3) return fail(h, TGP_ERR_ARG, "unknown acquisition kind %d", acq_kind);
+  if (acq_kind < 0 || acq_kind > ACQ_KIND_MAX) return fail(h, TGP_ERR_ARG, "unknown acquisition kind %d", acq_kind);
   if (!h->have_data) return fail(h, TGP_ERR_STATE, "model has no data: call tgp_set_data first");
   if (int rc = set_device(h)) return rc;
   // acquisition values stay on the device (8 B / candidate), then k extraction passes
@@ -1024,15 +1146,7 @@ int tgp_acq_topk(tgp_handle h, int acq_kind, double param, const double* Xq, int
   {
     const double* dXq;
     if (int rc = stage_in(h, h->s_in, Xq, (size_t)M * h->d, where, &dXq)) return rc;
-    SweepArgs a{};
-    a.m = model_dev(h);
-    a.Xq = dXq;
-    a.M = M;
-    a.acq_out = dvals;
-    a.acq_kind = acq_kind;
-    a.acq_param = param;
-    HIPCHK(h, launch_sweep_timed(h, a, false));
-    apply_penalization(h, dvals, dXq, M);
+    if (int rc = acq_values_device(h, acq_kind, param, dXq, M, dvals)) return rc;
   }
   HIPCHK(h, h->s_blkv.reserve(512 * sizeof(double)));
   HIPCHK(h, h->s_blki.reserve(512 * sizeof(int64_t)));

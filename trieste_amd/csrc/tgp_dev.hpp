@@ -10,7 +10,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
 constexpr int KIND_RBF = 0, KIND_M12 = 1, KIND_M32 = 2, KIND_M52 = 3;
-constexpr int ACQ_EI = 0, ACQ_PI = 1, ACQ_NLCB = 2, ACQ_AEI = 3;
+constexpr int ACQ_EI = 0, ACQ_PI = 1, ACQ_NLCB = 2, ACQ_AEI = 3, ACQ_MES = 4, ACQ_GIBBON = 5, ACQ_LOGYVAR = 6;
 constexpr double VAR_FLOOR = 1e-12;  // reference interface.py:123
 
 // v_mfma_f64_16x16x4_f64: D(16x16) += A(16x4) * B(4x16).
@@ -206,6 +206,66 @@ __device__ __forceinline__ double acq_tail(int acq, double param, double mean, d
 
 // ---- (value, index) ordering: larger value wins, ties -> smaller index (tf.math.argmax) -----
 // NaN never wins (TF's argmax would propagate NaN; a NaN acquisition value is an upstream bug).
+// log Phi(x), stable in both tails -- tfp.distributions.Normal.log_cdf (special_math.log_ndtr, float64):
+// x > 8: -Phi(-x);  -20 <= x <= 8: log Phi(x);  x < -20: the asymptotic series of order 3
+//   -x^2/2 - log(-x) - log(2 pi)/2 + log(1 - 1/x^2 + 3/x^4 - 15/x^6).
+__device__ __forceinline__ double log_normal_cdf(double x) {
+  if (x > 8.0) return -normal_cdf(-x);
+  if (x >= -20.0) return log(normal_cdf(x));
+  const double x2 = x * x;
+  return -0.5 * x2 - log(-x) - 0.9189385332046727 + log(1.0 - 1.0 / x2 + 3.0 / (x2 * x2) - 15.0 / (x2 * x2 * x2));
+}
+
+// Entropy-search tails on (mean, var) and the min-value samples s_1..s_S (reference
+// acquisition/function/entropy.py): with gamma_s = (s - mean) / sd, sd = max(sqrt(var), 1e-8) (CLAMP_LB :47),
+// ratio = pdf(gamma) / Phi(-gamma) computed as exp(log pdf - log Phi(-gamma)):
+//   ACQ_MES     (min_value_entropy_search.__call__ :195-214): mean_s [-gamma ratio / 2 - log Phi(-gamma)]
+//   ACQ_GIBBON  (gibbon_quality_term.__call__ :479-500):      -1/2 mean_s log(1 + rho^2 ratio (gamma - ratio)),
+//                                                              rho^2 = var / (var + noise)
+//   ACQ_LOGYVAR: log(var + noise) -- the two halves of GIBBON's repulsion term (:580-619)
+// Returns the value and its partial derivatives w.r.t. mean and var (for the L-BFGS-B refinement).
+__device__ __forceinline__ void entropy_tail(int acq, double mean, double var, double noise,
+                                             const double* __restrict__ samples, int S, double& v,
+                                             double& dv_dmu, double& dv_dvar) {
+  if (acq == ACQ_LOGYVAR) {
+    v = log(var + noise);
+    dv_dmu = 0.0;
+    dv_dvar = 1.0 / (var + noise);
+    return;
+  }
+  const double sd_raw = sqrt(var);
+  const bool clamped = !(sd_raw > 1e-8);
+  const double sd = clamped ? 1e-8 : sd_raw;
+  const double rho2 = var / (var + noise);
+  double acc = 0.0, acc_u = 0.0, acc_rho = 0.0, acc_uu = 0.0;
+  for (int t = 0; t < S; ++t) {
+    const double u = (samples[t] - mean) / sd;
+    const double lmc = log_normal_cdf(-u);
+    const double r = exp(-0.5 * u * u - 0.9189385332046727 - lmc);
+    double f, fu;  // per-sample value and d/du;  dr/du = r (r - u)
+    if (acq == ACQ_MES) {
+      f = -0.5 * u * r - lmc;
+      fu = 0.5 * r - 0.5 * u * r * (r - u);
+    } else {
+      const double hh = r * (u - r);
+      const double inner = 1.0 + rho2 * hh;
+      const double dh = -r * (u - r) * (u - r) + r - r * r * (r - u);
+      f = -0.5 * log(inner);
+      fu = -0.5 * rho2 * dh / inner;
+      acc_rho += -0.5 * hh / inner;  // d/d rho^2
+    }
+    acc += f;
+    acc_u += fu;
+    acc_uu += fu * u;
+  }
+  const double inv = 1.0 / (double)S;
+  v = acc * inv;
+  // du/dmean = -1/sd;  du/dvar = -u / (2 var) (zero where sd is clamped)
+  dv_dmu = -acc_u * inv / sd;
+  dv_dvar = clamped ? 0.0 : -acc_uu * inv / (2.0 * var);
+  if (acq == ACQ_GIBBON) dv_dvar += acc_rho * inv * noise / ((var + noise) * (var + noise));
+}
+
 __device__ __forceinline__ bool better(double v, int64_t i, double bv, int64_t bi) {
   return (v > bv) || (v == bv && i < bi);
 }

@@ -123,7 +123,10 @@ void launch_qei_tail(hipStream_t s, const double* mean, const double* cov, int64
 void launch_kstar_t(hipStream_t s, const ModelDev& m, const double* Xq, int64_t P, int64_t Ppad, double* B);
 void launch_grad_tail(hipStream_t s, const ModelDev& m, const double* Xq, int64_t P, int64_t Ppad,
                       const double* B, const double* C1, const double* Z, int acq, double param, double* val,
-                      double* grad);
+                      double* grad, const double* samples = nullptr, int S = 0, double rep_w = 0.0,
+                      double accum = 0.0);
+void launch_entropy_tail(hipStream_t s, const double* mean, const double* var, const double* var_twin, int64_t M,
+                         int acq, double noise, const double* samples, int S, double weight, double* out);
 int64_t nlml_blocks(int64_t Npad);
 void launch_nlml(hipStream_t s, const ModelDev& m, const double* Kinv, const double* L, const double* err,
                  double* partial, double* out);

@@ -155,7 +155,9 @@ __global__ __launch_bounds__(GT_THREADS) void grad_tail_kernel(ModelDev m, const
                                                                const double* __restrict__ B,
                                                                const double* __restrict__ C1,
                                                                const double* __restrict__ Z, int acq,
-                                                               double param, double* __restrict__ val,
+                                                               double param, const double* __restrict__ samples,
+                                                               int S, double rep_w, double accum,
+                                                               double* __restrict__ val,
                                                                double* __restrict__ grad) {
   __shared__ double red[4][2 + 2 * MAX_D];
   const int64_t p = blockIdx.x;
@@ -224,16 +226,24 @@ __global__ __launch_bounds__(GT_THREADS) void grad_tail_kernel(ModelDev m, const
       v = normal_cdf(z);
       dv_dmu = -pdf / sd;
       dv_dvar = -pdf * z / (2.0 * var);
+    } else if (acq >= ACQ_MES) {  // entropy tails; GIBBON's repulsion: this model's half, -w/2 log(var + noise)
+      entropy_tail(acq, mu, var, m.noise, samples, S, v, dv_dmu, dv_dvar);
+      if (rep_w != 0.0) {
+        v -= 0.5 * rep_w * log(var + m.noise);
+        dv_dvar -= 0.5 * rep_w / (var + m.noise);
+      }
     } else {
       v = -(mu - param * sd);
       dv_dmu = -1.0;
       dv_dvar = param / (2.0 * sd);
     }
-    val[p] = v;
+    // accum != 0: add accum * (value, gradient) to what is there (the conditioned twin's half of the repulsion)
+    val[p] = accum != 0.0 ? val[p] + accum * v : v;
     for (int c = 0; c < d; ++c) {
       const double dmu = tot(2 + c);
       const double dvar = clipped ? 0.0 : -2.0 * tot(2 + MAX_D + c);  // clip_by_value has zero gradient
-      grad[p * d + c] = dv_dmu * dmu + dv_dvar * dvar;
+      const double g = dv_dmu * dmu + dv_dvar * dvar;
+      grad[p * d + c] = accum != 0.0 ? grad[p * d + c] + accum * g : g;
     }
   }
 }
@@ -245,9 +255,9 @@ void launch_kstar_t(hipStream_t s, const ModelDev& m, const double* Xq, int64_t 
 
 void launch_grad_tail(hipStream_t s, const ModelDev& m, const double* Xq, int64_t P, int64_t Ppad,
                       const double* B, const double* C1, const double* Z, int acq, double param, double* val,
-                      double* grad) {
+                      double* grad, const double* samples, int S, double rep_w, double accum) {
   hipLaunchKernelGGL(grad_tail_kernel, dim3((unsigned)P), dim3(GT_THREADS), 0, s, m, Xq, P, Ppad, B, C1, Z, acq,
-                     param, val, grad);
+                     param, samples, S, rep_w, accum, val, grad);
 }
 
 }  // namespace tgp

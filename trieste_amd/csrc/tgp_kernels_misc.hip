@@ -397,6 +397,32 @@ void launch_penalize_grad(hipStream_t s, double* val, double* grad, const double
 }
 
 // ---------------------------------------------------------------------------------------------
+// Entropy-search acquisition values from a sweep's (mean, var) arrays (entropy_tail in tgp_dev.hpp): one thread
+// per candidate, the S min-value samples through scalar loads.  var_twin != nullptr adds GIBBON's repulsion term
+//   weight / 2 * (log(var_twin + noise) - log(var + noise)),
+// var_twin being the variance of the model conditioned additionally on the pending points:
+// yvar - A^T (B + noise I)^-1 A of gibbon_repulsion_term.__call__ (entropy.py:596-612) IS that variance + noise.
+__global__ __launch_bounds__(256) void entropy_tail_kernel(const double* __restrict__ mean,
+                                                           const double* __restrict__ var,
+                                                           const double* __restrict__ var_twin, int64_t M, int acq,
+                                                           double noise, const double* __restrict__ samples, int S,
+                                                           double weight, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  double v, dmu, dvar;
+  entropy_tail(acq, mean[i], var[i], noise, samples, S, v, dmu, dvar);
+  if (var_twin) v += 0.5 * weight * (log(var_twin[i] + noise) - log(var[i] + noise));
+  out[i] = v;
+}
+
+void launch_entropy_tail(hipStream_t s, const double* mean, const double* var, const double* var_twin, int64_t M,
+                         int acq, double noise, const double* samples, int S, double weight, double* out) {
+  if (M <= 0) return;
+  hipLaunchKernelGGL(entropy_tail_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, mean, var, var_twin, M,
+                     acq, noise, samples, S, weight, out);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Box.sample (reference space.py:843-867) on device: uniform in [lower, upper).
 __global__ void sample_box_kernel(uint64_t seed, int64_t first, int64_t M, int d,
                                   const double* __restrict__ lower, const double* __restrict__ upper,

@@ -116,6 +116,24 @@ class GPEngine:
         self._chk(self._lib.tgp_set_penalization(self._h, _lib.PENALIZERS[kind], pts.ctypes.data, r.ctypes.data,
                                                  sc.ctypes.data, P))
 
+    def set_min_value_samples(self, samples) -> None:
+        """Samples of the objective's minimum value used by the "mes" / "gibbon" acquisition kinds
+        (tgp_set_min_value_samples); an empty array clears them."""
+        sm = np.ascontiguousarray(np.asarray(samples, dtype=_NP).reshape(-1))
+        self._chk(self._lib.tgp_set_min_value_samples(self._h, sm.ctypes.data if sm.size else None, int(sm.size)))
+
+    def set_repulsion(self, twin: "GPEngine" = None, weight: float = 1.0) -> None:
+        """GIBBON's repulsion term: ``twin`` is this model conditioned additionally on the pending points
+        (tgp_set_repulsion); None clears.  The engine keeps a reference so the twin outlives the setting."""
+        if twin is None:
+            self._chk(self._lib.tgp_set_repulsion(self._h, None, 0.0))
+            self._twin = None
+            return
+        if not isinstance(twin, GPEngine):
+            raise TypeError(f"the repulsion twin must be a GPEngine, got {twin!r}")
+        self._chk(self._lib.tgp_set_repulsion(self._h, twin._h, float(weight)))
+        self._twin = twin
+
     def penalization_values(self, Xq):
         """prod_p phi_p(x) of the penalization currently set, at Xq [..., d] -> [...]."""
         a, lead, M = self._flat(Xq)
