@@ -348,3 +348,29 @@ def test_entropy_search_rules_on_gpu():
     assert_close(fused(xs[:, None, :])[:, 0], ref, rtol=1e-6, atol=1e-8, what="batch GIBBON == reference form")
     assert float(fused(pts[3:4, None, :])[0, 0]) >= float(ref.max()) - 1e-8
     assert model.engine.N == 60
+
+
+def test_asynchronous_rules_on_gpu():
+    """AsynchronousOptimization (batch qEI over [pending; candidate]) and AsynchronousGreedy (LocalPenalization /
+    Fantasizer / GIBBON) through an Ask-Tell loop on the real engine (rule.py:492-833)."""
+    import trieste_amd.acquisition as A
+    from trieste_amd import objectives as OBJ
+    from trieste_amd.ask_tell_optimization import AskTellOptimizer
+    from trieste_amd.data import Dataset
+
+    for make in (lambda s: A.AsynchronousOptimization(A.BatchMonteCarloExpectedImprovement(256),
+                                                      optimizer=A.generate_random_search_optimizer(2000, seed=1)),
+                 lambda s: A.AsynchronousGreedy(A.LocalPenalization(s, num_samples=200), num_query_points=2),
+                 lambda s: A.AsynchronousGreedy(A.Fantasizer()),
+                 lambda s: A.AsynchronousGreedy(A.GIBBON(s, grid_size=200))):
+        space, data, model, st = _setup(n=40, noise=1e-2)
+        rule = make(space)
+        loop = AskTellOptimizer(space, data, model, rule, fit_model=False)
+        p1 = loop.ask()
+        p2 = loop.ask()
+        q = p1.shape[0]
+        assert p1.shape == (q, 2) and len(loop.acquisition_state.pending_points) == 2 * q
+        loop.tell(Dataset(p1, OBJ.scaled_branin(p1)))
+        p3 = loop.ask()
+        np.testing.assert_allclose(loop.acquisition_state.pending_points, np.concatenate([p2, p3]))
+        assert model.engine.N == 40 + q and np.all((p3 >= 0) & (p3 <= 1))

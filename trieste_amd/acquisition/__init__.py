@@ -16,6 +16,7 @@ from .interface import (AcquisitionFunctionBuilder, AcquisitionFunctionClass, Gr
 from .optimizer import (FailedOptimizationError, automatic_optimizer_selector, batchify_joint, batchify_vectorize,
                         generate_continuous_optimizer, generate_initial_points, generate_random_search_optimizer,
                         optimize_discrete, sample_from_space)
-from .rule import AcquisitionRule, DiscreteThompsonSampling, EfficientGlobalOptimization, RandomSampling
+from .rule import (AcquisitionRule, AsynchronousGreedy, AsynchronousOptimization, AsynchronousRuleState,
+                   DiscreteThompsonSampling, EfficientGlobalOptimization, RandomSampling)
 from .sampler import ExactThompsonSampler, GumbelSampler, ThompsonSampler, ThompsonSamplerFromTrajectory
 from .utils import select_nth_output, split_acquisition_function, split_acquisition_function_calls

@@ -17,8 +17,8 @@ def _as_map(x):
 
 class AskTellOptimizer:
     def __init__(self, search_space: SearchSpace, datasets: Union[Mapping, Dataset], models,
-                 acquisition_rule: Optional[AcquisitionRule] = None, *, fit_model: bool = True,
-                 track_data: bool = True):
+                 acquisition_rule: Optional[AcquisitionRule] = None, acquisition_state=None, *,
+                 fit_model: bool = True, track_data: bool = True):
         self._search_space = search_space
         self._datasets = dict(_as_map(datasets))
         self._models = dict(_as_map(models))
@@ -33,6 +33,7 @@ class AskTellOptimizer:
                                  f"got keys {self._datasets.keys()}")
             acquisition_rule = EfficientGlobalOptimization()
         self._acquisition_rule = acquisition_rule
+        self._acquisition_state = acquisition_state  # of stateful rules (ask_tell_optimization.py:237)
         self._track_data = track_data
         self._fit_model = fit_model
         if fit_model:
@@ -64,9 +65,19 @@ class AskTellOptimizer:
             return next(iter(self._models.values()))
         raise ValueError(f"Expected a single model, found {len(self._models)}")
 
+    @property
+    def acquisition_state(self):
+        """The state of a stateful acquisition rule (ask_tell_optimization.py:431-433)."""
+        return self._acquisition_state
+
     def ask(self):
-        """Suggest the next query point(s) (ask_tell_optimization.py:595-640)."""
-        return self._acquisition_rule.acquire(self._search_space, self._models, datasets=self._datasets)
+        """Suggest the next query point(s) (ask_tell_optimization.py:595-640).  A stateful rule returns a
+        function ``state -> (new state, points)``; the optimizer threads its state through it (:613-618)."""
+        points_or_stateful = self._acquisition_rule.acquire(self._search_space, self._models, datasets=self._datasets)
+        if callable(points_or_stateful):
+            self._acquisition_state, query_points = points_or_stateful(self._acquisition_state)
+            return query_points
+        return points_or_stateful
 
     def tell(self, new_data: Union[Mapping, Dataset]) -> None:
         """Add observations and refresh the models (ask_tell_optimization.py:642-729)."""

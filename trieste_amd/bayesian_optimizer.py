@@ -39,6 +39,7 @@ class Err:
 class Record:
     datasets: Mapping
     models: Mapping
+    acquisition_state: object = None
 
     @property
     def dataset(self) -> Dataset:
@@ -79,7 +80,8 @@ class BayesianOptimizer:
     def __repr__(self) -> str:
         return f"BayesianOptimizer({self._observer!r}, {self._search_space!r})"
 
-    def optimize(self, num_steps: int, datasets, models, acquisition_rule: Optional[AcquisitionRule] = None, *,
+    def optimize(self, num_steps: int, datasets, models, acquisition_rule: Optional[AcquisitionRule] = None,
+                 acquisition_state=None, *,
                  track_state: bool = True, fit_model: bool = True, fit_initial_model: bool = True,
                  early_stop_callback: Optional[Callable] = None) -> OptimizationResult:
         datasets = dict(_as_map(datasets))
@@ -100,21 +102,23 @@ class BayesianOptimizer:
         for step in range(1, num_steps + 1):
             try:
                 if track_state:
-                    history.append(Record(dict(datasets), models))
+                    history.append(Record(dict(datasets), models, acquisition_state))
                 if step == 1 and fit_model and fit_initial_model:
                     for tag, model in models.items():
                         model.update(datasets[tag])
                         model.optimize(datasets[tag])
                 points = acquisition_rule.acquire(self._search_space, models, datasets=datasets)
+                if callable(points):  # stateful rule (bayesian_optimizer.py:796-800)
+                    acquisition_state, points = points(acquisition_state)
                 observed = _as_map(self._observer(points))
                 datasets = {tag: datasets[tag] + observed[tag] for tag in datasets}
                 for tag, model in models.items():
                     model.update(datasets[tag])
                     if fit_model:
                         model.optimize(datasets[tag])
-                if early_stop_callback is not None and early_stop_callback(datasets, models):
+                if early_stop_callback is not None and early_stop_callback(datasets, models, acquisition_state):
                     break
             except Exception as error:  # noqa: BLE001 -- the reference returns Err for any failure
                 traceback.print_exc()
                 return OptimizationResult(Err(error), history)
-        return OptimizationResult(Ok(Record(datasets, models)), history)
+        return OptimizationResult(Ok(Record(datasets, models, acquisition_state)), history)
