@@ -263,3 +263,98 @@ def test_ego_with_fantasizer_returns_a_batch_and_leaves_the_model_alone():
     assert model.engine.N == 15
     pts2 = rule.acquire_single(space, model, data)  # next step: same objects, fresh clone
     assert pts2.shape == (3, 2)
+
+
+# ---- small siblings (reference tests/unit/acquisition/function/test_function.py) --------------------------
+def test_negative_predictive_mean_probability_of_feasibility_and_predictive_variance():
+    from scipy.stats import norm
+
+    from trieste_amd.acquisition import (NegativePredictiveMean, PredictiveVariance, ProbabilityOfFeasibility,
+                                         predictive_variance)
+
+    model, data = _model()
+    xs = _grid(6)
+    mean, var = model.predict(xs)
+    npm = NegativePredictiveMean().prepare_acquisition_function(model, data)
+    np.testing.assert_allclose(npm(xs[:, None, :]), -mean, rtol=1e-12)
+    with pytest.raises(ValueError):
+        ProbabilityOfFeasibility(np.array([1.0, 2.0]))
+    pof = ProbabilityOfFeasibility(0.3)
+    assert pof.threshold == 0.3
+    fn = pof.prepare_acquisition_function(model)
+    np.testing.assert_allclose(fn(xs[:, None, :]), norm.cdf((0.3 - mean) / np.sqrt(var)), rtol=1e-10)
+    assert pof.update_acquisition_function(fn, model) is fn
+    pv = PredictiveVariance().prepare_acquisition_function(model)
+    np.testing.assert_allclose(pv(xs[:, None, :]), var + 1e-6, rtol=1e-9)  # batch of one: the variance (+ jitter)
+    batch = np.random.default_rng(0).uniform(size=(5, 3, 2))
+    _, cov = model.predict_joint(batch)
+    np.testing.assert_allclose(pv(batch), np.exp(np.linalg.slogdet(cov + 1e-6)[1]), rtol=1e-10)
+
+    class NoJoint:
+        pass
+
+    with pytest.raises(NotImplementedError):
+        predictive_variance(NoJoint(), 1e-6)
+
+
+def test_make_positive_keeps_the_fused_entry_points_and_feeds_local_penalization():
+    from trieste_amd.acquisition import MakePositive, NegativePredictiveMean
+
+    model, data = _model()
+    builder = MakePositive(NegativePredictiveMean())
+    fn = builder.prepare_acquisition_function(model, data)
+    xs = np.random.default_rng(2).uniform(size=(150, 2))
+    base = -model.predict(xs)[0]
+    vals = fn(xs[:, None, :])
+    np.testing.assert_allclose(vals, np.log1p(np.exp(base)), rtol=1e-12)
+    assert np.all(vals > 0)
+    assert builder.update_acquisition_function(fn, model, data) is fn
+    v, i, x = fn.argmax(xs)
+    assert i == int(np.argmax(vals)) and np.isclose(v, vals[i, 0]) and np.array_equal(x, xs[i])
+    tv, ti = fn.top_k(xs, 4)
+    np.testing.assert_array_equal(ti, np.argsort(-vals[:, 0], kind="stable")[:4])
+    val, grad = fn.value_and_gradient(xs[:5])
+    h = 1e-6
+    num = np.stack([(fn((xs[:5] + h * e)[:, None, :]) - fn((xs[:5] - h * e)[:, None, :]))[:, 0] / (2 * h) for e in np.eye(2)], axis=1)
+    np.testing.assert_allclose(grad, num, rtol=1e-5, atol=1e-8)
+    assert not hasattr(MakePositive(ExpectedImprovement()).prepare_acquisition_function(model, data), "nonexistent")
+    # the reference's use: a strictly positive base for local penalization (greedy_batch.py:86-91)
+    space = Box([0, 0], [1, 1])
+    rule = EfficientGlobalOptimization(LocalPenalization(space, num_samples=100, base_acquisition_function_builder=builder),
+                                       optimizer=generate_random_search_optimizer(500, seed=2, on_device=False),
+                                       num_query_points=3)
+    pts = rule.acquire_single(space, model, data)
+    assert pts.shape == (3, 2)
+
+
+def test_multiple_optimism_lower_confidence_bound():
+    from scipy.stats import norm
+
+    from trieste_amd.acquisition import MultipleOptimismNegativeLowerConfidenceBound, multiple_optimism_lower_confidence_bound
+
+    model, data = _model()
+    space = Box([0, 0], [1, 1])
+    with pytest.raises(ValueError):
+        multiple_optimism_lower_confidence_bound(model, 0)
+    builder = MultipleOptimismNegativeLowerConfidenceBound(space)
+    fn = builder.prepare_acquisition_function(model, data)
+    assert builder.update_acquisition_function(fn, model, data) is fn
+    with pytest.raises(ValueError):
+        builder.update_acquisition_function(lambda x: x, model, data)
+    B = 4
+    x = np.random.default_rng(1).uniform(size=(30, B, 2))
+    vals = fn(x)
+    assert vals.shape == (30, B)
+    betas = 5.0 * 2 * norm.ppf(0.5 + 0.5 * np.arange(1, B + 1) / (B + 1.0))
+    mean, var = model.predict(x)
+    np.testing.assert_allclose(vals, -mean[..., 0] + np.sqrt(var[..., 0]) * betas, rtol=1e-10)
+    with pytest.raises(ValueError):  # fixed batch size
+        fn(x[:, :2, :])
+    val, grad = fn.value_and_gradient(x[:3])
+    assert val.shape == (3, B) and grad.shape == (3, B, 2)
+    np.testing.assert_allclose(val, vals[:3], rtol=1e-10)
+    # a vectorized builder: EGO optimises the B columns independently
+    rule = EfficientGlobalOptimization(MultipleOptimismNegativeLowerConfidenceBound(space), num_query_points=3,
+                                       optimizer=generate_continuous_optimizer(num_initial_samples=200, num_optimization_runs=3))
+    pts = rule.acquire_single(space, model, data)
+    assert pts.shape == (3, 2) and np.all((pts >= 0) & (pts <= 1))

@@ -4,7 +4,10 @@ from .continuous_thompson_sampling import (GreedyContinuousThompsonSampling, Par
 from .entropy import (GIBBON, GibbonAcquisition, MinValueEntropySearch, gibbon_quality_term,
                       gibbon_repulsion_term, min_value_entropy_search)
 from .function import (AugmentedExpectedImprovement, BatchMonteCarloExpectedImprovement, ExpectedImprovement,
-                       MonteCarloExpectedImprovement, NegativeLowerConfidenceBound, ProbabilityOfImprovement,
+                       MakePositive, MonteCarloExpectedImprovement, MultipleOptimismNegativeLowerConfidenceBound,
+                       NegativeLowerConfidenceBound, NegativePredictiveMean, PredictiveVariance,
+                       ProbabilityOfFeasibility, ProbabilityOfImprovement, multiple_optimism_lower_confidence_bound,
+                       predictive_variance,
                        augmented_expected_improvement, batch_monte_carlo_expected_improvement, expected_improvement,
                        monte_carlo_expected_improvement, negative_lower_confidence_bound,
                        probability_below_threshold)
