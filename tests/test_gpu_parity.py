@@ -740,3 +740,30 @@ def test_entropy_sweeps_and_gradients_match_oracle(cfg):
         eng.set_repulsion(GPEngine(d, kname), 1.0)  # a twin without data
     with pytest.raises(ValueError):
         eng.set_repulsion(twin, -1.0)
+
+
+@pytest.mark.parametrize("N0", [1100, 2050])
+def test_append_with_split_k_products_equals_full_refactorisation(N0):
+    """Appending to a model with >= 1024 kept rows takes the split-k form of the three strip products
+    (L21, Schur complement, T): same factor as a full refactorisation and as the oracle."""
+    d, kind, noise = 5, "matern52", 1e-3
+    X, Y = O.synthetic_problem(O.ackley, d, N0 + 40, seed=N0)
+    ls = O.default_lengthscales(d)
+    c = float(np.mean(Y))
+    eng = _engine(kind, d, 1.0, ls, noise, c, X[:N0], Y[:N0])
+    eng.append_data(X[N0:N0 + 1], Y[N0:N0 + 1])
+    eng.append_data(X[N0 + 1:], Y[N0 + 1:])
+    full = _engine(kind, d, 1.0, ls, noise, c, X, Y)
+    sto = O.gpr_update(kind, 1.0, ls, noise, c, X, Y)
+    floor = cancellation_floor(N0 + 40, 1.0, noise)
+    La, Wa, aa = eng.get_factor()
+    Lf, Wf, af = full.get_factor()
+    assert_close(La, sto.L, atol=floor, what="L after append")
+    assert_close(La, Lf, rtol=1e-9, atol=floor, what="L append == full")
+    assert_close(Wa, Wf, rtol=1e-7, atol=floor * 1e3 / noise ** 0.5, what="W append == full")
+    assert_close(aa, af, rtol=1e-7, atol=floor * max(1.0, np.abs(af).max()) / noise, what="alpha append == full")
+    Xq = np.random.default_rng(1).uniform(size=(300, d))
+    ma, va = eng.predict(Xq)
+    mo, vo = O.predict(sto, Xq)
+    assert_close(ma, mo, atol=floor * 10, what="mean after append")
+    assert_close(va, vo, atol=floor, what="var after append")

@@ -580,12 +580,14 @@ static int factorise(tgp_handle h, int64_t N, int64_t keep_rows) {
     double* A21 = As + (size_t)lo * Npad;
     double* L21 = L + (size_t)lo * Npad;
     double* A22 = As + (size_t)lo * Npad + lo;
-    launch_gemm(s, true, (int)s2, (int)lo, (int)lo, 1.0, A21, Npad, W, Npad, 0.0, L21, Npad, false, 1);
-    launch_gemm(s, true, (int)s2, (int)s2, (int)lo, -1.0, L21, Npad, L21, Npad, 1.0, A22, Npad, true);
+    // a strip of s2 <= 256 + 63 rows against lo ~ N columns: few output tiles, each walking k = lo alone --
+    // the three long-k products split k over up to 8 workgroups per tile (fixed-order reduction)
+    if (int rc = gemm_tall(h, true, (int)s2, (int)lo, (int)lo, 1.0, A21, Npad, W, Npad, 0.0, L21, Npad, 1)) return rc;
+    if (int rc = gemm_tall(h, true, (int)s2, (int)s2, (int)lo, -1.0, L21, Npad, L21, Npad, 1.0, A22, Npad, 0)) return rc;
     chol_inv(s, FactorWs{As, L, W, Npad, h->d_info.as<int>()}, lo, Npad);
     double* W22 = W + (size_t)lo * Npad + lo;
     double* W21 = W + (size_t)lo * Npad;
-    launch_gemm(s, false, (int)s2, (int)lo, (int)lo, 1.0, L21, Npad, W, Npad, 0.0, A21, Npad, false, 2);
+    if (int rc = gemm_tall(h, false, (int)s2, (int)lo, (int)lo, 1.0, L21, Npad, W, Npad, 0.0, A21, Npad, 2)) return rc;
     launch_gemm(s, false, (int)s2, (int)lo, (int)s2, -1.0, W22, Npad, A21, Npad, 0.0, W21, Npad, false, 3);
   }
   // err = Y - c (zero padded)  -- gpflow GPRPosterior._precompute: err = Y - mean_function(X)
