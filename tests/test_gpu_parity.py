@@ -767,3 +767,24 @@ def test_append_with_split_k_products_equals_full_refactorisation(N0):
     mo, vo = O.predict(sto, Xq)
     assert_close(ma, mo, atol=floor * 10, what="mean after append")
     assert_close(va, vo, atol=floor, what="var after append")
+
+
+@pytest.mark.parametrize("M,k", [(100, 100), (8000, 80), (8192, 1024), (8193, 160), (20000, 333), (65536, 1024),
+                                 (70000, 50)])
+def test_topk_by_sorting_equals_stable_descending_sort(M, k):
+    """tgp_acq_topk: one sorting workgroup (M <= 8192), chunk sort + merge (M <= 65536), threshold passes above; all
+    equal the stable descending sort of the engine's own values (value desc, index asc; optimizer.py:326-335),
+    with duplicated candidates (ties) across chunk boundaries and an index base."""
+    d, kind = 3, "matern52"
+    X, Y = O.synthetic_problem(O.ackley, d, 90)
+    eng = _engine(kind, d, 1.0, O.default_lengthscales(d), 1e-2, float(np.mean(Y)), X, Y)
+    rng = np.random.default_rng(M)
+    Xq = rng.uniform(size=(M, d))
+    dup = rng.integers(0, M, size=min(M, 4000))
+    Xq[dup] = Xq[(dup * 7 + 8191) % M]  # exact ties, many of them in different 8192-chunks
+    eta = eng.eta()
+    vals = eng.acq_values("ei", eta, Xq)
+    tv, ti = eng.acq_topk("ei", eta, Xq, k, index_base=12345)
+    ov, oi = O.top_k(vals, k)
+    np.testing.assert_array_equal(ti, oi + 12345)
+    np.testing.assert_array_equal(tv, ov)

@@ -1150,13 +1150,13 @@ int tgp_acq_topk(tgp_handle h, int acq_kind, double param, const double* Xq, int
     if (int rc = stage_in(h, h->s_in, Xq, (size_t)M * h->d, where, &dXq)) return rc;
     if (int rc = acq_values_device(h, acq_kind, param, dXq, M, dvals)) return rc;
   }
-  HIPCHK(h, h->s_blkv.reserve(512 * sizeof(double)));
-  HIPCHK(h, h->s_blki.reserve(512 * sizeof(int64_t)));
+  HIPCHK(h, h->s_blkv.reserve((size_t)std::max(512, 8 * k) * sizeof(double)));
+  HIPCHK(h, h->s_blki.reserve((size_t)std::max(512, 8 * k) * sizeof(int64_t)));
   HIPCHK(h, h->s_small.reserve((size_t)k * 16 + 64));
   double* fv = h->s_small.as<double>();       // [k] winners' values
   int64_t* fi = (int64_t*)(fv + k);           // [k] winners' indices
   if (M <= topk_small_max()) {
-    launch_topk_small(h->stream, dvals, M, index_base, k, fv, fi);
+    launch_topk_small(h->stream, dvals, M, index_base, k, fv, fi, h->s_blkv.as<double>(), h->s_blki.as<int64_t>());
   } else {
     for (int t = 0; t < k; ++t)  // thresholds stay on the device: no host round trip per pass
       launch_topk_pass(h->stream, dvals, M, index_base, t ? fv + t - 1 : nullptr, t ? fi + t - 1 : nullptr,

@@ -112,7 +112,7 @@ void launch_topk_pass(hipStream_t s, const double* vals, int64_t M, int64_t inde
                       const int64_t* prev_idx, double* scratch_val, int64_t* scratch_idx, double* out_val,
                       int64_t* out_idx);
 void launch_topk_small(hipStream_t s, const double* vals, int64_t M, int64_t index_base, int k, double* out_val,
-                       int64_t* out_idx);
+                       int64_t* out_idx, double* scratch_val, int64_t* scratch_idx);
 int64_t topk_small_max();
 void launch_sample_box(hipStream_t s, uint64_t seed, int64_t first, int64_t M, int d,
                        const double* lower, const double* upper, double* out);
