@@ -243,59 +243,13 @@ void launch_topk_pass(hipStream_t s, const double* vals, int64_t M, int64_t inde
   launch_argmax_final(s, scratch_val, scratch_idx, TOPK_BLOCKS, out_val, out_idx);
 }
 
-// Small candidate sets (EGO's default initial sweep: max(5000, 1000 d) values): all k extraction steps in
-// ONE workgroup / ONE launch, the values stay in L2 (<= 512 KiB), each step is a block arg-max with the
-// previous winner as threshold.
+// Small candidate sets (EGO's default initial sweep: max(5000, 1000 d) values) are sorted instead of scanned k
+// times.
 constexpr int64_t TOPK_SMALL_MAX = 65536;
-__global__ __launch_bounds__(1024) void topk_small_kernel(const double* __restrict__ vals, int64_t M,
-                                                          int64_t index_base, int k, double* __restrict__ out_val,
-                                                          int64_t* __restrict__ out_idx) {
-  __shared__ double wv[16];
-  __shared__ int64_t wi[16];
-  __shared__ double bv;
-  __shared__ int64_t bi;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  double pv = 0.0;
-  int64_t pi = 0;
-  for (int t = 0; t < k; ++t) {
-    double v = -INFINITY;
-    int64_t i = INT64_MAX;
-    for (int64_t e = tid; e < M; e += 1024) {
-      const double x = vals[e];
-      const int64_t xi = index_base + e;
-      if (x != x) continue;
-      const bool after = t == 0 || (x < pv) || (x == pv && xi > pi);
-      if (after && better(x, xi, v, i)) {
-        v = x;
-        i = xi;
-      }
-    }
-    wave_argmax(v, i);
-    if (lane == 0) {
-      wv[w] = v;
-      wi[w] = i;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      for (int ww = 1; ww < 16; ++ww)
-        if (better(wv[ww], wi[ww], v, i)) {
-          v = wv[ww];
-          i = wi[ww];
-        }
-      bv = v;
-      bi = i;
-      out_val[t] = v;
-      out_idx[t] = i;
-    }
-    __syncthreads();
-    pv = bv;
-    pi = bi;
-  }
-}
-// The same result by sorting: a workgroup holds 8192 (value, offset) pairs in LDS (96 KiB) and runs a bitonic
+// A workgroup holds 8192 (value, offset) pairs in LDS (96 KiB) and runs a bitonic
 // network in the order (value descending, index ascending) -- 91 compare-exchange stages instead of k passes
-// over the values (top 80 of 8000: 3.3 ms -> well under 0.1 ms).  NaNs rank after everything (they are never
-// "better"); slots beyond the non-NaN count come out as (-inf, INT64_MAX) like the pass form.  More than 8192
+// over the values.  NaNs rank after everything (they are never
+// "better"); slots beyond the non-NaN count come out as (-inf, INT64_MAX), like in the pass form.  More than 8192
 // values: one workgroup per 8192-chunk emits its top k, a second launch sorts the <= 8 k survivors.
 constexpr int TOPK_SORT_N = 8192;
 __global__ __launch_bounds__(1024) void topk_sort_kernel(const double* __restrict__ vals,
