@@ -73,6 +73,26 @@ def test_box_and_discrete_space():
     assert ds.sample(100).shape == (6, 2) and ds.sample(3).shape == (3, 2)
 
 
+def test_box_halton_and_sobol_samples():
+    """reference tests/unit/test_space.py (sample_halton / sample_sobol): shapes, bounds, reproducibility given the
+    seed / skip, different otherwise, negative counts rejected; Sobol skip shifts the stream."""
+    box = Box([0.0, -1.0, 2.0], [1.0, 2.0, 2.5])
+    for sampler, key in ((box.sample_halton, "seed"), (box.sample_sobol, "skip")):
+        s = sampler(64, **{key: 5})
+        assert s.shape == (64, 3) and np.all(s >= box.lower) and np.all(s <= box.upper)
+        np.testing.assert_array_equal(s, sampler(64, **{key: 5}))
+        assert not np.array_equal(s, sampler(64, **{key: 6}))
+        assert sampler(0).shape == (0, 3)
+        with pytest.raises(ValueError):
+            sampler(-1)
+        assert not np.array_equal(sampler(8), sampler(8))  # unseeded: fresh randomisation / random skip
+        # low discrepancy: every coordinate's 64 points hit all 8 octiles of its range
+        u = (s - box.lower) / (box.upper - box.lower)
+        assert all(len(set(np.floor(u[:, c] * 8).astype(int))) == 8 for c in range(3))
+    np.testing.assert_array_equal(box.sample_sobol(10, skip=3)[2:], box.sample_sobol(8, skip=5))
+    np.testing.assert_allclose(Box([0.0, 0.0], [1.0, 1.0]).sample_sobol(1, skip=0), [[0.5, 0.5]])  # TF's first point
+
+
 def test_objective_known_answers():
     """objective(minimizers) == minimum, atol 1e-4 (reference test_single_objectives.py:64-72)."""
     np.testing.assert_allclose(OBJ.branin(OBJ.BRANIN_MINIMIZERS)[:, 0], OBJ.BRANIN_MINIMUM[0], atol=1e-4)

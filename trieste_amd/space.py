@@ -62,6 +62,41 @@ class Box(SearchSpace):
         rng = make_rng(seed)
         return rng.uniform(self._lower, self._upper, size=(num_samples, self.dimension))
 
+    def sample_halton(self, num_samples: int, seed: Optional[int] = None) -> np.ndarray:
+        """``num_samples`` points of a randomised Halton sequence [num_samples, D] (space.py:869-897: tfp's
+        ``sample_halton_sequence``, randomised unless seeded; here scipy's scrambled Halton generator -- TFP's
+        permutation stream cannot be reproduced outside TF, the low-discrepancy and seed-reproducibility
+        contracts are kept)."""
+        if num_samples < 0:
+            raise ValueError(f"num_samples must be non-negative, got {num_samples}")
+        if num_samples == 0:
+            return np.zeros((0, self.dimension))
+        from scipy.stats import qmc
+
+        gen = qmc.Halton(d=self.dimension, scramble=True, seed=make_rng(seed))
+        return (self._upper - self._lower) * gen.random(num_samples) + self._lower
+
+    def sample_sobol(self, num_samples: int, skip: Optional[int] = None) -> np.ndarray:
+        """``num_samples`` points of the (unscrambled) Sobol sequence after skipping ``skip`` points
+        [num_samples, D] (space.py:899-917: ``tf.math.sobol_sample``; same direction numbers, TF's stream starts
+        after the all-zero point).  ``skip=None`` draws a random skip below 2^16 like the reference."""
+        if num_samples < 0:
+            raise ValueError(f"num_samples must be non-negative, got {num_samples}")
+        if num_samples == 0:
+            return np.zeros((0, self.dimension))
+        import warnings
+
+        from scipy.stats import qmc
+
+        if skip is None:
+            skip = int(make_rng().integers(0, 2 ** 16))
+        gen = qmc.Sobol(d=self.dimension, scramble=False)
+        gen.fast_forward(int(skip) + 1)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")  # scipy warns when num_samples is not a power of two
+            pts = gen.random(num_samples)
+        return (self._upper - self._lower) * pts + self._lower
+
     def sample_device(self, engine, num_samples: int, seed: int = 0, first: int = 0):
         """The same distribution generated on the GPU (Philox4x32-10): a torch CUDA tensor
         [num_samples, D]; row ``first + i`` depends only on (seed, first + i), so shards agree."""
