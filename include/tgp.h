@@ -140,7 +140,10 @@ int tgp_set_min_value_samples(tgp_handle h, const double* samples, int S);
  * observations: variances do not depend on them).  The reference forms V_det = yvar - A^T (B + noise I)^-1 A
  * from covariance_between_points(x, pending) and predict_joint(pending); that Schur complement IS the
  * twin's predictive variance + noise.  weight = 1 / m^2 for rescaled_repulsion, else 1.  `twin` is not owned
- * and must outlive the setting; twin == NULL clears. */
+ * and must outlive the setting; twin == NULL clears.  When the twin is literally this model's data plus m <= 16
+ * appended rows with equal hyper-parameters (verified on the device once per data version) its variance is
+ * evaluated as the rank-m correction var(x) - sum_r (W'_r . k'(x))^2 over the twin's last m rows of W' = L'^-1
+ * -- m kernel sums per candidate -- instead of a second N^2 sweep; any other twin is swept itself. */
 int tgp_set_repulsion(tgp_handle h, tgp_handle twin, double weight);
 
 /* The penalization alone, prod_p phi_p(x) at Xq [M,d] -> out [M] (the penalizer objects are callables in the

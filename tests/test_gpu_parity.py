@@ -788,3 +788,54 @@ def test_topk_by_sorting_equals_stable_descending_sort(M, k):
     ov, oi = O.top_k(vals, k)
     np.testing.assert_array_equal(ti, oi + 12345)
     np.testing.assert_array_equal(tv, ov)
+
+
+@pytest.mark.parametrize("cfg", CONFIGS[:5], ids=[c[0] for c in CONFIGS[:5]])
+def test_gibbon_repulsion_by_rank_m_update_equals_the_twin_sweep(cfg, monkeypatch):
+    """A twin that is this model + m <= 16 appended rows gives its variance as var - sum_r (W'_r . k')^2 (m kernel
+    sums per candidate); any other twin -- more rows, or forced with TGP_NO_LOWRANK -- is swept itself.  Both equal
+    the oracle's block-determinant form; a changed base model or twin invalidates the cached check."""
+    _, obj, d, kname, N, noise = cfg
+    X, Y, ls, c, st, Xq = _problem(obj, d, kname, N, noise, M=1200)
+    floor = cancellation_floor(N, 1.0, noise)
+    rng = np.random.default_rng(17)
+    samples = O.eta_min_mean(st) - np.array([0.02, 0.1, 0.3])
+    om, ov = O.predict(st, Xq)
+    gmax = np.max((samples[None, :] - om[:, None]) / np.sqrt(ov)[:, None], axis=1)
+    ok = gmax <= 30.0
+
+    def batch_values(pending, weight):
+        eng = _engine(kname, d, 1.0, ls, noise, c, X, Y)
+        eng.set_min_value_samples(samples)
+        twin = eng.clone()
+        twin.append_data(pending[:1], np.zeros(1))
+        if len(pending) > 1:
+            twin.append_data(pending[1:], rng.standard_normal(len(pending) - 1))  # observations do not matter
+        eng.set_repulsion(twin, weight)
+        return eng, twin, eng.acq_values("gibbon", 0.0, Xq)
+
+    for m in (1, 5, 16, 17):  # 17 rows: beyond the rank-m form, the twin is swept
+        pending = rng.uniform(size=(m, d))
+        w = 1.0 / m ** 2
+        ref = O.gibbon_quality_term(om, ov, samples, noise) + O.gibbon_repulsion_term(st, Xq, pending, True)
+        eng, twin, low = batch_values(pending, w)
+        monkeypatch.setenv("TGP_NO_LOWRANK", "1")
+        _, _, swept = batch_values(pending, w)
+        monkeypatch.delenv("TGP_NO_LOWRANK")
+        sens = floor * 100 * (1.0 + np.abs(gmax)) / np.sqrt(ov) + floor / noise + 1e-13
+        assert_close(low[ok], ref[ok], rtol=1e-6, atol=sens[ok], what=f"rank-{m} form == reference form")
+        assert_close(low, swept, rtol=1e-7, atol=floor / noise + 1e-13, what=f"rank-{m} form == twin sweep")
+        # the cached check follows the data: grow the twin, then change the base model
+        extra = rng.uniform(size=(1, d))
+        twin.append_data(extra, np.zeros(1))
+        grown = eng.acq_values("gibbon", 0.0, Xq)
+        ref2 = O.gibbon_quality_term(om, ov, samples, noise) + w * (m + 1) ** 2 * O.gibbon_repulsion_term(
+            st, Xq, np.concatenate([pending, extra]), True)
+        assert_close(grown[ok], ref2[ok], rtol=1e-6, atol=sens[ok], what="after growing the twin")
+        eng.set_data(X[:-3], Y[:-3])  # the twin is no longer this model + rows: swept, whatever it is
+        st3 = O.gpr_update(kname, 1.0, ls, noise, c, X[:-3], Y[:-3])
+        m3, v3 = O.predict(st3, Xq)
+        _, vt = O.predict(O.fantasized_state(st, np.concatenate([pending, extra]), np.zeros(m + 1)), Xq)
+        ref3 = O.gibbon_quality_term(m3, v3, samples, noise) + 0.5 * w * (np.log(vt + noise) - np.log(v3 + noise))
+        g3 = np.max((samples[None, :] - m3[:, None]) / np.sqrt(v3)[:, None], axis=1) <= 30.0
+        assert_close(eng.acq_values("gibbon", 0.0, Xq)[g3], ref3[g3], rtol=1e-6, atol=sens[g3] * 10, what="foreign twin")

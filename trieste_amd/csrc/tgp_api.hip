@@ -12,6 +12,7 @@
 #include <new>
 #include <string>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <vector>
 
@@ -37,6 +38,7 @@ using namespace tgp;
 namespace {
 
 thread_local std::string g_create_error;
+std::atomic<uint64_t> g_data_version{0};  // stamps factorisations: unique across handles and threads
 
 struct DevBuf {  // grow-only device buffer
   void* p = nullptr;
@@ -106,6 +108,13 @@ struct tgp_handle_s {
   DevBuf d_ent;  // [S]
   tgp_handle rep_twin = nullptr;  // not owned: this model conditioned additionally on the pending points
   double rep_weight = 0.0;
+  // when the twin is literally this model's data + m <= 16 appended rows (same hyper-parameters), its variance is
+  // a rank-m correction of this model's: checked once per (data, twin data) version pair
+  uint64_t data_version = 0;       // process-wide unique stamp of the current factorisation (0: none)
+  uint64_t rep_self_version = 0, rep_twin_version = 0;
+  bool rep_checked = false, rep_lowrank = false;
+  int rep_m = 0;
+  DevBuf d_repv;                   // [N + m][m]: the twin's last m rows of W as weight columns
   // scratch
   DevBuf s_ent, s_in, s_in2, s_out1, s_out2, s_out3, s_blkv, s_blki, s_small, s_kcache, s_ssq, s_aslab, s_grad, s_ks, s_part;
   // timing of the dominant kernel
@@ -365,6 +374,40 @@ int gemm_tall(tgp_handle h, bool tb, int m, int n, int k, double alpha, const do
 constexpr int ACQ_KIND_MAX = TGP_ACQ_GIBBON;  // public kinds: EI, PI, -LCB, AEI, MES, GIBBON
 constexpr int ACQ_LOGYVAR = 6;  // internal tail log(var + noise): tgp::ACQ_LOGYVAR of tgp_dev.hpp
 
+// Is the repulsion twin this model + m <= 16 appended rows with equal hyper-parameters?  Then (see
+// lowrank_var_kernel) its variance needs m kernel sums per candidate instead of a second sweep.  The answer and
+// the weight columns are cached per (this model's data, the twin's data) version pair.
+int prepare_repulsion(tgp_handle h) {
+  tgp_handle t = h->rep_twin;
+  if (h->rep_checked && h->rep_self_version == h->data_version && h->rep_twin_version == t->data_version)
+    return TGP_OK;
+  h->rep_checked = false;
+  h->rep_lowrank = false;
+  const int64_t m = t->N - h->N;
+  const bool no_lowrank = getenv("TGP_NO_LOWRANK") != nullptr;  // A/B aid (read per check: tests toggle it)
+  bool ok = !no_lowrank && m >= 1 && m <= 16 && t->variance == h->variance && t->noise == h->noise && t->ls == h->ls;
+  if (ok) {
+    HIPCHK(h, h->s_small.reserve(64));
+    int* flag = h->s_small.as<int>();
+    HIPCHK(h, hipMemsetAsync(flag, 0, sizeof(int), h->stream));
+    launch_prefix_differs(h->stream, h->d_X.as<double>(), t->d_X.as<double>(), h->N * h->d, flag);
+    int differs = 0;
+    HIPCHK(h, hipMemcpyAsync(&differs, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    ok = differs == 0;
+  }
+  if (ok) {
+    HIPCHK(h, h->d_repv.reserve((size_t)t->Npad * m * sizeof(double)));
+    launch_rows_to_columns(h->stream, t->d_W.as<double>(), t->Npad, h->N, (int)m, t->Npad, h->d_repv.as<double>());
+    h->rep_m = (int)m;
+    h->rep_lowrank = true;
+  }
+  h->rep_self_version = h->data_version;
+  h->rep_twin_version = t->data_version;
+  h->rep_checked = true;
+  return TGP_OK;
+}
+
 // Acquisition values of M device-resident candidates into dvals (device, [M]): the fused sweep for the posterior
 // tails; sweep -> (mean, var) -> tail kernel for the entropy tails (their S-sample loop stays out of the MFMA
 // kernel's register budget; 16 B per candidate of extra HBM traffic against N^2 flops); then the local
@@ -393,14 +436,28 @@ int acq_values_device(tgp_handle h, int acq_kind, double param, const double* dX
     if (acq_kind == TGP_ACQ_GIBBON && h->rep_twin) {
       tgp_handle t = h->rep_twin;
       if (!t->have_data) return fail(h, TGP_ERR_STATE, "the repulsion twin has no data");
-      SweepArgs b{};
-      b.m = model_dev(t);
-      b.Xq = dXq;
-      b.M = M;
+      if (int rc = prepare_repulsion(h)) return rc;
       var_twin = var + M;
-      b.var_out = var_twin;
-      b.acq_kind = -1;
-      HIPCHK(h, launch_sweep_timed(h, b, false));
+      if (h->rep_lowrank) {  // rank-m correction of this model's variance
+        const int m = h->rep_m;
+        HIPCHK(h, h->s_ks.reserve((size_t)M * m * sizeof(double)));
+        TrajDev tr{};
+        tr.m = model_dev(t);
+        tr.F = 0;
+        tr.B = m;
+        tr.v = h->d_repv.as<double>();
+        tr.canonical = 1;
+        launch_kernel_sums(h->stream, tr, dXq, M, h->s_ks.as<double>());
+        launch_lowrank_var(h->stream, var, h->s_ks.as<double>(), M, m, var_twin);
+      } else {  // any other twin: its own variance sweep
+        SweepArgs b{};
+        b.m = model_dev(t);
+        b.Xq = dXq;
+        b.M = M;
+        b.var_out = var_twin;
+        b.acq_kind = -1;
+        HIPCHK(h, launch_sweep_timed(h, b, false));
+      }
     }
     launch_entropy_tail(h->stream, mean, var, var_twin, M, acq_kind, h->noise, h->d_ent.as<double>(), h->ent_S,
                         h->rep_weight, dvals);
@@ -471,7 +528,7 @@ int tgp_destroy(tgp_handle h) {
     (void)hipStreamSynchronize(nullptr);
   }
   for (DevBuf* b : {&h->d_xn, &h->d_ls, &h->d_X, &h->d_Y, &h->d_Xs, &h->d_A, &h->d_L, &h->d_W, &h->d_alpha,
-                    &h->d_err, &h->d_tmp1, &h->d_tmp2, &h->d_info, &h->d_pen, &h->d_ent, &h->s_ent, &h->s_in, &h->s_in2, &h->s_out1,
+                    &h->d_err, &h->d_tmp1, &h->d_tmp2, &h->d_info, &h->d_pen, &h->d_ent, &h->d_repv, &h->s_ent, &h->s_in, &h->s_in2, &h->s_out1,
                     &h->s_out2, &h->s_out3, &h->s_blkv, &h->s_blki, &h->s_small, &h->s_kcache, &h->s_ssq, &h->s_aslab, &h->s_grad, &h->s_ks, &h->s_part})
     b->release();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -605,6 +662,7 @@ static int factorise(tgp_handle h, int64_t N, int64_t keep_rows) {
     return fail(h, TGP_ERR_NOT_PD, "Cholesky failed: K + noise*I is not positive definite (pivot %d)",
                 info - 1);
   h->have_data = true;
+  h->data_version = ++g_data_version;
   return TGP_OK;
 }
 
@@ -683,6 +741,7 @@ int tgp_clone_from(tgp_handle dst, tgp_handle src) {
     dst->Npad = src->Npad;
     HIPCHK(dst, hipStreamSynchronize(s));
     dst->have_data = true;
+    dst->data_version = ++g_data_version;
   }
   return TGP_OK;
 }

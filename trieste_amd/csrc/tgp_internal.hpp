@@ -145,6 +145,10 @@ void launch_rff_project(hipStream_t s, const TrajDev& t, const double* Xs_pts, i
                         double* out /*[npts][B]*/);
 void launch_traj_eval(hipStream_t s, const TrajDev& t, const double* Xq, int64_t M, int per_traj,
                       double* out, double* blk_val, int64_t* blk_idx, int64_t index_base);
+void launch_kernel_sums(hipStream_t s, const TrajDev& t, const double* Xq, int64_t M, double* out);
+void launch_lowrank_var(hipStream_t s, const double* var, const double* u, int64_t M, int m, double* var_out);
+void launch_rows_to_columns(hipStream_t s, const double* W, int64_t ld, int64_t row0, int m, int64_t n, double* out);
+void launch_prefix_differs(hipStream_t s, const double* a, const double* b, int64_t n, int* flag);
 int64_t traj_grid(int64_t M);
 void launch_rff_features(hipStream_t s, const TrajDev& t, double scale, int64_t Fp, double* Phi);
 void launch_sym_finish(hipStream_t s, double* A, int64_t n, int64_t np, double scale, double shift, int negate);

@@ -442,6 +442,47 @@ void launch_entropy_tail(hipStream_t s, const double* mean, const double* var, c
 }
 
 // ---------------------------------------------------------------------------------------------
+// GIBBON's repulsion through a rank-m update instead of a second sweep.  The twin is this model plus m appended
+// rows, so its factor inverse W' agrees with W on the first N rows and
+//     var'(x) = k** - sum_{r < N + m} (W'_r . k'(x))^2 = var(x) - sum_{r = N}^{N + m - 1} (W'_r . k'(x))^2:
+// m dot products of length N + m per candidate (launch_kernel_sums) instead of (N + m)^2 / 2 flops.
+__global__ __launch_bounds__(256) void lowrank_var_kernel(const double* __restrict__ var,
+                                                          const double* __restrict__ u, int64_t M, int m,
+                                                          double* __restrict__ var_out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  double s = 0.0;
+  for (int b = 0; b < m; ++b) s = fma(u[i * m + b], u[i * m + b], s);
+  var_out[i] = fmax(var[i] - s, VAR_FLOOR);
+}
+void launch_lowrank_var(hipStream_t s, const double* var, const double* u, int64_t M, int m, double* var_out) {
+  if (M <= 0) return;
+  hipLaunchKernelGGL(lowrank_var_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, var, u, M, m, var_out);
+}
+
+// out[k][b] = W[(row0 + b) * ld + k], k < n: the last m rows of the twin's W as [n][m] weight columns
+__global__ void rows_to_columns_kernel(const double* __restrict__ W, int64_t ld, int64_t row0, int m, int64_t n,
+                                       double* __restrict__ out) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  for (int b = 0; b < m; ++b) out[k * m + b] = W[(row0 + b) * ld + k];
+}
+void launch_rows_to_columns(hipStream_t s, const double* W, int64_t ld, int64_t row0, int m, int64_t n, double* out) {
+  hipLaunchKernelGGL(rows_to_columns_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, ld, row0, m, n, out);
+}
+
+// *flag = 1 if a[i] != b[i] for some i < n (flag must be zeroed by the caller)
+__global__ void prefix_differs_kernel(const double* __restrict__ a, const double* __restrict__ b, int64_t n,
+                                      int* __restrict__ flag) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && a[i] != b[i]) *flag = 1;
+}
+void launch_prefix_differs(hipStream_t s, const double* a, const double* b, int64_t n, int* flag) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(prefix_differs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, b, n, flag);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Box.sample (reference space.py:843-867) on device: uniform in [lower, upper).
 __global__ void sample_box_kernel(uint64_t seed, int64_t first, int64_t M, int d,
                                   const double* __restrict__ lower, const double* __restrict__ upper,

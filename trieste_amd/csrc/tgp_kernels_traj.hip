@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void traj_eval_kernel(TrajDev t, const double*
         if (b < B) acc[b] = fma(ph, ws[(int64_t)f * B + b], acc[b]);
     }
   }
-  if (!rff_only) {
+  if (rff_only == 0 || rff_only == 3) {
     const cptr xs = as_const(t.m.Xs);
     const cptr xn = as_const(t.m.xn);
     const cptr vv = as_const(t.v);
@@ -76,7 +76,8 @@ __global__ __launch_bounds__(256) void traj_eval_kernel(TrajDev t, const double*
       }
     }
   }
-  const double c0 = (rff_only == 1) ? 0.0 : t.m.mean_const;  // 1: bare projection Phi w; 2: RFF trajectory (+ mean)
+  // 1: bare projection Phi w; 2: RFF trajectory (+ mean); 3: bare kernel sums sum_k k(x, X_k) v[k][b]
+  const double c0 = (rff_only == 1 || rff_only == 3) ? 0.0 : t.m.mean_const;
   if (out && valid) {
     if (per_traj) out[item] = acc[0] + c0;
     else {
@@ -153,6 +154,12 @@ static void launch_traj_any(hipStream_t s, const TrajDev& t, const double* Xq, i
 }
 
 int64_t traj_grid(int64_t M) { return (M + 255) / 256; }
+
+// out[M][B] = sum_k k(x, X_k) v[k][b] for B <= 16 weight vectors over the model's training inputs (t.F must be 0):
+// the m = rank-of-the-update dot products GIBBON's conditioned variance needs per candidate.
+void launch_kernel_sums(hipStream_t s, const TrajDev& t, const double* Xq, int64_t M, double* out) {
+  launch_traj_any(s, t, Xq, M, 0, 3, out, nullptr, nullptr, 0);
+}
 
 void launch_traj_eval(hipStream_t s, const TrajDev& t, const double* Xq, int64_t M, int per_traj,
                       double* out, double* blk_val, int64_t* blk_idx, int64_t index_base) {
