@@ -26,6 +26,9 @@
  *     synchronised before returning).  Every call clears the calling thread's sticky HIP error first.
  *   - a trajectory (tgp_traj) must not be used after its model handle is destroyed; destroying it
  *     afterwards is allowed (garbage collectors finalise in arbitrary order).
+ *   - acquisition modifiers are handle state: tgp_set_penalization / tgp_set_min_value_samples /
+ *     tgp_set_repulsion apply to every later tgp_acq_* call on that handle until cleared; none of them touches
+ *     the model (data, hyper-parameters, factorisation).
  *   - no torch types, no C++ types: plain pointers and sizes only.
  */
 #ifndef TGP_H
