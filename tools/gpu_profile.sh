@@ -20,3 +20,7 @@ python tools/bench_update.py 1024 2048 4096 8192 > $OUT/update_${ROUND}.txt 2>&1
 python tools/bench_c4c5.py > $OUT/c4c5_${ROUND}.txt 2>&1; cat $OUT/c4c5_${ROUND}.txt
 python tools/bench_gemm.py 2048 4096 8192 > $OUT/gemm_${ROUND}.txt 2>&1; tail -15 $OUT/gemm_${ROUND}.txt
 python tools/quick_bench.py > $OUT/sizes_${ROUND}.txt 2>&1; tail -12 $OUT/sizes_${ROUND}.txt
+# host-level latencies: one BO step, hyper-parameter fit workers, greedy-batch / entropy-search rules
+python tools/bench_acquire.py > $OUT/acquire_${ROUND}.txt 2>&1; tail -4 $OUT/acquire_${ROUND}.txt
+python tools/bench_optimize.py > $OUT/optimize_${ROUND}.txt 2>&1; tail -3 $OUT/optimize_${ROUND}.txt
+python tools/bench_greedy.py 4000 > $OUT/greedy_${ROUND}.txt 2>&1; tail -6 $OUT/greedy_${ROUND}.txt
