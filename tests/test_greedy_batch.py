@@ -358,3 +358,84 @@ def test_multiple_optimism_lower_confidence_bound():
                                        optimizer=generate_continuous_optimizer(num_initial_samples=200, num_optimization_runs=3))
     pts = rule.acquire_single(space, model, data)
     assert pts.shape == (3, 2) and np.all((pts >= 0) & (pts <= 1))
+
+
+# ---- ExpectedConstrainedImprovement (reference test_function.py:928-1128) ---------------------------------
+class _FnBuilder:
+    """A constraint builder returning a fixed function of x [..., 1, D] -> [..., 1]."""
+
+    def __new__(cls, fn):
+        from trieste_amd.acquisition import AcquisitionFunctionBuilder
+
+        class B(AcquisitionFunctionBuilder):
+            def prepare_acquisition_function(self, models, datasets=None):
+                return fn
+
+        return B()
+
+
+def test_expected_constrained_improvement():
+    from trieste_amd.acquisition import ExpectedConstrainedImprovement, ProbabilityOfFeasibility
+
+    FOO, CON = "foo", "constraint"
+    model, data = _model(n=14)
+    models, datasets = {FOO: model}, {FOO: data}
+    certainty = _FnBuilder(lambda x: np.ones(np.asarray(x).shape[:-2] + (1,)))
+    for bad in (np.array([0.5, 0.5]),):  # :928-931
+        with pytest.raises(ValueError):
+            ExpectedConstrainedImprovement(FOO, certainty, bad)
+    for bad in (-0.1, 1.1):  # :934-938
+        with pytest.raises(ValueError):
+            ExpectedConstrainedImprovement(FOO, certainty, bad)
+    with pytest.raises(ValueError):  # :1046-1073
+        ExpectedConstrainedImprovement(FOO, certainty).prepare_acquisition_function(
+            models, datasets={FOO: Dataset(np.zeros((0, 2)), np.zeros((0, 1)))})
+    with pytest.raises(ValueError):
+        ExpectedConstrainedImprovement(FOO, certainty).prepare_acquisition_function(models)
+    # a certain constraint reproduces EI, also after an update (:954-982)
+    builder = ExpectedConstrainedImprovement(FOO, certainty, 0)
+    eci = builder.prepare_acquisition_function(models, datasets=datasets)
+    ei = ExpectedImprovement().using(FOO).prepare_acquisition_function(models, datasets=datasets)
+    at = np.random.default_rng(0).uniform(size=(7, 1, 2))
+    np.testing.assert_allclose(eci(at), ei(at), rtol=1e-12)
+    for a in (np.zeros((2, 2, 2)),):  # batch size must be one
+        with pytest.raises(ValueError):
+            eci(a)
+    assert builder.update_acquisition_function(eci, models, datasets=datasets) is eci
+    # improvement is relative to the best FEASIBLE point (:995-1019)
+    half = _FnBuilder(lambda x: (np.asarray(x)[..., 0, :1] >= 0.5).astype(float))
+    eci2 = ExpectedConstrainedImprovement(FOO, half).prepare_acquisition_function(models, datasets=datasets)
+    feas = data.query_points[:, 0] >= 0.5
+    eta = float(np.min(model.predict(data.query_points[feas])[0]))
+    x = np.array([[[0.7, 0.3]]])
+    np.testing.assert_allclose(eci2(x), expected_improvement(model, eta)(x), rtol=1e-12)
+    assert float(eci2(np.array([[[0.2, 0.3]]]))[0, 0]) == 0.0  # infeasible candidate
+    # no feasible point: the constraint function itself (:1076-1103)
+    never = _FnBuilder(lambda x: np.zeros(np.asarray(x).shape[:-2] + (1,)))
+    fn = ExpectedConstrainedImprovement(FOO, never).prepare_acquisition_function(models, datasets=datasets)
+    np.testing.assert_array_equal(fn(at), np.zeros((7, 1)))
+    # the bound is inclusive (:1106-1128)
+    thr = float(1 / (1 + np.exp(-1.0)))
+    sig = _FnBuilder(lambda x: 1 / (1 + np.exp(-np.asarray(x)[..., 0, :1] * 0 - 1.0)))  # pof == sigmoid(1) everywhere
+    eci3 = ExpectedConstrainedImprovement(FOO, sig, min_feasibility_probability=thr).prepare_acquisition_function(
+        models, datasets=datasets)
+    np.testing.assert_allclose(eci3(at), ei(at) * thr, rtol=1e-12)
+    # the real thing: a second GPR as the constraint model, PoF as the constraint, EGO with the gradient optimizer
+    cx = np.random.default_rng(5).uniform(size=(12, 2))
+    cdata = Dataset(cx, (cx[:, :1] - 0.5))  # feasible where x0 < 0.5 (values below the threshold 0)
+    cmodel = M.GaussianProcessRegression(M.build_gpr(cdata, Box([0, 0], [1, 1]), likelihood_variance=1e-3))
+    builder = ExpectedConstrainedImprovement(FOO, ProbabilityOfFeasibility(0.0).using(CON), 0.5)
+    models2, datasets2 = {FOO: model, CON: cmodel}, {FOO: data, CON: cdata}
+    fn = builder.prepare_acquisition_function(models2, datasets2)
+    pts = np.random.default_rng(6).uniform(size=(6, 2))
+    val, grad = fn.value_and_gradient(pts)
+    np.testing.assert_allclose(val, fn(pts[:, None, :])[:, 0], rtol=1e-10, atol=1e-14)
+    h = 1e-6
+    num = np.stack([(fn((pts + h * e)[:, None, :]) - fn((pts - h * e)[:, None, :]))[:, 0] / (2 * h) for e in np.eye(2)], axis=1)
+    np.testing.assert_allclose(grad, num, rtol=1e-5, atol=1e-8)
+    space = Box([0, 0], [1, 1])
+    rule = EfficientGlobalOptimization(builder, optimizer=generate_continuous_optimizer(num_initial_samples=300,
+                                                                                         num_optimization_runs=3))
+    pt = rule.acquire(space, models2, datasets2)
+    assert pt.shape == (1, 2)
+    assert float(ProbabilityOfFeasibility(0.0).prepare_acquisition_function(cmodel)(pt[:, None, :])[0, 0]) > 0.3

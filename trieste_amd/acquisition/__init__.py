@@ -3,7 +3,8 @@ from .continuous_thompson_sampling import (GreedyContinuousThompsonSampling, Par
                                            negate_trajectory_function)
 from .entropy import (GIBBON, GibbonAcquisition, MinValueEntropySearch, gibbon_quality_term,
                       gibbon_repulsion_term, min_value_entropy_search)
-from .function import (AugmentedExpectedImprovement, BatchMonteCarloExpectedImprovement, ExpectedImprovement,
+from .function import (AugmentedExpectedImprovement, BatchMonteCarloExpectedImprovement,
+                       ExpectedConstrainedImprovement, ExpectedImprovement,
                        MakePositive, MonteCarloExpectedImprovement, MultipleOptimismNegativeLowerConfidenceBound,
                        NegativeLowerConfidenceBound, NegativePredictiveMean, PredictiveVariance,
                        ProbabilityOfFeasibility, ProbabilityOfImprovement, multiple_optimism_lower_confidence_bound,

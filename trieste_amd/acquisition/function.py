@@ -13,7 +13,7 @@ import numpy as np
 
 from ..data import Dataset
 from ..sampler import JITTER
-from .interface import (AcquisitionFunctionClass, SingleModelAcquisitionBuilder,
+from .interface import (AcquisitionFunctionBuilder, AcquisitionFunctionClass, SingleModelAcquisitionBuilder,
                         SingleModelVectorizedAcquisitionBuilder)
 
 
@@ -524,3 +524,102 @@ class PredictiveVariance(SingleModelAcquisitionBuilder):
 
     def update_acquisition_function(self, function, model, dataset: Optional[Dataset] = None):
         return function  # no need to update anything
+
+
+# ---- constrained improvement: two models, two engines ----------------------------------------------------
+class _product_of(AcquisitionFunctionClass):
+    """x -> f(x) g(x) for two acquisition functions on DIFFERENT models (engines): each factor is evaluated by
+    its own engine, the product and the product-rule gradient are formed on the returned arrays.  No fused
+    arg-max exists across two engines; optimizers take their generic path."""
+
+    def __init__(self, first, second):
+        self._first, self._second = first, second
+
+    def __call__(self, x):
+        return np.asarray(self._first(x), dtype=np.float64) * np.asarray(self._second(x), dtype=np.float64)
+
+    def __getattr__(self, name):
+        first, second = self.__dict__.get("_first"), self.__dict__.get("_second")
+        if name != "value_and_gradient" or first is None or not (hasattr(first, name) and hasattr(second, name)):
+            raise AttributeError(name)
+
+        def value_and_gradient(points):
+            a, da = first.value_and_gradient(points)
+            b, db = second.value_and_gradient(points)
+            a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+            return a * b, np.asarray(da) * b[..., None] + np.asarray(db) * a[..., None]
+
+        return value_and_gradient
+
+
+class ExpectedConstrainedImprovement(AcquisitionFunctionBuilder):
+    """Expected constrained improvement (Gardner et al. 2014; function.py:608-783): EI over the best *feasible*
+    observed point times the constraint function (e.g. ``ProbabilityOfFeasibility(...).using(CONSTRAINT)``); with no
+    feasible point yet, the constraint function alone."""
+
+    def __init__(self, objective_tag, constraint_builder: AcquisitionFunctionBuilder,
+                 min_feasibility_probability: float = 0.5, search_space=None):
+        if np.ndim(min_feasibility_probability) != 0:
+            raise ValueError("min_feasibility_probability must be a scalar")
+        if not 0.0 <= float(min_feasibility_probability) <= 1.0:
+            raise ValueError(f"min_feasibility_probability must be in [0, 1], got {min_feasibility_probability}")
+        if search_space is not None and getattr(search_space, "has_constraints", False):
+            raise NotImplementedError("explicitly constrained search spaces are outside the engine's path")
+        self._objective_tag = objective_tag
+        self._constraint_builder = constraint_builder
+        self._search_space = search_space
+        self._min_feasibility_probability = float(min_feasibility_probability)
+        self._constraint_fn = None
+        self._expected_improvement_fn = None
+        self._constrained_improvement_fn = None
+
+    def __repr__(self) -> str:
+        return (f"ExpectedConstrainedImprovement({self._objective_tag!r}, {self._constraint_builder!r}, "
+                f"{self._min_feasibility_probability!r}, {self._search_space!r})")
+
+    def _feasible_mean(self, models, datasets):
+        if datasets is None:
+            raise ValueError("datasets must be provided")
+        objective_model, objective_dataset = models[self._objective_tag], datasets[self._objective_tag]
+        if len(objective_dataset) == 0:
+            raise ValueError("Expected improvement is defined with respect to existing points in the objective data, "
+                             "but the objective data is empty.")
+        pof = np.asarray(self._constraint_fn(objective_dataset.query_points[:, None, :]))
+        is_feasible = (pof >= self._min_feasibility_probability).reshape(-1)
+        if not is_feasible.any():
+            return objective_model, None
+        feasible_mean, _ = objective_model.predict(objective_dataset.query_points[is_feasible])
+        return objective_model, np.asarray(feasible_mean)
+
+    def _update_expected_improvement_fn(self, objective_model, feasible_mean) -> None:
+        eta = float(np.min(feasible_mean))
+        if self._expected_improvement_fn is None:
+            self._expected_improvement_fn = expected_improvement(objective_model, eta)
+        else:
+            self._expected_improvement_fn.update(eta)
+
+    def prepare_acquisition_function(self, models, datasets=None):
+        if datasets is None:
+            raise ValueError("datasets must be provided")
+        self._constraint_fn = self._constraint_builder.prepare_acquisition_function(models, datasets=datasets)
+        objective_model, feasible_mean = self._feasible_mean(models, datasets)
+        if feasible_mean is None:
+            return self._constraint_fn
+        self._update_expected_improvement_fn(objective_model, feasible_mean)
+        self._constrained_improvement_fn = _product_of(self._expected_improvement_fn, self._constraint_fn)
+        return self._constrained_improvement_fn
+
+    def update_acquisition_function(self, function, models, datasets=None):
+        if datasets is None:
+            raise ValueError("datasets must be provided")
+        if self._constraint_fn is None:
+            raise ValueError("update_acquisition_function called before prepare_acquisition_function")
+        self._constraint_fn = self._constraint_builder.update_acquisition_function(self._constraint_fn, models,
+                                                                                   datasets=datasets)
+        objective_model, feasible_mean = self._feasible_mean(models, datasets)
+        if feasible_mean is None:
+            return self._constraint_fn
+        self._update_expected_improvement_fn(objective_model, feasible_mean)
+        if self._constrained_improvement_fn is None or self._constrained_improvement_fn._second is not self._constraint_fn:
+            self._constrained_improvement_fn = _product_of(self._expected_improvement_fn, self._constraint_fn)
+        return self._constrained_improvement_fn
