@@ -374,3 +374,49 @@ def test_asynchronous_rules_on_gpu():
         p3 = loop.ask()
         np.testing.assert_allclose(loop.acquisition_state.pending_points, np.concatenate([p2, p3]))
         assert model.engine.N == 40 + q and np.all((p3 >= 0) & (p3 <= 1))
+
+
+def test_small_sibling_builders_on_gpu():
+    """MakePositive / MultipleOptimism -LCB / PredictiveVariance / ExpectedConstrainedImprovement on the real engine
+    against the oracle's posterior (function.py:608-783, 1808-1990; active_learning.py:86-110)."""
+    import trieste_amd.acquisition as A
+    import trieste_amd.models as M
+    from scipy.stats import norm
+    from trieste_amd.data import Dataset
+
+    space, data, model, st = _setup(n=50, noise=1e-2)
+    xs = np.random.default_rng(8).uniform(size=(400, 2))
+    om, ov = O.predict(st, xs)
+    mp = A.MakePositive(A.NegativePredictiveMean()).prepare_acquisition_function(model, data)
+    assert_close(mp(xs[:, None, :])[:, 0], np.log1p(np.exp(-om)), rtol=1e-9, what="softplus(-mean)")
+    v, i, x = mp.argmax(xs)
+    assert i == int(np.argmax(-om)) or abs(om[i] - om.min()) < 1e-9
+    B = 3
+    molcb = A.MultipleOptimismNegativeLowerConfidenceBound(space).prepare_acquisition_function(model, data)
+    xb = xs[:300].reshape(100, B, 2)
+    betas = 5.0 * 2 * norm.ppf(0.5 + 0.5 * np.arange(1, B + 1) / (B + 1.0))
+    mb, vb = O.predict(st, xb.reshape(-1, 2))
+    assert_close(molcb(xb), -mb.reshape(100, B) + np.sqrt(vb.reshape(100, B)) * betas, rtol=1e-8, atol=1e-9, what="MOLCB")
+    pts = A.EfficientGlobalOptimization(A.MultipleOptimismNegativeLowerConfidenceBound(space), num_query_points=B
+                                        ).acquire_single(space, model, data)
+    assert pts.shape == (B, 2)
+    pv = A.PredictiveVariance().prepare_acquisition_function(model)
+    _, cov = O.predict_joint(st, xb)
+    assert_close(pv(xb)[:, 0], np.exp(np.linalg.slogdet(cov + 1e-6)[1]), rtol=1e-6, atol=1e-12, what="det cov")
+    # constrained improvement with a second engine as the constraint model
+    cx = np.random.default_rng(5).uniform(size=(30, 2))
+    cdata = Dataset(cx, cx[:, :1] - 0.5)
+    cmodel = M.GaussianProcessRegression(M.build_gpr(cdata, space, likelihood_variance=1e-3))
+    cst = O.gpr_update("matern52", cmodel.get_kernel().variance, cmodel.get_kernel().lengthscales, 1e-3,
+                       cmodel.get_mean_function().c, cx, cdata.observations[:, 0])
+    builder = A.ExpectedConstrainedImprovement("OBJECTIVE", A.ProbabilityOfFeasibility(0.0).using("CONSTRAINT"), 0.5)
+    models, datasets = {"OBJECTIVE": model, "CONSTRAINT": cmodel}, {"OBJECTIVE": data, "CONSTRAINT": cdata}
+    eci = builder.prepare_acquisition_function(models, datasets)
+    cm, cv = O.predict(cst, xs)
+    pof = O.probability_of_improvement(cm, cv, 0.0)
+    dm, dv = O.predict(cst, data.query_points)
+    feas = O.probability_of_improvement(dm, dv, 0.0) >= 0.5
+    eta = float(np.min(O.predict(st, data.query_points[feas])[0]))
+    assert_close(eci(xs[:, None, :])[:, 0], O.expected_improvement(om, ov, eta) * pof, rtol=1e-6, atol=1e-10, what="ECI")
+    pt = A.EfficientGlobalOptimization(builder).acquire(space, models, datasets)
+    assert pt.shape == (1, 2) and float(eci(pt[:, None, :])[0, 0]) >= float(eci(xs[:, None, :]).max()) - 1e-9
