@@ -439,3 +439,41 @@ def test_expected_constrained_improvement():
     pt = rule.acquire(space, models2, datasets2)
     assert pt.shape == (1, 2)
     assert float(ProbabilityOfFeasibility(0.0).prepare_acquisition_function(cmodel)(pt[:, None, :])[0, 0]) > 0.3
+
+
+def test_reducers_sum_product_map():
+    """reference tests/unit/acquisition/test_combination.py: constituent functions are prepared / updated
+    individually, outputs reduced elementwise."""
+    from trieste_amd.acquisition import (Map, NegativeLowerConfidenceBound, ProbabilityOfFeasibility, Product, Reducer,
+                                         Sum)
+
+    model, data = _model()
+    models, datasets = {OBJECTIVE: model}, {OBJECTIVE: data}
+    with pytest.raises(ValueError):
+        Sum()
+    ei = ExpectedImprovement().using(OBJECTIVE)
+    lcb = NegativeLowerConfidenceBound(1.0).using(OBJECTIVE)
+    pof = ProbabilityOfFeasibility(0.4).using(OBJECTIVE)
+    xs = np.random.default_rng(3).uniform(size=(40, 1, 2))
+    parts = [b.prepare_acquisition_function(models, datasets)(xs) for b in (ei, lcb, pof)]
+    s = Sum(ei, lcb, pof)
+    assert s.acquisitions == (ei, lcb, pof) and "Sum(" in repr(s)
+    fs = s.prepare_acquisition_function(models, datasets)
+    np.testing.assert_allclose(fs(xs), parts[0] + parts[1] + parts[2], rtol=1e-12)
+    fp = Product(ei, pof).prepare_acquisition_function(models, datasets)
+    np.testing.assert_allclose(fp(xs), parts[0] * parts[2], rtol=1e-12)
+    fm = Map(lambda v: -2.0 * v, lcb).prepare_acquisition_function(models, datasets)
+    np.testing.assert_allclose(fm(xs), -2.0 * parts[1], rtol=1e-12)
+    # update re-uses the constituent functions (EI's eta is refreshed in place)
+    more = data + Dataset(np.array([[0.5, 0.5]]), np.array([[-5.0]]))
+    model.update(more)
+    before = s.functions[0]
+    fs2 = s.update_acquisition_function(fs, models, {OBJECTIVE: more})
+    assert s.functions[0] is before
+    ei2 = ExpectedImprovement().using(OBJECTIVE).prepare_acquisition_function(models, {OBJECTIVE: more})
+    np.testing.assert_allclose(fs2(xs) - s.functions[1](xs) - s.functions[2](xs), ei2(xs), rtol=1e-9, atol=1e-12)
+    # drives EGO through the generic optimizer path
+    pt = EfficientGlobalOptimization(Product(ei, pof), optimizer=generate_random_search_optimizer(
+        400, seed=1, on_device=False)).acquire(Box([0, 0], [1, 1]), models, datasets)
+    assert pt.shape == (1, 2)
+    assert issubclass(Sum, Reducer)

@@ -1,4 +1,5 @@
 """Acquisition functions, optimizers, rules and samplers of the hot path."""
+from .combination import Map, Product, Reducer, Sum
 from .continuous_thompson_sampling import (GreedyContinuousThompsonSampling, ParallelContinuousThompsonSampling,
                                            negate_trajectory_function)
 from .entropy import (GIBBON, GibbonAcquisition, MinValueEntropySearch, gibbon_quality_term,
