@@ -24,4 +24,6 @@ from .optimizer import (FailedOptimizationError, automatic_optimizer_selector, b
 from .rule import (AcquisitionRule, AsynchronousGreedy, AsynchronousOptimization, AsynchronousRuleState,
                    DiscreteThompsonSampling, EfficientGlobalOptimization, RandomSampling)
 from .sampler import ExactThompsonSampler, GumbelSampler, ThompsonSampler, ThompsonSamplerFromTrajectory
+from .trust_region import (BatchTrustRegionBox, BatchTrustRegionState, SingleObjectiveTrustRegionBox, TREGOBox,
+                           UpdatableTrustRegionBox)
 from .utils import select_nth_output, split_acquisition_function, split_acquisition_function_calls

@@ -36,6 +36,11 @@ class AskTellOptimizer:
         self._acquisition_state = acquisition_state  # of stateful rules (ask_tell_optimization.py:237)
         self._track_data = track_data
         self._fit_model = fit_model
+        # rules with regions (trust regions) set them up against the search space and see every new data set
+        # (ask_tell_optimization.py:316-330; bayesian_optimizer.py:755-770)
+        if hasattr(acquisition_rule, "initialize_subspaces"):
+            acquisition_rule.initialize_subspaces(search_space)
+        self._filter_datasets()
         if fit_model:
             for tag, model in self._models.items():
                 model.update(self._datasets[tag])
@@ -65,6 +70,16 @@ class AskTellOptimizer:
             return next(iter(self._models.values()))
         raise ValueError(f"Expected a single model, found {len(self._models)}")
 
+    def _filter_datasets(self) -> None:
+        """Let the rule look at (models, datasets): a stateful rule returns ``state -> (state, datasets)`` and
+        updates its regions there.  Global datasets come back unchanged."""
+        hook = getattr(self._acquisition_rule, "filter_datasets", None)
+        if hook is None:
+            return
+        filtered = hook(self._models, self._datasets)
+        if callable(filtered):
+            self._acquisition_state, filtered = filtered(self._acquisition_state)
+
     @property
     def acquisition_state(self):
         """The state of a stateful acquisition rule (ask_tell_optimization.py:431-433)."""
@@ -86,6 +101,7 @@ class AskTellOptimizer:
             raise ValueError(f"new_data keys {new_data.keys()} doesn't match dataset keys {self._datasets.keys()}")
         for tag, ds in new_data.items():
             self._datasets[tag] = (self._datasets[tag] + ds) if self._track_data else ds
+        self._filter_datasets()
         for tag, model in self._models.items():
             model.update(self._datasets[tag])
             if self._fit_model:

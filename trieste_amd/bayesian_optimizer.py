@@ -5,6 +5,7 @@ the history so far (855-875) instead of propagating."""
 from __future__ import annotations
 
 import traceback
+import numpy as np
 from dataclasses import dataclass, field
 from typing import Callable, List, Mapping, Optional, Union
 
@@ -99,10 +100,24 @@ class BayesianOptimizer:
                                  f"got keys {datasets.keys()}")
             acquisition_rule = EfficientGlobalOptimization()
         history: List[Record] = []
+
+        def filter_datasets(state):  # stateful rules (trust regions) update their regions from the newest data
+            hook = getattr(acquisition_rule, "filter_datasets", None)
+            if hook is None:
+                return state
+            filtered = hook(models, datasets)
+            if callable(filtered):
+                state, _ = filtered(state)
+            return state
+
         for step in range(1, num_steps + 1):
             try:
                 if track_state:
                     history.append(Record(dict(datasets), models, acquisition_state))
+                if step == 1:
+                    if hasattr(acquisition_rule, "initialize_subspaces"):
+                        acquisition_rule.initialize_subspaces(self._search_space)
+                    acquisition_state = filter_datasets(acquisition_state)
                 if step == 1 and fit_model and fit_initial_model:
                     for tag, model in models.items():
                         model.update(datasets[tag])
@@ -110,8 +125,12 @@ class BayesianOptimizer:
                 points = acquisition_rule.acquire(self._search_space, models, datasets=datasets)
                 if callable(points):  # stateful rule (bayesian_optimizer.py:796-800)
                     acquisition_state, points = points(acquisition_state)
+                points = np.asarray(points)
+                if points.ndim == 3:  # one point per region [N, V, D]: the observer sees the flat batch
+                    points = points.reshape(-1, points.shape[-1])
                 observed = _as_map(self._observer(points))
                 datasets = {tag: datasets[tag] + observed[tag] for tag in datasets}
+                acquisition_state = filter_datasets(acquisition_state)
                 for tag, model in models.items():
                     model.update(datasets[tag])
                     if fit_model:
