@@ -9,7 +9,7 @@ import trieste_amd.models as M
 from tests.fakes import FakeEngine
 from trieste_amd import objectives as OBJ
 from trieste_amd.acquisition import (BatchTrustRegionBox, BatchTrustRegionState, DiscreteThompsonSampling,
-                                     EfficientGlobalOptimization, SingleObjectiveTrustRegionBox, TREGOBox,
+                                     EfficientGlobalOptimization, SingleObjectiveTrustRegionBox, TREGOBox, TURBOBox,
                                      generate_continuous_optimizer)
 from trieste_amd.acquisition.rule import AcquisitionRule
 from trieste_amd.ask_tell_optimization import AskTellOptimizer
@@ -221,3 +221,94 @@ def test_trego_through_the_loops_alternates_modes_and_improves():
         flat = pts.reshape(-1, 2)
         loop.tell(Dataset(flat, OBJ.scaled_branin(flat)))
     assert len(loop.dataset) == 10 + 6 and model2.engine.N == 16
+
+
+# ---- TURBOBox (reference test_rule.py:878-1246) -------------------------------------------------------------
+class _KernelOnly:
+    """A model exposing only what TURBOBox needs."""
+
+    def __init__(self, lengthscales):
+        self._k = M.SquaredExponential(1.0, np.asarray(lengthscales, dtype=float))
+
+    def get_kernel(self):
+        return self._k
+
+
+def test_turbo_parameter_checks_and_heuristics():
+    space = Box([-2.2, -1.0], [1.3, 3.3])
+    for kwargs in ({"L_init": -1.0}, {"L_max": 0.0}, {"L_min": -0.1}, {"failure_tolerance": 0}, {"success_tolerance": -2}):
+        with pytest.raises(ValueError):  # :897-915
+            TURBOBox(space, **kwargs)
+    big = Box([-2.0] * 20, [1.0] * 20)  # :918-938
+    rule = BatchTrustRegionBox(TURBOBox(big))
+    rule.acquire(big, {OBJECTIVE: _KernelOnly(np.ones(20))}, {OBJECTIVE: Dataset(np.zeros((1, 20)), np.zeros((1, 1)))})
+    region = rule._init_subspaces[0]
+    assert region.L_init == 0.8 * 3.0 and region.L_min == (0.5 ** 7) * 3.0 and region.L_max == 1.6 * 3.0
+    assert region.failure_tolerance == 20
+    assert isinstance(rule._rule, DiscreteThompsonSampling) and rule._rule._num_search_space_samples == 2_000
+    rule = BatchTrustRegionBox(TURBOBox(big), rule=EfficientGlobalOptimization())
+    rule.acquire(big, {OBJECTIVE: _KernelOnly(np.ones(20))}, None)
+    assert isinstance(rule._rule, EfficientGlobalOptimization)
+    with pytest.raises(ValueError):
+        TURBOBox(space).get_dataset_min({"foo": Dataset(np.zeros((1, 2)), np.zeros((1, 1)))})
+    with pytest.raises(ValueError):
+        TURBOBox(space)._set_tr_width({"foo": _KernelOnly([1.0, 1.0])})
+
+
+def _turbo_region(space, L, failure_counter, success_counter, previous_y_min):
+    region = TURBOBox(space)  # reference turbo_create_region (test_rule.py:1000-1021)
+    region.L, region.failure_counter, region.success_counter, region.y_min = L, failure_counter, success_counter, previous_y_min
+    region._initialized = True
+    return region
+
+
+def _turbo_step(region, dataset, models):
+    tr = BatchTrustRegionBox(region, _Midpoint())
+    state = BatchTrustRegionState([region], ["0"])
+    state, _ = tr.acquire(region.global_search_space, models, {OBJECTIVE: dataset})(state)
+    state, _ = tr.filter_datasets(models, {OBJECTIVE: dataset})(state)
+    return state.subspaces[0]
+
+
+def test_turbo_changes_size_only_when_a_tolerance_is_reached_and_restarts_when_too_small():
+    dataset = Dataset(np.array([[0.0, 0.0]]), np.array([[0.012]]))
+    models = {OBJECTIVE: _KernelOnly([4.0, 1.0])}
+    space = Box([0.0, 0.0], [1.0, 1.0])
+    # success, below the tolerance: size unchanged, the box follows the lengthscales at fixed volume (:1024-1063)
+    for fc in (0, 1):
+        for sc in (0, 1):
+            r = _turbo_step(_turbo_region(space, 0.8, fc, sc, 0.012 + 2.0), dataset, models)
+            assert r.L == 0.8 and r.success_counter == sc + 1 and r.failure_counter == 0
+            np.testing.assert_allclose(r.lower, [0.0, 0.0])
+            np.testing.assert_allclose(r.upper, [0.8, 0.2])
+    # failure, below the tolerance (:1065-1101)
+    for sc in (0, 1, 2):
+        r = _turbo_step(_turbo_region(space, 0.8, 0, sc, 0.012), dataset, models)
+        assert r.L == 0.8 and r.success_counter == 0 and r.failure_counter == 1
+    # the third success in a row doubles L (capped at L_max = 1.6), the second failure (D = 2) halves it (:1104-1177)
+    r = _turbo_step(_turbo_region(space, 0.8, 0, 2, 0.012 + 2.0), dataset, models)
+    assert r.L == 1.6 and r.success_counter == 0
+    np.testing.assert_allclose(r.upper, [1.0, 0.4])
+    r = _turbo_step(_turbo_region(space, 1.6, 0, 2, 0.012 + 2.0), dataset, models)
+    assert r.L == 1.6  # capped
+    r = _turbo_step(_turbo_region(space, 0.8, 1, 0, 0.012), dataset, models)
+    assert r.L == 0.4 and r.failure_counter == 0
+    np.testing.assert_allclose(r.upper, [0.4, 0.1])
+    # below L_min the region restarts from L_init (:1180-1245)
+    r = _turbo_step(_turbo_region(space, (0.5 ** 7) * 1.0, 1, 0, 0.012), dataset, models)
+    assert r.L == 0.8 and r.failure_counter == 0 and r.success_counter == 0
+    dc = copy.deepcopy(BatchTrustRegionState([r], ["0"]))
+    assert dc.subspaces[0] is not r and dc.subspaces[0].L == r.L
+
+
+def test_turbo_with_thompson_sampling_through_the_loop():
+    space = Box([0, 0], [1, 1])
+    model, data = _model(n=12, seed=2)
+    res = BayesianOptimizer(lambda x: Dataset(x, OBJ.scaled_branin(x)), space).optimize(
+        6, data, model, BatchTrustRegionBox(TURBOBox(space)), fit_model=False)
+    final = res.final_result.unwrap()
+    assert len(final.dataset) == 18 and final.dataset.observations.min() <= data.observations.min()
+    region = final.acquisition_state.subspaces[0]
+    best = final.dataset.query_points[int(np.argmin(final.dataset.observations[:, 0]))]
+    np.testing.assert_allclose(region.location, best)  # centred on the best observation
+    assert np.all(region.lower >= 0) and np.all(region.upper <= 1) and best in region

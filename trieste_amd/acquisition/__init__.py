@@ -25,5 +25,5 @@ from .rule import (AcquisitionRule, AsynchronousGreedy, AsynchronousOptimization
                    DiscreteThompsonSampling, EfficientGlobalOptimization, RandomSampling)
 from .sampler import ExactThompsonSampler, GumbelSampler, ThompsonSampler, ThompsonSamplerFromTrajectory
 from .trust_region import (BatchTrustRegionBox, BatchTrustRegionState, SingleObjectiveTrustRegionBox, TREGOBox,
-                           UpdatableTrustRegionBox)
+                           TURBOBox, UpdatableTrustRegionBox)
 from .utils import select_nth_output, split_acquisition_function, split_acquisition_function_calls

@@ -1,14 +1,14 @@
 """Trust-region rules for box spaces over GLOBAL models and datasets (reference trieste/acquisition/rule.py:
 UpdatableTrustRegion 1039-1237, BatchTrustRegionState 1240-1258, BatchTrustRegion 1261-1566, HypercubeTrustRegion
 1569-1777, UpdatableTrustRegionBox 1780-1820, SingleObjectiveTrustRegionBox 1823-1860, BatchTrustRegionBox 1863-1920,
-TREGOBox 1923-2035).
+TREGOBox 1923-2035, TURBOBox 2038-2218).
 
 These rules are host orchestration over the same posterior arithmetic: each region is a ``Box`` whose bounds move
 with the data, and the base rule (EGO by default) maximises its acquisition function inside it -- every sweep,
 top-k and L-BFGS-B refinement runs on the engine exactly as for the global space.  What is restated is the
 single-objective region logic (success test with ``kappa`` x volume, growth / shrinkage by ``beta``, re-initialisation
 below ``min_eps``, TREGO's global / local alternation) and the rule plumbing (``acquire`` / ``filter_datasets`` state
-functions).  Local models / local datasets per region, product and discrete regions and TURBO are not built: with
+functions), and TURBO's box.  Local models / local datasets per region, product and discrete regions are not built: with
 global models the base rule (one query point) runs once per region, on a copy of the rule (the reference batches
 EGO over a tagged multi-space instead; for one region -- TREGO -- the two coincide).
 """
@@ -178,6 +178,94 @@ class TREGOBox(SingleObjectiveTrustRegionBox):
         return self.get_values_min(dataset.query_points, dataset.observations, in_region_only=False)  # global minimum
 
 
+class TURBOBox(UpdatableTrustRegionBox):
+    """TURBO's region (Eriksson et al. 2019; rule.py:2038-2218): a box centred on the best observation whose side
+    lengths follow the model's lengthscales at fixed volume ``L^D``; ``L`` doubles after ``success_tolerance``
+    consecutive improvements, halves after ``failure_tolerance`` consecutive failures, is capped at ``L_max`` and
+    restarts from ``L_init`` below ``L_min``.  Here it works with the global model (the reference pairs it with a
+    local model per region)."""
+
+    def __init__(self, global_search_space: Box, L_min: Optional[float] = None, L_init: Optional[float] = None,
+                 L_max: Optional[float] = None, success_tolerance: int = 3, failure_tolerance: Optional[int] = None,
+                 region_index: Optional[int] = None):
+        super().__init__(global_search_space, region_index)
+        width = float(np.max(global_search_space.upper - global_search_space.lower))
+        L_min = (0.5 ** 7) * width if L_min is None else L_min
+        L_init = 0.8 * width if L_init is None else L_init
+        L_max = 1.6 * width if L_max is None else L_max
+        for name, value in (("L_min", L_min), ("L_init", L_init), ("L_max", L_max)):
+            if value <= 0:
+                raise ValueError(f"{name} must be postive, got {value}")
+        self.L_min, self.L_init, self.L_max = L_min, L_init, L_max
+        self.L = L_init
+        self.success_tolerance = success_tolerance
+        self.failure_tolerance = failure_tolerance if failure_tolerance is not None else global_search_space.dimension
+        self.success_counter = 0
+        self.failure_counter = 0
+        if self.success_tolerance <= 0:
+            raise ValueError(f"success tolerance must be an integer greater than 0, got {self.success_tolerance}")
+        if self.failure_tolerance <= 0:
+            raise ValueError(f"success tolerance must be an integer greater than 0, got {self.failure_tolerance}")
+        self.y_min = np.inf
+        self.tr_width = global_search_space.upper - global_search_space.lower  # the full space to begin with
+        self._update_domain()
+
+    @property
+    def requires_initialization(self) -> bool:
+        return not self._initialized
+
+    def _set_tr_width(self, models: Optional[Mapping]) -> None:
+        """Stretch the region along the model's lengthscales at fixed volume (rule.py:2113-2138)."""
+        if models is None or len(models) != 1 or next(iter(models)) != OBJECTIVE:
+            raise ValueError("a single OBJECTIVE model must be provided")
+        model = next(iter(models.values()))
+        if not hasattr(model, "get_kernel"):
+            raise TypeError(f"the model should support get_kernel, got {type(model)}")
+        d = self._global_search_space.dimension
+        lengthscales = np.broadcast_to(np.asarray(model.get_kernel().lengthscales, dtype=np.float64), (d,))
+        self.tr_width = lengthscales * self.L / np.prod(lengthscales) ** (1.0 / d)
+
+    def _update_domain(self) -> None:
+        self._set_bounds(np.maximum(self._global_search_space.lower, self.location - self.tr_width / 2.0),
+                         np.minimum(self._global_search_space.upper, self.location + self.tr_width / 2.0))
+
+    def initialize(self, models: Optional[Mapping] = None, datasets: Optional[Mapping] = None,
+                   location_candidate=None) -> None:
+        x_min, self.y_min = self.get_dataset_min(datasets)
+        self.location = x_min
+        self.L, self.failure_counter, self.success_counter = self.L_init, 0, 0
+        self._set_tr_width(models)
+        self._update_domain()
+        self._initialized = True
+
+    def update(self, models: Optional[Mapping] = None, datasets: Optional[Mapping] = None) -> None:
+        x_min, y_min = self.get_dataset_min(datasets)
+        self.location = x_min
+        step_is_success = y_min < self.y_min - 1e-10
+        self.y_min = y_min
+        self.failure_counter = 0 if step_is_success else self.failure_counter + 1
+        self.success_counter = self.success_counter + 1 if step_is_success else 0
+        if self.success_counter == self.success_tolerance:
+            self.L *= 2.0
+            self.success_counter = 0
+        elif self.failure_counter == self.failure_tolerance:
+            self.L *= 0.5
+            self.failure_counter = 0
+        self.L = min(self.L, self.L_max)
+        if self.L < self.L_min:  # too small: start again
+            self.L, self.failure_counter, self.success_counter = self.L_init, 0, 0
+        self._set_tr_width(models)
+        self._update_domain()
+
+    def get_dataset_min(self, datasets: Optional[Mapping]) -> Tuple[np.ndarray, float]:
+        """The best observation of the whole data set (rule.py:2202-2218)."""
+        if datasets is None or len(datasets) != 1 or next(iter(datasets)) != OBJECTIVE:
+            raise ValueError("a single OBJECTIVE dataset must be provided")
+        dataset = next(iter(datasets.values()))
+        ix = int(np.argmin(np.asarray(dataset.observations)[:, 0]))
+        return np.asarray(dataset.query_points)[ix], float(np.asarray(dataset.observations)[ix, 0])
+
+
 @dataclass(frozen=True)
 class BatchTrustRegionState:
     """The acquisition state of :class:`BatchTrustRegionBox`: its regions (rule.py:1240-1258)."""
@@ -238,8 +326,14 @@ class BatchTrustRegionBox(AcquisitionRule):
             self._tags = ("0",)
 
     def _region_rules(self, count: int):
-        if self._rule is None:
-            self._rule = EfficientGlobalOptimization()
+        if self._rule is None:  # the reference's defaults (rule.py:1351-1360)
+            if isinstance(self._init_subspaces[0], TURBOBox):
+                from .rule import DiscreteThompsonSampling
+
+                dim = self._init_subspaces[0].global_search_space.dimension
+                self._rule = DiscreteThompsonSampling(min(100 * dim, 5_000), 1)
+            else:
+                self._rule = EfficientGlobalOptimization()
         if self._rules is None:
             if getattr(self._rule, "_num_query_points", 1) != 1:
                 raise NotImplementedError(
