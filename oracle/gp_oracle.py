@@ -21,7 +21,8 @@ Pinning status (see DESIGN.md "Oracle"):
     self-consistency identities and Monte-Carlo bounds).  The oracle is therefore pinned
     against (i) 50-digit mpmath golden vectors committed under tests/golden/ (generated
     by oracle/make_goldens.py) and (ii) every identity the reference's tests assert
-    (tests/test_host_logic.py, tests/test_oracle_gradient.py).  Bit-level parity with GPflow itself is UNPINNED
+    (tests/test_host_logic.py, tests/test_oracle_gradient.py) and (iii) scikit-learn's exact GPR on the same
+    model (tests/test_oracle_vs_sklearn.py).  Bit-level parity with GPflow itself is UNPINNED
     and cannot be established in this container.
 """
 from __future__ import annotations
