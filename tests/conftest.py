@@ -9,6 +9,15 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+try:  # property tests draw the same examples on every run: the suite is a gate, not a fuzzer
+    from hypothesis import settings as _hyp_settings
+
+    _hyp_settings.register_profile("deterministic", derandomize=True, deadline=None)
+    _hyp_settings.load_profile("deterministic")
+except ImportError:  # hypothesis is optional for everything but tests/test_host_properties.py
+    pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu)")
 
