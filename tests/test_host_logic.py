@@ -104,6 +104,24 @@ def test_objective_known_answers():
 
 
 # ---- model wrapper (reference tests/unit/models/gpflow/test_models.py, test_builders.py) --------------
+@pytest.mark.parametrize("problem", OBJ.PROBLEMS, ids=[p.name for p in OBJ.PROBLEMS])
+def test_single_objective_suite_known_answers(problem):
+    """reference tests/unit/objectives/test_single_objectives.py:64-110: the value at every stated minimizer is the
+    stated minimum (atol 1e-4), nothing sampled from the search space does better, shapes and dimension checks."""
+    values = problem.objective(problem.minimizers)
+    assert values.shape == (len(problem.minimizers), 1)
+    np.testing.assert_allclose(values[:, 0], np.broadcast_to(problem.minimum, (len(problem.minimizers),)), atol=1e-4)
+    for point in problem.minimizers:
+        assert point in problem.search_space
+    samples = problem.search_space.sample(20_000, seed=1)
+    assert float(np.min(problem.objective(samples))) >= float(problem.minimum[0]) - 1e-4
+    assert problem.objective(samples[:7][None]).shape == (1, 7, 1)  # leading dimensions pass through
+    assert problem.dim == problem.search_space.dimension and len(problem.bounds) == 2
+    if problem.name not in ("Branin", "Scaled Branin", "Hartmann 6"):  # the benchmark inputs take any trailing size
+        with pytest.raises(ValueError):
+            problem.objective(np.zeros((3, problem.dim + 1)))
+
+
 def test_build_gpr_defaults():
     rng = np.random.default_rng(1)
     x = rng.uniform(size=(20, 3))
