@@ -60,3 +60,32 @@ def test_engine_raises_without_gpu():
 
     with pytest.raises(Exception):
         GPEngine(2, "matern52")
+
+
+def test_fake_engine_mirrors_the_engine_surface():
+    """The CPU host-logic tests replace GPEngine by tests/fakes.py::FakeEngine at the engine boundary: the stand-in
+    must offer every public method of the real class with the same parameter names, or those tests would exercise
+    a different interface than the product's (and the trajectory stand-ins likewise)."""
+    import inspect
+
+    from tests.fakes import FakeEngine, FakeRffTrajectory, FakeTrajectory
+    from trieste_amd.engine import GPEngine, Trajectory
+
+    def public(cls):
+        return {n: f for n, f in inspect.getmembers(cls, predicate=inspect.isfunction) if not n.startswith("_")}
+
+    def params(f):
+        return [p for p in inspect.signature(f).parameters if p != "self"]
+
+    real, fake = public(GPEngine), public(FakeEngine)
+    missing = sorted(set(real) - set(fake))
+    assert not missing, f"FakeEngine lacks {missing}"
+    for name, f in real.items():
+        assert params(f) == params(fake[name]), (name, params(f), params(fake[name]))
+    assert params(GPEngine.__init__) == params(FakeEngine.__init__)
+    # one engine class serves both trajectory kinds (v: decoupled only, theta: RFF weight posterior only)
+    both = set(public(FakeTrajectory)) | set(public(FakeRffTrajectory))
+    lacking = sorted(set(public(Trajectory)) - both)
+    assert not lacking, f"the trajectory stand-ins lack {lacking}"
+    for stand_in, own in ((FakeTrajectory, "v"), (FakeRffTrajectory, "theta")):
+        assert not sorted(set(public(Trajectory)) - set(public(stand_in)) - {"v", "theta"}) and own in public(stand_in)
