@@ -89,3 +89,44 @@ def test_fake_engine_mirrors_the_engine_surface():
     assert not lacking, f"the trajectory stand-ins lack {lacking}"
     for stand_in, own in ((FakeTrajectory, "v"), (FakeRffTrajectory, "theta")):
         assert not sorted(set(public(Trajectory)) - set(public(stand_in)) - {"v", "theta"}) and own in public(stand_in)
+
+
+def test_the_oracle_is_test_infrastructure_only():
+    """The rule of the build: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch
+    oracle/ (or tests/); the product package and the measurement tools never do, and nothing in the package falls
+    back to a CPU evaluation when the HIP library is missing."""
+    import ast
+    import pathlib
+
+    root = pathlib.Path(__file__).resolve().parents[1]
+
+    def offending_imports(path, allowed_functions=()):
+        tree = ast.parse(path.read_text())
+        allowed_nodes = set()
+        for node in ast.walk(tree):
+            if isinstance(node, ast.FunctionDef) and node.name in allowed_functions:
+                allowed_nodes.update(id(n) for n in ast.walk(node))
+        bad = []
+        for node in ast.walk(tree):
+            names = []
+            if isinstance(node, ast.Import):
+                names = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom) and node.level == 0:
+                names = [node.module or ""]
+            for name in names:
+                if name.split(".")[0] in ("oracle", "tests") and id(node) not in allowed_nodes:
+                    bad.append((path.name, node.lineno, name))
+        return bad
+
+    bad = []
+    for path in list((root / "trieste_amd").rglob("*.py")) + list((root / "tools").glob("*.py")):
+        bad += offending_imports(path)
+    bad += offending_imports(root / "bench.py", allowed_functions=("cpu_baseline",))
+    bad += offending_imports(root / "__graft_entry__.py", allowed_functions=("smoke",))
+    assert not bad, bad
+    # a missing library is an error, never a fallback
+    from trieste_amd import _lib
+
+    src = (root / "trieste_amd" / "_lib.py").read_text()
+    assert "no CPU fallback" in src or "no CPU path" in src
+    assert callable(_lib.load)
