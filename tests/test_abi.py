@@ -130,3 +130,26 @@ def test_the_oracle_is_test_infrastructure_only():
     src = (root / "trieste_amd" / "_lib.py").read_text()
     assert "no CPU fallback" in src or "no CPU path" in src
     assert callable(_lib.load)
+
+
+def test_missing_library_is_an_import_error_not_a_fallback(monkeypatch, tmp_path):
+    """No libtgp.so -> ImportError with build instructions from the loader, and therefore from every engine /
+    model construction: nothing computes on the CPU instead."""
+    import numpy as np
+
+    import trieste_amd.models as M
+    from trieste_amd import _lib
+    from trieste_amd.data import Dataset
+    from trieste_amd.engine import GPEngine
+    from trieste_amd.space import Box
+
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libtgp.so"))
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _lib.load()
+    with pytest.raises(ImportError):
+        GPEngine(2, "matern52")
+    x = np.random.default_rng(0).uniform(size=(5, 2))
+    data = Dataset(x, x[:, :1])
+    with pytest.raises(ImportError):
+        M.GaussianProcessRegression(M.build_gpr(data, Box([0, 0], [1, 1])))
