@@ -18,8 +18,15 @@ except ImportError:  # hypothesis is optional for everything but tests/test_host
     pass
 
 
+def pytest_addoption(parser):
+    # like the reference (tests/conftest.py: --runslow): seed-tuned end-to-end runs are opt-in
+    parser.addoption("--runslow", action="store", default="no", choices=("yes", "no", "only"),
+                     help="whether to run tests marked slow")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "slow: long, seed-tuned end-to-end runs (enable with --runslow yes)")
 
 
 def _has_gpu() -> bool:
@@ -32,6 +39,12 @@ def _has_gpu() -> bool:
 
 
 def pytest_collection_modifyitems(config, items):
+    runslow = config.getoption("--runslow")
+    for item in items:
+        if runslow == "no" and "slow" in item.keywords:
+            item.add_marker(pytest.mark.skip(reason="need --runslow yes to run"))
+        if runslow == "only" and "slow" not in item.keywords:
+            item.add_marker(pytest.mark.skip(reason="--runslow only"))
     if _has_gpu():
         return
     skip = pytest.mark.skip(reason="no GPU visible")

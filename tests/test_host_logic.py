@@ -623,6 +623,31 @@ def test_continuous_thompson_sampling_builders_with_ego():
     assert pts2.shape == (3, 2)
 
 
+def test_negated_trajectory_gradient_has_the_same_sign_for_flat_and_batched_inputs():
+    """Regression: batch-size-one optimizers hand [P, D] points to ``value_and_gradient``; the negated trajectory must
+    negate exactly once there too (L-BFGS-B otherwise climbed the trajectory instead of descending it)."""
+    from trieste_amd.acquisition.continuous_thompson_sampling import negate_trajectory_function
+
+    model, data = _model(n=15)
+    traj = model.trajectory_sampler().get_trajectory()
+    pts = np.random.default_rng(0).uniform(size=(6, 2))
+    v3, g3 = traj.value_and_gradient(pts[:, None, :])
+    v2, g2 = traj.value_and_gradient(pts)
+    np.testing.assert_allclose(v2, v3[:, 0])
+    np.testing.assert_allclose(g2, g3[:, 0, :])
+    neg = negate_trajectory_function(traj)
+    nv3, ng3 = neg.value_and_gradient(pts[:, None, :])
+    nv2, ng2 = neg.value_and_gradient(pts)
+    np.testing.assert_allclose(nv3, -v3)
+    np.testing.assert_allclose(nv2, -v2)
+    np.testing.assert_allclose(ng2, -g2)
+    np.testing.assert_allclose(neg(pts[:, None, :]), nv3[..., None] if np.ndim(neg(pts[:, None, :])) == 3 else nv3)
+    h = 1e-6
+    num = np.stack([(neg((pts + h * e)[:, None, :]) - neg((pts - h * e)[:, None, :])).reshape(6) / (2 * h)
+                    for e in np.eye(2)], axis=1)
+    np.testing.assert_allclose(ng2, num, rtol=1e-5, atol=1e-7)
+
+
 def test_covariance_between_points_and_conditional_predict_equal_refit():
     """reference test_models.py (covariance_between_points, conditional_predict_* cases): cross-
     covariance blocks agree with the joint posterior; conditioning on additional data equals

@@ -162,9 +162,14 @@ def test_single_objective_region_shrinks_grows_and_reinitialises():
 def test_batch_trust_region_box_rule_checks_and_duplicate_centres():
     space = Box([0.0, 0.0], [1.0, 1.0])
     data = Dataset(np.array([[0.2, 0.2], [0.8, 0.8]]), np.array([[1.0], [2.0]]))
-    with pytest.raises(NotImplementedError):  # one query point per region
-        BatchTrustRegionBox(TREGOBox(space), DiscreteThompsonSampling(10, 2)).acquire(space, {OBJECTIVE: None},
-                                                                                      {OBJECTIVE: data})
+    from trieste_amd.acquisition import BatchMonteCarloExpectedImprovement, ParallelContinuousThompsonSampling
+
+    with pytest.raises(NotImplementedError):  # a joint batch builder across regions needs the tagged multi-space
+        BatchTrustRegionBox([TREGOBox(space), TREGOBox(space)], EfficientGlobalOptimization(
+            BatchMonteCarloExpectedImprovement(10), num_query_points=2)).acquire(space, {OBJECTIVE: None}, {OBJECTIVE: data})
+    with pytest.raises(ValueError):  # as many batch elements as regions
+        BatchTrustRegionBox([TREGOBox(space)], EfficientGlobalOptimization(
+            ParallelContinuousThompsonSampling(), num_query_points=2)).acquire(space, {OBJECTIVE: None}, {OBJECTIVE: data})
     with pytest.raises(ValueError):  # a different global space
         BatchTrustRegionBox(TREGOBox(space), _Midpoint()).acquire(Box([0.0, 0.0], [2.0, 1.0]), {OBJECTIVE: None},
                                                                   {OBJECTIVE: data})

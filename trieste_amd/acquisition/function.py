@@ -299,6 +299,27 @@ class monte_carlo_expected_improvement(AcquisitionFunctionClass):
             eps = torch.from_numpy(eps).to(at.device)
         return self._engine.qei(at, eps, self._eta, self._jitter)[..., None]
 
+    def value_and_gradient(self, points):
+        """points [P, D] -> (values [P], gradients [P, D]): the derivative TF autodiff takes through the
+        reparametrised samples mu(x) + sqrt(var(x) + jitter) eps_s (optimizer.py:628-629), in closed form:
+        mean_s 1[eta > sample_s] (-dmu - eps_s ds), ds = dvar / (2 sqrt(var + jitter)).  Mean, sd and their
+        gradients come from the engine's analytic path (-LCB at beta = 0 and 1); the S-sample reduction over the
+        few hundred L-BFGS-B iterates is host arithmetic."""
+        pts = np.asarray(points, dtype=np.float64)
+        eps = np.asarray(self._sampler.eps(1), dtype=np.float64).reshape(-1)          # [S]
+        neg_mu, neg_dmu = (np.asarray(a) for a in self._engine.acq_value_grad("nlcb", 0.0, pts))
+        lcb1, dlcb1 = (np.asarray(a) for a in self._engine.acq_value_grad("nlcb", 1.0, pts))
+        mu, dmu = -neg_mu, -neg_dmu
+        sd, dsd = lcb1 - neg_mu, dlcb1 - neg_dmu                                        # sqrt(var), its gradient
+        s = np.sqrt(sd * sd + self._jitter)
+        ds = (sd / s)[:, None] * dsd                                                    # d sqrt(var + jitter)
+        improvement = self._eta - (mu[:, None] + s[:, None] * eps[None, :])             # [P, S]
+        active = improvement > 0.0
+        value = np.mean(np.where(active, improvement, 0.0), axis=1)
+        weight = active.mean(axis=1)                                                    # mean_s 1[...]
+        weight_eps = (active * eps[None, :]).mean(axis=1)                               # mean_s 1[...] eps_s
+        return value, -weight[:, None] * dmu - weight_eps[:, None] * ds
+
 
 class MonteCarloExpectedImprovement(SingleModelAcquisitionBuilder):
     """Builder for Monte-Carlo EI; eta = min over the data of the SAMPLE mean (function.py:786-880)."""

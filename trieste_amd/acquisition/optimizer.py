@@ -37,6 +37,14 @@ def _is_torch(x) -> bool:
     return type(x).__module__.startswith("torch")
 
 
+def _fresh_seed() -> int:
+    """A seed for the device-side candidate generator drawn from the package's host generator (reproducible under
+    ``trieste_amd.set_seed``, fresh otherwise)."""
+    from ..rng import make_rng
+
+    return int(make_rng().integers(0, 2 ** 31 - 1))
+
+
 def _split(target_func) -> Tuple[Callable, int]:
     if isinstance(target_func, tuple):
         fn, V = target_func
@@ -88,7 +96,8 @@ def generate_random_search_optimizer(num_samples: int = NUM_SAMPLES_MIN, seed: O
         eng = getattr(fn, "_engine", None)
         if on_device and V == 1 and eng is not None and hasattr(fn, "argmax") and isinstance(space, Box) \
                 and hasattr(eng, "sample_box"):
-            pts = space.sample_device(eng, num_samples, seed=0 if seed is None else seed)
+            # unseeded: a fresh candidate set per call, like space.sample(n) (not the same Philox stream every step)
+            pts = space.sample_device(eng, num_samples, seed=_fresh_seed() if seed is None else seed)
             _, _, x = fn.argmax(pts)
             return np.asarray(x)[None, :]
         points = space.sample(num_samples, seed=seed)[:, None, :]

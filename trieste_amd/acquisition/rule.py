@@ -14,7 +14,7 @@ from ..space import SearchSpace
 from .function import BatchMonteCarloExpectedImprovement, ExpectedImprovement
 from .interface import (AcquisitionFunctionBuilder, GreedyAcquisitionFunctionBuilder, SingleModelAcquisitionBuilder,
                         SingleModelGreedyAcquisitionBuilder, VectorizedAcquisitionFunctionBuilder)
-from .optimizer import automatic_optimizer_selector, batchify_joint, batchify_vectorize
+from .optimizer import _fresh_seed, automatic_optimizer_selector, batchify_joint, batchify_vectorize
 from .sampler import ExactThompsonSampler, ThompsonSampler
 from .utils import select_nth_output
 
@@ -54,6 +54,7 @@ class EfficientGlobalOptimization(AcquisitionRule):
             builder = builder.using(OBJECTIVE)
         if not isinstance(builder, (AcquisitionFunctionBuilder, GreedyAcquisitionFunctionBuilder)):
             raise TypeError(f"unsupported acquisition builder {builder!r}")
+        self._base_optimizer = optimizer  # before any batch wrapping (trust-region rules re-use it per region)
         if num_query_points > 1:
             if isinstance(builder, VectorizedAcquisitionFunctionBuilder):
                 optimizer = batchify_vectorize(optimizer, num_query_points)  # batch elements independently
@@ -303,7 +304,7 @@ class DiscreteThompsonSampling(AcquisitionRule):
         eng = getattr(model, "engine", None)
         if self._on_device and eng is not None and hasattr(search_space, "sample_device") and hasattr(eng, "sample_box"):
             query_points = search_space.sample_device(eng, self._num_search_space_samples,
-                                                      seed=0 if self._seed is None else self._seed)
+                                                      seed=_fresh_seed() if self._seed is None else self._seed)
         else:
             query_points = search_space.sample(self._num_search_space_samples, seed=self._seed)
         return self._thompson_sampler.sample(model, self._num_query_points, query_points,

@@ -9,8 +9,8 @@ top-k and L-BFGS-B refinement runs on the engine exactly as for the global space
 single-objective region logic (success test with ``kappa`` x volume, growth / shrinkage by ``beta``, re-initialisation
 below ``min_eps``, TREGO's global / local alternation) and the rule plumbing (``acquire`` / ``filter_datasets`` state
 functions), and TURBO's box.  Local models / local datasets per region, product and discrete regions are not built: with
-global models the base rule (one query point) runs once per region, on a copy of the rule (the reference batches
-EGO over a tagged multi-space instead; for one region -- TREGO -- the two coincide).
+global models the base rule runs once per region, on a copy of the rule (the reference batches EGO over a tagged
+multi-space instead; for one region -- TREGO -- and for vectorized builders the two coincide).
 """
 from __future__ import annotations
 
@@ -290,8 +290,8 @@ def get_unique_points_mask(points, tolerance: float = 1e-6) -> np.ndarray:
 
 
 class BatchTrustRegionBox(AcquisitionRule):
-    """One query point per trust region per step, each region with its own base-rule instance (rule.py:1261-1566,
-    1863-1920).  ``acquire`` returns ``state -> (state, points [1, V, D])``; ``filter_datasets`` returns
+    """Query points per trust region, each region with its own base-rule instance (rule.py:1261-1566, 1863-1920).
+    ``acquire`` returns ``state -> (state, points [N, V, D])`` (N points of the base rule in each of the V regions); ``filter_datasets`` returns
     ``state -> (state, datasets)`` and is where the regions are updated from the newest data (the loops call it
     after every observation).  Regions whose centres coincide are re-initialised."""
 
@@ -335,11 +335,26 @@ class BatchTrustRegionBox(AcquisitionRule):
             else:
                 self._rule = EfficientGlobalOptimization()
         if self._rules is None:
-            if getattr(self._rule, "_num_query_points", 1) != 1:
-                raise NotImplementedError(
-                    "the base rule must ask for one query point: every trust region runs its own copy of it (batched "
-                    "acquisition over a tagged multi-space, as the reference does for EGO, is not built)")
-            self._rules = [copy.deepcopy(self._rule) for _ in range(count)]
+            base = self._rule
+            q = getattr(base, "_num_query_points", 1)
+            if isinstance(base, EfficientGlobalOptimization) and q > 1:
+                # the reference optimises such a rule ONCE over the tagged product of the regions, column v of the
+                # batch inside region v (rule.py:1476-1493).  For a vectorized builder the columns are independent
+                # functions, so one single-point rule per region is the same computation
+                from .interface import VectorizedAcquisitionFunctionBuilder
+
+                if q != count:
+                    raise ValueError(f"the base rule asks for {q} query points but there are {count} trust regions")
+                if not isinstance(base._builder, VectorizedAcquisitionFunctionBuilder):
+                    raise NotImplementedError("joint / greedy batch builders over several trust regions need the "
+                                              "tagged multi-space optimisation of the reference, which is not built")
+                if base._acquisition_function is not None:
+                    raise ValueError("the base rule must not have been used before")
+                inner = getattr(base._builder, "single_builder", base._builder)
+                self._rules = [EfficientGlobalOptimization(copy.deepcopy(inner), base._base_optimizer, 1)
+                               for _ in range(count)]
+            else:  # any other rule runs per region as it is: its N points x V regions make the batch
+                self._rules = [copy.deepcopy(base) for _ in range(count)]
         return self._rules
 
     def _subspaces_of(self, state: Optional[BatchTrustRegionState]):

@@ -68,6 +68,43 @@ class OptimizationResult:
     def try_get_final_model(self):
         return self.final_result.unwrap().model
 
+    def try_get_optimal_point(self):
+        """(best query point [D], its observation [1], its index) of a single-objective run
+        (bayesian_optimizer.py:266-284)."""
+        dataset = self.try_get_final_dataset()
+        obs = np.asarray(dataset.observations)
+        if obs.ndim != 2 or obs.shape[1] != 1:
+            raise ValueError("Expected a single objective")
+        arg_min_idx = int(np.argmin(obs[:, 0]))
+        return dataset.query_points[arg_min_idx], obs[arg_min_idx], arg_min_idx
+
+
+def stop_at_minimum(minimum=None, minimizers=None, minimum_atol: float = 0, minimum_rtol: float = 0.05,
+                    minimizers_atol: float = 0, minimizers_rtol: float = 0.05, objective_tag=OBJECTIVE,
+                    minimum_step_number: Optional[int] = None) -> Callable:
+    """An early-stop callback that ends a BO loop once the best observation is close to ``minimum`` [1] and / or the
+    best query point is close to one of the ``minimizers`` [N, D] (bayesian_optimizer.py:1160-1207).  The step
+    number the reference reads from its logging module is counted by the callback itself (one call per step)."""
+    calls = {"n": 0}
+
+    def early_stop_callback(datasets: Mapping, _models: Mapping, _acquisition_state) -> bool:
+        calls["n"] += 1
+        if minimum_step_number is not None and calls["n"] < minimum_step_number:
+            return False
+        dataset = datasets[objective_tag]
+        obs = np.asarray(dataset.observations)
+        arg_min_idx = int(np.argmin(obs[:, 0]))
+        if minimum is not None and not np.all(np.isclose(obs[arg_min_idx], minimum, atol=minimum_atol, rtol=minimum_rtol)):
+            return False
+        if minimizers is not None:
+            close_x = np.isclose(np.asarray(dataset.query_points)[arg_min_idx], np.asarray(minimizers),
+                                 atol=minimizers_atol, rtol=minimizers_rtol)
+            if not np.any(np.all(close_x, axis=-1)):
+                return False
+        return True
+
+    return early_stop_callback
+
 
 def _as_map(x):
     return x if isinstance(x, Mapping) else {OBJECTIVE: x}
