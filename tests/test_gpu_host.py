@@ -420,3 +420,36 @@ def test_small_sibling_builders_on_gpu():
     assert_close(eci(xs[:, None, :])[:, 0], O.expected_improvement(om, ov, eta) * pof, rtol=1e-6, atol=1e-10, what="ECI")
     pt = A.EfficientGlobalOptimization(builder).acquire(space, models, datasets)
     assert pt.shape == (1, 2) and float(eci(pt[:, None, :])[0, 0]) >= float(eci(xs[:, None, :]).max()) - 1e-9
+
+
+def _quadratic_rules():
+    from tests.test_integration_rules import RULES
+
+    return RULES
+
+
+@pytest.mark.slow  # opt-in (--runslow yes): the CPU twin of this test runs in the default suite on the engine stand-in
+@pytest.mark.parametrize("name,make_rule", _quadratic_rules(), ids=[r[0] for r in _quadratic_rules()])
+def test_every_rule_solves_the_simple_quadratic_on_gpu(name, make_rule):
+    """tests/test_integration_rules.py::test_bayesian_optimizer_with_gpr_finds_minima_of_simple_quadratic on the real
+    engine: every rule, through the BO loop with model fitting, within 6 steps."""
+    import trieste_amd
+    import trieste_amd.models as M
+    from trieste_amd import objectives as OBJ
+    from trieste_amd.bayesian_optimizer import BayesianOptimizer, stop_at_minimum
+    from trieste_amd.data import Dataset
+    from trieste_amd.space import Box
+
+    trieste_amd.set_seed(1793)
+    space = Box([0.0, 0.0], [1.0, 1.0])
+    problem = OBJ.SimpleQuadratic
+    initial = space.sample(10, seed=7)
+    data = Dataset(initial, problem.objective(initial))
+    model = M.GaussianProcessRegression(M.build_gpr(data, space, likelihood_variance=1e-7))
+    result = BayesianOptimizer(lambda x: Dataset(x, problem.objective(x)), space).optimize(
+        6, data, model, make_rule(), fit_initial_model=False,
+        early_stop_callback=stop_at_minimum(problem.minimum, problem.minimizers, minimum_rtol=0.05, minimum_step_number=2))
+    assert result.final_result.is_ok, result.final_result
+    best_x, best_y, _ = result.try_get_optimal_point()
+    assert np.any(np.all(np.abs((best_x - problem.minimizers) / problem.minimizers) < 0.05, axis=-1)), (name, best_x)
+    np.testing.assert_allclose(best_y, problem.minimum, rtol=0.05)
