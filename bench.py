@@ -1,21 +1,33 @@
 """bench.py -- acquisition-candidate evaluations / second on MI355X (BASELINE.json's metric).
 
-A "step" is one fused sweep of the hot path over one batch of synthetic candidates:
-    K* generation -> W K* (f64 MFMA) -> variance/mean -> Expected Improvement -> arg-max
-followed, for N > 1 GPUs, by the RCCL all-gather of the per-rank (value, index) winners.
-Inputs (model state, candidates) are resident in HBM when the timed region starts; `update`
-(K assembly + Cholesky + inverse) is outside it and reported separately in `config`.
+A "step" is one pass of the hot path over one batch of synthetic candidates resident in HBM:
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload headline|c2|c3]
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+  headline / c2 / c3   fused EI sweep: K* generation -> W K* (f64 MFMA) -> variance / mean -> Expected Improvement
+                       -> arg-max                                                      unit: candidates/s
+  c4                   batch Monte-Carlo EI: joint posterior of G q-batches (f64 MFMA sweep + Gram) -> chol(cov + jitter I)
+                       -> reparametrised samples -> qEI -> arg-max over the batches    unit: q-batches/s
+  c5                   decoupled Thompson sampling: B trajectories (RFF features + canonical kernel sums) over the
+                       candidates -> per-trajectory arg-min                             unit: candidate-trajectory evals/s
 
-Prints ONE JSON line on rank 0.
+followed, for N > 1 GPUs, by ONE RCCL all-gather of the per-rank (value, index) winners, a merge kernel and one
+16-byte device-to-host copy.  `update` (K assembly + Cholesky + inverse) is outside the timed region and reported in
+`config`.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload headline|c2|c3|c4|c5]
+                    [--scaling weak|strong] [--mode ranks|group]
+
+`--gpus N` with N > 1 and no torch.distributed environment re-launches itself as N ranks (one process per GPU,
+`python -m torch.distributed.run --nproc-per-node N ...`, backend nccl = RCCL); under torchrun it is one of the ranks.
+`--mode group` instead drives all N GPUs from ONE process through the C-ABI's single-controller group
+(tgp_group_*: in-process RCCL communicator).  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,57 +37,98 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix peak (public spec; measured 78.0, profiles/r01_ubench_fp64.txt)
+FP64_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix = fp64 vector peak (public spec; MFMA measured 78.0, profiles/r01_ubench_fp64.txt)
 
 WORKLOADS = {
-    # name: (objective, d, kernel, N, M per GPU, noise)        -- BASELINE.md section 4
-    "headline": ("ackley", 8, "matern52", 4096, 1 << 20, 1e-2),  # north-star: N=4096, d=8, 1 GPU
-    "c3": ("ackley", 8, "matern52", 4096, 1_000_000, 1e-2),      # Ackley-8, 10^6 candidates / GPU
-    "c2": ("hartmann_6", 6, "rbf", 1024, 1_000_000, 1e-2),       # Hartmann-6 RBF N=1024
+    # BASELINE.md section 4 / SURVEY.md section 8(d).  "M" = units per GPU (weak scaling)
+    "headline": dict(kind="ei", objective="ackley", d=8, kernel="matern52", N=4096, M=1 << 20, noise=1e-2),
+    "c3": dict(kind="ei", objective="ackley", d=8, kernel="matern52", N=4096, M=1_000_000, noise=1e-2),
+    "c2": dict(kind="ei", objective="hartmann_6", d=6, kernel="rbf", N=1024, M=1_000_000, noise=1e-2),
+    "c4": dict(kind="qei", objective="hartmann_6", d=6, kernel="matern52", N=2048, M=100_000, noise=1e-2, q=50, S=512),
+    "c5": dict(kind="ts", objective="ackley", d=16, kernel="matern52", N=8192, M=2_000_000, noise=1e-2, F=2048, B=4),
 }
+UNITS = {"ei": "candidates/s", "qei": "q-batches/s", "ts": "candidate-trajectory evals/s"}
 KERNEL_FLOPS = {"rbf": 12, "matern12": 16, "matern32": 18, "matern52": 20}  # c_k of SURVEY 8(d)
+COS_FLOPS = 20  # c_cos: one RFF feature (range reduction + polynomial)
 
 
-def algorithmic_flops_per_candidate(N: int, d: int, kernel: str) -> float:
-    """N^2 + N (3d + c_k) + 2N + 60."""
-    return float(N) * N + N * (3 * d + KERNEL_FLOPS[kernel]) + 2.0 * N + 60.0
+def flops_per_unit(w) -> float:
+    """Algorithmic flops per unit, SURVEY.md section 8(d)."""
+    N, d, ck = float(w["N"]), w["d"], KERNEL_FLOPS[w["kernel"]]
+    if w["kind"] == "ei":        # per candidate: N^2 + N (3d + c_k) + 2N + 60
+        return N * N + N * (3 * d + ck) + 2.0 * N + 60.0
+    if w["kind"] == "qei":       # per q-batch: q N^2 + q N (3d + c_k) + q^2 N + q^3/3 + q^2 S + 3 q S
+        q, S = w["q"], w["S"]
+        return q * N * N + q * N * (3 * d + ck) + q * q * N + q ** 3 / 3.0 + q * q * S + 3.0 * q * S
+    F = w["F"]                   # per candidate-trajectory: 2 F d + c_cos F + 2 F + N (3d + c_k) + 2 N
+    return 2.0 * F * d + COS_FLOPS * F + 2.0 * F + N * (3 * d + ck) + 2.0 * N
 
 
-def cpu_baseline(obj_name, d, kernel, N, noise, budget_s=15.0):
-    """The oracle's reference-shaped sweep (materialise K*, two triangular solves, column norms,
-    EI, arg-max per chunk) on the host cores.  kind = "port": trieste's own GPflow/TF path cannot
-    be installed here."""
+# ---------------------------------------------------------------------------------------------------------------
+# CPU baselines (rank 0, N = 1 only): the oracle side of the repo is imported HERE and nowhere else in this file
+# ---------------------------------------------------------------------------------------------------------------
+def cpu_baseline(w, budget_s=12.0):
+    """kind = "port": trieste's own GPflow/TF path cannot be installed here.  The EI sweeps
+    use torch-CPU (MKL trsm/gemm) float64 in chunks of 16384 candidates on all host cores, in the reference's
+    algorithmic shape; `improved` is the same sweep with the engine's algorithmic savings (cached alpha, one solve)
+    so that the GPU/CPU ratio is not inflated by them.  c4 / c5 time the numpy oracle's batch MC-EI / trajectory."""
+    from oracle import cpu_baseline as CB
     from oracle import gp_oracle as O
 
+    X, Y = O.synthetic_problem(getattr(O, w["objective"]), w["d"], w["N"])
+    st = O.gpr_update(w["kernel"], 1.0, O.default_lengthscales(w["d"]), w["noise"], float(Y.mean()), X, Y)
+    d, N = w["d"], w["N"]
+    if w["kind"] == "ei":
+        eta = O.eta_min_mean(st)
+        chunk = 16384
+        rate, done, el, threads = CB.timed_sweep(st, eta, d, chunk, budget_s, improved=False)
+        rate2, done2, el2, _ = CB.timed_sweep(st, eta, d, chunk, budget_s / 2, improved=True)
+        return {"value": rate, "unit": UNITS["ei"], "cores": threads, "kind": "port",
+                "sample": f"{done} candidates at N={N}, d={d}, {w['kernel']}: torch-CPU float64 ({threads} threads, MKL), "
+                          f"reference-shaped chunks of {chunk} (K* [N,{chunk}], 2 trsm, EI, arg-max), {el:.1f} s",
+                "improved": {"value": rate2, "unit": UNITS["ei"], "cores": threads,
+                             "sample": f"{done2} candidates, same sweep with cached alpha (gemv mean) and one trsm, {el2:.1f} s"}}
     try:
         from threadpoolctl import threadpool_info
 
         threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
         threads = os.cpu_count() or 1
-    X, Y = O.synthetic_problem(getattr(O, obj_name), d, N)
-    st = O.gpr_update(kernel, 1.0, O.default_lengthscales(d), noise, float(Y.mean()), X, Y)
-    eta = O.eta_min_mean(st)
     rng = np.random.default_rng(5678)
-    chunk = 2000
-    done, t0 = 0, time.perf_counter()
+    if w["kind"] == "qei":
+        q, S = w["q"], w["S"]
+        eps = np.random.default_rng(91011).standard_normal((q, S))
+        eta = O.eta_min_mean(st)
+        g, done, t0 = 8, 0, time.perf_counter()
+        while True:
+            O.batch_mc_ei(st, rng.uniform(size=(g, q, d)), eps, eta)
+            done += g
+            el = time.perf_counter() - t0
+            if el > budget_s:
+                break
+        return {"value": done / el, "unit": UNITS["qei"], "cores": int(threads), "kind": "port",
+                "sample": f"{done} q-batches (q={q}, S={S}) at N={N}, d={d}: numpy/scipy float64 restatement "
+                          f"(predict_joint, chol(cov + jitter I), reparametrised samples), {el:.1f} s"}
+    F, B = w["F"], w["B"]
+    r2 = np.random.default_rng(7)
+    Wf, b = r2.standard_t(5, size=(F, d)), r2.uniform(0, 2 * np.pi, F)
+    wts, xi = r2.standard_normal((F, B)), r2.standard_normal((N, B))
+    v = O.decoupled_weights(st, Wf, b, wts, xi)
+    chunk, done, t0 = 4096, 0, time.perf_counter()
     while True:
-        Xq = rng.uniform(size=(chunk, d))
-        O.ei_sweep_reference_shape(st, Xq, eta, chunk=chunk)
-        done += chunk
+        O.trajectory_eval(st, Wf, b, wts, v, rng.uniform(size=(chunk, d)))
+        done += chunk * B
         el = time.perf_counter() - t0
-        if el > budget_s or done >= 60 * chunk:
+        if el > budget_s:
             break
-    return {"value": done / el, "unit": "candidates/s", "cores": int(threads), "kind": "port",
-            "sample": f"{done} candidates at N={N}, d={d}, {kernel}: numpy/scipy fp64 restatement of the "
-                      f"reference algorithm (K* [N,{chunk}], 2 triangular solves, EI, arg-max), {el:.1f} s"}
+    return {"value": done / el, "unit": UNITS["ts"], "cores": int(threads), "kind": "port",
+            "sample": f"{done} candidate-trajectory evaluations (F={F}, B={B}) at N={N}, d={d}: numpy float64 restatement "
+                      f"(features [chunk, F+N] materialised per chunk of {chunk}), {el:.1f} s"}
 
 
-def end_to_end_acquire_ms(X, Y, d, kernel, noise):
+def end_to_end_acquire_ms(X, Y, w):
     """Informational (outside the timed region, SURVEY 8d "end-to-end acquire time"): one
-    EfficientGlobalOptimization().acquire on the same model through the reference-shaped host API --
-    eta, max(5000, 1000 d) random candidates swept + top-k on the device, 10 d greenlet-batched
-    L-BFGS-B runs on the analytic EI gradient (the reference's default for a Box)."""
+    EfficientGlobalOptimization().acquire on the same model through the reference-shaped host API."""
     try:
         import trieste_amd.models as M
         from trieste_amd import objectives as O
@@ -83,10 +136,11 @@ def end_to_end_acquire_ms(X, Y, d, kernel, noise):
         from trieste_amd.data import Dataset
         from trieste_amd.space import Box
 
-        kern = M.Kernel(variance=1.0, lengthscales=O.default_lengthscales(d), kind=kernel)
+        d = w["d"]
+        kern = M.Kernel(variance=1.0, lengthscales=O.default_lengthscales(d), kind=w["kernel"])
         model = M.GaussianProcessRegression(M.GPR(data=(X, Y[:, None]), kernel=kern,
                                                   mean_function=M.Constant(float(Y.mean())),
-                                                  likelihood_variance=noise))
+                                                  likelihood_variance=w["noise"]))
         data = Dataset(X, Y[:, None])
         rule = EfficientGlobalOptimization()
         space = Box([0.0] * d, [1.0] * d)
@@ -98,66 +152,175 @@ def end_to_end_acquire_ms(X, Y, d, kernel, noise):
         return f"failed: {type(e).__name__}: {e}"
 
 
+def respawn_as_ranks(n: int) -> None:
+    """`python bench.py --gpus N` (N > 1, no torch.distributed environment): become N ranks, one per GPU."""
+    import torch
+
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible -- refusing to report an {n}-GPU number")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
-    ap.add_argument("--m-per-gpu", type=int, default=0, help="override candidates per GPU")
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"),
+                    help="weak: the workload's units per GPU; strong: 8 x that in total, split over the GPUs")
+    ap.add_argument("--mode", default="ranks", choices=("ranks", "group"),
+                    help="ranks: one process per GPU over torch.distributed/RCCL; group: one process, tgp_group_*")
+    ap.add_argument("--merge", default="rccl", choices=("rccl", "peer"), help="group mode: winner exchange")
+    ap.add_argument("--m-per-gpu", type=int, default=0, help="override the units per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-acquire", action="store_true", help="skip the informational end-to-end acquire timing")
-    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--variant", type=int, default=0, help="tgp_set_variant launch-policy bits (experiments)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.mode == "ranks" and args.gpus > 1 and not under_launcher:
+        respawn_as_ranks(args.gpus)
 
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: trieste_amd has no CPU fallback")
+    group_mode = args.mode == "group"
+    if group_mode:
+        if under_launcher and int(os.environ["WORLD_SIZE"]) > 1:
+            raise SystemExit("--mode group is a single process: do not launch it under torchrun with several ranks")
+        if torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"--mode group --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible")
+        world, rank, local_rank, use_dist = 1, 0, 0, False
+        nshards = args.gpus
+    else:
+        world = int(os.environ.get("WORLD_SIZE", "1")) if under_launcher else 1
+        rank = int(os.environ.get("RANK", "0")) if under_launcher else 0
+        local_rank = int(os.environ.get("LOCAL_RANK", "0")) if under_launcher else 0
+        if world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {args.gpus}-GPU number "
+                             f"from {world} rank(s)")
+        use_dist = under_launcher  # also with --nproc-per-node 1: the RCCL path at world size 1
+        nshards = world
     torch.cuda.set_device(local_rank)
-    # launched by torch.distributed.run (also with --nproc-per-node 1): one process per GPU over RCCL
-    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    rccl_ranks = 0
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        rccl_ranks = dist.get_world_size()
 
     from trieste_amd import objectives as O  # the seeded synthetic problem (inputs)
-    from trieste_amd.distributed import all_gather_best
+    from trieste_amd.distributed import all_gather_winners
     from trieste_amd.engine import GPEngine
 
-    obj_name, d, kernel, N, M, noise = WORKLOADS[args.workload]
-    if args.m_per_gpu:
-        M = args.m_per_gpu
-    X, Y = O.synthetic_problem(getattr(O, obj_name), d, N)  # seed 1234, standardised
-    eng = GPEngine(d, kernel, device=local_rank)
-    eng.set_variant(args.variant)
-    eng.use_torch_stream()
-    eng.set_hyper(1.0, O.default_lengthscales(d), noise, float(Y.mean()))
-    eng.set_data(X, Y)  # warm-up (allocations)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    eng.set_data(X, Y)  # every rank runs the same deterministic update (replicated model state)
-    torch.cuda.synchronize()
-    update_ms = (time.perf_counter() - t0) * 1e3
-    eta = eng.eta()
-    # weak scaling: M candidates per GPU; rank r owns global rows [r*M, (r+1)*M) of ONE logical
-    # Philox sample (seed 5678), generated on the device
-    Xq = eng.sample_box(5678, rank * M, M, 0.0, 1.0)
+    w = dict(WORKLOADS[args.workload])
+    kind, d, kernel, N, noise = w["kind"], w["d"], w["kernel"], w["N"], w["noise"]
+    per_gpu = args.m_per_gpu or w["M"]
+    if args.scaling == "strong":  # fixed total = the config's 8-GPU job, split over the GPUs in use
+        total_units = 8 * per_gpu
+        per = -(-total_units // nshards)
+    else:
+        total_units, per = per_gpu * nshards, per_gpu
+    X, Y = O.synthetic_problem(getattr(O, w["objective"]), d, N)  # seed 1234, standardised
+    ls = O.default_lengthscales(d)
+    dev = f"cuda:{local_rank}"
 
-    def step():
-        val, idx, _ = eng.acq_argmax("ei", eta, Xq, index_base=rank * M)
-        gv, gi = all_gather_best(val, idx, device=f"cuda:{local_rank}", force=use_dist)
-        return float(gv[0]), int(gi[0])
+    if group_mode:
+        from trieste_amd.group import GPEngineGroup
 
-    if use_dist:  # communicator set-up (lazy in RCCL) must not land in the timed region even with --warmup 0
-        all_gather_best(0.0, rank * M, device=f"cuda:{local_rank}", force=True)
-    best = (float("nan"), -1)
+        if kind == "qei":
+            raise SystemExit("--mode group benches the resident-candidate sweeps (headline, c2, c3, c5)")
+        grp = GPEngineGroup(d, kernel, devices=list(range(args.gpus)), merge=args.merge)
+        info = grp.info()
+        rccl_ranks = info["rccl_ranks"]
+        for m in grp.members:
+            m.set_variant(args.variant)
+        grp.set_hyper(1.0, ls, noise, float(Y.mean()))
+        grp.set_data(X, Y)  # warm-up (allocations)
+        t0 = time.perf_counter()
+        grp.set_data(X, Y)  # every member runs the same deterministic update, concurrently
+        update_ms = (time.perf_counter() - t0) * 1e3
+        eta = grp.eta()
+        grp.sample_candidates(5678, total_units, 0.0, 1.0)  # ONE logical Philox sample, sharded
+        eng = grp.primary
+        if kind == "ts":
+            r2 = np.random.default_rng(7)
+            traj = grp.trajectory(r2.standard_t(5, size=(w["F"], d)), r2.uniform(0, 2 * np.pi, w["F"]),
+                                  r2.standard_normal((w["F"], w["B"])), r2.standard_normal((N, w["B"])))
+
+            def step():
+                v, i = traj.argmin()
+                return float(v[0]), int(i[0])
+        else:
+            def step():
+                v, i, _ = grp.acq_argmax("ei", eta)
+                return float(v), int(i)
+
+        def kernel_ms_of_step():
+            return grp.last_kernel_ms()
+    else:
+        eng = GPEngine(d, kernel, device=local_rank)
+        eng.set_variant(args.variant)
+        eng.use_torch_stream()
+        eng.set_hyper(1.0, ls, noise, float(Y.mean()))
+        eng.set_data(X, Y)  # warm-up (allocations)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.set_data(X, Y)  # every rank runs the same deterministic update (replicated model state)
+        torch.cuda.synchronize()
+        update_ms = (time.perf_counter() - t0) * 1e3
+        eta = eng.eta()
+        lo = min(rank * per, total_units)
+        mine = max(0, min(lo + per, total_units) - lo)
+        if mine == 0:
+            raise SystemExit("empty shard: fewer units than ranks")
+        if kind == "ei":
+            # rank r owns global rows [lo, lo + mine) of ONE logical Philox sample (seed 5678), generated on the device
+            Xq = eng.sample_box(5678, lo, mine, 0.0, 1.0)
+
+            def step():
+                pair = eng.acq_argmax_pair("ei", eta, Xq, index_base=lo)      # enqueue only
+                v, i = all_gather_winners(eng, pair)                          # all-gather + merge + ONE sync
+                return float(v[0]), int(i[0])
+        elif kind == "qei":
+            q, S = w["q"], w["S"]
+            eps = torch.from_numpy(np.random.default_rng(91011).standard_normal((q, S))).to(dev)
+            Xq = eng.sample_box(5678, lo * q, mine * q, 0.0, 1.0).reshape(mine, q, d)
+
+            def step():
+                vals = eng.qei(Xq, eps, eta, 1e-6)                             # [G] on the device
+                v, i = torch.max(vals, 0)
+                pair = torch.stack([v, (i + lo).view(1).view(torch.float64)[0]])
+                gv, gi = all_gather_winners(eng, pair)
+                return float(gv[0]), int(gi[0])
+        else:
+            F, B = w["F"], w["B"]
+            r2 = np.random.default_rng(7)
+            traj = eng.trajectory(r2.standard_t(5, size=(F, d)), r2.uniform(0, 2 * np.pi, F),
+                                  r2.standard_normal((F, B)), r2.standard_normal((N, B)))
+            Xq = eng.sample_box(5678, lo, mine, 0.0, 1.0)
+
+            def step():
+                pairs = traj.argmin_pairs(Xq, index_base=lo)
+                v, i = all_gather_winners(eng, pairs, minimize=True)
+                return float(v[0]), int(i[0])
+
+        def kernel_ms_of_step():
+            return eng.last_kernel_ms()[0]  # HIP events on the launch stream, this step's dominant kernel
+
+    best = step()  # first call: allocations and (lazy in RCCL) communicator set-up, never in the timed region
     for _ in range(args.warmup):
         best = step()
     kernel_ms = []
@@ -167,63 +330,74 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         best = step()
-        kernel_ms.append(eng.last_kernel_ms()[0])  # HIP events on the launch stream, this launch
+        kernel_ms.append(kernel_ms_of_step())
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = world * M * args.steps / elapsed
+        units_per_unit = w.get("B", 1) if kind == "ts" else 1
+        value = total_units * units_per_unit * args.steps / elapsed
         k_ms = float(np.mean(kernel_ms))
-        flops = algorithmic_flops_per_candidate(N, d, kernel) * M
-        achieved = flops / (k_ms * 1e-3) * 1e-12
-        traffic = None
+        fl = flops_per_unit(w)
+        my_units = (per if not group_mode else -(-total_units // nshards)) * units_per_unit
+        achieved = fl * my_units / (k_ms * 1e-3) * 1e-12 if k_ms > 0 else float("nan")
+        traffic, traffic_src = None, None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tfile) and not args.m_per_gpu:  # measured for the workload's own candidate count
+        if os.path.exists(tfile) and not args.m_per_gpu and args.scaling == "weak":
             try:
-                traffic = json.load(open(tfile)).get(args.workload)
+                tj = json.load(open(tfile))
+                traffic = tj.get(args.workload)
+                if traffic is not None:
+                    traffic_src = (f"profiles/traffic.json: rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE) of round "
+                                   f"{tj.get('_round', '?')} on this workload -- NOT measured in this run")
             except Exception:
                 traffic = None
+        kern_name = {"ei": "sweep_kernel<KIND, DP, JOINT=false, SPLIT=false>", "qei": "sweep_kernel<KIND, DP, JOINT=true>",
+                     "ts": "traj_eval_kernel"}[kind]
+        par = (f"single-controller group x{nshards} (tgp_group_*, merge={args.merge})" if group_mode else
+               f"candidate-sharded x{world}, one process per GPU, replicated model, (val,idx) all-gather")
         out = {
             "metric": "acquisition-candidate evals/sec (N train, d dim)",
             "value": value,
-            "unit": "candidates/s",
-            "n_gpus": world,
+            "unit": UNITS[kind],
+            "n_gpus": nshards,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.workload}: EI sweep + arg-max, {obj_name} d={d}, {kernel}, N={N} train, "
-                            f"{M} candidates/GPU, noise={noise:g}",
-                "N": N, "d": d, "kernel": kernel, "candidates_per_gpu": M,
-                "parallelism": f"candidate-sharded x{world}, replicated model, (val,idx) all-gather",
-                "update_ms": update_ms, "best_ei": best[0], "best_index": best[1],
+                "workload": f"{args.workload}: {kind} step, {w['objective']} d={d}, {kernel}, N={N} train, "
+                            f"{per} units/GPU ({total_units} total), noise={noise:g}"
+                            + (f", q={w['q']}, S={w['S']}" if kind == "qei" else "")
+                            + (f", F={w['F']}, B={w['B']}" if kind == "ts" else ""),
+                "N": N, "d": d, "kernel": kernel, "units_per_gpu": per, "total_units": total_units,
+                "parallelism": par, "rccl_ranks": rccl_ranks,
+                "update_ms": update_ms, "best_value": best[0], "best_index": best[1],
             },
             "roofline": {
-                "bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                "kernel": {0: "sweep_u16_kernel", 1: "sweep_kernel", 2: "sweep_ws_kernel"}.get(args.variant & 0xff, "?"),
-                "kernel_ms": k_ms, "flops_per_candidate": algorithmic_flops_per_candidate(N, d, kernel),
+                "bound": "mfma" if kind != "ts" else "valu_f64", "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                "kernel": kern_name, "kernel_ms": k_ms, "flops_per_unit": fl,
                 # the other roofline (SURVEY 8d asks for both): PMC traffic / kernel time against 8 TB/s HBM3E
                 "hbm_GBps": (traffic / (k_ms * 1e-3) * 1e-9) if traffic else None,
                 "hbm_frac": (traffic / (k_ms * 1e-3) / 8.0e12) if traffic else None,
             },
         }
-        if world == 1 and not args.no_acquire:
-            out["config"]["acquire_ms"] = end_to_end_acquire_ms(X, Y, d, kernel, noise)
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(obj_name, d, kernel, N, noise)
+        if nshards == 1 and not args.no_acquire and kind == "ei":
+            out["config"]["acquire_ms"] = end_to_end_acquire_ms(X, Y, w)
+        if not args.no_cpu_baseline and nshards == 1:
+            out["cpu_baseline"] = cpu_baseline(w)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

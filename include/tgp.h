@@ -280,11 +280,92 @@ int tgp_traj_value_grad(tgp_traj t, const double* Xq, int64_t P, double* val, do
 int tgp_traj_argmin(tgp_traj t, const double* Xq, int64_t M, int64_t index_base, double* best_val,
                     int64_t* best_idx, int where);
 
+/* ---- device-resident winners (one synchronisation per step) ----------------------------------
+ * The synchronous arg-max / arg-min above hand their winners back as host scalars.  These forms leave
+ * them on the device and only ENQUEUE work on the handle's stream (tgp_set_stream /
+ * tgp_use_private_stream): no host synchronisation, so a sharded step is sweep -> all-gather of the
+ * pairs (RCCL, on the same stream) -> tgp_merge_winners_async -> ONE device-to-host copy.  Candidates
+ * must be device-resident.  Same arithmetic, same first-index tie-break as tgp_acq_argmax /
+ * tgp_traj_argmin (== tf.math.argmax in _get_max_discrete_points, acquisition/optimizer.py:149-150;
+ * tf.math.argmin in ThompsonSamplerFromTrajectory.sample, acquisition/sampler.py:262-271).
+ *   pair_device   DEVICE [2]:    value, global index (int64 stored in the second 8-byte slot)
+ *   pairs_device  DEVICE [2][B]: B values, then B global indices (int64 bit patterns)
+ * tgp_merge_winners_async: gathered_device [P][2][V] (what an all-gather of P ranks' [2][V] pairs
+ * yields) -> out_device [2][V]; larger value wins (smaller if minimize != 0), ties go to the smaller
+ * global index, NaN values and negative / "nothing found" indices never win; no valid entry: (NaN, -1).
+ * tgp_stream_synchronize waits for everything enqueued on the handle's stream. */
+int tgp_acq_argmax_async(tgp_handle h, int acq_kind, double param, const double* Xq_device, int64_t M,
+                         int64_t index_base, double* pair_device);
+int tgp_traj_argmin_async(tgp_traj t, const double* Xq_device, int64_t M, int64_t index_base,
+                          double* pairs_device);
+int tgp_merge_winners_async(tgp_handle h, const double* gathered_device, int P, int V, int minimize,
+                            double* out_device);
+int tgp_stream_synchronize(tgp_handle h);
+
+/* ---- single-controller multi-GPU group -------------------------------
+ * One host process, one model replica per device: the BayesianOptimizer / Ask-Tell loop -- and the
+ * user's observer, which the reference calls exactly once per step (bayesian_optimizer.py:793-806) --
+ * runs ONCE, while the candidate sweep shards over the devices.  The reference has no multi-device
+ * path; this is the form its single-process loop can call.
+ *   - every member is an ordinary tgp_handle on its own device with a private stream
+ *     (tgp_group_member borrows it: posterior queries, gradients, fits go to member 0 or any replica);
+ *   - model state is REPLICATED: set_hyper / set_data / append_data run the same deterministic update on
+ *     every device concurrently (one host worker thread per member), bit-identical on identical GPUs;
+ *   - candidates are SHARDED: member r owns the contiguous rows shard(M, r) = [r*ceil(M/n), ...) of the
+ *     logical candidate table, with index_base = its first row, so global indices and the first-index
+ *     tie-break survive;
+ *   - the only exchange is the winners: every member's sweep leaves its (value, index) pairs on its device,
+ *     one all-gather over an in-process RCCL communicator (ncclCommInitAll over xGMI; 16 B per member and
+ *     vectorised function) brings them together, a merge kernel on member 0 picks (max value, min index)
+ *     and ONE 16-byte copy reaches the host.  merge = TGP_MERGE_PEER replaces the all-gather by 16-byte
+ *     peer copies into member 0 (no RCCL needed).  RCCL is resolved at run time (dlopen librccl.so.1):
+ *     TGP_MERGE_RCCL fails with TGP_ERR_STATE if it is not loadable.
+ * One host thread drives a group at a time.  Group calls are synchronous on return. */
+typedef struct tgp_group_s* tgp_group;
+typedef struct tgp_group_traj_s* tgp_group_traj;
+enum tgp_merge { TGP_MERGE_RCCL = 0, TGP_MERGE_PEER = 1 };
+
+int tgp_group_create(const int* device_ids, int n_dev, int d, int kernel_kind, int merge, tgp_group* out);
+int tgp_group_destroy(tgp_group g);
+const char* tgp_group_last_error(tgp_group g); /* g may be NULL: message of the last failed create */
+/* n_dev, the merge actually in use, and the number of RCCL ranks the communicator reports (0 for PEER) */
+int tgp_group_info(tgp_group g, int* n_dev, int* merge, int* rccl_ranks);
+int tgp_group_member(tgp_group g, int i, tgp_handle* out); /* borrowed: do not destroy */
+/* replicated model state: same arguments as tgp_set_hyper / tgp_set_data / tgp_append_data, HOST buffers */
+int tgp_group_set_hyper(tgp_group g, double variance, const double* lengthscales, double noise_variance,
+                        double mean_const);
+int tgp_group_set_data(tgp_group g, const double* X, const double* Y, int64_t N);
+int tgp_group_append_data(tgp_group g, const double* Xnew, const double* Ynew, int64_t k);
+/* The group's resident candidate table [M,d], sharded: either scattered from a HOST array
+ * (DiscreteSearchSpace.points, space.py:394-407) or generated on the devices as ONE logical Philox sample --
+ * element (row, col) depends on (seed, row, col) only, so the table does not depend on n_dev
+ * (Box.sample, space.py:843-867; see tgp_sample_box). */
+int tgp_group_set_candidates(tgp_group g, const double* Xq, int64_t M);
+int tgp_group_sample_candidates(tgp_group g, uint64_t seed, int64_t M, const double* lower, const double* upper);
+/* == tgp_acq_argmax over the resident table; best_x [d] (host, may be NULL) is read from the owning member */
+int tgp_group_acq_argmax(tgp_group g, int acq_kind, double param, double* best_val, int64_t* best_idx,
+                         double* best_x);
+/* == tgp_acq_topk over the resident table: every member's top-k (k <= 1024, shard size >= k or the shard's
+ * size), merged on the host (value desc, index asc). */
+int tgp_group_acq_topk(tgp_group g, int acq_kind, double param, int k, double* vals, int64_t* idx);
+/* == tgp_qei with the G q-batches sharded over the members: Xq host [G,q,d], eps host [q,S], out host [G] */
+int tgp_group_qei(tgp_group g, const double* Xq, int64_t G, int q, const double* eps, int S, double eta,
+                  double jitter, double* out);
+/* decoupled Thompson trajectories replicated on every member (same draws): tgp_traj_create per member;
+ * tgp_group_traj_argmin = tgp_traj_argmin over the resident table (host outputs [B]). */
+int tgp_group_traj_create(tgp_group g, const double* rff_W, const double* rff_b, int F, const double* w,
+                          const double* xi, int B, tgp_group_traj* out);
+int tgp_group_traj_destroy(tgp_group_traj t);
+int tgp_group_traj_argmin(tgp_group_traj t, double* best_val, int64_t* best_idx);
+/* duration (ms) of the slowest member's dominant kernel in the most recent sharded sweep */
+int tgp_group_last_kernel_ms(tgp_group g, double* ms);
+
 /* ---- measurement ------------------------------------------------------------------------- */
 /* Duration (ms, HIP events on the handle's stream) and launch count of the dominant kernel of
  * the most recent sweep-type call (predict / acq_values / acq_argmax / qei / traj_*). */
 int tgp_last_kernel_ms(tgp_handle h, double* ms, int* launches);
-/* Sweep tile configuration knob for experiments: variant id (0 = default). */
+/* Sweep launch policy knob for experiments and tests (0 = default): bit 0 = never use the row-group split of
+ * small launches, bit 1 = always use it.  Every setting computes the same arithmetic on every candidate. */
 int tgp_set_variant(tgp_handle h, int variant);
 
 #ifdef __cplusplus

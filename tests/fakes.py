@@ -37,6 +37,16 @@ class FakeTrajectory:
         idx = np.argmin(vals, axis=0)
         return vals[idx, np.arange(self.B)], idx + index_base
 
+    def argmin_pairs(self, Xq, index_base=0):
+        return _pairs(*self.argmin(Xq, index_base))
+
+
+def _pairs(vals, idx):
+    """[2, V] float64: values, then the int64 indices bit-cast (the device pair layout of include/tgp.h)."""
+    vals = np.atleast_1d(np.asarray(vals, np.float64))
+    idx = np.atleast_1d(np.asarray(idx, np.int64))
+    return np.stack([vals, idx.view(np.float64)])
+
 
 class FakeRffTrajectory:
     def __init__(self, eng, W, b, eps):
@@ -50,6 +60,9 @@ class FakeRffTrajectory:
 
     def theta(self):
         return self._theta
+
+    def argmin_pairs(self, Xq, index_base=0):
+        return _pairs(*self.argmin(Xq, index_base))
 
     def __call__(self, Xq):
         return O.rff_trajectory_eval(self._eng.state, self.W, self.b, self._theta, np.asarray(Xq, float))
@@ -295,16 +308,32 @@ class FakeEngine:
         i = int(np.argmax(vals))
         return float(vals[i]), i + index_base, Xq[i].copy()
 
+    def acq_argmax_pair(self, acq, param, Xq, index_base=0):
+        v, i, _ = self.acq_argmax(acq, param, np.asarray(Xq, float), index_base)
+        return _pairs(v, i)[:, 0]
+
+    def merge_winners(self, gathered, minimize=False):
+        from trieste_amd.distributed import merge_best
+
+        g = np.asarray(gathered, np.float64)
+        vals, idxs = g[:, 0, :], np.ascontiguousarray(g[:, 1, :]).view(np.int64)
+        v, i = merge_best(vals, idxs, minimize)
+        return _pairs(v, i)
+
+    def synchronize(self):
+        pass
+
     def acq_topk(self, acq, param, Xq, k, index_base=0):
         vals = self.acq_values(acq, param, np.asarray(Xq, float))
         v, i = O.top_k(vals, k)
         return v, i + index_base
 
     def sample_box(self, seed, first, M, lower, upper):
-        rng = np.random.default_rng([seed, first])
+        from oracle.philox import sample_box
+
         lo = np.broadcast_to(np.asarray(lower, float), (self.d,))
         up = np.broadcast_to(np.asarray(upper, float), (self.d,))
-        return rng.uniform(lo, up, size=(M, self.d))
+        return sample_box(seed, first, M, lo, up)  # the engine's Philox map, bit for bit
 
     def qei(self, Xq, eps, eta, jitter=1e-6):
         Xq = np.asarray(Xq, float)

@@ -208,3 +208,76 @@ def test_greedy_batches_over_sharded_candidates_world_size_2_gloo_match_single_p
             assert sharded == single, name  # every rank returns the single-process batch, bit for bit
             assert len(sharded) == 3
     assert out[0][1] == out[1][1]
+
+
+def _winners_worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # the device-resident protocol of bench.py's step -- pair on the "device", ONE all-gather of the pairs, the
+        # engine's merge, one copy to the host -- with the oracle-backed stand-in at the engine boundary
+        from oracle import gp_oracle as O
+        from tests.fakes import FakeEngine
+        from trieste_amd.distributed import all_gather_winners
+
+        X, Y = O.synthetic_problem(O.branin, 2, 30)
+        eng = FakeEngine(2, "matern52")
+        eng.set_hyper(1.0, O.default_lengthscales(2), 1e-3, 0.0)
+        eng.set_data(X, Y)
+        eta = eng.eta()
+        M = 1001
+        lo, hi = shard_range(M, rank, world)
+        Xq = eng.sample_box(5678, lo, hi - lo, 0.0, 1.0)          # shard of ONE logical Philox sample
+        pair = eng.acq_argmax_pair("ei", eta, Xq, index_base=lo)
+        gv, gi = all_gather_winners(eng, pair)
+        full = eng.sample_box(5678, 0, M, 0.0, 1.0)
+        v, i, _ = eng.acq_argmax("ei", eta, full)
+        q.put(("ei", rank, float(gv[0]), int(gi[0]), float(v), int(i)))
+        rng = np.random.default_rng(3)
+        F, B = 16, 3
+        traj = eng.trajectory(rng.standard_normal((F, 2)), rng.uniform(0, 6.28, F), rng.standard_normal((F, B)),
+                              rng.standard_normal((30, B)))
+        tv, ti = all_gather_winners(eng, traj.argmin_pairs(Xq, index_base=lo), minimize=True)
+        wv, wi = traj.argmin(full)
+        q.put(("ts", rank, tv.tolist(), ti.tolist(), np.asarray(wv).tolist(), np.asarray(wi).tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_all_gather_winners_world_size_2_gloo():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_winners_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=180) for _ in range(4)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    eis = [o for o in out if o[0] == "ei"]
+    tss = [o for o in out if o[0] == "ts"]
+    assert len(eis) == 2 and len(tss) == 2
+    for _, _, gv, gi, v, i in eis:
+        assert (gv, gi) == (v, i)      # every rank holds the unsharded winner, bit for bit
+    for _, _, tv, ti, wv, wi in tss:
+        assert tv == wv and ti == wi
+
+
+def test_all_gather_winners_single_process_is_the_merge_of_one():
+    from tests.fakes import _pairs
+    from trieste_amd.distributed import all_gather_winners
+
+    class _E:
+        def merge_winners(self, gathered, minimize=False):
+            from tests.fakes import FakeEngine
+
+            return FakeEngine.merge_winners(self, gathered, minimize)
+
+    v, i = all_gather_winners(_E(), _pairs([1.5, -2.0], [42, 7]))
+    assert v.tolist() == [1.5, -2.0] and i.tolist() == [42, 7]

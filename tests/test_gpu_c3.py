@@ -1,0 +1,74 @@
+"""Config C3 at the size that is timed (BENCH headline): N = 4096, d = 8, Matern-5/2, the FUSED launch of
+the sweep kernel (>= 1024 candidate blocks, i.e. no row-group split), both noise levels of SURVEY 8(d).  The whole
+sweep is re-done on the host cores by the reference-shaped CPU restatement (oracle/cpu_baseline.py, validated against
+oracle/gp_oracle.py in tests/test_oracle_golden.py) over the SAME Philox candidates, restated bit-exactly on the host
+(oracle/philox.py): arg-max value AND index must agree."""
+import numpy as np
+import pytest
+
+from oracle import gp_oracle as O
+from oracle import philox as P
+from oracle.cpu_baseline import TorchCpuSweep
+from tests.util import assert_close, cancellation_floor
+
+pytestmark = pytest.mark.gpu
+
+N, D, KIND = 4096, 8, "matern52"
+M = (1 << 17) + 37  # 1025 candidate blocks of 128 (the last one ragged): the fused instantiation
+
+
+@pytest.mark.parametrize("noise", [1e-2, 1e-5], ids=["noise1e-2", "noise1e-5"])
+def test_fused_sweep_at_n4096_matches_the_cpu_restatement(noise):
+    from trieste_amd.engine import GPEngine
+
+    X, Y = O.synthetic_problem(O.ackley, D, N)
+    ls = O.default_lengthscales(D)
+    c = float(np.mean(Y))
+    eng = GPEngine(D, KIND)
+    eng.set_hyper(1.0, ls, noise, c)
+    eng.set_data(X, Y)
+    st = O.gpr_update(KIND, 1.0, ls, noise, c, X, Y)
+    floor = cancellation_floor(N, 1.0, noise)
+    eta = eng.eta()
+    assert_close(eta, O.eta_min_mean(st), atol=floor * 10, what="eta")
+
+    Xq = eng.sample_box(5678, 0, M, 0.0, 1.0)
+    host = P.sample_box(5678, 0, M, np.zeros(D), np.ones(D))
+    np.testing.assert_array_equal(Xq.cpu().numpy(), host)   # candidates: bit-exact integer path
+
+    eng.set_variant(0)
+    val, idx, x = eng.acq_argmax("ei", eta, Xq)             # 1025 blocks >= 4 * #CU: fused launch
+    np.testing.assert_array_equal(x, host[idx])
+    vals = eng.acq_values("ei", eta, Xq).cpu().numpy()      # the same fused kernel, values written out
+    assert idx == int(np.argmax(vals)) and val == vals[idx]
+
+    sw = TorchCpuSweep(st)
+    oracle_vals = np.concatenate([sw.chunk_values(host[s:s + 16384], eta, improved=False).numpy()
+                                  for s in range(0, M, 16384)])
+    tol = 1e-5 * np.abs(oracle_vals) + floor * 10
+    err = np.abs(vals - oracle_vals)
+    assert np.all(err <= tol), (int(np.argmax(err - tol)), float(err.max()))
+    oi = int(np.argmax(oracle_vals))
+    band = 1e-5 * oracle_vals[oi] + floor * 10
+    assert idx == oi or abs(oracle_vals[oi] - oracle_vals[idx]) <= band, (idx, oi)
+    assert abs(val - oracle_vals[oi]) <= band
+
+    # fused vs the row-group split on a shared subset: the same products, partial sums added in another order
+    sub = Xq[5000:5000 + 3000]
+    eng.set_variant(2)
+    split_vals = eng.acq_values("ei", eta, sub).cpu().numpy()
+    eng.set_variant(0)
+    assert_close(split_vals, vals[5000:8000], rtol=1e-9, atol=1e-13, what="fused vs split")
+
+    # chunked call path (split_acquisition_function, reference acquisition/utils.py:31-80) on the engine
+    from trieste_amd.acquisition.utils import split_acquisition_function
+
+    calls = []
+
+    def fn(xx):
+        calls.append(xx.shape[0])
+        return eng.acq_values("ei", eta, xx[:, 0, :])[:, None]
+
+    chunked = split_acquisition_function(fn, 20000 * D)(Xq[:50000, None, :])
+    assert calls == [20000, 20000, 10000]
+    assert_close(chunked[:, 0].cpu().numpy(), vals[:50000], rtol=1e-9, atol=1e-13, what="chunked vs one launch")

@@ -87,33 +87,39 @@ def _problem(obj, d, kind, N, noise, M=1500, seed=5678):
     return X, Y, ls, c, st, Xq
 
 
-@pytest.mark.parametrize("variant", [0, 3, 1, 2], ids=["u16-rowsplit", "u16", "v1", "ws"])
+def _oracle_argmax_agrees(idx, oracle_vals, tol):
+    """The engine's arg-max index must be the oracle's whenever the oracle's top-2 gap exceeds the tolerance; inside
+    the tolerance band any index whose oracle value is within it is a correct answer of equal standing."""
+    oi = int(np.argmax(oracle_vals))
+    if idx == oi:
+        return True
+    return abs(oracle_vals[oi] - oracle_vals[idx]) <= tol
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2], ids=["default-policy", "fused", "rowsplit"])
 @pytest.mark.parametrize("cfg", CONFIGS, ids=[c[0] for c in CONFIGS])
-def test_sweep_matches_oracle(cfg, variant, monkeypatch):
-    """Every sweep kernel: the default u16 kernel in its row-group-split form (what a launch with few
-    candidate blocks uses) and in its fused form (forced here with TGP_NO_SPLIT; large launches use
-    it), the first-generation kernel and the wave-specialised one."""
-    if variant == 3:
-        monkeypatch.setenv("TGP_NO_SPLIT", "1")
-        variant = 0
+def test_sweep_matches_oracle(cfg, variant):
+    """The sweep kernel under every launch policy: the default (row-group split for launches with few candidate
+    blocks), the fused form forced (tgp_set_variant bit 0: what large launches use) and the split forced (bit 1)."""
     _, obj, d, kind, N, noise = cfg
     X, Y, ls, c, st, Xq = _problem(obj, d, kind, N, noise)
     floor = cancellation_floor(N, 1.0, noise)
     eng = _engine(kind, d, 1.0, ls, noise, c, X, Y, variant)
     mean, var = eng.predict(Xq)
     om, ov = O.predict(st, Xq)
-    assert_close(mean, om, atol=floor * 100, what="mean")
+    assert_close(mean, om, atol=floor * 10, what="mean")
     assert_close(var, ov, atol=floor, what="var")
     eta = eng.eta()
-    assert_close(eta, O.eta_min_mean(st), atol=floor * 100, what="eta")
+    assert_close(eta, O.eta_min_mean(st), atol=floor * 10, what="eta")
     ei = eng.acq_values("ei", eta, Xq)
     oei = O.expected_improvement(om, ov, eta)
     assert_close(ei, oei, atol=floor * 10, what="ei")
-    # fused arg-max == arg-max of the engine's own values (first index on ties), and its value
-    # agrees with the oracle's maximum
+    # fused arg-max == arg-max of the engine's own values (first index on ties); its value agrees with the
+    # oracle's maximum and its INDEX with the oracle's arg-max (up to the tolerance band)
     val, idx, x = eng.acq_argmax("ei", eta, Xq)
     assert idx == int(np.argmax(ei)) and val == ei[idx]
     assert_close(val, np.max(oei), atol=floor * 10, what="max ei")
+    assert _oracle_argmax_agrees(idx, oei, 1e-5 * np.max(oei) + floor * 10), (idx, int(np.argmax(oei)))
     np.testing.assert_array_equal(x, Xq[idx])
     # top-k == stable descending sort of the engine's values
     k = 17
@@ -121,6 +127,23 @@ def test_sweep_matches_oracle(cfg, variant, monkeypatch):
     ov_, oi_ = O.top_k(ei, k)
     np.testing.assert_array_equal(ti, oi_)
     np.testing.assert_array_equal(tv, ov_)
+
+
+@pytest.mark.parametrize("cfg", [CONFIGS[2], CONFIGS[3], CONFIGS[1]], ids=lambda c: c[0])
+def test_launch_policies_agree_to_rounding(cfg):
+    """Fused and row-group-split launches form the same products; only the order in which the row blocks' partial
+    column norms / mean terms are added differs (one chain vs per-group partials + combine): they agree to a few
+    ulps of the accumulated sums, far below the parity tolerance, and pick the same arg-max."""
+    _, obj, d, kind, N, noise = cfg
+    X, Y, ls, c, st, Xq = _problem(obj, d, kind, N, noise, M=700)
+    outs = []
+    for variant in (1, 2):
+        eng = _engine(kind, d, 1.0, ls, noise, c, X, Y, variant)
+        m, v = eng.predict(Xq)
+        outs.append((np.asarray(m), np.asarray(v), eng.acq_argmax("ei", eng.eta(), Xq)[:2]))
+    assert_close(outs[0][1], outs[1][1], rtol=0, atol=1e-13, what="var")
+    assert_close(outs[0][0], outs[1][0], rtol=0, atol=1e-13 * max(1.0, np.abs(outs[0][0]).max()), what="mean")
+    assert outs[0][2][1] == outs[1][2][1]
 
 
 def test_ties_pick_first_index_and_sharding_is_consistent():
@@ -225,13 +248,13 @@ def test_joint_and_qei_match_oracle():
         Xg[0, 0] = X[0]
         jm, jc = eng.predict_joint(Xg)
         om, oc = O.predict_joint(st, Xg)
-        assert_close(jm, om, atol=floor * 100, what=f"joint mean q={q}")
+        assert_close(jm, om, atol=floor * 10, what=f"joint mean q={q}")
         assert_close(jc, oc, atol=floor, what=f"joint cov q={q}")
         eps = rng.normal(size=(q, S))
         eta = O.eta_min_mean(st)
         got = eng.qei(Xg, eps, eta, 1e-6)
         want = O.batch_mc_ei(st, Xg, eps, eta, 1e-6)
-        assert_close(got, want, atol=floor * 100, what=f"qei q={q}")
+        assert_close(got, want, atol=floor * 10, what=f"qei q={q}")
     # q = 1 qEI with many draws is close to analytic EI (reference test_function.py:1359-1371)
 
 
@@ -303,7 +326,7 @@ def test_headline_size_properties():
     om, ov = O.predict(st, Xq)
     gm, gv = eng.predict(Xq)
     floor = cancellation_floor(N, 1.0, noise)
-    assert_close(gm, om, atol=floor * 100, what="mean vs oracle")
+    assert_close(gm, om, atol=floor * 10, what="mean vs oracle")
     assert_close(gv, ov, atol=floor, what="var vs oracle")
     # (4) far field: var -> variance, mean -> c, EI underflows to exactly 0 (tf semantics)
     far = 10.0 + rng.uniform(size=(4, d))
@@ -325,7 +348,7 @@ def test_acq_value_and_gradient_match_oracle(cfg):
         val, grad = eng.acq_value_grad(acq, par, Xq)
         oval, ograd = O.acq_value_and_grad(st, acq, par, Xq)
         floor = cancellation_floor(N, 1.0, noise)
-        assert_close(val, oval, atol=floor * 100, what=f"{acq} value")
+        assert_close(val, oval, atol=floor * 10, what=f"{acq} value")
         # gradients of the variance inherit the cancellation floor times |d k / dx| ~ 1 / lengthscale
         gscale = np.abs(ograd).max() + 1e-300
         assert_close(grad, ograd, rtol=1e-5, atol=max(floor * 1e3, 1e-9 * gscale), what=f"{acq} gradient")
@@ -578,7 +601,7 @@ def test_penalized_sweeps_match_oracle(cfg, kind):
     np.testing.assert_array_equal(ti, oi_)
     np.testing.assert_array_equal(tv, ov_)
     oval, ograd = O.penalized_value_and_grad(st, "ei", eta, kind, pending, radius, scale, Xq[:64])
-    assert_close(gv, oval, atol=floor * 100, what="penalized value")
+    assert_close(gv, oval, atol=floor * 10, what="penalized value")
     gscale = np.abs(ograd).max() + 1e-300
     assert_close(gg, ograd, rtol=1e-5, atol=max(floor * 1e3, 1e-9 * gscale), what="penalized gradient")
     assert np.all(np.isfinite(gg))
@@ -616,15 +639,15 @@ def test_clone_then_append_is_the_fantasized_posterior(cfg):
     sto = O.fantasized_state(st, pend, O.predict(st, pend)[0])
     fm, fv = twin.predict(Xq)
     om, ov = O.predict(sto, Xq)
-    assert_close(fm, om, atol=floor * 100, what="fantasized mean")
+    assert_close(fm, om, atol=floor * 10, what="fantasized mean")
     assert_close(fv, ov, atol=floor, what="fantasized var")
     if noise >= 1e-3:
         cm, cv = O.conditional_predict_f(st, Xq, pend, O.predict(st, pend)[0])
-        assert_close(fm, cm, atol=floor * 1000, what="== conditional_predict_f mean")
+        assert_close(fm, cm, atol=floor * 100, what="== conditional_predict_f mean")
         assert_close(fv, np.maximum(cv, 1e-12), atol=floor * 10, what="== conditional_predict_f var")
     assert_close(fm, m0, atol=max(floor * 1e4, 1e-6), what="kriging believer keeps the mean")  # test_greedy_batch.py:233-257
     assert np.all(fv <= v0 + floor)  # :260-296
-    assert_close(twin.eta(), O.eta_min_mean(sto), atol=floor * 100, what="fantasized eta")
+    assert_close(twin.eta(), O.eta_min_mean(sto), atol=floor * 10, what="fantasized eta")
     np.testing.assert_array_equal(eng.predict(Xq)[0], m0)
     assert eng.N == N and twin.N == N + 6
     twin.clone_from(eng)  # reset
@@ -656,7 +679,7 @@ def test_entropy_tails_match_mpmath_goldens(c):
     gmax = np.max((smp[None, :] - gm[:, None]) / np.sqrt(gv)[:, None], axis=1)
     ok = gmax <= 30.0
     # sensitivity of the tails to the posterior's own rounding: d/dmean ~ gamma / sd
-    sens = floor * 100 * (1.0 + np.abs(gmax[ok])) / np.sqrt(gv[ok])
+    sens = floor * 10 * (1.0 + np.abs(gmax[ok])) / np.sqrt(gv[ok])
     with pytest.raises(RuntimeError):
         eng.acq_values("mes", 0.0, Xq)  # no samples yet
     eng.set_min_value_samples(smp)
@@ -695,7 +718,7 @@ def test_entropy_sweeps_and_gradients_match_oracle(cfg):
     sto = O.fantasized_state(st, pending, np.zeros(4))
     gmax = np.max((samples[None, :] - om[:, None]) / np.sqrt(ov)[:, None], axis=1)
     ok = gmax <= 30.0
-    sens = floor * 100 * (1.0 + np.abs(gmax)) / np.sqrt(ov) + 1e-13
+    sens = floor * 10 * (1.0 + np.abs(gmax)) / np.sqrt(ov) + 1e-13
     for acq, ref in (("mes", O.min_value_entropy_search(om, ov, samples)),
                      ("gibbon", O.gibbon_quality_term(om, ov, samples, noise))):
         vals = eng.acq_values(acq, 0.0, Xq)
@@ -822,7 +845,7 @@ def test_gibbon_repulsion_by_rank_m_update_equals_the_twin_sweep(cfg, monkeypatc
         monkeypatch.setenv("TGP_NO_LOWRANK", "1")
         _, _, swept = batch_values(pending, w)
         monkeypatch.delenv("TGP_NO_LOWRANK")
-        sens = floor * 100 * (1.0 + np.abs(gmax)) / np.sqrt(ov) + floor / noise + 1e-13
+        sens = floor * 10 * (1.0 + np.abs(gmax)) / np.sqrt(ov) + floor / noise + 1e-13
         assert_close(low[ok], ref[ok], rtol=1e-6, atol=sens[ok], what=f"rank-{m} form == reference form")
         assert_close(low, swept, rtol=1e-7, atol=floor / noise + 1e-13, what=f"rank-{m} form == twin sweep")
         # the cached check follows the data: grow the twin, then change the base model

@@ -594,8 +594,7 @@ def test_continuous_thompson_sampling_builders_with_ego():
     x = np.random.default_rng(0).uniform(size=(9, 3, 2))
     vals = neg(x)
     assert vals.shape == (9, 3)
-    tr = b._trajectory
-    np.testing.assert_allclose(vals, -type(tr).__mro__[1].__call__(tr, x)[..., 0])
+    np.testing.assert_allclose(vals, -neg.trajectory(x)[..., 0])
     v, g = neg.value_and_gradient(x)
     np.testing.assert_allclose(v, vals, rtol=1e-10, atol=1e-12)
     h = 1e-6
@@ -799,3 +798,89 @@ def test_set_seed_makes_unseeded_draws_reproducible():
     np.testing.assert_array_equal(box.sample(7, seed=3), box.sample(7, seed=3))
     trieste_amd.set_seed(None)
     assert not np.array_equal(box.sample(7), box.sample(7))
+
+
+# ---- round-2 regressions (advisor findings) ---------------------------------------------------------------------
+def test_history_records_hold_per_step_model_copies():
+    """track_state=True: every Record owns deep copies of the models (reference bayesian_optimizer.py:745-760), so
+    history[i].model still is the model as it was BEFORE step i + 1, not the final one."""
+    model, data = _model(n=8)
+    box = Box([0.0, 0.0], [1.0, 1.0])
+    bo = BayesianOptimizer(lambda x: Dataset(x, OBJ.scaled_branin(x)), box)
+    rule = EfficientGlobalOptimization(optimizer=generate_random_search_optimizer(200, seed=1, on_device=False))
+    res = bo.optimize(3, data, model, rule, fit_model=True, fit_initial_model=False)
+    final = res.final_result.unwrap()
+    sizes = [len(rec.models[OBJECTIVE].get_internal_data()) for rec in res.history]
+    assert sizes == [8, 9, 10] and len(final.models[OBJECTIVE].get_internal_data()) == 11
+    assert all(rec.models[OBJECTIVE] is not final.models[OBJECTIVE] for rec in res.history)
+    assert all(rec.models[OBJECTIVE].engine is not final.models[OBJECTIVE].engine for rec in res.history)
+    assert [rec.models[OBJECTIVE].engine.N for rec in res.history] == [8, 9, 10]
+
+
+def test_fit_model_false_leaves_the_models_alone():
+    """fit_model=False: neither optimize nor update (reference bayesian_optimizer.py:828-834,
+    AskTellOptimizerNoTraining.update_model)."""
+    model, data = _model(n=8)
+    box = Box([0.0, 0.0], [1.0, 1.0])
+    rule = EfficientGlobalOptimization(optimizer=generate_random_search_optimizer(100, seed=1, on_device=False))
+    bo = BayesianOptimizer(lambda x: Dataset(x, OBJ.scaled_branin(x)), box)
+    res = bo.optimize(2, data, model, rule, fit_model=False, track_state=False)
+    assert len(res.final_result.unwrap().datasets[OBJECTIVE]) == 10 and model.engine.N == 8
+    at = AskTellOptimizer(box, data, model, rule, fit_model=False)
+    at.tell(Dataset(at.ask(), OBJ.scaled_branin(at.ask())))
+    assert model.engine.N == 8
+
+
+def test_multiple_optimism_lcb_accepts_flat_points_and_single_query_point():
+    from trieste_amd.acquisition import MultipleOptimismNegativeLowerConfidenceBound
+
+    model, data = _model(n=10)
+    box = Box([0.0, 0.0], [1.0, 1.0])
+    fn = MultipleOptimismNegativeLowerConfidenceBound(box).prepare_acquisition_function(model, dataset=data)
+    pts = np.random.default_rng(0).uniform(size=(5, 2))
+    v2, g2 = fn.value_and_gradient(pts)                 # [P, D]: what batch-size-one optimizers pass
+    v3, g3 = fn.value_and_gradient(pts[:, None, :])
+    assert v2.shape == (5,) and g2.shape == (5, 2)
+    np.testing.assert_array_equal(v2, v3[:, 0])
+    np.testing.assert_array_equal(g2, g3[:, 0, :])
+    rule = EfficientGlobalOptimization(MultipleOptimismNegativeLowerConfidenceBound(box), num_query_points=1)
+    assert rule.acquire_single(box, model, dataset=data).shape == (1, 2)
+
+
+def test_split_wrapper_keeps_the_fused_api_and_rejects_zero_vectorization():
+    model, data = _model(n=10)
+    fn = ExpectedImprovement().prepare_acquisition_function(model, dataset=data)
+    wrapped = split_acquisition_function(fn, 7)
+    for attr in ("argmax", "top_k", "value_and_gradient", "_engine"):
+        assert getattr(wrapped, attr) == getattr(fn, attr) or getattr(wrapped, attr) is getattr(fn, attr)
+    with pytest.raises(ValueError):
+        optimize_discrete(DiscreteSearchSpace(np.zeros((3, 2))), (fn, 0))
+
+
+def test_a_failed_fit_does_not_poison_the_append_path():
+    """If `optimize` dies after trying other hyper-parameters the engine is restored (or marked out of sync), so the
+    next update never extends a factor built with the wrong kernel."""
+    model, data = _model(n=9)
+    ref_mean, _ = model.predict(data.query_points[:3])
+    calls = {"n": 0}
+    orig = model._loss_at
+
+    def flaky(*a, **k):
+        calls["n"] += 1
+        out = orig(*a, **k)
+        if calls["n"] >= 3:
+            raise KeyboardInterrupt  # not an ArithmeticError: escapes scipy
+        return out
+
+    model._loss_at = flaky
+    model._num_kernel_samples = 0
+    with pytest.raises(KeyboardInterrupt):
+        model.optimize(data)
+    model._loss_at = orig
+    assert model._in_sync
+    np.testing.assert_allclose(model.predict(data.query_points[:3])[0], ref_mean, rtol=1e-12)
+    x_new = np.array([[0.3, 0.3]])
+    model.update(data + Dataset(x_new, OBJ.scaled_branin(x_new)))
+    fresh, _ = _model(n=9)
+    fresh.update(data + Dataset(x_new, OBJ.scaled_branin(x_new)))
+    np.testing.assert_allclose(model.predict(x_new)[0], fresh.predict(x_new)[0], rtol=1e-9)

@@ -225,7 +225,8 @@ def test_trego_through_the_loops_alternates_modes_and_improves():
             assert pts[0, v] in sub
         flat = pts.reshape(-1, 2)
         loop.tell(Dataset(flat, OBJ.scaled_branin(flat)))
-    assert len(loop.dataset) == 10 + 6 and model2.engine.N == 16
+    # fit_model=False: the caller manages the model -- neither refitted nor updated (reference :828-834)
+    assert len(loop.dataset) == 10 + 6 and model2.engine.N == 10
 
 
 # ---- TURBOBox (reference test_rule.py:878-1246) -------------------------------------------------------------

@@ -65,6 +65,27 @@ SIGNATURES = {
     "tgp_sample_joint": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int, C.c_double, _vp, C.c_int]),
     "tgp_cov_between": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int]),
     "tgp_traj_argmin": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, _vp, _vp, C.c_int]),
+    "tgp_acq_argmax_async": (C.c_int, [_vp, C.c_int, C.c_double, _vp, C.c_int64, C.c_int64, _vp]),
+    "tgp_traj_argmin_async": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, _vp]),
+    "tgp_merge_winners_async": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "tgp_stream_synchronize": (C.c_int, [_vp]),
+    "tgp_group_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "tgp_group_destroy": (C.c_int, [_vp]),
+    "tgp_group_last_error": (C.c_char_p, [_vp]),
+    "tgp_group_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "tgp_group_member": (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
+    "tgp_group_set_hyper": (C.c_int, [_vp, C.c_double, _vp, C.c_double, C.c_double]),
+    "tgp_group_set_data": (C.c_int, [_vp, _vp, _vp, C.c_int64]),
+    "tgp_group_append_data": (C.c_int, [_vp, _vp, _vp, C.c_int64]),
+    "tgp_group_set_candidates": (C.c_int, [_vp, _vp, C.c_int64]),
+    "tgp_group_sample_candidates": (C.c_int, [_vp, C.c_uint64, C.c_int64, _vp, _vp]),
+    "tgp_group_acq_argmax": (C.c_int, [_vp, C.c_int, C.c_double, _dp, _ip, _vp]),
+    "tgp_group_acq_topk": (C.c_int, [_vp, C.c_int, C.c_double, C.c_int, _vp, _vp]),
+    "tgp_group_qei": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, C.c_int, C.c_double, C.c_double, _vp]),
+    "tgp_group_traj_create": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, C.POINTER(_vp)]),
+    "tgp_group_traj_destroy": (C.c_int, [_vp]),
+    "tgp_group_traj_argmin": (C.c_int, [_vp, _vp, _vp]),
+    "tgp_group_last_kernel_ms": (C.c_int, [_vp, _dp]),
     "tgp_last_kernel_ms": (C.c_int, [_vp, _dp, C.POINTER(C.c_int)]),
     "tgp_set_variant": (C.c_int, [_vp, C.c_int]),
 }
@@ -103,10 +124,13 @@ def load():
     return lib
 
 
-def check(lib, handle, rc):
+MERGES = {"rccl": 0, "peer": 1}
+
+
+def check(lib, handle, rc, group=False):
     if rc == TGP_OK:
         return
-    msg = lib.tgp_last_error(handle)
+    msg = (lib.tgp_group_last_error if group else lib.tgp_last_error)(handle)
     msg = msg.decode() if msg else ""
     if rc in (TGP_ERR_SHAPE, TGP_ERR_ARG):
         raise ValueError(msg)

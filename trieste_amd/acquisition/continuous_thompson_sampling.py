@@ -1,8 +1,12 @@
-"""Continuous Thompson sampling builders (reference
-trieste/acquisition/function/continuous_thompson_sampling.py:30-245): acquisition functions that are
-the NEGATIVES of decoupled posterior trajectories, maximised by the (gradient-based) optimizers to
-find the trajectories' minimisers.  Values and gradients come from libtgp's trajectory kernels
-(tgp_traj_eval / tgp_traj_value_grad)."""
+"""Continuous Thompson sampling on the engine's trajectories.
+
+The reference's builders (trieste/acquisition/function/continuous_thompson_sampling.py:30-245) hand the optimizer
+the NEGATIVE of a posterior trajectory so that a maximiser finds the trajectory's minimiser.  Here a trajectory
+is a device object (``tgp_traj``: RFF features + canonical kernel sums, values by ``tgp_traj_eval``, analytic
+gradients by ``tgp_traj_value_grad``), so the negation is a thin VIEW over it -- :class:`NegatedTrajectory` --
+instead of the reference's in-place class swap: the view owns nothing, flips the sign of values and gradients on
+the way out, and keeps pointing at the same trajectory while the sampler redraws its weights or basis in place.
+"""
 from __future__ import annotations
 
 from typing import Callable, Optional
@@ -12,84 +16,76 @@ from .interface import SingleModelGreedyAcquisitionBuilder, SingleModelVectorize
 from .utils import select_nth_output
 
 
-def negate_trajectory_function(function, select_output: Optional[Callable] = None):
-    """Negate a trajectory (and select its output) so that maximisers find its minimisers
-    (continuous_thompson_sampling.py:188-245).  Like the reference, the trajectory OBJECT is kept --
-    its class is swapped for a subclass with a negated ``__call__`` -- so that ``resample`` /
-    ``update`` still act on it in place."""
-    base = type(function)
-    if getattr(base, "_is_negated_trajectory", False):
-        return function
+class NegatedTrajectory:
+    """``x [N, B, D] -> -select_output(trajectory(x))``; ``value_and_gradient`` flips both signs exactly once,
+    for [P, B, D] and for the [P, D] points batch-size-one optimizers pass."""
 
-    class NegatedTrajectory(base):
-        _is_negated_trajectory = True
+    def __init__(self, trajectory, select_output: Optional[Callable] = None):
+        self.trajectory = trajectory
+        self._select_output = select_output
 
-        def __call__(self, x):  # [N, B, D] -> [N, B]
-            out = base.__call__(self, x)
-            return -1.0 * (select_output(out) if select_output is not None else out)
+    def __call__(self, x):
+        out = self.trajectory(x)
+        return -(out if self._select_output is None else self._select_output(out))
 
-        def value_and_gradient(self, x):
-            val, grad = base.value_and_gradient(self, x)
-            return -1.0 * val, -1.0 * grad
-
-    function.__class__ = NegatedTrajectory
-    return function
+    def value_and_gradient(self, x):
+        val, grad = self.trajectory.value_and_gradient(x)
+        return -val, -grad
 
 
-def _require_sampler(model):
-    if not hasattr(model, "trajectory_sampler"):
-        raise ValueError("Thompson sampling from trajectory only supports models with a trajectory_sampler method; "
-                         f"received {model!r}")
-    return model.trajectory_sampler()
+def negate_trajectory_function(function, select_output: Optional[Callable] = None) -> NegatedTrajectory:
+    """The maximisable view of a trajectory (continuous_thompson_sampling.py:188-245); a view is returned as is."""
+    return function if isinstance(function, NegatedTrajectory) else NegatedTrajectory(function, select_output)
 
 
-class GreedyContinuousThompsonSampling(SingleModelGreedyAcquisitionBuilder):
-    """One negated trajectory per batch element, drawn sequentially
-    (continuous_thompson_sampling.py:30-106)."""
+class _TrajectoryViewBuilder:
+    """What the two builders share: a trajectory sampler taken from the model, one view handed out, and a refresh
+    of the trajectory BEHIND that view (fresh basis + weights after a model update; fresh weights only inside a
+    step) so the optimizer-facing object never changes identity."""
 
     def __init__(self, select_output: Callable = select_nth_output):
         self._select_output = select_output
+        self._sampler = None
+        self._view: Optional[NegatedTrajectory] = None
 
     def __repr__(self) -> str:
-        return f"GreedyContinuousThompsonSampling({self._select_output!r})"
+        return f"{type(self).__name__}({self._select_output!r})"
+
+    def _fresh_view(self, model) -> NegatedTrajectory:
+        if not hasattr(model, "trajectory_sampler"):
+            raise ValueError("Thompson sampling from trajectory only supports models with a trajectory_sampler "
+                             f"method; received {model!r}")
+        self._sampler = model.trajectory_sampler()
+        self._view = NegatedTrajectory(self._sampler.get_trajectory(), self._select_output)
+        return self._view
+
+    def _refresh(self, view: NegatedTrajectory, new_basis: bool) -> NegatedTrajectory:
+        redraw = self._sampler.update_trajectory if new_basis else self._sampler.resample_trajectory
+        view.trajectory = redraw(view.trajectory)  # in place on this engine; rebinding covers samplers that copy
+        return view
+
+
+class GreedyContinuousThompsonSampling(_TrajectoryViewBuilder, SingleModelGreedyAcquisitionBuilder):
+    """One trajectory at a time (continuous_thompson_sampling.py:30-106): EGO's greedy loop asks for an update per
+    batch element -- new weights inside a step, a new basis as well when a new optimisation step begins."""
 
     def prepare_acquisition_function(self, model, dataset: Optional[Dataset] = None, pending_points=None):
-        self._trajectory_sampler = _require_sampler(model)
-        function = self._trajectory_sampler.get_trajectory()
-        return negate_trajectory_function(function, self._select_output)
+        return self._fresh_view(model)
 
     def update_acquisition_function(self, function, model, dataset: Optional[Dataset] = None, pending_points=None,
                                     new_optimization_step: bool = True):
-        if new_optimization_step:  # update the sampler (new basis) and resample the trajectory
-            new_function = self._trajectory_sampler.update_trajectory(function)
-        else:  # same step: only fresh weights
-            new_function = self._trajectory_sampler.resample_trajectory(function)
-        if new_function is not function:
-            function = negate_trajectory_function(new_function, self._select_output)
-        return function
+        view = negate_trajectory_function(function, self._select_output)
+        return self._refresh(view, new_basis=new_optimization_step)
 
 
-class ParallelContinuousThompsonSampling(SingleModelVectorizedAcquisitionBuilder):
-    """A batch of negated trajectories optimised in parallel, one per batch element
-    (continuous_thompson_sampling.py:109-180)."""
-
-    def __init__(self, select_output: Callable = select_nth_output):
-        self._select_output = select_output
-
-    def __repr__(self) -> str:
-        return f"ParallelContinuousThompsonSampling({self._select_output!r})"
+class ParallelContinuousThompsonSampling(_TrajectoryViewBuilder, SingleModelVectorizedAcquisitionBuilder):
+    """B trajectories optimised together, column b at its own point (continuous_thompson_sampling.py:109-180): the
+    engine evaluates all B columns and their gradients in one launch."""
 
     def prepare_acquisition_function(self, model, dataset: Optional[Dataset] = None):
-        self._trajectory_sampler = _require_sampler(model)
-        self._trajectory = self._trajectory_sampler.get_trajectory()
-        self._negated_trajectory = negate_trajectory_function(self._trajectory, self._select_output)
-        return self._negated_trajectory
+        return self._fresh_view(model)
 
     def update_acquisition_function(self, function, model, dataset: Optional[Dataset] = None):
-        if function is not self._negated_trajectory:
+        if function is not self._view:
             raise ValueError("Wrong trajectory function passed into update_acquisition_function")
-        new_function = self._trajectory_sampler.update_trajectory(self._trajectory)
-        if new_function is not self._trajectory:  # negate again if it was not modified in place
-            self._trajectory = new_function
-            self._negated_trajectory = negate_trajectory_function(new_function, self._select_output)
-        return self._negated_trajectory
+        return self._refresh(self._view, new_basis=True)

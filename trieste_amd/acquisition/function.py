@@ -486,8 +486,12 @@ class multiple_optimism_lower_confidence_bound(AcquisitionFunctionClass):
         return np.stack(cols, axis=-1)
 
     def value_and_gradient(self, x):
-        """x [R, B, D] -> (values [R, B], gradients [R, B, D]); column b differentiates function b."""
+        """x [R, B, D] -> (values [R, B], gradients [R, B, D]); column b differentiates function b.  Batch-size-one
+        optimizers pass [P, D] points: the single column B = 1 (values [P], gradients [P, D])."""
         x = np.asarray(x, dtype=np.float64)
+        if x.ndim == 2:
+            val, grad = self.value_and_gradient(x[:, None, :])
+            return val[:, 0], grad[:, 0, :]
         betas = self._betas_for(x.shape[-2])
         pairs = [self._engine.acq_value_grad("nlcb", float(b), x[..., j, :]) for j, b in enumerate(betas)]
         return (np.stack([np.asarray(p[0]) for p in pairs], axis=-1),

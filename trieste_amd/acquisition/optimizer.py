@@ -50,7 +50,7 @@ def _split(target_func) -> Tuple[Callable, int]:
         fn, V = target_func
     else:
         fn, V = target_func, 1
-    if V < 0:
+    if V <= 0:
         raise ValueError(f"vectorization must be positive, got {V}")
     return fn, V
 

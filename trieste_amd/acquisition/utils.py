@@ -30,7 +30,10 @@ def split_acquisition_function(fn, split_size: int):
             return torch.cat(outs, dim=0)
         return np.concatenate(outs, axis=0)
 
-    for attr in ("argmax", "top_k"):  # the fused sweeps need no chunking: pass them through
+    # the engine-backed function objects stream candidate tiles themselves: their fused sweeps, their analytic
+    # gradient (the L-BFGS-B refinement of automatic_optimizer_selector) and the engine handle (on-device
+    # candidate generation in generate_random_search_optimizer) pass through the wrapper unchanged
+    for attr in ("argmax", "top_k", "value_and_gradient", "_engine", "_group"):
         if hasattr(fn, attr):
             setattr(wrapper, attr, getattr(fn, attr))
     return wrapper

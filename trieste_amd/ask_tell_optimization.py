@@ -102,7 +102,7 @@ class AskTellOptimizer:
         for tag, ds in new_data.items():
             self._datasets[tag] = (self._datasets[tag] + ds) if self._track_data else ds
         self._filter_datasets()
-        for tag, model in self._models.items():
-            model.update(self._datasets[tag])
-            if self._fit_model:
+        if self._fit_model:  # fit_model=False: the caller trains / updates the models (AskTellOptimizerNoTraining)
+            for tag, model in self._models.items():
+                model.update(self._datasets[tag])
                 model.optimize(self._datasets[tag])

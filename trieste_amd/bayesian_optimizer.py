@@ -4,6 +4,7 @@ wrapped so a failure (e.g. a non-positive-definite Cholesky) is returned as ``Er
 the history so far (855-875) instead of propagating."""
 from __future__ import annotations
 
+import copy
 import traceback
 import numpy as np
 from dataclasses import dataclass, field
@@ -149,8 +150,8 @@ class BayesianOptimizer:
 
         for step in range(1, num_steps + 1):
             try:
-                if track_state:
-                    history.append(Record(dict(datasets), models, acquisition_state))
+                if track_state:  # per-step copies, like the reference (bayesian_optimizer.py:745-760)
+                    history.append(Record(dict(datasets), copy.deepcopy(models), copy.deepcopy(acquisition_state)))
                 if step == 1:
                     if hasattr(acquisition_rule, "initialize_subspaces"):
                         acquisition_rule.initialize_subspaces(self._search_space)
@@ -168,9 +169,9 @@ class BayesianOptimizer:
                 observed = _as_map(self._observer(points))
                 datasets = {tag: datasets[tag] + observed[tag] for tag in datasets}
                 acquisition_state = filter_datasets(acquisition_state)
-                for tag, model in models.items():
-                    model.update(datasets[tag])
-                    if fit_model:
+                if fit_model:  # fit_model=False: the caller manages the models (bayesian_optimizer.py:828-834)
+                    for tag, model in models.items():
+                        model.update(datasets[tag])
                         model.optimize(datasets[tag])
                 if early_stop_callback is not None and early_stop_callback(datasets, models, acquisition_state):
                     break

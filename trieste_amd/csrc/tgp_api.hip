@@ -16,21 +16,13 @@
 #include <chrono>
 #include <vector>
 
-#include "tgp_internal.hpp"
+#include "tgp_host.hpp"
 
 namespace tgp {
 hipError_t launch_sweep_kind0(hipStream_t, const SweepArgs&, bool, int64_t);
 hipError_t launch_sweep_kind1(hipStream_t, const SweepArgs&, bool, int64_t);
 hipError_t launch_sweep_kind2(hipStream_t, const SweepArgs&, bool, int64_t);
 hipError_t launch_sweep_kind3(hipStream_t, const SweepArgs&, bool, int64_t);
-hipError_t launch_sweep_ws_kind0(hipStream_t, const SweepArgs&, int64_t);
-hipError_t launch_sweep_ws_kind1(hipStream_t, const SweepArgs&, int64_t);
-hipError_t launch_sweep_ws_kind2(hipStream_t, const SweepArgs&, int64_t);
-hipError_t launch_sweep_ws_kind3(hipStream_t, const SweepArgs&, int64_t);
-hipError_t launch_sweep_u16_kind0(hipStream_t, const SweepArgs&, bool, int64_t);
-hipError_t launch_sweep_u16_kind1(hipStream_t, const SweepArgs&, bool, int64_t);
-hipError_t launch_sweep_u16_kind2(hipStream_t, const SweepArgs&, bool, int64_t);
-hipError_t launch_sweep_u16_kind3(hipStream_t, const SweepArgs&, bool, int64_t);
 }  // namespace tgp
 
 using namespace tgp;
@@ -40,96 +32,7 @@ namespace {
 thread_local std::string g_create_error;
 std::atomic<uint64_t> g_data_version{0};  // stamps factorisations: unique across handles and threads
 
-struct DevBuf {  // grow-only device buffer
-  void* p = nullptr;
-  size_t cap = 0;
-  hipError_t reserve(size_t bytes) {
-    if (bytes <= cap) return hipSuccess;
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    cap = 0;
-    hipError_t e = hipMalloc(&p, bytes);
-    if (e == hipSuccess) {
-      cap = bytes;
-      // TGP_POISON=1 (tests): fill fresh allocations with NaNs so that any read of memory the engine did
-      // not write shows up deterministically instead of depending on what the allocator recycled
-      static const bool poison = getenv("TGP_POISON") != nullptr;
-      if (poison) e = hipMemset(p, 0xFF, bytes);
-    }
-    return e;
-  }
-  hipError_t grow_keep(size_t bytes, size_t keep, hipStream_t st) {  // like reserve, but keeps the first `keep` bytes
-    if (bytes <= cap) return hipSuccess;
-    void* q = nullptr;
-    hipError_t e = hipMalloc(&q, bytes);
-    if (e != hipSuccess) return e;
-    if (p && keep) {
-      e = hipMemcpyAsync(q, p, keep, hipMemcpyDeviceToDevice, st);
-      if (e == hipSuccess) e = hipStreamSynchronize(st);
-      if (e != hipSuccess) {
-        (void)hipFree(q);
-        return e;
-      }
-    }
-    if (p) (void)hipFree(p);
-    p = q;
-    cap = bytes;
-    return hipSuccess;
-  }
-  void release() {
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    cap = 0;
-  }
-  template <class T>
-  T* as() const { return (T*)p; }
-};
-
 }  // namespace
-
-struct tgp_handle_s {
-  int device = 0, d = 0, dp = 0, kind = 0, num_cu = 256;
-  hipStream_t stream = nullptr;      // where the kernels go (default stream, a caller's, or own_stream)
-  hipStream_t own_stream = nullptr;  // created by tgp_use_private_stream, destroyed with the handle
-  std::string err;
-  // hyper-parameters
-  bool have_hyper = false, have_data = false;
-  double variance = 1.0, noise = 1.0, mean_const = 0.0;
-  std::vector<double> ls;  // [d]
-  int64_t N = 0, Npad = 0;
-  int variant = 0;
-  // model state on device
-  DevBuf d_xn, d_ls, d_X, d_Y, d_Xs, d_A, d_L, d_W, d_alpha, d_err, d_tmp1, d_tmp2, d_info;
-  // local penalization applied to every tgp_acq_* result while pen_kind != 0 (tgp_set_penalization)
-  int pen_kind = 0, pen_P = 0;
-  DevBuf d_pen;  // [P, d] pending points, [P] radius, [P] scale
-  // entropy-search tails (TGP_ACQ_MES / TGP_ACQ_GIBBON): min-value samples; GIBBON's repulsion twin
-  int ent_S = 0;
-  DevBuf d_ent;  // [S]
-  tgp_handle rep_twin = nullptr;  // not owned: this model conditioned additionally on the pending points
-  double rep_weight = 0.0;
-  // when the twin is literally this model's data + m <= 16 appended rows (same hyper-parameters), its variance is
-  // a rank-m correction of this model's: checked once per (data, twin data) version pair
-  uint64_t data_version = 0;       // process-wide unique stamp of the current factorisation (0: none)
-  uint64_t rep_self_version = 0, rep_twin_version = 0;
-  bool rep_checked = false, rep_lowrank = false;
-  int rep_m = 0;
-  DevBuf d_repv;                   // [N + m][m]: the twin's last m rows of W as weight columns
-  // scratch
-  DevBuf s_ent, s_in, s_in2, s_out1, s_out2, s_out3, s_blkv, s_blki, s_small, s_kcache, s_ssq, s_aslab, s_grad, s_ks, s_part;
-  // timing of the dominant kernel
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  double last_ms = 0.0;
-  int last_launches = 0;
-};
-
-struct tgp_traj_s {
-  tgp_handle h = nullptr;
-  int F = 0, B = 0;
-  DevBuf d_W, d_b, d_ws, d_v, d_theta;
-  int canonical = 1;
-  int device = 0;  // copied from the handle: destruction must not dereference `h` (it may be gone already)
-};
 
 namespace {
 
@@ -226,24 +129,25 @@ void apply_penalization(tgp_handle h, double* dvals, const double* dXq, int64_t 
                   pend + (size_t)h->pen_P * (h->d + 1));
 }
 
+// Sweep launch policy.  tgp_set_variant bits (experiments / tests; 0 = default):
+//   VARIANT_NO_SPLIT (1): never use the row-group split    VARIANT_FORCE_SPLIT (2): use it whenever Npad allows
+constexpr int VARIANT_NO_SPLIT = 1, VARIANT_FORCE_SPLIT = 2;
+
 hipError_t launch_sweep_timed(tgp_handle h, const SweepArgs& a, bool joint) {
   const int64_t grid = sweep_grid(a, joint);
   if (grid <= 0) return hipSuccess;
   hipError_t e;
-  // variant 0 (default): uniform 16-wave kernel (plain and joint mode); 1: the v1 (4-wave, 128x128)
-  // kernel; 2: wave-specialised (8 MFMA + 4 producer waves) kernel for plain sweeps, v1 for joint.
-  const bool ws = (h->variant & 0xff) != 1 && !(joint && (h->variant & 0xff) == 2);  // persistent kernels
   SweepArgs& am = const_cast<SweepArgs&>(a);
-  am.dbg = h->variant >> 8;
-  int64_t wgrid = grid;
   am.split_g = 0;
-  const bool u16 = ws && (h->variant & 0xff) != 2;
-  if (u16 && !joint && grid < 4 * (int64_t)h->num_cu && !getenv("TGP_NO_SPLIT")) {
+  const bool want_split = (h->variant & VARIANT_FORCE_SPLIT) ||
+                          (grid < 4 * (int64_t)h->num_cu && !(h->variant & VARIANT_NO_SPLIT));
+  if (!joint && want_split) {
     // Few candidate blocks (EGO's default sweep is max(5000, 1000 d) candidates = 63 blocks at d = 8): one
     // workgroup per block walks all of W alone (7.5 ms at N = 4096) on a quarter of the CUs.  Split every
     // block's row blocks of W into up to 8 groups of roughly equal triangular work.
     const int nb = (int)(a.m.Npad / 256);
     int g = (int)std::min<int64_t>(std::min(8, nb), (8 * (int64_t)h->num_cu + grid - 1) / grid);
+    if (h->variant & VARIANT_FORCE_SPLIT) g = std::min(8, nb);
     if (g > 1) {
       const int total = nb * (nb + 1) / 2;
       am.split_ib[0] = 0;
@@ -263,43 +167,23 @@ hipError_t launch_sweep_timed(tgp_handle h, const SweepArgs& a, bool joint) {
       }
     }
   }
-  if (ws) {
-    wgrid = grid * std::max(1, am.split_g);
-    wgrid = wgrid < h->num_cu ? wgrid : h->num_cu;  // persistent: one workgroup per CU
-    hipError_t ea = h->s_kcache.reserve((size_t)wgrid * (size_t)a.m.Npad * SW_BN * sizeof(double));
+  // persistent: one workgroup per CU, each with a private K* slab (and a C slab in joint mode)
+  int64_t wgrid = grid * std::max(1, am.split_g);
+  wgrid = wgrid < h->num_cu ? wgrid : h->num_cu;
+  hipError_t ea = h->s_kcache.reserve((size_t)wgrid * (size_t)a.m.Npad * SW_BN * sizeof(double));
+  if (ea != hipSuccess) return ea;
+  am.kcache = h->s_kcache.as<double>();
+  if (joint) {
+    ea = h->s_aslab.reserve((size_t)wgrid * (size_t)a.m.Npad * SW_BN * sizeof(double));
     if (ea != hipSuccess) return ea;
-    am.kcache = h->s_kcache.as<double>();
-    if (joint) {
-      ea = h->s_aslab.reserve((size_t)wgrid * (size_t)a.m.Npad * SW_BN * sizeof(double));
-      if (ea != hipSuccess) return ea;
-      am.aslab = h->s_aslab.as<double>();
-    }
-    ea = h->s_ssq.reserve((size_t)wgrid * SW_BN * MAX_D * sizeof(double));  // scaled-candidate scratch
-    if (ea != hipSuccess) return ea;
-    am.ssq_scratch = h->s_ssq.as<double>();
+    am.aslab = h->s_aslab.as<double>();
   }
   (void)hipEventRecord(h->ev0, h->stream);
-  if (ws && (h->variant & 0xff) == 2) {  // barrier-synchronised wave-specialised kernel (A/B reference)
-    switch (h->kind) {
-      case TGP_RBF: e = launch_sweep_ws_kind0(h->stream, a, wgrid); break;
-      case TGP_MATERN12: e = launch_sweep_ws_kind1(h->stream, a, wgrid); break;
-      case TGP_MATERN32: e = launch_sweep_ws_kind2(h->stream, a, wgrid); break;
-      default: e = launch_sweep_ws_kind3(h->stream, a, wgrid); break;
-    }
-  } else if (ws) {  // default: uniform 16-wave kernel
-    switch (h->kind) {
-      case TGP_RBF: e = launch_sweep_u16_kind0(h->stream, a, joint, wgrid); break;
-      case TGP_MATERN12: e = launch_sweep_u16_kind1(h->stream, a, joint, wgrid); break;
-      case TGP_MATERN32: e = launch_sweep_u16_kind2(h->stream, a, joint, wgrid); break;
-      default: e = launch_sweep_u16_kind3(h->stream, a, joint, wgrid); break;
-    }
-  } else {
-    switch (h->kind) {
-      case TGP_RBF: e = launch_sweep_kind0(h->stream, a, joint, grid); break;
-      case TGP_MATERN12: e = launch_sweep_kind1(h->stream, a, joint, grid); break;
-      case TGP_MATERN32: e = launch_sweep_kind2(h->stream, a, joint, grid); break;
-      default: e = launch_sweep_kind3(h->stream, a, joint, grid); break;
-    }
+  switch (h->kind) {
+    case TGP_RBF: e = launch_sweep_kind0(h->stream, a, joint, wgrid); break;
+    case TGP_MATERN12: e = launch_sweep_kind1(h->stream, a, joint, wgrid); break;
+    case TGP_MATERN32: e = launch_sweep_kind2(h->stream, a, joint, wgrid); break;
+    default: e = launch_sweep_kind3(h->stream, a, joint, wgrid); break;
   }
   if (e == hipSuccess && am.split_g > 1) launch_sweep_combine(h->stream, a, grid);
   (void)hipEventRecord(h->ev1, h->stream);
@@ -469,6 +353,15 @@ int acq_values_device(tgp_handle h, int acq_kind, double param, const double* dX
 }  // namespace
 
 namespace tgp {
+int host_set_device(tgp_handle h) { return set_device(h); }
+int host_fail(tgp_handle h, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  return fail(h, code, "%s", buf);
+}
 int64_t sweep_grid(const SweepArgs& a, bool joint) {
   if (!joint) return (a.M + SW_BN - 1) / SW_BN;
   const int gp = 64 / a.q;
@@ -529,7 +422,7 @@ int tgp_destroy(tgp_handle h) {
   }
   for (DevBuf* b : {&h->d_xn, &h->d_ls, &h->d_X, &h->d_Y, &h->d_Xs, &h->d_A, &h->d_L, &h->d_W, &h->d_alpha,
                     &h->d_err, &h->d_tmp1, &h->d_tmp2, &h->d_info, &h->d_pen, &h->d_ent, &h->d_repv, &h->s_ent, &h->s_in, &h->s_in2, &h->s_out1,
-                    &h->s_out2, &h->s_out3, &h->s_blkv, &h->s_blki, &h->s_small, &h->s_kcache, &h->s_ssq, &h->s_aslab, &h->s_grad, &h->s_ks, &h->s_part})
+                    &h->s_out2, &h->s_out3, &h->s_blkv, &h->s_blki, &h->s_small, &h->s_kcache, &h->s_aslab, &h->s_grad, &h->s_ks, &h->s_part})
     b->release();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -875,8 +768,7 @@ int tgp_get_factor(tgp_handle h, double* L, double* Winv, double* alpha, int whe
 }
 
 static int sweep_common(tgp_handle h, const double* Xq, int64_t M, double* mean, double* var, double* acq,
-                        int acq_kind, double param, int where, bool want_best, int64_t index_base,
-                        double* best_val, int64_t* best_idx, double* best_x) {
+                        int acq_kind, double param, int where) {
   if (!h) return TGP_ERR_ARG;
   if (!h->have_data) return fail(h, TGP_ERR_STATE, "model has no data: call tgp_set_data first");
   if (M < 0) return fail(h, TGP_ERR_SHAPE, "M must be >= 0");
@@ -884,10 +776,7 @@ static int sweep_common(tgp_handle h, const double* Xq, int64_t M, double* mean,
   if (int rc = set_device(h)) return rc;
   h->last_launches = 0;
   h->last_ms = 0.0;
-  if (M == 0) {
-    if (want_best) return fail(h, TGP_ERR_SHAPE, "arg-max over an empty candidate set");
-    return TGP_OK;
-  }
+  if (M == 0) return TGP_OK;
   const double* dXq;
   if (int rc = stage_in(h, h->s_in, Xq, (size_t)M * h->d, where, &dXq)) return rc;
   SweepArgs a{};
@@ -899,37 +788,8 @@ static int sweep_common(tgp_handle h, const double* Xq, int64_t M, double* mean,
   if (int rc = stage_out_prepare(h, h->s_out3, acq, M, where, &a.acq_out)) return rc;
   a.acq_kind = acq_kind;
   a.acq_param = param;
-  a.index_base = index_base;
-  const int64_t grid = sweep_grid(a, false);
-  if (want_best) {
-    HIPCHK(h, h->s_blkv.reserve(grid * sizeof(double)));
-    HIPCHK(h, h->s_blki.reserve(grid * sizeof(int64_t)));
-    HIPCHK(h, h->s_small.reserve(64));
-    a.blk_val = h->s_blkv.as<double>();
-    a.blk_idx = h->s_blki.as<int64_t>();
-  }
   HIPCHK(h, launch_sweep_timed(h, a, false));
-  if (acq_kind >= 0 && !want_best) apply_penalization(h, a.acq_out, dXq, M);
-  if (want_best) {
-    double* fv = h->s_small.as<double>();
-    int64_t* fi = (int64_t*)(fv + 1);
-    launch_argmax_final(h->stream, a.blk_val, a.blk_idx, grid, fv, fi);
-    double hv;
-    int64_t hi;
-    HIPCHK(h, hipMemcpyAsync(&hv, fv, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(&hi, fi, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-    if (int rc = sync(h)) return rc;
-    if (best_val) *best_val = hv;
-    if (best_idx) *best_idx = hi;
-    if (best_x) {
-      const int64_t local = hi - index_base;
-      if (local < 0 || local >= M) return fail(h, TGP_ERR_HIP, "arg-max produced no valid index (all NaN?)");
-      if (where == TGP_DEVICE)
-        HIPCHK(h, hipMemcpy(best_x, dXq + local * h->d, h->d * sizeof(double), hipMemcpyDeviceToHost));
-      else
-        memcpy(best_x, Xq + local * h->d, h->d * sizeof(double));
-    }
-  }
+  if (acq_kind >= 0) apply_penalization(h, a.acq_out, dXq, M);
   if (int rc = stage_out_finish(h, a.mean_out, mean, M, where)) return rc;
   if (int rc = stage_out_finish(h, a.var_out, var, M, where)) return rc;
   if (int rc = stage_out_finish(h, a.acq_out, acq, M, where)) return rc;
@@ -939,7 +799,7 @@ static int sweep_common(tgp_handle h, const double* Xq, int64_t M, double* mean,
 }
 
 int tgp_predict(tgp_handle h, const double* Xq, int64_t M, double* mean, double* var, int where) {
-  return sweep_common(h, Xq, M, mean, var, nullptr, -1, 0.0, where, false, 0, nullptr, nullptr, nullptr);
+  return sweep_common(h, Xq, M, mean, var, nullptr, -1, 0.0, where);
 }
 
 int tgp_predict_mean(tgp_handle h, const double* Xq, int64_t M, double* mean, int where) {
@@ -993,8 +853,7 @@ int tgp_acq_values(tgp_handle h, int acq_kind, double param, const double* Xq, i
     HIPCHK(h, hipGetLastError());
     return TGP_OK;
   }
-  return sweep_common(h, Xq, M, nullptr, nullptr, out, acq_kind, param, where, false, 0, nullptr, nullptr,
-                      nullptr);
+  return sweep_common(h, Xq, M, nullptr, nullptr, out, acq_kind, param, where);
 }
 
 int tgp_acq_value_grad(tgp_handle h, int acq_kind, double param, const double* Xq, int64_t P, double* val,
@@ -1165,32 +1024,110 @@ int tgp_debug_gemm(tgp_handle h, int m, int n, int k, int tb, int tri, int lower
   return TGP_OK;
 }
 
-int tgp_acq_topk(tgp_handle h, int acq_kind, double param, const double* Xq, int64_t M, int64_t index_base, int k,
-                 double* vals, int64_t* idx, int where);
+// The k best (value desc, index asc) of device-resident values into device slots fv [k], fi [k]: enqueue only.
+static int enqueue_topk_of_values(tgp_handle h, const double* dvals, int64_t M, int64_t index_base, int k, double* fv,
+                                  int64_t* fi) {
+  HIPCHK(h, h->s_blkv.reserve((size_t)std::max(512, 8 * k) * sizeof(double)));
+  HIPCHK(h, h->s_blki.reserve((size_t)std::max(512, 8 * k) * sizeof(int64_t)));
+  if (M <= topk_small_max()) {
+    launch_topk_small(h->stream, dvals, M, index_base, k, fv, fi, h->s_blkv.as<double>(), h->s_blki.as<int64_t>());
+  } else {
+    for (int t = 0; t < k; ++t)  // thresholds stay on the device: no host round trip per pass
+      launch_topk_pass(h->stream, dvals, M, index_base, t ? fv + t - 1 : nullptr, t ? fi + t - 1 : nullptr,
+                       h->s_blkv.as<double>(), h->s_blki.as<int64_t>(), fv + t, fi + t);
+  }
+  return TGP_OK;
+}
+
+// Fused predict + acquisition + arg-max over device-resident candidates: the winner's value and global index go
+// to the DEVICE slots dval / didx; nothing is synchronised.  The posterior tails run the fused sweep (values never
+// reach HBM); penalised / entropy tails take one trip through HBM (8 B per candidate) between sweep and arg-max.
+static int enqueue_argmax(tgp_handle h, int acq_kind, double param, const double* dXq, int64_t M, int64_t index_base,
+                          double* dval, int64_t* didx) {
+  h->last_launches = 0;
+  h->last_ms = 0.0;
+  if ((h->pen_kind != 0 && h->pen_P > 0) || acq_kind >= TGP_ACQ_MES) {
+    HIPCHK(h, h->s_out3.reserve((size_t)M * sizeof(double)));
+    double* dvals = h->s_out3.as<double>();
+    if (int rc = acq_values_device(h, acq_kind, param, dXq, M, dvals)) return rc;
+    return enqueue_topk_of_values(h, dvals, M, index_base, 1, dval, didx);
+  }
+  SweepArgs a{};
+  a.m = model_dev(h);
+  a.Xq = dXq;
+  a.M = M;
+  a.acq_kind = acq_kind;
+  a.acq_param = param;
+  a.index_base = index_base;
+  const int64_t grid = sweep_grid(a, false);
+  HIPCHK(h, h->s_blkv.reserve(grid * sizeof(double)));
+  HIPCHK(h, h->s_blki.reserve(grid * sizeof(int64_t)));
+  a.blk_val = h->s_blkv.as<double>();
+  a.blk_idx = h->s_blki.as<int64_t>();
+  HIPCHK(h, launch_sweep_timed(h, a, false));
+  launch_argmax_final(h->stream, a.blk_val, a.blk_idx, grid, dval, didx);
+  return TGP_OK;
+}
+
+static int argmax_checks(tgp_handle h, int acq_kind, const double* Xq, int64_t M) {
+  if (!h) return TGP_ERR_ARG;
+  if (acq_kind < 0 || acq_kind > ACQ_KIND_MAX) return fail(h, TGP_ERR_ARG, "unknown acquisition kind %d", acq_kind);
+  if (!h->have_data) return fail(h, TGP_ERR_STATE, "model has no data: call tgp_set_data first");
+  if (M < 1) return fail(h, TGP_ERR_SHAPE, "arg-max over an empty candidate set");
+  if (!Xq) return fail(h, TGP_ERR_ARG, "Xq is NULL");
+  if (acq_kind >= TGP_ACQ_MES && h->ent_S == 0)
+    return fail(h, TGP_ERR_STATE, "entropy-search acquisition needs min-value samples: call tgp_set_min_value_samples");
+  return TGP_OK;
+}
 
 int tgp_acq_argmax(tgp_handle h, int acq_kind, double param, const double* Xq, int64_t M,
                    int64_t index_base, double* best_val, int64_t* best_idx, double* best_x, int where) {
-  if (acq_kind < 0 || acq_kind > ACQ_KIND_MAX) return fail(h, TGP_ERR_ARG, "unknown acquisition kind %d", acq_kind);
-  if (h && ((h->pen_kind != 0 && h->pen_P > 0) || acq_kind >= TGP_ACQ_MES)) {
-    // penalised / entropy tails: the values take one trip through HBM (8 B per candidate) between the sweep and the arg-max
-    if (M < 1) return fail(h, TGP_ERR_SHAPE, "arg-max over an empty candidate set");
-    double v;
-    int64_t i;
-    if (int rc = tgp_acq_topk(h, acq_kind, param, Xq, M, index_base, 1, &v, &i, where)) return rc;
-    if (best_val) *best_val = v;
-    if (best_idx) *best_idx = i;
-    if (best_x) {
-      const int64_t local = i - index_base;
-      if (local < 0 || local >= M) return fail(h, TGP_ERR_HIP, "arg-max produced no valid index (all NaN?)");
-      if (where == TGP_DEVICE)
-        HIPCHK(h, hipMemcpy(best_x, Xq + local * h->d, h->d * sizeof(double), hipMemcpyDeviceToHost));
-      else
-        memcpy(best_x, Xq + local * h->d, h->d * sizeof(double));
-    }
-    return TGP_OK;
+  if (int rc = argmax_checks(h, acq_kind, Xq, M)) return rc;
+  if (int rc = set_device(h)) return rc;
+  const double* dXq;
+  if (int rc = stage_in(h, h->s_in, Xq, (size_t)M * h->d, where, &dXq)) return rc;
+  HIPCHK(h, h->s_small.reserve(64));
+  double* fv = h->s_small.as<double>();
+  int64_t* fi = (int64_t*)(fv + 1);
+  if (int rc = enqueue_argmax(h, acq_kind, param, dXq, M, index_base, fv, fi)) return rc;
+  double hv;
+  int64_t hi;
+  HIPCHK(h, hipMemcpyAsync(&hv, fv, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(&hi, fi, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+  if (int rc = sync(h)) return rc;
+  HIPCHK(h, hipGetLastError());
+  if (best_val) *best_val = hv;
+  if (best_idx) *best_idx = hi;
+  if (best_x) {
+    const int64_t local = hi - index_base;
+    if (local < 0 || local >= M) return fail(h, TGP_ERR_HIP, "arg-max produced no valid index (all NaN?)");
+    if (where == TGP_DEVICE)
+      HIPCHK(h, hipMemcpy(best_x, dXq + local * h->d, h->d * sizeof(double), hipMemcpyDeviceToHost));
+    else
+      memcpy(best_x, Xq + local * h->d, h->d * sizeof(double));
   }
-  return sweep_common(h, Xq, M, nullptr, nullptr, nullptr, acq_kind, param, where, true, index_base,
-                      best_val, best_idx, best_x);
+  return TGP_OK;
+}
+
+int tgp_acq_argmax_async(tgp_handle h, int acq_kind, double param, const double* Xq_device, int64_t M,
+                         int64_t index_base, double* pair_device) {
+  if (int rc = argmax_checks(h, acq_kind, Xq_device, M)) return rc;
+  if (!pair_device) return fail(h, TGP_ERR_ARG, "pair_device is NULL");
+  if (int rc = set_device(h)) return rc;
+  if (int rc = enqueue_argmax(h, acq_kind, param, Xq_device, M, index_base, pair_device, (int64_t*)(pair_device + 1)))
+    return rc;
+  HIPCHK(h, hipGetLastError());
+  return TGP_OK;
+}
+
+int tgp_merge_winners_async(tgp_handle h, const double* gathered_device, int P, int V, int minimize,
+                            double* out_device) {
+  if (!h) return TGP_ERR_ARG;
+  if (P < 1 || V < 1 || !gathered_device || !out_device) return fail(h, TGP_ERR_ARG, "bad arguments");
+  if (int rc = set_device(h)) return rc;
+  launch_merge_winners(h->stream, gathered_device, P, V, minimize ? 1 : 0, out_device);
+  HIPCHK(h, hipGetLastError());
+  return TGP_OK;
 }
 
 int tgp_acq_topk(tgp_handle h, int acq_kind, double param, const double* Xq, int64_t M,
@@ -1209,18 +1146,10 @@ int tgp_acq_topk(tgp_handle h, int acq_kind, double param, const double* Xq, int
     if (int rc = stage_in(h, h->s_in, Xq, (size_t)M * h->d, where, &dXq)) return rc;
     if (int rc = acq_values_device(h, acq_kind, param, dXq, M, dvals)) return rc;
   }
-  HIPCHK(h, h->s_blkv.reserve((size_t)std::max(512, 8 * k) * sizeof(double)));
-  HIPCHK(h, h->s_blki.reserve((size_t)std::max(512, 8 * k) * sizeof(int64_t)));
   HIPCHK(h, h->s_small.reserve((size_t)k * 16 + 64));
   double* fv = h->s_small.as<double>();       // [k] winners' values
   int64_t* fi = (int64_t*)(fv + k);           // [k] winners' indices
-  if (M <= topk_small_max()) {
-    launch_topk_small(h->stream, dvals, M, index_base, k, fv, fi, h->s_blkv.as<double>(), h->s_blki.as<int64_t>());
-  } else {
-    for (int t = 0; t < k; ++t)  // thresholds stay on the device: no host round trip per pass
-      launch_topk_pass(h->stream, dvals, M, index_base, t ? fv + t - 1 : nullptr, t ? fi + t - 1 : nullptr,
-                       h->s_blkv.as<double>(), h->s_blki.as<int64_t>(), fv + t, fi + t);
-  }
+  if (int rc = enqueue_topk_of_values(h, dvals, M, index_base, k, fv, fi)) return rc;
   HIPCHK(h, hipMemcpyAsync(vals, fv, (size_t)k * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipMemcpyAsync(idx, fi, (size_t)k * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
   if (int rc = sync(h)) return rc;
@@ -1624,6 +1553,23 @@ int tgp_traj_value_grad(tgp_traj t, const double* Xq, int64_t P, double* val, do
   return TGP_OK;
 }
 
+// arg-min of the B trajectories over device-resident candidates into DEVICE slots fv [B], fi [B]: enqueue only
+static int enqueue_traj_argmin(tgp_traj t, const double* dXq, int64_t M, int64_t index_base, double* fv, int64_t* fi) {
+  tgp_handle h = t->h;
+  const int64_t grid = traj_grid(M);
+  const int B = t->B;
+  HIPCHK(h, h->s_blkv.reserve((size_t)grid * B * sizeof(double)));
+  HIPCHK(h, h->s_blki.reserve((size_t)grid * B * sizeof(int64_t)));
+  (void)hipEventRecord(h->ev0, h->stream);
+  launch_traj_eval(h->stream, traj_dev(t), dXq, M, 0, nullptr, h->s_blkv.as<double>(),
+                   h->s_blki.as<int64_t>(), index_base);
+  (void)hipEventRecord(h->ev1, h->stream);
+  h->last_launches = 1;
+  h->last_ms = -1.0;
+  launch_argmin_final_multi(h->stream, h->s_blkv.as<double>(), h->s_blki.as<int64_t>(), grid, B, fv, fi);
+  return TGP_OK;
+}
+
 int tgp_traj_argmin(tgp_traj t, const double* Xq, int64_t M, int64_t index_base, double* best_val,
                     int64_t* best_idx, int where) {
   if (!t) return TGP_ERR_ARG;
@@ -1633,22 +1579,34 @@ int tgp_traj_argmin(tgp_traj t, const double* Xq, int64_t M, int64_t index_base,
   if (int rc = set_device(h)) return rc;
   const double* dXq;
   if (int rc = stage_in(h, h->s_in, Xq, (size_t)M * h->d, where, &dXq)) return rc;
-  const int64_t grid = traj_grid(M);
   const int B = t->B;
-  HIPCHK(h, h->s_blkv.reserve((size_t)grid * B * sizeof(double)));
-  HIPCHK(h, h->s_blki.reserve((size_t)grid * B * sizeof(int64_t)));
   HIPCHK(h, h->s_small.reserve(64 + 2 * 16 * 8));
   double* fv = h->s_small.as<double>();
   int64_t* fi = (int64_t*)(fv + 16);
-  (void)hipEventRecord(h->ev0, h->stream);
-  launch_traj_eval(h->stream, traj_dev(t), dXq, M, 0, nullptr, h->s_blkv.as<double>(),
-                   h->s_blki.as<int64_t>(), index_base);
-  (void)hipEventRecord(h->ev1, h->stream);
-  h->last_launches = 1;
-  h->last_ms = -1.0;
-  launch_argmin_final_multi(h->stream, h->s_blkv.as<double>(), h->s_blki.as<int64_t>(), grid, B, fv, fi);
+  if (int rc = enqueue_traj_argmin(t, dXq, M, index_base, fv, fi)) return rc;
   if (best_val) HIPCHK(h, hipMemcpyAsync(best_val, fv, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   if (best_idx) HIPCHK(h, hipMemcpyAsync(best_idx, fi, B * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+  if (int rc = sync(h)) return rc;
+  HIPCHK(h, hipGetLastError());
+  return TGP_OK;
+}
+
+int tgp_traj_argmin_async(tgp_traj t, const double* Xq_device, int64_t M, int64_t index_base, double* pairs_device) {
+  if (!t) return TGP_ERR_ARG;
+  tgp_handle h = t->h;
+  if (M < 1 || !Xq_device) return fail(h, TGP_ERR_SHAPE, "arg-min needs M >= 1 candidates");
+  if (!pairs_device) return fail(h, TGP_ERR_ARG, "pairs_device is NULL");
+  if (t->B > 16) return fail(h, TGP_ERR_SHAPE, "supports B <= 16 trajectories per call, got %d", t->B);
+  if (int rc = set_device(h)) return rc;
+  if (int rc = enqueue_traj_argmin(t, Xq_device, M, index_base, pairs_device, (int64_t*)(pairs_device + t->B)))
+    return rc;
+  HIPCHK(h, hipGetLastError());
+  return TGP_OK;
+}
+
+int tgp_stream_synchronize(tgp_handle h) {
+  if (!h) return TGP_ERR_ARG;
+  if (int rc = set_device(h)) return rc;
   if (int rc = sync(h)) return rc;
   HIPCHK(h, hipGetLastError());
   return TGP_OK;
@@ -1657,6 +1615,7 @@ int tgp_traj_argmin(tgp_traj t, const double* Xq, int64_t M, int64_t index_base,
 int tgp_last_kernel_ms(tgp_handle h, double* ms, int* launches) {
   if (!h) return TGP_ERR_ARG;
   if (h->last_ms < 0.0) {
+    (void)hipSetDevice(h->device);  // the events belong to the handle's device
     float f = 0.f;
     if (hipEventElapsedTime(&f, h->ev0, h->ev1) == hipSuccess) h->last_ms = f;
     else h->last_ms = 0.0;

@@ -1,0 +1,115 @@
+// Host-side state behind the opaque handles of include/tgp.h, shared by the translation units that
+// implement the C-ABI (tgp_api.hip: single-device entry points; tgp_group.hip: the multi-device group).
+#pragma once
+#include "../../include/tgp.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "tgp_internal.hpp"
+
+namespace tgp {
+
+struct DevBuf {  // grow-only device buffer
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipSuccess) {
+      cap = bytes;
+      // TGP_POISON=1 (tests): fill fresh allocations with NaNs so that any read of memory the engine did
+      // not write shows up deterministically instead of depending on what the allocator recycled
+      static const bool poison = getenv("TGP_POISON") != nullptr;
+      if (poison) e = hipMemset(p, 0xFF, bytes);
+    }
+    return e;
+  }
+  hipError_t grow_keep(size_t bytes, size_t keep, hipStream_t st) {  // like reserve, but keeps the first `keep` bytes
+    if (bytes <= cap) return hipSuccess;
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) return e;
+    if (p && keep) {
+      e = hipMemcpyAsync(q, p, keep, hipMemcpyDeviceToDevice, st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
+      if (e != hipSuccess) {
+        (void)hipFree(q);
+        return e;
+      }
+    }
+    if (p) (void)hipFree(p);
+    p = q;
+    cap = bytes;
+    return hipSuccess;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <class T>
+  T* as() const { return (T*)p; }
+};
+
+}  // namespace tgp
+
+using tgp::DevBuf;
+
+struct tgp_handle_s {
+  int device = 0, d = 0, dp = 0, kind = 0, num_cu = 256;
+  hipStream_t stream = nullptr;      // where the kernels go (default stream, a caller's, or own_stream)
+  hipStream_t own_stream = nullptr;  // created by tgp_use_private_stream, destroyed with the handle
+  std::string err;
+  // hyper-parameters
+  bool have_hyper = false, have_data = false;
+  double variance = 1.0, noise = 1.0, mean_const = 0.0;
+  std::vector<double> ls;  // [d]
+  int64_t N = 0, Npad = 0;
+  int variant = 0;
+  // model state on device
+  DevBuf d_xn, d_ls, d_X, d_Y, d_Xs, d_A, d_L, d_W, d_alpha, d_err, d_tmp1, d_tmp2, d_info;
+  // local penalization applied to every tgp_acq_* result while pen_kind != 0 (tgp_set_penalization)
+  int pen_kind = 0, pen_P = 0;
+  DevBuf d_pen;  // [P, d] pending points, [P] radius, [P] scale
+  // entropy-search tails (TGP_ACQ_MES / TGP_ACQ_GIBBON): min-value samples; GIBBON's repulsion twin
+  int ent_S = 0;
+  DevBuf d_ent;  // [S]
+  tgp_handle rep_twin = nullptr;  // not owned: this model conditioned additionally on the pending points
+  double rep_weight = 0.0;
+  // when the twin is literally this model's data + m <= 16 appended rows (same hyper-parameters), its variance is
+  // a rank-m correction of this model's: checked once per (data, twin data) version pair
+  uint64_t data_version = 0;       // process-wide unique stamp of the current factorisation (0: none)
+  uint64_t rep_self_version = 0, rep_twin_version = 0;
+  bool rep_checked = false, rep_lowrank = false;
+  int rep_m = 0;
+  DevBuf d_repv;                   // [N + m][m]: the twin's last m rows of W as weight columns
+  // scratch
+  DevBuf s_ent, s_in, s_in2, s_out1, s_out2, s_out3, s_blkv, s_blki, s_small, s_kcache, s_aslab, s_grad, s_ks, s_part;
+  // timing of the dominant kernel
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double last_ms = 0.0;
+  int last_launches = 0;
+};
+
+struct tgp_traj_s {
+  tgp_handle h = nullptr;
+  int F = 0, B = 0;
+  DevBuf d_W, d_b, d_ws, d_v, d_theta;
+  int canonical = 1;
+  int device = 0;  // copied from the handle: destruction must not dereference `h` (it may be gone already)
+};
+
+// ---- internal entry points shared between the translation units (not part of the C-ABI) -------------
+namespace tgp {
+// set the thread's device to the handle's and clear the thread's sticky HIP error; TGP_OK or TGP_ERR_HIP
+int host_set_device(tgp_handle h);
+// record `msg` as the handle's last error and return `code`
+int host_fail(tgp_handle h, int code, const char* fmt, ...);
+}  // namespace tgp

@@ -5,10 +5,8 @@
 
 namespace tgp {
 
-constexpr int SW_BM = 128;  // rows of W per tile        (sweep kernel)
-constexpr int SW_BN = 128;  // candidates per workgroup
-constexpr int SW_BK = 16;   // k-step
-constexpr int NPAD_MULT = 256;  // row-block of the wave-specialised sweep (also a multiple of SW_BM)
+constexpr int SW_BN = 128;  // candidates per workgroup (sweep kernel)
+constexpr int NPAD_MULT = 256;  // row block of W per workgroup tile of the sweep
 constexpr int LEAF = 64;    // Cholesky / inverse leaf block
 constexpr int MAX_D = 32;
 constexpr int MAX_Q = 64;
@@ -49,11 +47,9 @@ struct SweepArgs {
   int q;              // group size (joint mode only)
   int64_t G;          // number of groups
   double* cov_out;    // [G][q][q]
-  double* kcache;     // [grid][Npad][128] K* slabs of the wave-specialised sweep (device scratch)
+  double* kcache;     // [grid][Npad][128] per-workgroup K* slabs (device scratch)
   double* aslab;      // [grid][Npad][128] C = W K* slabs of joint mode (device scratch)
-  double* ssq_scratch; // [grid][8 waves][4][64] column-norm partials of the flag-synchronised sweep
-  int dbg;            // development only: bit0 skip K* generation, bit1 skip W loads, bit2 skip MFMA
-  // row-group split of small sweeps (u16 SPLIT instantiation): group g of a candidate block owns the row
+  // row-group split of small sweeps (SPLIT instantiation): group g of a candidate block owns the row
   // blocks [split_ib[g], split_ib[g+1]) of W and leaves partial (mean, sum c^2) in `part`
   int split_g;            // 0/1: off
   int split_ib[9];
@@ -97,7 +93,6 @@ void launch_axpby_vec(hipStream_t s, int64_t n, double a, const double* x, doubl
 
 // ---- sweep (tgp_kernels_sweep_*.hip) ----
 int64_t sweep_grid(const SweepArgs& a, bool joint);
-constexpr int WS_MAX_GRID = 256;  // persistent workgroups of the wave-specialised sweep (1 per CU)
 
 // ---- misc (tgp_kernels_misc.hip) ----
 void launch_predict_mean(hipStream_t s, const ModelDev& m, const double* Xq, int64_t M, double* mean);
@@ -156,6 +151,7 @@ void launch_theta_tail(hipStream_t s, const double* mean, int64_t ldm, const dou
                        double scale, double* theta, double* ws);
 void launch_traj_grad(hipStream_t s, const TrajDev& t, const double* Xq, int64_t nitems, double* val,
                       double* grad);
+void launch_merge_winners(hipStream_t s, const double* gathered, int P, int V, int minimize, double* out);
 void launch_argmin_final_multi(hipStream_t s, const double* blk_val, const int64_t* blk_idx,
                                int64_t nblk, int B, double* out_val, int64_t* out_idx);
 

@@ -86,7 +86,7 @@ void launch_predict_mean(hipStream_t s, const ModelDev& m, const double* Xq, int
 }
 
 // ---------------------------------------------------------------------------------------------
-// Second half of a row-group-split sweep (tgp_kernels_sweep_u16.inc, SPLIT): sum the groups' partial
+// Second half of a row-group-split sweep (tgp_kernels_sweep.inc, SPLIT): sum the groups' partial
 // (k*.alpha, sum c^2) in a fixed order, then the same tail as the fused epilogue -- clip, acquisition value,
 // outputs, per-block (max value, min index).  One 128-thread workgroup per candidate block.
 __global__ __launch_bounds__(128) void sweep_combine_kernel(SweepArgs a) {
@@ -492,7 +492,8 @@ __global__ void sample_box_kernel(uint64_t seed, int64_t first, int64_t M, int d
   const int64_t row = t / d;
   const int c = (int)(t % d);
   const double u = philox_uniform(seed, (uint64_t)((first + row) * d + c));
-  out[t] = fma(u, upper[c] - lower[c], lower[c]);
+  // three separately rounded operations (no fma contraction): the numpy restatement oracle/philox.py is bit-exact
+  out[t] = __dadd_rn(lower[c], __dmul_rn(__dsub_rn(upper[c], lower[c]), u));
 }
 void launch_sample_box(hipStream_t s, uint64_t seed, int64_t first, int64_t M, int d,
                        const double* lower, const double* upper, double* out) {
@@ -605,6 +606,37 @@ void launch_argmin_final_multi(hipStream_t s, const double* blk_val, const int64
                                int64_t nblk, int B, double* out_val, int64_t* out_idx) {
   hipLaunchKernelGGL(argmin_final_multi_kernel, dim3((unsigned)B), dim3(256), 0, s, blk_val, blk_idx,
                      nblk, B, out_val, out_idx);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cross-device merge of per-shard winners (host mirror: trieste_amd/distributed.py merge_best):
+// gathered [P][2][V] -- rank p's V values followed by its V global indices (int64 bit patterns in the 8-byte
+// slots, exactly what the all-gather moved).  Larger value wins (smaller if `minimize`), ties go to the
+// smaller global index (tf.math.argmax / argmin over the unsharded set); a NaN value or an index < 0 / the
+// INT64_MAX "nothing found" mark never wins.  No valid entry: (NaN, -1).  One thread per v, fixed order.
+__global__ void merge_winners_kernel(const double* __restrict__ gathered, int P, int V, int minimize,
+                                     double* __restrict__ out) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  double bv = -INFINITY, braw = __builtin_nan("");
+  int64_t bi = INT64_MAX;
+  for (int p = 0; p < P; ++p) {
+    const double raw = gathered[((size_t)p * 2 + 0) * V + v];
+    const int64_t idx = ((const int64_t*)gathered)[((size_t)p * 2 + 1) * V + v];
+    if (raw != raw || idx < 0 || idx == INT64_MAX) continue;
+    const double key = minimize ? -raw : raw;
+    if (bi == INT64_MAX || better(key, idx, bv, bi)) {
+      bv = key;
+      bi = idx;
+      braw = raw;
+    }
+  }
+  out[v] = braw;
+  ((int64_t*)out)[V + v] = bi == INT64_MAX ? -1 : bi;
+}
+void launch_merge_winners(hipStream_t s, const double* gathered, int P, int V, int minimize, double* out) {
+  hipLaunchKernelGGL(merge_winners_kernel, dim3((unsigned)((V + 63) / 64)), dim3(64), 0, s, gathered, P, V,
+                     minimize, out);
 }
 
 }  // namespace tgp

@@ -68,6 +68,37 @@ def all_gather_best(val, idx, minimize: bool = False, group=None, device=None, f
     return merge_best(vals, idxs, minimize)
 
 
+def all_gather_winners(engine, pairs, minimize: bool = False, group=None):
+    """The device-resident form of :func:`all_gather_best`: ``pairs`` is what ``engine.acq_argmax_pair`` /
+    ``trajectory.argmin_pairs`` left on the device ([2] or [2, V]: values, then global indices as int64 bit
+    patterns).  One all-gather of the pairs (RCCL on GPUs), the merge kernel of the engine
+    (``tgp_merge_winners_async``: max value -- min if ``minimize`` --, min global index), and ONE device-to-host
+    copy: a single host synchronisation per sharded step instead of three.  The engine must queue its kernels on
+    torch's current stream (``engine.use_torch_stream()``) so that sweep, collective and merge are ordered.
+    Returns (values [V], global indices [V]) as numpy arrays; identity for a single process."""
+    import torch
+    import torch.distributed as dist
+
+    t = pairs if _is_tensor(pairs) else torch.as_tensor(np.asarray(pairs, dtype=np.float64))
+    V = int(t.numel() // 2)
+    t = t.reshape(2, V)
+    active = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if active else 1
+    if active:
+        out = torch.empty((world, 2, V), dtype=torch.float64, device=t.device)
+        dist.all_gather_into_tensor(out.view(-1), t.contiguous().view(-1), group=group)
+    else:
+        out = t.reshape(1, 2, V)
+    merged = engine.merge_winners(out, minimize)
+    host = merged.cpu() if _is_tensor(merged) else torch.as_tensor(np.asarray(merged))
+    host = host.reshape(2, V)
+    return host[0].numpy().copy(), host[1].contiguous().view(torch.int64).numpy().copy()
+
+
+def _is_tensor(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
 def generate_sharded_discrete_optimizer(group=None, device=None):
     """An ``AcquisitionOptimizer`` (reference acquisition/optimizer.py:73-87) for one process per GPU: every
     rank holds the same model and the same ``DiscreteSearchSpace``; rank r sweeps the contiguous shard

@@ -49,13 +49,25 @@ class GPEngine:
         rc = self._lib.tgp_create(int(device), int(d), _lib.KERNELS[kernel], C.byref(h))
         _lib.check(self._lib, None, rc)
         self._h = h
+        self._owned = True
         self.d, self.kernel, self.device = int(d), kernel, int(device)
         self.N = 0
+
+    @classmethod
+    def _borrowed(cls, handle, d: int, kernel: str, device: int) -> "GPEngine":
+        """A view of a handle owned by someone else (a :class:`~trieste_amd.group.GPEngineGroup` member):
+        same methods, never destroys the handle."""
+        self = cls.__new__(cls)
+        self._lib = _lib.load()
+        self._h, self._owned = handle, False
+        self.d, self.kernel, self.device, self.N = int(d), kernel, int(device), 0
+        return self
 
     # -- lifetime ------------------------------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None):
-            self._lib.tgp_destroy(self._h)
+            if getattr(self, "_owned", True):
+                self._lib.tgp_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -301,6 +313,39 @@ class GPEngine:
                                            C.byref(bv), C.byref(bi), bx.ctypes.data, a.where))
         return bv.value, bi.value, bx
 
+    def acq_argmax_pair(self, acq: str, param: float, Xq, index_base: int = 0):
+        """The fused arg-max with the winner left ON THE DEVICE: Xq a CUDA tensor [M, d] -> CUDA float64 tensor
+        [2] = (value, global index as an int64 bit pattern).  Only enqueues on the engine's stream
+        (tgp_acq_argmax_async): no host synchronisation -- gather the pairs of all ranks, merge them with
+        :meth:`merge_winners`, read the result once."""
+        import torch
+
+        a, _, M = self._flat(Xq)
+        if a.where != _lib.DEVICE:
+            raise ValueError("acq_argmax_pair needs device-resident candidates (a CUDA tensor)")
+        pair = torch.empty(2, dtype=torch.float64, device=a.device)
+        self._chk(self._lib.tgp_acq_argmax_async(self._h, _lib.ACQ[acq], float(param), a.ptr, M, int(index_base),
+                                                 pair.data_ptr()))
+        return pair
+
+    def merge_winners(self, gathered, minimize: bool = False):
+        """gathered: CUDA float64 tensor [P, 2, V] (an all-gather of P ranks' [2, V] pairs) -> CUDA tensor [2, V]
+        with the winners under (max value -- min if ``minimize`` --, min global index); enqueue only."""
+        import torch
+
+        if not (_is_torch(gathered) and gathered.is_cuda and gathered.dtype == torch.float64 and gathered.dim() == 3
+                and gathered.shape[1] == 2):
+            raise ValueError("gathered must be a CUDA float64 tensor [P, 2, V]")
+        g = gathered.contiguous()
+        out = torch.empty((2, g.shape[2]), dtype=torch.float64, device=g.device)
+        self._chk(self._lib.tgp_merge_winners_async(self._h, g.data_ptr(), int(g.shape[0]), int(g.shape[2]),
+                                                    1 if minimize else 0, out.data_ptr()))
+        return out
+
+    def synchronize(self) -> None:
+        """Wait for everything enqueued on the engine's stream (tgp_stream_synchronize)."""
+        self._chk(self._lib.tgp_stream_synchronize(self._h))
+
     def acq_topk(self, acq: str, param: float, Xq, k: int, index_base: int = 0):
         a, _, M = self._flat(Xq)
         vals, idx = np.empty(k), np.empty(k, dtype=np.int64)
@@ -450,6 +495,21 @@ class Trajectory:
         grad, pg = GPEngine._out(a, (P, self.B, d))
         self._eng._chk(self._eng._lib.tgp_traj_value_grad(self._t, a.ptr, P, pv, pg, a.where))
         return val, grad
+
+    def argmin_pairs(self, Xq, index_base: int = 0):
+        """The arg-min of all B trajectories with the winners left ON THE DEVICE: Xq a CUDA tensor [M, d] -> CUDA
+        float64 tensor [2, B] (values, then global indices as int64 bit patterns); enqueue only
+        (tgp_traj_argmin_async)."""
+        import torch
+
+        self._live()
+        a = _Arg(Xq)
+        if len(a.shape) != 2 or a.shape[1] != self._eng.d or a.where != _lib.DEVICE:
+            raise ValueError("argmin_pairs needs device-resident candidates [M, d] (a CUDA tensor)")
+        pairs = torch.empty((2, self.B), dtype=torch.float64, device=a.device)
+        self._eng._chk(self._eng._lib.tgp_traj_argmin_async(self._t, a.ptr, a.shape[0], int(index_base),
+                                                            pairs.data_ptr()))
+        return pairs
 
     def argmin(self, Xq, index_base: int = 0):
         self._live()

@@ -158,9 +158,32 @@ class GaussianProcessRegression:
     def _push(self) -> None:
         m = self._model
         x, y = m.data
+        self._in_sync = False  # until the factorisation of the model's own hyper-parameters has succeeded
         self._engine.set_hyper(m.kernel.variance, np.broadcast_to(m.kernel.lengthscales, (x.shape[1],)),
                                m.likelihood_variance, m.mean_function.c)
         self._engine.set_data(x, y[:, 0])  # raises NotPositiveDefiniteError if the Cholesky fails
+        self._in_sync = True
+        self._data_version = getattr(self, "_data_version", 0) + 1
+
+    @property
+    def data_version(self) -> int:
+        """Increases whenever the engine's (data, hyper-parameters) state is replaced or extended."""
+        return getattr(self, "_data_version", 0)
+
+    def __deepcopy__(self, memo):
+        """A copy that shares nothing with this model: its own GPR record and its own engine holding a copy of the
+        factorisation (``tgp_clone_from``).  What ``BayesianOptimizer(track_state=True)`` stores per step (the
+        reference deep-copies its models, bayesian_optimizer.py:745-760)."""
+        import copy
+
+        twin = type(self).__new__(type(self))
+        memo[id(self)] = twin
+        for name, value in self.__dict__.items():
+            if name in ("_engine", "_eval_engines"):
+                continue
+            setattr(twin, name, copy.deepcopy(value, memo))
+        twin._engine = self._engine.clone()
+        return twin
 
     @property
     def engine(self) -> GPEngine:
@@ -310,13 +333,16 @@ class GaussianProcessRegression:
         if obs.shape[-1] != y.shape[-1]:
             raise ValueError(f"observations have dimension {obs.shape[-1]}, the model has {y.shape[-1]}")
         n0 = x.shape[0]
-        appended = (self._engine.N == n0 and qp.shape[0] > n0 and np.array_equal(qp[:n0], x)
-                    and np.array_equal(obs[:n0], y))
+        # the rank-k path extends the cached factor: only sound while the engine holds THIS model's
+        # hyper-parameters (a fit that died mid-way leaves trial hyper-parameters behind: _in_sync is False then)
+        appended = (getattr(self, "_in_sync", False) and self._engine.N == n0 and qp.shape[0] > n0
+                    and np.array_equal(qp[:n0], x) and np.array_equal(obs[:n0], y))
         self._model.data = (qp, obs)
         if appended:  # the BO loop's usual update: old data + new rows, same hyper-parameters -> rank-k path
             self._engine.append_data(qp[n0:], obs[n0:, 0])
+            self._data_version = getattr(self, "_data_version", 0) + 1
         else:
-            self._engine.set_data(qp, obs[:, 0])
+            self._push()
 
     def optimize(self, dataset: Dataset):
         """MAP / maximum-likelihood fit of (lengthscales, variance, constant mean[, noise variance])
@@ -358,8 +384,12 @@ class GaussianProcessRegression:
             return value, gu
 
         u0 = pack()
-        res = spo.minimize(loss_and_grad, u0, jac=True, method="L-BFGS-B")
-        best = res.x if res.fun <= loss_and_grad(u0)[0] else u0
+        try:
+            res = spo.minimize(loss_and_grad, u0, jac=True, method="L-BFGS-B")
+            best = res.x if res.fun <= loss_and_grad(u0)[0] else u0
+        except BaseException:
+            self._restore_engine()  # the engine must not keep trial hyper-parameters behind the model's back
+            raise
         self.set_hyperparameters(variance=math.exp(best[d]), lengthscales=np.exp(best[:d]), mean=float(best[d + 1]),
                                  likelihood_variance=math.exp(best[d + 2]) if train_noise else None)
         return res
@@ -369,6 +399,7 @@ class GaussianProcessRegression:
         given hyper-parameters (the engine is left at those hyper-parameters).  ``with_gradient=False``
         (comparing prior draws) returns (value, None)."""
         x, y = self._model.data
+        self._in_sync = False  # trial hyper-parameters: restored by set_hyperparameters / _push
         self._engine.set_hyper(var, ls, noise, c)
         self._engine.set_data(x, y[:, 0])
         value, g = self._engine.nlml(with_gradient)
@@ -378,6 +409,12 @@ class GaussianProcessRegression:
         if with_gradient:
             g[: len(pg)] += pg
         return value, g
+
+    def _restore_engine(self) -> None:
+        try:
+            self._push()
+        except Exception:  # noqa: BLE001 -- stays out of sync: the next update refactorises from scratch
+            pass
 
     def _log_prior(self, ls, var):
         """-log p(theta) of the LogNormal priors build_gpr sets (builders.py:401-408) and its gradient
@@ -575,7 +612,7 @@ class FantasizedGaussianProcessRegression(GaussianProcessRegression):
     def _base_stamp(self):
         m = self._base.model
         k = m.kernel
-        return (id(m.data[0]), m.data[0].shape, float(k.variance), np.array(k.lengthscales, dtype=np.float64).tobytes(),
+        return (getattr(self._base, "data_version", 0), m.data[0].shape, float(k.variance), np.array(k.lengthscales, dtype=np.float64).tobytes(),
                 float(m.likelihood_variance), float(m.mean_function.c))
 
     def _synced_with_base(self) -> bool:

@@ -203,8 +203,7 @@ class decoupled_trajectory:
         continuous Thompson-sampling builders consumes (there is no autodiff on this engine)."""
         x = x if type(x).__module__.startswith("torch") else np.asarray(x, dtype=np.float64)
         if len(x.shape) == 2:  # batch-size-one optimizers pass [P, D]: a single trajectory
-            # (this class's own method, not self.value_and_gradient: a negated subclass would negate twice)
-            val, grad = decoupled_trajectory.value_and_gradient(self, x[:, None, :])
+            val, grad = self.value_and_gradient(x[:, None, :])
             return val[:, 0], grad[:, 0, :]
         if len(x.shape) != 3:
             raise ValueError(f"trajectory inputs must be [P, B, D], got shape {tuple(x.shape)}")
