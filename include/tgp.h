@@ -364,6 +364,17 @@ int tgp_group_last_kernel_ms(tgp_group g, double* ms);
 /* Duration (ms, HIP events on the handle's stream) and launch count of the dominant kernel of
  * the most recent sweep-type call (predict / acq_values / acq_argmax / qei / traj_*). */
 int tgp_last_kernel_ms(tgp_handle h, double* ms, int* launches);
+/* Arithmetic of the plain posterior sweeps (tgp_predict / tgp_acq_values / tgp_acq_argmax(_async) / tgp_acq_topk;
+ * joint-mode, gradients, trajectories and `update` always run in float64):
+ *   TGP_PREC_F64  (default) W K* on the float64 matrix cores -- the parity path;
+ *   TGP_PREC_I8X4 W K* on the int8 matrix cores with both operands split error-free into four signed 8-bit digit
+ *                 planes (Ozaki scheme: 10 int8 products with exact int32 accumulation stand in for one float64
+ *                 product; truncation at 2^-32 of each row / column scale).  K* generation, mean, column norms,
+ *                 acquisition tail and arg-max stay float64.  Measured |var error| <= 0.4 x the parity tolerance
+ *                 1e-5 |var| + cancellation floor at N = 4096; an EMULATED-precision option
+ *                 for throughput, never the default and never what the float64 parity claims are made on. */
+enum tgp_precision { TGP_PREC_F64 = 0, TGP_PREC_I8X4 = 1 };
+int tgp_set_precision(tgp_handle h, int precision);
 /* Sweep launch policy knob for experiments and tests (0 = default): bit 0 = never use the row-group split of
  * small launches, bit 1 = always use it.  Every setting computes the same arithmetic on every candidate. */
 int tgp_set_variant(tgp_handle h, int variant);

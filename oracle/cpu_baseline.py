@@ -96,10 +96,32 @@ def torch_clamp0(torch, r2):
     return torch.clamp(r2, min=0.0)
 
 
+def best_thread_count(state, eta: float, d: int, improved: bool, probe: int = 4096) -> int:
+    """MKL's triangular solves stop scaling (and regress) well before 256 hyper-threads: time one small chunk at
+    every power-of-two fraction of the logical cores down to 16 and keep the fastest, so the baseline is the best
+    this host can do rather than whatever the default thread count gives."""
+    import torch
+
+    ncpu = os.cpu_count() or 1
+    cands = sorted({max(1, ncpu >> s) for s in range(0, 5)} | {min(ncpu, 16)}, reverse=True)
+    X = np.random.default_rng(1).uniform(size=(probe, d))
+    best_t, best_n = None, cands[0]
+    for n in cands:
+        sw = TorchCpuSweep(state, threads=n)
+        sw.chunk_values(X[:256], eta, improved)
+        t0 = time.perf_counter()
+        sw.chunk_values(X, eta, improved)
+        t = time.perf_counter() - t0
+        if best_t is None or t < best_t:
+            best_t, best_n = t, n
+    torch.set_num_threads(best_n)
+    return best_n
+
+
 def timed_sweep(state, eta: float, d: int, chunk: int, budget_s: float, improved: bool, seed: int = 5678,
-                max_chunks: int = 64):
+                max_chunks: int = 64, threads: int | None = None):
     """Sweep fresh uniform chunks for about ``budget_s`` seconds -> (candidates / s, candidates done, seconds, threads)."""
-    sw = TorchCpuSweep(state)
+    sw = TorchCpuSweep(state, threads=threads or best_thread_count(state, eta, d, improved))
     rng = np.random.default_rng(seed)
     sw.chunk_values(rng.uniform(size=(min(chunk, 2048), d)), eta, improved)  # warm-up (thread pools, allocations)
     done, t0 = 0, time.perf_counter()

@@ -110,6 +110,10 @@ class FakeEngine:
     def set_variant(self, v):
         pass
 
+    def set_precision(self, precision="f64"):
+        if precision not in ("f64", "i8x4"):
+            raise ValueError(f"unknown precision {precision!r}")
+
     def clone_from(self, other):
         if not isinstance(other, FakeEngine):
             raise TypeError(f"can only clone from an engine, got {other!r}")

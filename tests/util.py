@@ -42,3 +42,14 @@ def assert_close(actual, desired, rtol=RTOL, atol=0.0, what=""):
             f"{what}: {bad.sum()} / {bad.size} elements differ; worst at flat index {i}: "
             f"actual={actual.flat[i]!r} desired={desired.flat[i]!r} err={err.flat[i]:.3e} "
             f"tol={tol.flat[i] if np.ndim(tol) else tol:.3e}")
+
+
+def i8x4_variance_bound(N: int, variance: float, w_abs_max: float) -> float:
+    """Absolute error budget of the split-precision sweep (TGP_PREC_I8X4, csrc/tgp_kernels_sweep_i8.inc) on the
+    predictive variance, ON TOP of the parity tolerance: both operands are truncated at 2^-32 of their scale
+    (S_i = 2 max_k |W_ik| per row of W, S' = 2 variance for K*) and the digit pairs s + s' >= 4 are dropped, which
+    leaves an error of rms 2^-32 S_i S' sqrt(i / 3) on c_i = (W k*)_i (sum of i independent terms); with
+    var = variance - |c|^2, |c| <= sqrt(variance):  |d var| ~ 2 |c| 2^-32 S' S_max sqrt(N / 6).  Twice that
+    estimate is used as the budget (observed: 0.2 .. 0.5 of it); DESIGN.md section 4.5."""
+    s_max = 2.0 * w_abs_max
+    return 2.0 * (2.0 * np.sqrt(variance) * 2.0 ** -32 * (2.0 * variance) * s_max * np.sqrt(N / 6.0))

@@ -88,6 +88,7 @@ SIGNATURES = {
     "tgp_group_last_kernel_ms": (C.c_int, [_vp, _dp]),
     "tgp_last_kernel_ms": (C.c_int, [_vp, _dp, C.POINTER(C.c_int)]),
     "tgp_set_variant": (C.c_int, [_vp, C.c_int]),
+    "tgp_set_precision": (C.c_int, [_vp, C.c_int]),
 }
 
 _lib = None
@@ -125,6 +126,7 @@ def load():
 
 
 MERGES = {"rccl": 0, "peer": 1}
+PRECISIONS = {"f64": 0, "i8x4": 1}
 
 
 def check(lib, handle, rc, group=False):

@@ -23,6 +23,10 @@ hipError_t launch_sweep_kind0(hipStream_t, const SweepArgs&, bool, int64_t);
 hipError_t launch_sweep_kind1(hipStream_t, const SweepArgs&, bool, int64_t);
 hipError_t launch_sweep_kind2(hipStream_t, const SweepArgs&, bool, int64_t);
 hipError_t launch_sweep_kind3(hipStream_t, const SweepArgs&, bool, int64_t);
+hipError_t launch_sweep_i8_kind0(hipStream_t, const SweepArgs&, int64_t);
+hipError_t launch_sweep_i8_kind1(hipStream_t, const SweepArgs&, int64_t);
+hipError_t launch_sweep_i8_kind2(hipStream_t, const SweepArgs&, int64_t);
+hipError_t launch_sweep_i8_kind3(hipStream_t, const SweepArgs&, int64_t);
 }  // namespace tgp
 
 using namespace tgp;
@@ -133,12 +137,48 @@ void apply_penalization(tgp_handle h, double* dvals, const double* dXq, int64_t 
 //   VARIANT_NO_SPLIT (1): never use the row-group split    VARIANT_FORCE_SPLIT (2): use it whenever Npad allows
 constexpr int VARIANT_NO_SPLIT = 1, VARIANT_FORCE_SPLIT = 2;
 
+// number of per-block winner slots a fused arg-max over `a` fills (one per candidate block of the kernel in use)
+int64_t sweep_blocks(tgp_handle h, const SweepArgs& a, bool joint) {
+  if (!joint && h->precision == TGP_PREC_I8X4) return (a.M + 63) / 64;
+  return sweep_grid(a, joint);
+}
+
+// split-precision sweep: digit planes of W (once per factorisation), 64-candidate blocks, 4 B / entry K* slabs
+hipError_t launch_sweep_i8_timed(tgp_handle h, SweepArgs& am) {
+  const int64_t Npad = am.m.Npad;
+  hipError_t e;
+  if (h->wq_version != h->data_version) {
+    if ((e = h->d_wq.reserve((size_t)4 * Npad * Npad)) != hipSuccess) return e;
+    if ((e = h->d_rs.reserve((size_t)Npad * sizeof(double))) != hipSuccess) return e;
+    launch_w_digits(h->stream, h->d_W.as<double>(), h->N, Npad, h->d_rs.as<double>(), h->d_wq.p);
+    h->wq_version = h->data_version;
+  }
+  am.i8_wq = h->d_wq.p;
+  am.i8_rs = h->d_rs.as<double>();
+  const int64_t blocks = (am.M + 63) / 64;
+  const int64_t wgrid = blocks < h->num_cu ? blocks : h->num_cu;
+  if ((e = h->s_kcache.reserve((size_t)wgrid * (size_t)Npad * 64 * 4)) != hipSuccess) return e;
+  am.kcache = h->s_kcache.as<double>();
+  (void)hipEventRecord(h->ev0, h->stream);
+  switch (h->kind) {
+    case TGP_RBF: e = launch_sweep_i8_kind0(h->stream, am, wgrid); break;
+    case TGP_MATERN12: e = launch_sweep_i8_kind1(h->stream, am, wgrid); break;
+    case TGP_MATERN32: e = launch_sweep_i8_kind2(h->stream, am, wgrid); break;
+    default: e = launch_sweep_i8_kind3(h->stream, am, wgrid); break;
+  }
+  (void)hipEventRecord(h->ev1, h->stream);
+  h->last_launches = 1;
+  h->last_ms = -1.0;
+  return e;
+}
+
 hipError_t launch_sweep_timed(tgp_handle h, const SweepArgs& a, bool joint) {
   const int64_t grid = sweep_grid(a, joint);
   if (grid <= 0) return hipSuccess;
   hipError_t e;
   SweepArgs& am = const_cast<SweepArgs&>(a);
   am.split_g = 0;
+  if (!joint && h->precision == TGP_PREC_I8X4) return launch_sweep_i8_timed(h, am);
   const bool want_split = (h->variant & VARIANT_FORCE_SPLIT) ||
                           (grid < 4 * (int64_t)h->num_cu && !(h->variant & VARIANT_NO_SPLIT));
   if (!joint && want_split) {
@@ -421,7 +461,7 @@ int tgp_destroy(tgp_handle h) {
     (void)hipStreamSynchronize(nullptr);
   }
   for (DevBuf* b : {&h->d_xn, &h->d_ls, &h->d_X, &h->d_Y, &h->d_Xs, &h->d_A, &h->d_L, &h->d_W, &h->d_alpha,
-                    &h->d_err, &h->d_tmp1, &h->d_tmp2, &h->d_info, &h->d_pen, &h->d_ent, &h->d_repv, &h->s_ent, &h->s_in, &h->s_in2, &h->s_out1,
+                    &h->d_err, &h->d_tmp1, &h->d_tmp2, &h->d_info, &h->d_pen, &h->d_ent, &h->d_repv, &h->d_wq, &h->d_rs, &h->s_ent, &h->s_in, &h->s_in2, &h->s_out1,
                     &h->s_out2, &h->s_out3, &h->s_blkv, &h->s_blki, &h->s_small, &h->s_kcache, &h->s_aslab, &h->s_grad, &h->s_ks, &h->s_part})
     b->release();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -442,6 +482,14 @@ int tgp_use_private_stream(tgp_handle h) {
   if (int rc = set_device(h)) return rc;
   if (!h->own_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
   h->stream = h->own_stream;
+  return TGP_OK;
+}
+
+int tgp_set_precision(tgp_handle h, int precision) {
+  if (!h) return TGP_ERR_ARG;
+  if (precision != TGP_PREC_F64 && precision != TGP_PREC_I8X4)
+    return fail(h, TGP_ERR_ARG, "unknown precision %d", precision);
+  h->precision = precision;
   return TGP_OK;
 }
 
@@ -1059,7 +1107,7 @@ static int enqueue_argmax(tgp_handle h, int acq_kind, double param, const double
   a.acq_kind = acq_kind;
   a.acq_param = param;
   a.index_base = index_base;
-  const int64_t grid = sweep_grid(a, false);
+  const int64_t grid = sweep_blocks(h, a, false);
   HIPCHK(h, h->s_blkv.reserve(grid * sizeof(double)));
   HIPCHK(h, h->s_blki.reserve(grid * sizeof(int64_t)));
   a.blk_val = h->s_blkv.as<double>();

@@ -73,6 +73,11 @@ struct tgp_handle_s {
   std::vector<double> ls;  // [d]
   int64_t N = 0, Npad = 0;
   int variant = 0;
+  // arithmetic of the plain (non-joint) sweeps: TGP_PREC_F64, or TGP_PREC_I8X4 = W K* on the int8 matrix cores with
+  // four digit planes per operand (tgp_set_precision); the planes of W are rebuilt lazily per factorisation
+  int precision = 0;
+  DevBuf d_wq, d_rs;
+  uint64_t wq_version = 0;
   // model state on device
   DevBuf d_xn, d_ls, d_X, d_Y, d_Xs, d_A, d_L, d_W, d_alpha, d_err, d_tmp1, d_tmp2, d_info;
   // local penalization applied to every tgp_acq_* result while pen_kind != 0 (tgp_set_penalization)

@@ -484,6 +484,14 @@ void launch_prefix_differs(hipStream_t s, const double* a, const double* b, int6
 
 // ---------------------------------------------------------------------------------------------
 // Box.sample (reference space.py:843-867) on device: uniform in [lower, upper).
+// Three separately rounded operations: the numpy restatement oracle/philox.py is bit-exact (hipcc's default
+// -ffp-contract=fast would fuse the multiply and the add into one fma, which rounds differently).
+__device__ __forceinline__ double box_map(double u, double lo, double up) {
+#pragma clang fp contract(off)
+  const double width = up - lo;
+  const double scaled = width * u;
+  return lo + scaled;
+}
 __global__ void sample_box_kernel(uint64_t seed, int64_t first, int64_t M, int d,
                                   const double* __restrict__ lower, const double* __restrict__ upper,
                                   double* __restrict__ out) {
@@ -492,8 +500,7 @@ __global__ void sample_box_kernel(uint64_t seed, int64_t first, int64_t M, int d
   const int64_t row = t / d;
   const int c = (int)(t % d);
   const double u = philox_uniform(seed, (uint64_t)((first + row) * d + c));
-  // three separately rounded operations (no fma contraction): the numpy restatement oracle/philox.py is bit-exact
-  out[t] = __dadd_rn(lower[c], __dmul_rn(__dsub_rn(upper[c], lower[c]), u));
+  out[t] = box_map(u, lower[c], upper[c]);
 }
 void launch_sample_box(hipStream_t s, uint64_t seed, int64_t first, int64_t M, int d,
                        const double* lower, const double* upper, double* out) {
@@ -606,6 +613,61 @@ void launch_argmin_final_multi(hipStream_t s, const double* blk_val, const int64
                                int64_t nblk, int B, double* out_val, int64_t* out_idx) {
   hipLaunchKernelGGL(argmin_final_multi_kernel, dim3((unsigned)B), dim3(256), 0, s, blk_val, blk_idx,
                      nblk, B, out_val, out_idx);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Digit planes of W = L^-1 for the split-precision sweep (tgp_kernels_sweep_i8.inc): row i is scaled by
+// S_i = 2 max_k |W_ik| (so |W_ik / S_i| <= 1/2), x = rint(W_ik / S_i * 2^31) is an int32, and its four balanced
+// base-256 digits (each in [-128, 127], most significant first) go to the planes
+//   Wq[s][k / 32][i][k % 32]      (a [256 rows x 32 k] operand tile of one plane is 8 KiB contiguous).
+// One workgroup per 32 rows; thread (r = tid >> 3, c = tid & 7) owns 4 consecutive k of row r per 32-wide k block.
+// Only k blocks up to the end of the row's 256-row block are written (the sweep never reads beyond).  The padding of
+// the factor workspace (rows / columns >= N carry the identity) is masked to zero, as in the transposed f64 operand.
+__global__ __launch_bounds__(256) void w_digits_kernel(const double* __restrict__ W, int64_t N, int64_t Npad,
+                                                       double* __restrict__ rs, unsigned char* __restrict__ Wq) {
+  const int tid = threadIdx.x, r = tid >> 3, c = tid & 7;
+  const int64_t i0 = (int64_t)blockIdx.x * 32, i = i0 + r;
+  const int64_t kb_end = ((i0 + 31) / 256 + 1) * 8;  // k blocks of 32 inside the row's 256-row block and before
+  const double* row = W + i * Npad;
+  double amax = 0.0;
+  for (int64_t kb = 0; kb * 32 <= i0 + 31; ++kb) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t k = kb * 32 + 4 * c + j;
+      if (i < N && k < N) amax = fmax(amax, fabs(row[k]));
+    }
+  }
+  amax = fmax(amax, __shfl_xor(amax, 1, 64));
+  amax = fmax(amax, __shfl_xor(amax, 2, 64));
+  amax = fmax(amax, __shfl_xor(amax, 4, 64));
+  const double S = amax > 0.0 ? 2.0 * amax : 1.0;
+  if (c == 0) rs[i] = S;
+  const double to_fixed = 2147483648.0 / S;
+  const size_t plane = (size_t)Npad * (size_t)Npad;
+  for (int64_t kb = 0; kb < kb_end; ++kb) {
+    uint32_t p[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t k = kb * 32 + 4 * c + j;
+      int q = (i < N && k < N) ? (int)rint(row[k] * to_fixed) : 0;
+      const int d3 = ((q + 128) & 255) - 128;
+      q = (q - d3) >> 8;
+      const int d2 = ((q + 128) & 255) - 128;
+      q = (q - d2) >> 8;
+      const int d1 = ((q + 128) & 255) - 128;
+      const int d0 = (q - d1) >> 8;
+      p[0] |= (uint32_t)(d0 & 255) << (8 * j);
+      p[1] |= (uint32_t)(d1 & 255) << (8 * j);
+      p[2] |= (uint32_t)(d2 & 255) << (8 * j);
+      p[3] |= (uint32_t)(d3 & 255) << (8 * j);
+    }
+    unsigned char* dst = Wq + ((size_t)kb * Npad + i) * 32 + 4 * c;
+#pragma unroll
+    for (int sdx = 0; sdx < 4; ++sdx) *(uint32_t*)(dst + sdx * plane) = p[sdx];
+  }
+}
+void launch_w_digits(hipStream_t s, const double* W, int64_t N, int64_t Npad, double* rs, void* Wq) {
+  hipLaunchKernelGGL(w_digits_kernel, dim3((unsigned)(Npad / 32)), dim3(256), 0, s, W, N, Npad, rs, (unsigned char*)Wq);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -95,6 +95,13 @@ class GPEngine:
     def set_variant(self, v: int):
         self._chk(self._lib.tgp_set_variant(self._h, int(v)))
 
+    def set_precision(self, precision: str = "f64"):
+        """Arithmetic of the plain sweeps: "f64" (default, the parity path) or "i8x4" -- W K* on the int8 matrix
+        cores with four 8-bit digit planes per operand (an emulated-precision throughput option, tgp_set_precision)."""
+        if precision not in _lib.PRECISIONS:
+            raise ValueError(f"unknown precision {precision!r}; choose from {sorted(_lib.PRECISIONS)}")
+        self._chk(self._lib.tgp_set_precision(self._h, _lib.PRECISIONS[precision]))
+
     # -- model state -----------------------------------------------------------------------------
     def clone_from(self, other: "GPEngine") -> None:
         """Become a copy of ``other`` (hyper-parameters, data, cached factorisation): tgp_clone_from."""
