@@ -7,7 +7,7 @@ import pytest
 import trieste_amd.models as M
 from tests.fakes import FakeEngine
 from trieste_amd import objectives as OBJ
-from trieste_amd.acquisition import (GIBBON, AsynchronousGreedy, AsynchronousOptimization, AsynchronousRuleState,
+from trieste_amd.extras import (GIBBON, AsynchronousGreedy, AsynchronousOptimization, AsynchronousRuleState,
                                      BatchMonteCarloExpectedImprovement, Fantasizer, LocalPenalization,
                                      NegativeLowerConfidenceBound, generate_continuous_optimizer,
                                      generate_random_search_optimizer)

@@ -162,7 +162,7 @@ def _greedy_worker(rank, world, port, q):
         import trieste_amd.models as M
         from tests.fakes import FakeEngine
         from trieste_amd import objectives as OBJ
-        from trieste_amd.acquisition import (GIBBON, EfficientGlobalOptimization, Fantasizer, GumbelSampler,
+        from trieste_amd.extras import (GIBBON, EfficientGlobalOptimization, Fantasizer, GumbelSampler,
                                              LocalPenalization, optimize_discrete)
         from trieste_amd.data import Dataset
         from trieste_amd.distributed import generate_sharded_discrete_optimizer

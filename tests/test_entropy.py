@@ -8,7 +8,7 @@ import trieste_amd.models as M
 from oracle import gp_oracle as O
 from tests.fakes import FakeEngine
 from trieste_amd import objectives as OBJ
-from trieste_amd.acquisition import (GIBBON, EfficientGlobalOptimization, ExactThompsonSampler, GibbonAcquisition,
+from trieste_amd.extras import (GIBBON, EfficientGlobalOptimization, ExactThompsonSampler, GibbonAcquisition,
                                      GumbelSampler, LocalPenalization, MinValueEntropySearch,
                                      ThompsonSamplerFromTrajectory, generate_continuous_optimizer,
                                      gibbon_quality_term, gibbon_repulsion_term, min_value_entropy_search)

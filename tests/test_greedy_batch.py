@@ -444,7 +444,7 @@ def test_expected_constrained_improvement():
 def test_reducers_sum_product_map():
     """reference tests/unit/acquisition/test_combination.py: constituent functions are prepared / updated
     individually, outputs reduced elementwise."""
-    from trieste_amd.acquisition import (Map, NegativeLowerConfidenceBound, ProbabilityOfFeasibility, Product, Reducer,
+    from trieste_amd.extras import (Map, NegativeLowerConfidenceBound, ProbabilityOfFeasibility, Product, Reducer,
                                          Sum)
 
     model, data = _model()

@@ -80,7 +80,7 @@ def test_split_calls_are_equivalent_to_one_call(M, split, seed):
 def test_asynchronous_rule_state_add_then_remove_round_trips(data):
     """rule.py:426-489: removing the points just added restores the state; removal keeps the order of the rest
     and takes out one occurrence per requested removal."""
-    from trieste_amd.acquisition import AsynchronousRuleState
+    from trieste_amd.extras import AsynchronousRuleState
 
     d = data.draw(st.integers(1, 3))
     row = st.lists(st.sampled_from([0.0, 1.0, 2.0]), min_size=d, max_size=d)

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import trieste_amd
-import trieste_amd.acquisition as A
+import trieste_amd.extras as A
 import trieste_amd.models as M
 from tests.fakes import FakeEngine
 from trieste_amd import objectives as OBJ

@@ -8,7 +8,7 @@ import pytest
 import trieste_amd.models as M
 from tests.fakes import FakeEngine
 from trieste_amd import objectives as OBJ
-from trieste_amd.acquisition import (BatchTrustRegionBox, BatchTrustRegionState, DiscreteThompsonSampling,
+from trieste_amd.extras import (BatchTrustRegionBox, BatchTrustRegionState, DiscreteThompsonSampling,
                                      EfficientGlobalOptimization, SingleObjectiveTrustRegionBox, TREGOBox, TURBOBox,
                                      generate_continuous_optimizer)
 from trieste_amd.acquisition.rule import AcquisitionRule
@@ -162,7 +162,7 @@ def test_single_objective_region_shrinks_grows_and_reinitialises():
 def test_batch_trust_region_box_rule_checks_and_duplicate_centres():
     space = Box([0.0, 0.0], [1.0, 1.0])
     data = Dataset(np.array([[0.2, 0.2], [0.8, 0.8]]), np.array([[1.0], [2.0]]))
-    from trieste_amd.acquisition import BatchMonteCarloExpectedImprovement, ParallelContinuousThompsonSampling
+    from trieste_amd.extras import BatchMonteCarloExpectedImprovement, ParallelContinuousThompsonSampling
 
     with pytest.raises(NotImplementedError):  # a joint batch builder across regions needs the tagged multi-space
         BatchTrustRegionBox([TREGOBox(space), TREGOBox(space)], EfficientGlobalOptimization(

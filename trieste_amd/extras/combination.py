@@ -9,7 +9,7 @@ from typing import Callable, Mapping, Optional, Sequence
 
 import numpy as np
 
-from .interface import AcquisitionFunctionBuilder
+from ..acquisition.interface import AcquisitionFunctionBuilder
 
 
 class Reducer(AcquisitionFunctionBuilder):

@@ -17,9 +17,9 @@ import numpy as np
 
 from ..data import Dataset
 from ..space import SearchSpace
-from .function import _posterior_tail, _require_engine
-from .interface import SingleModelAcquisitionBuilder, SingleModelGreedyAcquisitionBuilder
-from .sampler import ExactThompsonSampler, ThompsonSampler
+from ..acquisition.function import _posterior_tail, _require_engine
+from ..acquisition.interface import SingleModelAcquisitionBuilder, SingleModelGreedyAcquisitionBuilder
+from ..acquisition.sampler import ExactThompsonSampler, ThompsonSampler
 
 
 def _check_samples(samples) -> np.ndarray:

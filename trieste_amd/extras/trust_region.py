@@ -22,7 +22,7 @@ import numpy as np
 
 from ..data import OBJECTIVE
 from ..space import Box, SearchSpace
-from .rule import AcquisitionRule, EfficientGlobalOptimization
+from ..acquisition.rule import AcquisitionRule, EfficientGlobalOptimization
 
 
 class UpdatableTrustRegionBox(Box):
@@ -328,7 +328,7 @@ class BatchTrustRegionBox(AcquisitionRule):
     def _region_rules(self, count: int):
         if self._rule is None:  # the reference's defaults (rule.py:1351-1360)
             if isinstance(self._init_subspaces[0], TURBOBox):
-                from .rule import DiscreteThompsonSampling
+                from ..acquisition.rule import DiscreteThompsonSampling
 
                 dim = self._init_subspaces[0].global_search_space.dimension
                 self._rule = DiscreteThompsonSampling(min(100 * dim, 5_000), 1)
@@ -341,7 +341,7 @@ class BatchTrustRegionBox(AcquisitionRule):
                 # the reference optimises such a rule ONCE over the tagged product of the regions, column v of the
                 # batch inside region v (rule.py:1476-1493).  For a vectorized builder the columns are independent
                 # functions, so one single-point rule per region is the same computation
-                from .interface import VectorizedAcquisitionFunctionBuilder
+                from ..acquisition.interface import VectorizedAcquisitionFunctionBuilder
 
                 if q != count:
                     raise ValueError(f"the base rule asks for {q} query points but there are {count} trust regions")
