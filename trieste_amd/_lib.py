@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtgp.so")
+LIB_PATH = os.environ.get("TGP_LIB") or os.path.join(_HERE, "libtgp.so")  # TGP_LIB: an experimental build (tools/)
 
 TGP_OK, TGP_ERR_SHAPE, TGP_ERR_NOT_PD, TGP_ERR_ALLOC, TGP_ERR_HIP, TGP_ERR_STATE, TGP_ERR_ARG = range(7)
 HOST, DEVICE = 0, 1
