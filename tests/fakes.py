@@ -359,3 +359,73 @@ class FakeEngine:
 
     def trajectory(self, rff_W, rff_b, w, xi):
         return FakeTrajectory(self, rff_W, rff_b, w, xi)
+
+
+class FakeGroup:
+    """Stand-in for ``trieste_amd.group.GPEngineGroup``: n oracle-backed replicas, contiguous candidate shards, winners
+    merged with the product's own host rule (``distributed.merge_best``)."""
+
+    def __init__(self, d, kernel="matern52", devices=None, merge="rccl"):
+        self.devices = list(devices if devices is not None else [0])
+        self.members = [FakeEngine(d, kernel, dev) for dev in self.devices]
+        self.d, self.kernel, self.merge, self.N, self.M = d, kernel, merge, 0, 0
+        self._cand = None
+
+    @property
+    def primary(self):
+        return self.members[0]
+
+    def info(self):
+        return {"n_dev": len(self.members), "merge": self.merge, "rccl_ranks": len(self.members)}
+
+    def close(self):
+        pass
+
+    def set_hyper(self, *a, **k):
+        for m in self.members:
+            m.set_hyper(*a, **k)
+
+    def set_data(self, X, Y):
+        for m in self.members:
+            m.set_data(X, Y)
+        self.N = self.primary.N
+
+    def append_data(self, X, Y):
+        for m in self.members:
+            m.append_data(X, Y)
+        self.N = self.primary.N
+
+    def eta(self):
+        return self.primary.eta()
+
+    def set_candidates(self, points):
+        self._cand = np.asarray(points, float)
+        self.M = len(self._cand)
+
+    def sample_candidates(self, seed, M, lower, upper):
+        self._cand = self.primary.sample_box(seed, 0, M, lower, upper)
+        self.M = M
+
+    def _shards(self):
+        from trieste_amd.distributed import shard_range
+
+        return [shard_range(self.M, r, len(self.members)) for r in range(len(self.members))]
+
+    def acq_argmax(self, acq, param):
+        from trieste_amd.distributed import merge_best
+
+        parts = [m.acq_argmax(acq, param, self._cand[lo:hi], index_base=lo)[:2] if hi > lo else (np.nan, -1)
+                 for m, (lo, hi) in zip(self.members, self._shards())]
+        v, i = merge_best(np.array([[p[0]] for p in parts]), np.array([[p[1]] for p in parts]))
+        return float(v[0]), int(i[0]), self._cand[int(i[0])].copy()
+
+    def acq_topk(self, acq, param, k):
+        vals, idxs = [], []
+        for m, (lo, hi) in zip(self.members, self._shards()):
+            if hi > lo:
+                v, i = m.acq_topk(acq, param, self._cand[lo:hi], min(k, hi - lo), index_base=lo)
+                vals.append(v)
+                idxs.append(i)
+        vals, idxs = np.concatenate(vals), np.concatenate(idxs)
+        order = np.lexsort((idxs, -vals))[:k]
+        return vals[order], idxs[order]

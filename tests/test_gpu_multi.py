@@ -230,3 +230,42 @@ def test_bench_prints_the_ranks_it_ran(how):
     out = json.loads(line)
     assert out["n_gpus"] == want_n and out["config"]["rccl_ranks"] == want_ranks
     assert out["value"] > 0 and out["roofline"]["kernel_ms"] > 0
+
+
+def test_model_with_devices_through_the_host_layer():
+    """GaussianProcessRegression(devices=[...]) on the real engine: EGO's sweeps shard over the group, the acquired point
+    equals the single-device model's, updates are replicated, the observer is called once per step."""
+    import torch
+
+    import trieste_amd.models as M
+    from trieste_amd import objectives as OBJ
+    from trieste_amd.acquisition import EfficientGlobalOptimization, ExpectedImprovement, generate_random_search_optimizer
+    from trieste_amd.bayesian_optimizer import BayesianOptimizer
+    from trieste_amd.data import OBJECTIVE, Dataset
+    from trieste_amd.space import Box
+
+    rng = np.random.default_rng(0)
+    x = rng.uniform(size=(40, 2))
+    data = Dataset(x, OBJ.scaled_branin(x))
+    box = Box([0.0, 0.0], [1.0, 1.0])
+    devices = list(range(torch.cuda.device_count()))
+    single = M.GaussianProcessRegression(M.build_gpr(data, box, likelihood_variance=1e-3))
+    multi = M.GaussianProcessRegression(M.build_gpr(data, box, likelihood_variance=1e-3), devices=devices)
+    assert multi.group.info()["rccl_ranks"] == len(devices)
+    fs = ExpectedImprovement().prepare_acquisition_function(single, dataset=data)
+    fm = ExpectedImprovement().prepare_acquisition_function(multi, dataset=data)
+    pts = rng.uniform(size=(5001, 2))
+    a, b = fs.argmax(pts), fm.argmax(pts)
+    assert (a[0], a[1]) == (b[0], b[1])
+    opt = generate_random_search_optimizer(20000, seed=11)
+    np.testing.assert_array_equal(opt(box, fs), opt(box, fm))
+    calls = []
+
+    def observer(q):
+        calls.append(len(q))
+        return Dataset(q, OBJ.scaled_branin(q))
+
+    res = BayesianOptimizer(observer, box).optimize(3, data, multi, EfficientGlobalOptimization(optimizer=opt),
+                                                    fit_model=True, fit_initial_model=False, track_state=False)
+    assert calls == [1, 1, 1] and all(m.N == 43 for m in multi.group.members)
+    assert len(res.final_result.unwrap().datasets[OBJECTIVE]) == 43

@@ -884,3 +884,41 @@ def test_a_failed_fit_does_not_poison_the_append_path():
     fresh, _ = _model(n=9)
     fresh.update(data + Dataset(x_new, OBJ.scaled_branin(x_new)))
     np.testing.assert_allclose(model.predict(x_new)[0], fresh.predict(x_new)[0], rtol=1e-9)
+
+
+def test_model_with_devices_shards_the_fused_sweeps(monkeypatch):
+    """GaussianProcessRegression(devices=[...]): one process, replicated updates, the fused arg-max / top-k of the plain
+    posterior tails sharded over the group -- same winners as the single-device model, and the loop runs once."""
+    import trieste_amd.group as G
+    from tests.fakes import FakeGroup
+
+    monkeypatch.setattr(G, "GPEngineGroup", FakeGroup)
+    rng = np.random.default_rng(0)
+    x = rng.uniform(size=(12, 2))
+    data = Dataset(x, OBJ.scaled_branin(x))
+    box = Box([0.0, 0.0], [1.0, 1.0])
+    single = M.GaussianProcessRegression(M.build_gpr(data, box, likelihood_variance=1e-3))
+    multi = M.GaussianProcessRegression(M.build_gpr(data, box, likelihood_variance=1e-3), devices=[0, 1, 2])
+    assert multi.group is not None and len(multi.group.members) == 3 and single.group is None
+    fs = ExpectedImprovement().prepare_acquisition_function(single, dataset=data)
+    fm = ExpectedImprovement().prepare_acquisition_function(multi, dataset=data)
+    pts = rng.uniform(size=(1001, 2))
+    pts[900] = pts[17]
+    a, b = fs.argmax(pts), fm.argmax(pts)
+    assert (a[0], a[1]) == (b[0], b[1]) and np.array_equal(a[2], b[2])
+    for u, v in zip(fs.top_k(pts, 7), fm.top_k(pts, 7)):
+        np.testing.assert_array_equal(u, v)
+    # device-side candidate generation: ONE logical Philox sample whatever the number of devices
+    opt = generate_random_search_optimizer(3000, seed=11)
+    np.testing.assert_array_equal(opt(box, fs), opt(box, fm))
+    # updates are replicated (rank-k append on every member); the BO loop calls the observer once per step
+    calls = []
+
+    def observer(q):
+        calls.append(len(q))
+        return Dataset(q, OBJ.scaled_branin(q))
+
+    res = BayesianOptimizer(observer, box).optimize(2, data, multi, EfficientGlobalOptimization(optimizer=opt),
+                                                    fit_model=True, fit_initial_model=False, track_state=False)
+    assert calls == [1, 1] and all(m.N == 14 for m in multi.group.members)
+    assert len(res.final_result.unwrap().datasets[OBJECTIVE]) == 14

@@ -38,6 +38,14 @@ class _posterior_tail(AcquisitionFunctionClass):
         self._model = model
         self._engine = _require_engine(model, type(self).__name__)
         self._param = float(np.asarray(param).reshape(()))
+        # a model built with devices=[...] drives one replica per GPU from this process: the fused sweeps of the
+        # plain posterior tails then shard over the group (trieste_amd.group.GPEngineGroup)
+        self._group = getattr(model, "group", None)
+
+    def _shards(self) -> bool:
+        """The group path serves the tails whose only state is (kind, param): a function that installs engine state
+        of its own before a call (entropy tails, penalized wrappers act on member 0) stays on the single engine."""
+        return self._group is not None and type(self)._prepare is _posterior_tail._prepare
 
     def _points(self, x):
         if not _is_torch(x):
@@ -76,11 +84,27 @@ class _posterior_tail(AcquisitionFunctionClass):
     def argmax(self, points, index_base: int = 0):
         """points [M, D] -> (value, global index, point [D])."""
         self._prepare()
+        if self._shards() and index_base == 0 and not _is_torch(points):
+            self._group.set_candidates(points)
+            return self._group.acq_argmax(self._acq, self._param)
         return self._argmax(points, index_base)
 
     def top_k(self, points, k: int, index_base: int = 0):
         self._prepare()
+        if self._shards() and index_base == 0 and not _is_torch(points):
+            self._group.set_candidates(points)
+            return self._group.acq_topk(self._acq, self._param, k)
         return self._top_k(points, k, index_base)
+
+    def argmax_sampled(self, seed: int, num_samples: int, lower, upper):
+        """Fused arg-max over ``num_samples`` uniform candidates of the box generated ON the device(s) (one logical
+        Philox sample, sharded over the group when the model has one) -> (value, index, point [D])."""
+        self._prepare()
+        if self._shards():
+            self._group.sample_candidates(seed, num_samples, lower, upper)
+            return self._group.acq_argmax(self._acq, self._param)
+        pts = self._engine.sample_box(seed, 0, num_samples, lower, upper)
+        return self._argmax(pts, 0)
 
 
 class expected_improvement(_posterior_tail):

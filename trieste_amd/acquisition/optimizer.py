@@ -97,8 +97,11 @@ def generate_random_search_optimizer(num_samples: int = NUM_SAMPLES_MIN, seed: O
         if on_device and V == 1 and eng is not None and hasattr(fn, "argmax") and isinstance(space, Box) \
                 and hasattr(eng, "sample_box"):
             # unseeded: a fresh candidate set per call, like space.sample(n) (not the same Philox stream every step)
-            pts = space.sample_device(eng, num_samples, seed=_fresh_seed() if seed is None else seed)
-            _, _, x = fn.argmax(pts)
+            the_seed = _fresh_seed() if seed is None else seed
+            if hasattr(fn, "argmax_sampled"):  # candidates generated where they are swept (all GPUs of a group)
+                _, _, x = fn.argmax_sampled(the_seed, num_samples, space.lower, space.upper)
+            else:
+                _, _, x = fn.argmax(space.sample_device(eng, num_samples, seed=the_seed))
             return np.asarray(x)[None, :]
         points = space.sample(num_samples, seed=seed)[:, None, :]
         return _get_max_discrete_points(points, target_func)

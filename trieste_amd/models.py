@@ -137,7 +137,7 @@ class GaussianProcessRegression:
     """
 
     def __init__(self, model: GPR, optimizer=None, num_kernel_samples: int = 10, num_rff_features: int = 1000,
-                 use_decoupled_sampler: bool = True, device: int = 0):
+                 use_decoupled_sampler: bool = True, device: int = 0, devices=None):
         if num_kernel_samples < 0:
             raise ValueError(f"num_kernel_samples must be greater or equal to zero but got {num_kernel_samples}.")
         if num_rff_features <= 0:
@@ -147,7 +147,17 @@ class GaussianProcessRegression:
         self._num_rff_features = num_rff_features
         self._use_decoupled_sampler = use_decoupled_sampler
         x, _ = model.data
-        self._engine = GPEngine(x.shape[1], model.kernel.kind, device=device)
+        # devices=[...]: ONE process, one model replica per GPU (trieste_amd.group.GPEngineGroup over the C-ABI's
+        # tgp_group_*): updates are replicated, the fused candidate sweeps of the acquisition functions shard over
+        # the devices, everything else (predictions, gradients, fits) runs on member 0.  The BO loop is unchanged.
+        self._group = None
+        if devices is not None:
+            from .group import GPEngineGroup
+
+            self._group = GPEngineGroup(x.shape[1], model.kernel.kind, devices=devices)
+            self._engine = self._group.primary
+        else:
+            self._engine = GPEngine(x.shape[1], model.kernel.kind, device=device)
         self._push()
 
     def __repr__(self) -> str:
@@ -159,9 +169,10 @@ class GaussianProcessRegression:
         m = self._model
         x, y = m.data
         self._in_sync = False  # until the factorisation of the model's own hyper-parameters has succeeded
-        self._engine.set_hyper(m.kernel.variance, np.broadcast_to(m.kernel.lengthscales, (x.shape[1],)),
-                               m.likelihood_variance, m.mean_function.c)
-        self._engine.set_data(x, y[:, 0])  # raises NotPositiveDefiniteError if the Cholesky fails
+        state = self._group if getattr(self, "_group", None) is not None else self._engine  # replicated on a group
+        state.set_hyper(m.kernel.variance, np.broadcast_to(m.kernel.lengthscales, (x.shape[1],)),
+                        m.likelihood_variance, m.mean_function.c)
+        state.set_data(x, y[:, 0])  # raises NotPositiveDefiniteError if the Cholesky fails
         self._in_sync = True
         self._data_version = getattr(self, "_data_version", 0) + 1
 
@@ -179,15 +190,21 @@ class GaussianProcessRegression:
         twin = type(self).__new__(type(self))
         memo[id(self)] = twin
         for name, value in self.__dict__.items():
-            if name in ("_engine", "_eval_engines"):
+            if name in ("_engine", "_eval_engines", "_group"):
                 continue
             setattr(twin, name, copy.deepcopy(value, memo))
+        twin._group = None  # the copy is a single-device model holding a copy of member 0's factorisation
         twin._engine = self._engine.clone()
         return twin
 
     @property
     def engine(self) -> GPEngine:
         return self._engine
+
+    @property
+    def group(self):
+        """The multi-GPU group of a model built with ``devices=[...]`` (else None)."""
+        return getattr(self, "_group", None)
 
     @property
     def model(self) -> GPR:
@@ -339,7 +356,7 @@ class GaussianProcessRegression:
                     and np.array_equal(qp[:n0], x) and np.array_equal(obs[:n0], y))
         self._model.data = (qp, obs)
         if appended:  # the BO loop's usual update: old data + new rows, same hyper-parameters -> rank-k path
-            self._engine.append_data(qp[n0:], obs[n0:, 0])
+            (self._group if self.group is not None else self._engine).append_data(qp[n0:], obs[n0:, 0])
             self._data_version = getattr(self, "_data_version", 0) + 1
         else:
             self._push()
