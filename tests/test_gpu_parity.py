@@ -237,13 +237,19 @@ def test_edge_cases_and_errors():
     assert_close(v, ov, atol=1e-10)
 
 
-def test_joint_and_qei_match_oracle():
-    _, obj, d, kind, N, noise = CONFIGS[1]
+@pytest.mark.parametrize("variant", [0, 4], ids=["packed-128x256", "slots-256x128"])
+@pytest.mark.parametrize("cfg", [CONFIGS[1], CONFIGS[2], CONFIGS[4]], ids=lambda c: c[0])
+def test_joint_and_qei_match_oracle(cfg, variant):
+    """Joint mode on both kernels: contiguously packed groups in 128 x 256 tiles with the LDS Gram phase (default,
+    dp <= 16) and the first-generation 64-column slots (variant bit 2).  Group counts around the block capacity
+    (floor(256 / q) groups per block), q from 1 to 64, a group starting at a training input."""
+    _, obj, d, kind, N, noise = cfg
     X, Y, ls, c, st, _ = _problem(obj, d, kind, N, noise)
     floor = cancellation_floor(N, 1.0, noise)
-    eng = _engine(kind, d, 1.0, ls, noise, c, X, Y)
+    eng = _engine(kind, d, 1.0, ls, noise, c, X, Y, variant)
     rng = np.random.default_rng(7)
-    for q, G, S in ((1, 9, 8), (3, 50, 16), (5, 11, 32), (50, 7, 64), (64, 3, 8), (17, 6, 8)):
+    for q, G, S in ((1, 9, 8), (1, 600, 4), (3, 50, 16), (3, 171, 4), (5, 11, 32), (50, 7, 64), (50, 5, 8), (64, 3, 8),
+                    (64, 9, 4), (17, 6, 8), (17, 31, 4), (33, 15, 4)):
         Xg = rng.uniform(size=(G, q, d))
         Xg[0, 0] = X[0]
         jm, jc = eng.predict_joint(Xg)

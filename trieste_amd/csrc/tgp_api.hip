@@ -23,6 +23,10 @@ hipError_t launch_sweep_kind0(hipStream_t, const SweepArgs&, bool, int64_t);
 hipError_t launch_sweep_kind1(hipStream_t, const SweepArgs&, bool, int64_t);
 hipError_t launch_sweep_kind2(hipStream_t, const SweepArgs&, bool, int64_t);
 hipError_t launch_sweep_kind3(hipStream_t, const SweepArgs&, bool, int64_t);
+hipError_t launch_joint_kind0(hipStream_t, const SweepArgs&, int64_t);
+hipError_t launch_joint_kind1(hipStream_t, const SweepArgs&, int64_t);
+hipError_t launch_joint_kind2(hipStream_t, const SweepArgs&, int64_t);
+hipError_t launch_joint_kind3(hipStream_t, const SweepArgs&, int64_t);
 hipError_t launch_sweep_i8_kind0(hipStream_t, const SweepArgs&, int64_t);
 hipError_t launch_sweep_i8_kind1(hipStream_t, const SweepArgs&, int64_t);
 hipError_t launch_sweep_i8_kind2(hipStream_t, const SweepArgs&, int64_t);
@@ -135,7 +139,8 @@ void apply_penalization(tgp_handle h, double* dvals, const double* dXq, int64_t 
 
 // Sweep launch policy.  tgp_set_variant bits (experiments / tests; 0 = default):
 //   VARIANT_NO_SPLIT (1): never use the row-group split    VARIANT_FORCE_SPLIT (2): use it whenever Npad allows
-constexpr int VARIANT_NO_SPLIT = 1, VARIANT_FORCE_SPLIT = 2;
+//   VARIANT_JOINT_V1 (4): joint mode on the first-generation kernel (64-column slots, Gram operands from L2)
+constexpr int VARIANT_NO_SPLIT = 1, VARIANT_FORCE_SPLIT = 2, VARIANT_JOINT_V1 = 4;
 
 // number of per-block winner slots a fused arg-max over `a` fills (one per candidate block of the kernel in use)
 int64_t sweep_blocks(tgp_handle h, const SweepArgs& a, bool joint) {
@@ -179,6 +184,29 @@ hipError_t launch_sweep_timed(tgp_handle h, const SweepArgs& a, bool joint) {
   SweepArgs& am = const_cast<SweepArgs&>(a);
   am.split_g = 0;
   if (!joint && h->precision == TGP_PREC_I8X4) return launch_sweep_i8_timed(h, am);
+  if (joint && a.m.dp <= 16 && !(h->variant & VARIANT_JOINT_V1)) {
+    // contiguously packed 128 x 256 tiles, Gram phase out of LDS (tgp_kernels_joint.inc)
+    const int gpb = 256 / a.q;
+    const int64_t blocks = (a.G + gpb - 1) / gpb;
+    const int64_t wg = blocks < h->num_cu ? blocks : h->num_cu;
+    const size_t slab = (size_t)wg * (size_t)a.m.Npad * 256 * sizeof(double);
+    hipError_t ea = h->s_kcache.reserve(slab);
+    if (ea == hipSuccess) ea = h->s_aslab.reserve(slab);
+    if (ea != hipSuccess) return ea;
+    am.kcache = h->s_kcache.as<double>();
+    am.aslab = h->s_aslab.as<double>();
+    (void)hipEventRecord(h->ev0, h->stream);
+    switch (h->kind) {
+      case TGP_RBF: e = launch_joint_kind0(h->stream, a, wg); break;
+      case TGP_MATERN12: e = launch_joint_kind1(h->stream, a, wg); break;
+      case TGP_MATERN32: e = launch_joint_kind2(h->stream, a, wg); break;
+      default: e = launch_joint_kind3(h->stream, a, wg); break;
+    }
+    (void)hipEventRecord(h->ev1, h->stream);
+    h->last_launches = 1;
+    h->last_ms = -1.0;
+    return e;
+  }
   const bool want_split = (h->variant & VARIANT_FORCE_SPLIT) ||
                           (grid < 4 * (int64_t)h->num_cu && !(h->variant & VARIANT_NO_SPLIT));
   if (!joint && want_split) {
