@@ -234,7 +234,7 @@ def test_fantasising_surfaces_on_gpu_equal_refit():
 def test_local_penalization_batches_on_gpu(penalizer):
     """EGO + LocalPenalization (rule.py:384-397, greedy_batch.py:54-247) on the real engine: every batch element
     is the maximiser of the penalised EI the oracle computes from the builder's own constants."""
-    import trieste_amd.acquisition as A
+    import trieste_amd.extras as A  # superset of trieste_amd.acquisition
 
     space, data, model, st = _setup(n=60, noise=1e-2)
     pen_cls = A.soft_local_penalizer if penalizer == "soft" else A.hard_local_penalizer
@@ -272,7 +272,7 @@ def test_local_penalization_batches_on_gpu(penalizer):
 def test_fantasizer_batches_on_gpu(method):
     """EGO + Fantasizer (greedy_batch.py:415-585) on the real engine: the fantasized model is a clone with appended
     rows and equals the reference's conditional posterior (oracle restatement)."""
-    import trieste_amd.acquisition as A
+    import trieste_amd.extras as A  # superset of trieste_amd.acquisition
     from trieste_amd.data import OBJECTIVE
 
     space, data, model, st = _setup(n=60, noise=1e-2)
@@ -311,7 +311,7 @@ def test_entropy_search_rules_on_gpu():
     acquisition built from the builder's own samples; a GIBBON batch spreads out; the Gumbel sampler's samples are
     the restated algorithm's."""
     import trieste_amd
-    import trieste_amd.acquisition as A
+    import trieste_amd.extras as A  # superset of trieste_amd.acquisition
     from trieste_amd.rng import make_rng
 
     space, data, model, st = _setup(n=60, noise=1e-2)
@@ -353,7 +353,7 @@ def test_entropy_search_rules_on_gpu():
 def test_asynchronous_rules_on_gpu():
     """AsynchronousOptimization (batch qEI over [pending; candidate]) and AsynchronousGreedy (LocalPenalization /
     Fantasizer / GIBBON) through an Ask-Tell loop on the real engine (rule.py:492-833)."""
-    import trieste_amd.acquisition as A
+    import trieste_amd.extras as A  # superset of trieste_amd.acquisition
     from trieste_amd import objectives as OBJ
     from trieste_amd.ask_tell_optimization import AskTellOptimizer
     from trieste_amd.data import Dataset
@@ -380,7 +380,7 @@ def test_asynchronous_rules_on_gpu():
 def test_small_sibling_builders_on_gpu():
     """MakePositive / MultipleOptimism -LCB / PredictiveVariance / ExpectedConstrainedImprovement on the real engine
     against the oracle's posterior (function.py:608-783, 1808-1990; active_learning.py:86-110)."""
-    import trieste_amd.acquisition as A
+    import trieste_amd.extras as A  # superset of trieste_amd.acquisition
     import trieste_amd.models as M
     from scipy.stats import norm
     from trieste_amd.data import Dataset
