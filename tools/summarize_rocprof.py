@@ -54,6 +54,8 @@ for w in workloads:
     open(os.path.join(out_dir, f"{rnd}_rocprof_{w}.txt"), "w").write("\n".join(lines))
     print("\n".join(lines))
     if traffic:
+        # the profiled command runs the bench's untimed first call + 1 timed step = 2 steps: per-step traffic = half
+        traffic = {k: v / 2.0 for k, v in traffic.items()}
         traffic_all[w] = traffic.get("FETCH_SIZE", 0.0) * 2.0 + traffic.get("WRITE_SIZE", 0.0)
         traffic_all.setdefault("_raw", {})
         if not isinstance(traffic_all["_raw"], dict) or "FETCH_SIZE" in traffic_all["_raw"]:
@@ -62,5 +64,5 @@ for w in workloads:
         traffic_all["_round"] = rnd
         traffic_all["_note"] = ("HBM bytes per step of the workload's dominant kernel = 2*FETCH_SIZE + WRITE_SIZE (KiB->bytes; the x2 "
                                 "on FETCH_SIZE is the gfx950 correction of MI355X_MICROARCH.md, WRITE_SIZE uncalibrated); "
-                                "one bench step with --steps 1 --warmup 0 plus the untimed first call = 2 launches -> halved below")
+                                "the profiled run = the bench's untimed first call + 1 timed step, so the sums over dispatches are halved")
 json.dump(traffic_all, open(tfile, "w"), indent=1)
