@@ -377,7 +377,7 @@ enum tgp_precision { TGP_PREC_F64 = 0, TGP_PREC_I8X4 = 1 };
 int tgp_set_precision(tgp_handle h, int precision);
 /* Sweep launch policy knob for experiments and tests (0 = default): bit 0 = never use the row-group split of
  * small launches, bit 1 = always use it, bit 2 = joint mode on the first-generation kernel (64-column group slots;
- * dp = 32 always uses it).  Every setting computes the same arithmetic on every candidate. */
+ * dp = 32 always uses it), bit 3 = fused plain launches on the register-staged kernel instead of the LDS-DMA one.  Every setting computes the same arithmetic on every candidate. */
 int tgp_set_variant(tgp_handle h, int variant);
 
 #ifdef __cplusplus

@@ -96,11 +96,12 @@ def _oracle_argmax_agrees(idx, oracle_vals, tol):
     return abs(oracle_vals[oi] - oracle_vals[idx]) <= tol
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2], ids=["default-policy", "fused", "rowsplit"])
+@pytest.mark.parametrize("variant", [0, 1, 2, 9], ids=["default-policy", "fused-dma", "rowsplit", "fused-regstage"])
 @pytest.mark.parametrize("cfg", CONFIGS, ids=[c[0] for c in CONFIGS])
 def test_sweep_matches_oracle(cfg, variant):
     """The sweep kernel under every launch policy: the default (row-group split for launches with few candidate
-    blocks), the fused form forced (tgp_set_variant bit 0: what large launches use) and the split forced (bit 1)."""
+    blocks), the fused form forced (tgp_set_variant bit 0: what large launches use -- the LDS-DMA kernel for dp <= 16, or the
+    register-staged one with bit 3) and the split forced (bit 1)."""
     _, obj, d, kind, N, noise = cfg
     X, Y, ls, c, st, Xq = _problem(obj, d, kind, N, noise)
     floor = cancellation_floor(N, 1.0, noise)
@@ -137,13 +138,17 @@ def test_launch_policies_agree_to_rounding(cfg):
     _, obj, d, kind, N, noise = cfg
     X, Y, ls, c, st, Xq = _problem(obj, d, kind, N, noise, M=700)
     outs = []
-    for variant in (1, 2):
+    for variant in (1, 2, 9):
         eng = _engine(kind, d, 1.0, ls, noise, c, X, Y, variant)
         m, v = eng.predict(Xq)
         outs.append((np.asarray(m), np.asarray(v), eng.acq_argmax("ei", eng.eta(), Xq)[:2]))
     assert_close(outs[0][1], outs[1][1], rtol=0, atol=1e-13, what="var")
     assert_close(outs[0][0], outs[1][0], rtol=0, atol=1e-13 * max(1.0, np.abs(outs[0][0]).max()), what="mean")
     assert outs[0][2][1] == outs[1][2][1]
+    # the two fused kernels (LDS-DMA staging / register staging) sum in the same order: identical bits
+    np.testing.assert_array_equal(outs[0][1], outs[2][1])
+    np.testing.assert_array_equal(outs[0][0], outs[2][0])
+    assert outs[0][2] == outs[2][2]
 
 
 def test_ties_pick_first_index_and_sharding_is_consistent():

@@ -23,6 +23,10 @@ hipError_t launch_sweep_kind0(hipStream_t, const SweepArgs&, bool, int64_t);
 hipError_t launch_sweep_kind1(hipStream_t, const SweepArgs&, bool, int64_t);
 hipError_t launch_sweep_kind2(hipStream_t, const SweepArgs&, bool, int64_t);
 hipError_t launch_sweep_kind3(hipStream_t, const SweepArgs&, bool, int64_t);
+hipError_t launch_sweep_dma_kind0(hipStream_t, const SweepArgs&, int64_t);
+hipError_t launch_sweep_dma_kind1(hipStream_t, const SweepArgs&, int64_t);
+hipError_t launch_sweep_dma_kind2(hipStream_t, const SweepArgs&, int64_t);
+hipError_t launch_sweep_dma_kind3(hipStream_t, const SweepArgs&, int64_t);
 hipError_t launch_joint_kind0(hipStream_t, const SweepArgs&, int64_t);
 hipError_t launch_joint_kind1(hipStream_t, const SweepArgs&, int64_t);
 hipError_t launch_joint_kind2(hipStream_t, const SweepArgs&, int64_t);
@@ -140,7 +144,8 @@ void apply_penalization(tgp_handle h, double* dvals, const double* dXq, int64_t 
 // Sweep launch policy.  tgp_set_variant bits (experiments / tests; 0 = default):
 //   VARIANT_NO_SPLIT (1): never use the row-group split    VARIANT_FORCE_SPLIT (2): use it whenever Npad allows
 //   VARIANT_JOINT_V1 (4): joint mode on the first-generation kernel (64-column slots, Gram operands from L2)
-constexpr int VARIANT_NO_SPLIT = 1, VARIANT_FORCE_SPLIT = 2, VARIANT_JOINT_V1 = 4;
+//   VARIANT_REG_STAGING (8): fused plain launches on the register-staged kernel instead of the LDS-DMA one
+constexpr int VARIANT_NO_SPLIT = 1, VARIANT_FORCE_SPLIT = 2, VARIANT_JOINT_V1 = 4, VARIANT_REG_STAGING = 8;
 
 // number of per-block winner slots a fused arg-max over `a` fills (one per candidate block of the kernel in use)
 int64_t sweep_blocks(tgp_handle h, const SweepArgs& a, bool joint) {
@@ -234,6 +239,24 @@ hipError_t launch_sweep_timed(tgp_handle h, const SweepArgs& a, bool joint) {
         am.part = h->s_part.as<double>();
       }
     }
+  }
+  if (!joint && am.split_g <= 1 && a.m.dp <= 16 && !(h->variant & VARIANT_REG_STAGING)) {
+    // fused plain launch: LDS-DMA staging, three A stages (tgp_kernels_sweep_dma.inc); same results bit for bit
+    const int64_t wg = grid < h->num_cu ? grid : h->num_cu;
+    hipError_t ea = h->s_kcache.reserve((size_t)wg * (size_t)a.m.Npad * SW_BN * sizeof(double));
+    if (ea != hipSuccess) return ea;
+    am.kcache = h->s_kcache.as<double>();
+    (void)hipEventRecord(h->ev0, h->stream);
+    switch (h->kind) {
+      case TGP_RBF: e = launch_sweep_dma_kind0(h->stream, a, wg); break;
+      case TGP_MATERN12: e = launch_sweep_dma_kind1(h->stream, a, wg); break;
+      case TGP_MATERN32: e = launch_sweep_dma_kind2(h->stream, a, wg); break;
+      default: e = launch_sweep_dma_kind3(h->stream, a, wg); break;
+    }
+    (void)hipEventRecord(h->ev1, h->stream);
+    h->last_launches = 1;
+    h->last_ms = -1.0;
+    return e;
   }
   // persistent: one workgroup per CU, each with a private K* slab (and a C slab in joint mode)
   int64_t wgrid = grid * std::max(1, am.split_g);
