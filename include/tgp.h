@@ -320,7 +320,9 @@ int tgp_stream_synchronize(tgp_handle h);
  *     and ONE 16-byte copy reaches the host.  merge = TGP_MERGE_PEER replaces the all-gather by 16-byte
  *     peer copies into member 0 (no RCCL needed).  RCCL is resolved at run time (dlopen librccl.so.1):
  *     TGP_MERGE_RCCL fails with TGP_ERR_STATE if it is not loadable.
- * One host thread drives a group at a time.  Group calls are synchronous on return. */
+ * One host thread drives a group at a time.  Group calls are synchronous on return.
+ * Test aid: with TGP_GROUP_ALLOW_DUPLICATES set in the environment and merge = TGP_MERGE_PEER a device may be listed
+ * several times (several members share one GPU), so the multi-member path can be exercised on a single-GPU box. */
 typedef struct tgp_group_s* tgp_group;
 typedef struct tgp_group_traj_s* tgp_group_traj;
 enum tgp_merge { TGP_MERGE_RCCL = 0, TGP_MERGE_PEER = 1 };

@@ -111,6 +111,58 @@ def test_group_winners_equal_the_single_handle(merge):
         grp.close()
 
 
+def test_three_members_on_one_gpu_equal_the_single_handle(monkeypatch):
+    """The whole multi-member path (worker threads, contiguous shards with index_base, per-member streams, peer copies
+    and events, the 3-way merge kernel, host merge of the top-k, sharded trajectories and q-batches) on a single-GPU
+    box: three members share device 0 (test aid TGP_GROUP_ALLOW_DUPLICATES, peer merge)."""
+    from trieste_amd.group import GPEngineGroup
+
+    monkeypatch.setenv("TGP_GROUP_ALLOW_DUPLICATES", "1")
+    X, Y, ls, c, kind, noise = _problem()
+    eng = _single(X, Y, ls, c, kind, noise)
+    eta = eng.eta()
+    grp = GPEngineGroup(X.shape[1], kind, devices=[0, 0, 0], merge="peer")
+    assert grp.info()["n_dev"] == 3
+    grp.set_hyper(1.0, ls, noise, c)
+    grp.set_data(X, Y)
+    for m in grp.members[1:]:
+        for a, b in zip(grp.members[0].get_factor(), m.get_factor()):
+            np.testing.assert_array_equal(a, b)
+    M = 50021  # ragged three-way shards
+    grp.sample_candidates(5678, M, 0.0, 1.0)
+    Xq = eng.sample_box(5678, 0, M, 0.0, 1.0)
+    want, got = eng.acq_argmax("ei", eta, Xq), grp.acq_argmax("ei", eta)
+    assert (got[0], got[1]) == (want[0], want[1])
+    np.testing.assert_array_equal(got[2], want[2])
+    tv, ti = grp.acq_topk("ei", eta, 41)
+    wv, wi = eng.acq_topk("ei", eta, Xq, 41)
+    np.testing.assert_array_equal(ti, wi)
+    np.testing.assert_array_equal(tv, wv)
+    pts = np.random.default_rng(1).uniform(size=(1000, X.shape[1]))
+    pts[700] = pts[17]            # a tie between the first and the last shard: the first index wins
+    pts[350] = pts[17]
+    grp.set_candidates(pts)
+    for acq, param in (("ei", eta), ("pi", eta), ("nlcb", 1.96), ("aei", eta)):
+        want, got = eng.acq_argmax(acq, param, pts), grp.acq_argmax(acq, param)
+        assert (got[0], got[1]) == (want[0], want[1]), acq
+    grp.set_candidates(pts[:2])   # fewer candidates than members: an empty shard never wins
+    want, got = eng.acq_argmax("ei", eta, pts[:2]), grp.acq_argmax("ei", eta)
+    assert (got[0], got[1]) == (want[0], want[1])
+    grp.set_candidates(pts)
+    rng = np.random.default_rng(11)
+    F, B = 64, 5
+    draws = (rng.standard_normal((F, X.shape[1])), rng.uniform(0, 2 * np.pi, F), rng.standard_normal((F, B)),
+             rng.standard_normal((X.shape[0], B)))
+    wv, wi = eng.trajectory(*draws).argmin(pts)
+    gv, gi = grp.trajectory(*draws).argmin()
+    np.testing.assert_array_equal(gi, wi)
+    np.testing.assert_array_equal(gv, wv)
+    Xg = rng.uniform(size=(100, 7, X.shape[1]))
+    eps = rng.standard_normal((7, 32))
+    np.testing.assert_array_equal(grp.qei(Xg, eps, eta), eng.qei(Xg, eps, eta))
+    grp.close()
+
+
 def test_group_errors_are_reported():
     from trieste_amd.group import GPEngineGroup
 

@@ -262,9 +262,14 @@ int tgp_group_create(const int* device_ids, int n_dev, int d, int kernel_kind, i
   *out = nullptr;
   if (!device_ids || n_dev < 1 || n_dev > 64) return gfail(nullptr, TGP_ERR_ARG, "need 1..64 device ids");
   if (merge != TGP_MERGE_RCCL && merge != TGP_MERGE_PEER) return gfail(nullptr, TGP_ERR_ARG, "unknown merge %d", merge);
+  // A device may be listed more than once only as a TEST AID (TGP_GROUP_ALLOW_DUPLICATES=1, peer merge): several
+  // members then share one GPU, which exercises the whole multi-member path -- worker threads, shards, per-member
+  // streams, peer copies + events, the P-way merge -- on a single-GPU box.  RCCL needs distinct devices.
+  const bool allow_dup = getenv("TGP_GROUP_ALLOW_DUPLICATES") != nullptr && merge == TGP_MERGE_PEER;
   for (int i = 0; i < n_dev; ++i)
     for (int j = 0; j < i; ++j)
-      if (device_ids[i] == device_ids[j]) return gfail(nullptr, TGP_ERR_ARG, "device %d listed twice", device_ids[i]);
+      if (device_ids[i] == device_ids[j] && !allow_dup)
+        return gfail(nullptr, TGP_ERR_ARG, "device %d listed twice", device_ids[i]);
   tgp_group g = new (std::nothrow) tgp_group_s();
   if (!g) return gfail(nullptr, TGP_ERR_ALLOC, "host allocation failed");
   g->n = n_dev;
