@@ -369,7 +369,7 @@ def main():
                                    f"{tj.get('_round', '?')} on this workload -- NOT measured in this run")
             except Exception:
                 traffic = None
-        kern_name = {"ei": "sweep_kernel<KIND, DP, JOINT=false, SPLIT=false>", "qei": "joint_kernel<KIND, DP>",
+        kern_name = {"ei": "sweep_dma_kernel<KIND, DP>" if d <= 16 else "sweep_kernel<KIND, DP, JOINT=false, SPLIT=false>", "qei": "joint_kernel<KIND, DP>",
                      "ts": "traj_eval_kernel"}[kind]
         emulated = args.precision == "i8x4" and kind == "ei"
         if emulated:  # priced on the int8 work the scheme NEEDS: 10 digit-plane products of N^2 ops per candidate
