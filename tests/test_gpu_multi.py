@@ -321,3 +321,22 @@ def test_model_with_devices_through_the_host_layer():
                                                     fit_model=True, fit_initial_model=False, track_state=False)
     assert calls == [1, 1, 1] and all(m.N == 43 for m in multi.group.members)
     assert len(res.final_result.unwrap().datasets[OBJECTIVE]) == 43
+
+
+def test_sharded_optimizer_keeps_winners_on_the_device():
+    """generate_sharded_discrete_optimizer on the real engine (single process: the merge of one): the device-pair path
+    returns the point the plain fused arg-max returns."""
+    import trieste_amd.models as M
+    from trieste_amd import objectives as OBJ
+    from trieste_amd.acquisition import ExpectedImprovement, optimize_discrete
+    from trieste_amd.data import Dataset
+    from trieste_amd.distributed import generate_sharded_discrete_optimizer
+    from trieste_amd.space import Box, DiscreteSearchSpace
+
+    rng = np.random.default_rng(0)
+    x = rng.uniform(size=(30, 2))
+    data = Dataset(x, OBJ.scaled_branin(x))
+    model = M.GaussianProcessRegression(M.build_gpr(data, Box([0, 0], [1, 1]), likelihood_variance=1e-3))
+    fn = ExpectedImprovement().prepare_acquisition_function(model, dataset=data)
+    space = DiscreteSearchSpace(rng.uniform(size=(4097, 2)))
+    np.testing.assert_array_equal(generate_sharded_discrete_optimizer()(space, fn), optimize_discrete(space, fn))

@@ -96,6 +96,14 @@ class _posterior_tail(AcquisitionFunctionClass):
             return self._group.acq_topk(self._acq, self._param, k)
         return self._top_k(points, k, index_base)
 
+    def argmax_pair(self, points, index_base: int = 0):
+        """The fused arg-max with the winner left where the engine put it (a [2] device pair: value, global index
+        bits) -- the sharded optimizers gather and merge such pairs without a host round trip per rank
+        (``trieste_amd.distributed.all_gather_winners``).  Only for the tails whose state is (kind, param)."""
+        if type(self)._prepare is not _posterior_tail._prepare:
+            raise TypeError(f"{type(self).__name__} installs engine state per call: use argmax()")
+        return self._engine.acq_argmax_pair(self._acq, self._param, points, index_base)
+
     def argmax_sampled(self, seed: int, num_samples: int, lower, upper):
         """Fused arg-max over ``num_samples`` uniform candidates of the box generated ON the device(s) (one logical
         Philox sample, sharded over the group when the model has one) -> (value, index, point [D])."""

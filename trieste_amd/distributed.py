@@ -95,6 +95,11 @@ def all_gather_winners(engine, pairs, minimize: bool = False, group=None):
     return host[0].numpy().copy(), host[1].contiguous().view(torch.int64).numpy().copy()
 
 
+# acquisition functions whose whole state is (kind, param): their arg-max may stay on the device
+_PAIR_OK = {"expected_improvement", "probability_below_threshold", "negative_lower_confidence_bound",
+            "augmented_expected_improvement"}
+
+
 def _is_tensor(x) -> bool:
     return type(x).__module__.startswith("torch")
 
@@ -118,6 +123,12 @@ def generate_sharded_discrete_optimizer(group=None, device=None):
         rank = dist.get_rank(group) if active else 0
         world = dist.get_world_size(group) if active else 1
         lo, hi = shard_range(points.shape[0], rank, world)
+        eng = getattr(target_func, "_engine", None)
+        if hasattr(target_func, "argmax_pair") and type(target_func).__name__ in _PAIR_OK and hi > lo:
+            # device-resident winners: sweep -> all-gather of the pairs -> merge kernel -> one copy to the host
+            pair = target_func.argmax_pair(points[lo:hi], index_base=lo)
+            _, gi = all_gather_winners(eng, pair, group=group)
+            return points[int(gi[0])][None, :]
         if hi > lo:
             val, idx, _ = target_func.argmax(points[lo:hi], index_base=lo)
         else:  # more ranks than points: an empty shard never wins

@@ -327,9 +327,9 @@ class GPEngine:
         :meth:`merge_winners`, read the result once."""
         import torch
 
+        if not _is_torch(Xq) or not Xq.is_cuda:  # host candidates: put them on this engine's device first
+            Xq = torch.as_tensor(np.ascontiguousarray(Xq, dtype=_NP)).to(f"cuda:{self.device}")
         a, _, M = self._flat(Xq)
-        if a.where != _lib.DEVICE:
-            raise ValueError("acq_argmax_pair needs device-resident candidates (a CUDA tensor)")
         pair = torch.empty(2, dtype=torch.float64, device=a.device)
         self._chk(self._lib.tgp_acq_argmax_async(self._h, _lib.ACQ[acq], float(param), a.ptr, M, int(index_base),
                                                  pair.data_ptr()))
