@@ -189,7 +189,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-acquire", action="store_true", help="skip the informational end-to-end acquire timing")
     ap.add_argument("--variant", type=int, default=0, help="tgp_set_variant launch-policy bits (experiments)")
-    ap.add_argument("--precision", default="f64", choices=("f64", "i8x4"),
+    ap.add_argument("--precision", default="f64", choices=("f64", "i8x4", "i8x5"),
                     help="arithmetic of the EI sweeps: f64 (default, the parity path) or i8x4 = W K* on the int8 matrix "
                          "cores with four digit planes per operand (emulated precision; its own line, never the headline)")
     args = ap.parse_args()
@@ -371,10 +371,10 @@ def main():
                 traffic = None
         kern_name = {"ei": "sweep_dma_kernel<KIND, DP>" if d <= 16 else "sweep_kernel<KIND, DP, JOINT=false, SPLIT=false>", "qei": "joint_kernel<KIND, DP>",
                      "ts": "traj_eval_kernel"}[kind]
-        emulated = args.precision == "i8x4" and kind == "ei"
+        emulated = args.precision in ("i8x4", "i8x5") and kind == "ei"
         if emulated:  # priced on the int8 work the scheme NEEDS: 10 digit-plane products of N^2 ops per candidate
             kern_name = "sweep_i8_kernel<KIND, DP>"
-            i8_ops = 10.0 * float(N) * N
+            i8_ops = (10.0 if args.precision == "i8x4" else 15.0) * float(N) * N
             i8_achieved = i8_ops * my_units / (k_ms * 1e-3) * 1e-12 if k_ms > 0 else float("nan")
         par = (f"single-controller group x{nshards} (tgp_group_*, merge={args.merge})" if group_mode else
                f"candidate-sharded x{world}, one process per GPU, replicated model, (val,idx) all-gather")
@@ -389,9 +389,10 @@ def main():
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": "f64" if not (args.precision == "i8x4" and kind == "ei") else
-                     "f64 emulated: W K* as 4 x 4 int8 digit planes (Ozaki, 10 int8 MFMA products, exact int32 sums); K*, "
-                     "mean, norms, EI, arg-max in f64",
+            "dtype": "f64" if not (args.precision != "f64" and kind == "ei") else
+                     (f"f64 emulated: W K* as {args.precision[-1]} x {args.precision[-1]} int8 digit planes (Ozaki, "
+                      f"{10 if args.precision == 'i8x4' else 15} int8 MFMA products, exact int32 sums); K*, mean, norms, EI, "
+                      "arg-max in f64"),
             "data": "synthetic",
             "config": {
                 "workload": f"{args.workload}: {kind} step, {w['objective']} d={d}, {kernel}, N={N} train, "

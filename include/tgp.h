@@ -374,8 +374,10 @@ int tgp_last_kernel_ms(tgp_handle h, double* ms, int* launches);
  *                 product; truncation at 2^-32 of each row / column scale).  K* generation, mean, column norms,
  *                 acquisition tail and arg-max stay float64.  Measured |var error| <= 0.4 x the parity tolerance
  *                 1e-5 |var| + cancellation floor at N = 4096; an EMULATED-precision option
- *                 for throughput, never the default and never what the float64 parity claims are made on. */
-enum tgp_precision { TGP_PREC_F64 = 0, TGP_PREC_I8X4 = 1 };
+ *                 for throughput, never the default and never what the float64 parity claims are made on.
+ *   TGP_PREC_I8X5 the same with five digit planes (15 int8 products, truncation at 2^-40 of the scales): |var error|
+ *                 <= 1.5e-3 x the parity tolerance at N = 4096 and below 1e-5 RELATIVE without any floor; d <= 16. */
+enum tgp_precision { TGP_PREC_F64 = 0, TGP_PREC_I8X4 = 1, TGP_PREC_I8X5 = 2 };
 int tgp_set_precision(tgp_handle h, int precision);
 /* Sweep launch policy knob for experiments and tests (0 = default): bit 0 = never use the row-group split of
  * small launches, bit 1 = always use it, bit 2 = joint mode on the first-generation kernel (64-column group slots;

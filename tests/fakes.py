@@ -111,7 +111,7 @@ class FakeEngine:
         pass
 
     def set_precision(self, precision="f64"):
-        if precision not in ("f64", "i8x4"):
+        if precision not in ("f64", "i8x4", "i8x5"):
             raise ValueError(f"unknown precision {precision!r}")
 
     def clone_from(self, other):

@@ -1,3 +1,5 @@
 set -u; OUT=gpurun_out; mkdir -p $OUT
 timeout 600 python -m pytest tests/test_gpu_i8.py tests/test_philox.py -m gpu -q -s > $OUT/r02_i8_tests.log 2>&1; echo "i8 tests rc=$?"; tail -25 $OUT/r02_i8_tests.log
-timeout 300 python bench.py --precision i8x4 --no-cpu-baseline --no-acquire > $OUT/r02_bench_i8.json 2> $OUT/r02_bench_i8.err; echo "bench i8 rc=$?"; cat $OUT/r02_bench_i8.json; tail -3 $OUT/r02_bench_i8.err
+for P in i8x4 i8x5; do
+timeout 300 python bench.py --precision $P --no-cpu-baseline --no-acquire --steps 3 2>/dev/null | python -c "import sys,json; o=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$P', o['value'], o['roofline']['frac'], o['roofline']['kernel_ms'], o['config']['best_index'], o['config']['best_value'])"
+done

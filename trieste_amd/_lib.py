@@ -126,7 +126,7 @@ def load():
 
 
 MERGES = {"rccl": 0, "peer": 1}
-PRECISIONS = {"f64": 0, "i8x4": 1}
+PRECISIONS = {"f64": 0, "i8x4": 1, "i8x5": 2}
 
 
 def check(lib, handle, rc, group=False):

@@ -31,10 +31,10 @@ hipError_t launch_joint_kind0(hipStream_t, const SweepArgs&, int64_t);
 hipError_t launch_joint_kind1(hipStream_t, const SweepArgs&, int64_t);
 hipError_t launch_joint_kind2(hipStream_t, const SweepArgs&, int64_t);
 hipError_t launch_joint_kind3(hipStream_t, const SweepArgs&, int64_t);
-hipError_t launch_sweep_i8_kind0(hipStream_t, const SweepArgs&, int64_t);
-hipError_t launch_sweep_i8_kind1(hipStream_t, const SweepArgs&, int64_t);
-hipError_t launch_sweep_i8_kind2(hipStream_t, const SweepArgs&, int64_t);
-hipError_t launch_sweep_i8_kind3(hipStream_t, const SweepArgs&, int64_t);
+hipError_t launch_sweep_i8_kind0(hipStream_t, const SweepArgs&, int64_t, int);
+hipError_t launch_sweep_i8_kind1(hipStream_t, const SweepArgs&, int64_t, int);
+hipError_t launch_sweep_i8_kind2(hipStream_t, const SweepArgs&, int64_t, int);
+hipError_t launch_sweep_i8_kind3(hipStream_t, const SweepArgs&, int64_t, int);
 }  // namespace tgp
 
 using namespace tgp;
@@ -149,7 +149,7 @@ constexpr int VARIANT_NO_SPLIT = 1, VARIANT_FORCE_SPLIT = 2, VARIANT_JOINT_V1 = 
 
 // number of per-block winner slots a fused arg-max over `a` fills (one per candidate block of the kernel in use)
 int64_t sweep_blocks(tgp_handle h, const SweepArgs& a, bool joint) {
-  if (!joint && h->precision == TGP_PREC_I8X4) return (a.M + 63) / 64;
+  if (!joint && h->precision != TGP_PREC_F64) return (a.M + 63) / 64;
   return sweep_grid(a, joint);
 }
 
@@ -157,24 +157,26 @@ int64_t sweep_blocks(tgp_handle h, const SweepArgs& a, bool joint) {
 hipError_t launch_sweep_i8_timed(tgp_handle h, SweepArgs& am) {
   const int64_t Npad = am.m.Npad;
   hipError_t e;
-  if (h->wq_version != h->data_version) {
-    if ((e = h->d_wq.reserve((size_t)4 * Npad * Npad)) != hipSuccess) return e;
+  const int planes = h->precision == TGP_PREC_I8X5 ? 5 : 4;
+  if (h->wq_version != h->data_version || h->wq_planes != planes) {
+    if ((e = h->d_wq.reserve((size_t)planes * Npad * Npad)) != hipSuccess) return e;
     if ((e = h->d_rs.reserve((size_t)Npad * sizeof(double))) != hipSuccess) return e;
-    launch_w_digits(h->stream, h->d_W.as<double>(), h->N, Npad, h->d_rs.as<double>(), h->d_wq.p);
+    launch_w_digits(h->stream, h->d_W.as<double>(), h->N, Npad, h->d_rs.as<double>(), h->d_wq.p, planes);
     h->wq_version = h->data_version;
+    h->wq_planes = planes;
   }
   am.i8_wq = h->d_wq.p;
   am.i8_rs = h->d_rs.as<double>();
   const int64_t blocks = (am.M + 63) / 64;
   const int64_t wgrid = blocks < h->num_cu ? blocks : h->num_cu;
-  if ((e = h->s_kcache.reserve((size_t)wgrid * (size_t)Npad * 64 * 4)) != hipSuccess) return e;
+  if ((e = h->s_kcache.reserve((size_t)wgrid * (size_t)Npad * 64 * planes)) != hipSuccess) return e;
   am.kcache = h->s_kcache.as<double>();
   (void)hipEventRecord(h->ev0, h->stream);
   switch (h->kind) {
-    case TGP_RBF: e = launch_sweep_i8_kind0(h->stream, am, wgrid); break;
-    case TGP_MATERN12: e = launch_sweep_i8_kind1(h->stream, am, wgrid); break;
-    case TGP_MATERN32: e = launch_sweep_i8_kind2(h->stream, am, wgrid); break;
-    default: e = launch_sweep_i8_kind3(h->stream, am, wgrid); break;
+    case TGP_RBF: e = launch_sweep_i8_kind0(h->stream, am, wgrid, planes); break;
+    case TGP_MATERN12: e = launch_sweep_i8_kind1(h->stream, am, wgrid, planes); break;
+    case TGP_MATERN32: e = launch_sweep_i8_kind2(h->stream, am, wgrid, planes); break;
+    default: e = launch_sweep_i8_kind3(h->stream, am, wgrid, planes); break;
   }
   (void)hipEventRecord(h->ev1, h->stream);
   h->last_launches = 1;
@@ -188,7 +190,7 @@ hipError_t launch_sweep_timed(tgp_handle h, const SweepArgs& a, bool joint) {
   hipError_t e;
   SweepArgs& am = const_cast<SweepArgs&>(a);
   am.split_g = 0;
-  if (!joint && h->precision == TGP_PREC_I8X4) return launch_sweep_i8_timed(h, am);
+  if (!joint && h->precision != TGP_PREC_F64) return launch_sweep_i8_timed(h, am);
   if (joint && a.m.dp <= 16 && !(h->variant & VARIANT_JOINT_V1)) {
     // contiguously packed 128 x 256 tiles, Gram phase out of LDS (tgp_kernels_joint.inc)
     const int gpb = 256 / a.q;
@@ -538,8 +540,10 @@ int tgp_use_private_stream(tgp_handle h) {
 
 int tgp_set_precision(tgp_handle h, int precision) {
   if (!h) return TGP_ERR_ARG;
-  if (precision != TGP_PREC_F64 && precision != TGP_PREC_I8X4)
+  if (precision != TGP_PREC_F64 && precision != TGP_PREC_I8X4 && precision != TGP_PREC_I8X5)
     return fail(h, TGP_ERR_ARG, "unknown precision %d", precision);
+  if (precision == TGP_PREC_I8X5 && h->dp > 16)
+    return fail(h, TGP_ERR_ARG, "TGP_PREC_I8X5 supports input dimensions up to 16 (LDS), got %d", h->d);
   h->precision = precision;
   return TGP_OK;
 }

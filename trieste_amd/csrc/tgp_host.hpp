@@ -78,6 +78,7 @@ struct tgp_handle_s {
   int precision = 0;
   DevBuf d_wq, d_rs;
   uint64_t wq_version = 0;
+  int wq_planes = 0;
   // model state on device
   DevBuf d_xn, d_ls, d_X, d_Y, d_Xs, d_A, d_L, d_W, d_alpha, d_err, d_tmp1, d_tmp2, d_info;
   // local penalization applied to every tgp_acq_* result while pen_kind != 0 (tgp_set_penalization)

@@ -48,7 +48,7 @@ struct SweepArgs {
   int64_t G;          // number of groups
   double* cov_out;    // [G][q][q]
   double* kcache;     // [grid][Npad][128] per-workgroup K* slabs (device scratch; int8 sweep: [grid][Npad][64][4] bytes)
-  const void* i8_wq;  // int8 sweep: digit planes of W, Wq[s][k/32][i][32] (4 planes of Npad^2 bytes)
+  const void* i8_wq;  // int8 sweep: digit planes of W, Wq[s][k/32][i][32] (4 or 5 planes of Npad^2 bytes)
   const double* i8_rs; // int8 sweep: [Npad] row scales S_i = 2 max_k |W_ik|
   double* aslab;      // [grid][Npad][128] C = W K* slabs of joint mode (device scratch)
   // row-group split of small sweeps (SPLIT instantiation): group g of a candidate block owns the row
@@ -153,7 +153,7 @@ void launch_theta_tail(hipStream_t s, const double* mean, int64_t ldm, const dou
                        double scale, double* theta, double* ws);
 void launch_traj_grad(hipStream_t s, const TrajDev& t, const double* Xq, int64_t nitems, double* val,
                       double* grad);
-void launch_w_digits(hipStream_t s, const double* W, int64_t N, int64_t Npad, double* rs, void* Wq);
+void launch_w_digits(hipStream_t s, const double* W, int64_t N, int64_t Npad, double* rs, void* Wq, int planes);
 void launch_merge_winners(hipStream_t s, const double* gathered, int P, int V, int minimize, double* out);
 void launch_argmin_final_multi(hipStream_t s, const double* blk_val, const int64_t* blk_idx,
                                int64_t nblk, int B, double* out_val, int64_t* out_idx);

@@ -617,12 +617,13 @@ void launch_argmin_final_multi(hipStream_t s, const double* blk_val, const int64
 
 // ---------------------------------------------------------------------------------------------
 // Digit planes of W = L^-1 for the split-precision sweep (tgp_kernels_sweep_i8.inc): row i is scaled by
-// S_i = 2 max_k |W_ik| (so |W_ik / S_i| <= 1/2), x = rint(W_ik / S_i * 2^31) is an int32, and its four balanced
+// S_i = 2 max_k |W_ik| (so |W_ik / S_i| <= 1/2), x = rint(W_ik / S_i * 2^(8 NS - 1)), and its NS (4 or 5) balanced
 // base-256 digits (each in [-128, 127], most significant first) go to the planes
 //   Wq[s][k / 32][i][k % 32]      (a [256 rows x 32 k] operand tile of one plane is 8 KiB contiguous).
 // One workgroup per 32 rows; thread (r = tid >> 3, c = tid & 7) owns 4 consecutive k of row r per 32-wide k block.
 // Only k blocks up to the end of the row's 256-row block are written (the sweep never reads beyond).  The padding of
 // the factor workspace (rows / columns >= N carry the identity) is masked to zero, as in the transposed f64 operand.
+template <int NS>
 __global__ __launch_bounds__(256) void w_digits_kernel(const double* __restrict__ W, int64_t N, int64_t Npad,
                                                        double* __restrict__ rs, unsigned char* __restrict__ Wq) {
   const int tid = threadIdx.x, r = tid >> 3, c = tid & 7;
@@ -642,32 +643,34 @@ __global__ __launch_bounds__(256) void w_digits_kernel(const double* __restrict_
   amax = fmax(amax, __shfl_xor(amax, 4, 64));
   const double S = amax > 0.0 ? 2.0 * amax : 1.0;
   if (c == 0) rs[i] = S;
-  const double to_fixed = 2147483648.0 / S;
+  const double to_fixed = (NS == 4 ? 2147483648.0 : 549755813888.0) / S;  // 2^(8 NS - 1) / S
   const size_t plane = (size_t)Npad * (size_t)Npad;
   for (int64_t kb = 0; kb < kb_end; ++kb) {
-    uint32_t p[4] = {0u, 0u, 0u, 0u};
+    uint32_t p[NS];
+#pragma unroll
+    for (int sdx = 0; sdx < NS; ++sdx) p[sdx] = 0u;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int64_t k = kb * 32 + 4 * c + j;
-      int q = (i < N && k < N) ? (int)rint(row[k] * to_fixed) : 0;
-      const int d3 = ((q + 128) & 255) - 128;
-      q = (q - d3) >> 8;
-      const int d2 = ((q + 128) & 255) - 128;
-      q = (q - d2) >> 8;
-      const int d1 = ((q + 128) & 255) - 128;
-      const int d0 = (q - d1) >> 8;
-      p[0] |= (uint32_t)(d0 & 255) << (8 * j);
-      p[1] |= (uint32_t)(d1 & 255) << (8 * j);
-      p[2] |= (uint32_t)(d2 & 255) << (8 * j);
-      p[3] |= (uint32_t)(d3 & 255) << (8 * j);
+      long long q = (i < N && k < N) ? (long long)rint(row[k] * to_fixed) : 0;  // |.| <= 2^(8 NS - 2)
+#pragma unroll
+      for (int sdx = NS - 1; sdx > 0; --sdx) {
+        const int dg = (int)((q + 128) & 255) - 128;
+        q = (q - dg) >> 8;
+        p[sdx] |= (uint32_t)(dg & 255) << (8 * j);
+      }
+      p[0] |= (uint32_t)((int)q & 255) << (8 * j);
     }
     unsigned char* dst = Wq + ((size_t)kb * Npad + i) * 32 + 4 * c;
 #pragma unroll
-    for (int sdx = 0; sdx < 4; ++sdx) *(uint32_t*)(dst + sdx * plane) = p[sdx];
+    for (int sdx = 0; sdx < NS; ++sdx) *(uint32_t*)(dst + sdx * plane) = p[sdx];
   }
 }
-void launch_w_digits(hipStream_t s, const double* W, int64_t N, int64_t Npad, double* rs, void* Wq) {
-  hipLaunchKernelGGL(w_digits_kernel, dim3((unsigned)(Npad / 32)), dim3(256), 0, s, W, N, Npad, rs, (unsigned char*)Wq);
+void launch_w_digits(hipStream_t s, const double* W, int64_t N, int64_t Npad, double* rs, void* Wq, int planes) {
+  if (planes == 5)
+    hipLaunchKernelGGL(w_digits_kernel<5>, dim3((unsigned)(Npad / 32)), dim3(256), 0, s, W, N, Npad, rs, (unsigned char*)Wq);
+  else
+    hipLaunchKernelGGL(w_digits_kernel<4>, dim3((unsigned)(Npad / 32)), dim3(256), 0, s, W, N, Npad, rs, (unsigned char*)Wq);
 }
 
 // ---------------------------------------------------------------------------------------------
