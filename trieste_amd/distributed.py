@@ -95,11 +95,6 @@ def all_gather_winners(engine, pairs, minimize: bool = False, group=None):
     return host[0].numpy().copy(), host[1].contiguous().view(torch.int64).numpy().copy()
 
 
-# acquisition functions whose whole state is (kind, param): their arg-max may stay on the device
-_PAIR_OK = {"expected_improvement", "probability_below_threshold", "negative_lower_confidence_bound",
-            "augmented_expected_improvement"}
-
-
 def _is_tensor(x) -> bool:
     return type(x).__module__.startswith("torch")
 
@@ -124,9 +119,19 @@ def generate_sharded_discrete_optimizer(group=None, device=None):
         world = dist.get_world_size(group) if active else 1
         lo, hi = shard_range(points.shape[0], rank, world)
         eng = getattr(target_func, "_engine", None)
-        if hasattr(target_func, "argmax_pair") and type(target_func).__name__ in _PAIR_OK and hi > lo:
-            # device-resident winners: sweep -> all-gather of the pairs -> merge kernel -> one copy to the host
-            pair = target_func.argmax_pair(points[lo:hi], index_base=lo)
+        pair = None
+        if hasattr(target_func, "argmax_pair"):  # (the choice of path must not depend on the rank: only on the function)
+            try:  # device-resident winners: sweep -> all-gather of the pairs -> merge kernel -> one copy to the host
+                if hi > lo:
+                    pair = target_func.argmax_pair(points[lo:hi], index_base=lo)
+                else:  # more ranks than points: an empty shard contributes (NaN, -1), which never wins
+                    pair = target_func.argmax_pair(points[:1], index_base=0)
+                    pair[0] = float("nan")
+                    ints = pair.view(np.int64) if isinstance(pair, np.ndarray) else pair.view(__import__("torch").int64)
+                    ints[1] = -1
+            except TypeError:  # a function that installs engine state per call: host-scalar form below
+                pair = None
+        if pair is not None:
             _, gi = all_gather_winners(eng, pair, group=group)
             return points[int(gi[0])][None, :]
         if hi > lo:
