@@ -190,7 +190,7 @@ class GaussianProcessRegression:
         twin = type(self).__new__(type(self))
         memo[id(self)] = twin
         for name, value in self.__dict__.items():
-            if name in ("_engine", "_eval_engines", "_group"):
+            if name in ("_engine", "_eval_engines", "_group", "_cond_twin"):
                 continue
             setattr(twin, name, copy.deepcopy(value, memo))
         twin._group = None  # the copy is a single-device model holding a copy of member 0's factorisation
@@ -220,25 +220,30 @@ class GaussianProcessRegression:
         """[..., B, D] -> (mean [..., B, 1], cov [..., 1, B, B]) (interface.py:126-133).  B <= 64 runs
         in the fused joint kernel; wider blocks are assembled from the mean and cross-covariance
         kernels (same formula, diagonal clipped to >= 1e-12)."""
+        m, c = self._joint_on(self._engine, query_points)
+        return m[..., None], c[..., None, :, :]
+
+    @staticmethod
+    def _joint_on(engine, query_points):
+        """(mean [..., B], cov [..., B, B]) of the joint posterior held by ``engine`` (this model's, or a conditioned
+        clone of it)."""
         q = query_points if type(query_points).__module__.startswith("torch") else np.asarray(query_points, np.float64)
         if q.shape[-2] <= 64:
-            m, c = self._engine.predict_joint(q)
-            return m[..., None], c[..., None, :, :]
+            return engine.predict_joint(q)
         q = np.asarray(q.cpu() if hasattr(q, "cpu") else q, dtype=np.float64)
         lead, B = q.shape[:-2], q.shape[-2]
         flat = q.reshape((-1, B, q.shape[-1]))
         means = np.empty((flat.shape[0], B))
         covs = np.empty((flat.shape[0], B, B))
         for g in range(flat.shape[0]):
-            means[g] = self._engine.predict_mean(flat[g])
-            cov = np.array(self._engine.cov_between(flat[g], flat[g]))
+            means[g] = engine.predict_mean(flat[g])
+            cov = np.array(engine.cov_between(flat[g], flat[g]))
             cov = 0.5 * (cov + cov.T)
             idx = np.diag_indices(B)
             cov[idx] = np.maximum(cov[idx], 1e-12)
             covs[g] = cov
-        return means.reshape(lead + (B, 1)), covs.reshape(lead + (1, B, B))
+        return means.reshape(lead + (B,)), covs.reshape(lead + (B, B))
 
-    # -- SupportsCovarianceBetweenPoints / FantasizableModel (models.py:188-254, 355-526) ------------
     def covariance_between_points(self, query_points_1, query_points_2):
         r"""Sigma_12 = K_12 - K_x1 (K_xx + sigma^2 I)^-1 K_x2 for query_points_1 [..., N, D] and
         query_points_2 [M, D] -> [..., 1, N, M] (one latent GP)."""
@@ -251,41 +256,36 @@ class GaussianProcessRegression:
         return cov.reshape(lead + (1, N, q2.shape[0]))
 
     def _conditional_terms(self, query_points, additional_data: Dataset, joint: bool):
-        """Shared algebra of conditional_predict_f / _joint (models.py:355-484): the posterior blocks
-        come from the engine (predict / predict_joint / cov_between); the n x n factorisation over the
-        n additional points (a pending batch: tens of points) and the two triangular solves against
-        it are host-side numpy, as they are per-leading-dimension TF ops in the reference."""
+        """Shared body of conditional_predict_f / _joint (models.py:355-484).  Conditioning on additional noisy
+        observations IS an exact GPR on (data + additional data) with the same hyper-parameters, so each leading group
+        gets the engine's fantasised model -- a clone of the cached factor with the additional rows appended
+        (tgp_clone_from + tgp_append_data, the path `Fantasizer` uses) -- and the posterior is read from it with the
+        ordinary sweeps: one implementation, all arithmetic on the device.  (Round 1 formed the reference's Schur
+        complement over the n additional points in host numpy; tests/test_host_logic.py and the goldens assert both
+        forms agree.)"""
         qp = np.asarray(query_points, dtype=np.float64)
         xa = np.asarray(additional_data.query_points, dtype=np.float64)
         ya = np.asarray(additional_data.observations, dtype=np.float64)
         if qp.ndim != 2 or xa.ndim < 2 or ya.shape[:-1] != xa.shape[:-1] or ya.shape[-1] != 1:
             raise ValueError("additional_data must have query_points with shape [..., N, D] and observations with "
                              "shape [..., N, 1], and query_points should have shape [M, D]")
-        import scipy.linalg as sl
-
         lead, n, M = xa.shape[:-2], xa.shape[-2], qp.shape[0]
         xa_f, ya_f = xa.reshape((-1, n, xa.shape[-1])), ya.reshape((-1, n))
-        noise = self.get_observation_noise()
         means = np.empty((xa_f.shape[0], M))
         seconds = np.empty((xa_f.shape[0], M, M) if joint else (xa_f.shape[0], M))
-        if not joint:
-            mean_qp, var_qp = (np.asarray(a)[..., 0] for a in self.predict(qp))
+        twin = getattr(self, "_cond_twin", None)
+        if twin is None:
+            twin = self._cond_twin = type(self._engine)(self._engine.d, self._model.kernel.kind, device=self._engine.device)
         for g in range(xa_f.shape[0]):
-            if joint:  # joint posterior at [additional; query] (models.py:438-452)
-                mean, cov = self.predict_joint(np.concatenate([xa_f[g], qp], axis=0))
-                mean, cov = np.asarray(mean)[:, 0], np.asarray(cov)[0]
-                mean_add, mean_q = mean[:n], mean[n:]
-                cov_add, cov_q, cov_cross = cov[:n, :n], cov[n:, n:], cov[:n, n:]
-            else:  # marginal form (models.py:381-389)
-                ma, ca = self.predict_joint(xa_f[g])
-                mean_add, cov_add = np.asarray(ma)[:, 0], np.asarray(ca)[0]
-                mean_q = mean_qp
-                cov_cross = self.covariance_between_points(xa_f[g], qp)[0]  # [n, M]
-            L_add = np.linalg.cholesky(cov_add + noise * np.eye(n))
-            A = sl.solve_triangular(L_add, cov_cross, lower=True)           # [n, M]
-            AM = sl.solve_triangular(L_add, ya_f[g] - mean_add, lower=True)  # [n]
-            means[g] = mean_q + A.T @ AM
-            seconds[g] = cov_q - A.T @ A if joint else var_qp - np.sum(A * A, axis=0)
+            twin.clone_from(self._engine)
+            if n:
+                twin.append_data(xa_f[g], ya_f[g])
+            if joint:
+                m, c = self._joint_on(twin, qp)
+                means[g], seconds[g] = np.asarray(m), np.asarray(c)
+            else:
+                m, v = twin.predict(qp)
+                means[g], seconds[g] = np.asarray(m), np.asarray(v)
         return lead, means, seconds
 
     def conditional_predict_f(self, query_points, additional_data: Dataset):
