@@ -303,6 +303,11 @@ void chol_inv(hipStream_t st, const FactorWs& f, int64_t lo, int64_t hi) {
     launch_leaf(st, A, L, W, ld, lo, f.info);
     return;
   }
+  static const bool leaf128 = getenv("TGP_NO_LEAF128") == nullptr;  // A/B aid
+  if (n == 2 * LEAF && leaf128) {  // two leaves and their parent's products in one workgroup
+    launch_leaf128(st, A, L, W, ld, lo, f.info);
+    return;
+  }
   const int64_t nblk = n / LEAF;
   const int64_t mid = lo + (nblk / 2) * LEAF;
   const int s1 = (int)(mid - lo), s2 = (int)(hi - mid);

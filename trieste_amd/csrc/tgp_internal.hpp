@@ -66,6 +66,7 @@ void launch_assemble_K(hipStream_t s, const double* Xs, double* A, int64_t N, in
                        int kind, double variance, double noise, int64_t row0 = 0);
 void launch_leaf(hipStream_t s, const double* A, double* L, double* W, int64_t ld, int64_t off,
                  int* info);
+void launch_leaf128(hipStream_t s, const double* A, double* L, double* W, int64_t ld, int64_t off, int* info);
 // C[m x n] = alpha * A[m x k] * op(B) + beta * C ;  TB: B stored [n x k] (row-major), else [k x n]
 void launch_gemm(hipStream_t s, bool tb, int m, int n, int k, double alpha, const double* A, int64_t lda,
                  const double* B, int64_t ldb, double beta, double* C, int64_t ldc, bool lower_only, int tri = 0,

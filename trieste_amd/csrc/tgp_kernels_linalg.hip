@@ -465,6 +465,90 @@ __global__ __launch_bounds__(512) void gemm_kernel8(int m, int n, int k, double 
   gemm8_body<TB>(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lower_only, tri, (int)blockIdx.x, As, Bs);
 }
 
+// Small-grid variant: 32 x 32 tile on eight waves = four 16 x 16 fragments x two halves of every 32-deep k step
+// (reduced through LDS at the end).  Below ~256 live 64 x 64 tiles the kernel above leaves most CUs idle while
+// each workgroup walks its whole k range alone (64 x 64 x k on one CU: 3.4 us per 128 of k at the f64 MFMA rate,
+// the 1024-node's longest tile 27 us); four times as many workgroups with a quarter of the work each, and the
+// triangular pruning at 32 instead of 64, shorten exactly that.  Same operand layout and rotation as above.
+constexpr int SB = 32, SLD = SB + 16;
+template <bool TB>
+__device__ __forceinline__ void gemm_small_body(int m, int n, int k, double alpha, const double* __restrict__ A,
+                                                int64_t lda, const double* __restrict__ B, int64_t ldb, double beta,
+                                                double* __restrict__ C, int64_t ldc, int lower_only, int tri,
+                                                int block_id, double (*As)[SLD], double (*Bs)[SLD], double* red) {
+  int tm, tn;
+  tile_of_block(lower_only, tri, m / SB, n / SB, tm, tn, block_id);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fm = (w >> 1) & 1, fn = w & 1, kh = w >> 2;
+  v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+  int klo = 0, khi = k;
+  if (tri == 1) khi = min(k, (tn + 1) * SB);
+  else if (tri == 2) klo = min(k, tn * SB);
+  else if (tri == 3) khi = min(k, (tm + 1) * SB);
+  else if (tri == 4) klo = min(k, max(tm, tn) * SB);
+  else if (tri == 5) klo = min(k, tm * SB);
+  const double* Ab = A + (int64_t)tm * SB * lda;
+  const double* Bb = TB ? B + (int64_t)tn * SB * ldb : B + (int64_t)tn * SB;
+  const int lr = tid >> 4, lk = (tid & 15) * 2;  // [row][k, k+1] loader (32 x 32), also [k][n, n+1] for B when !TB
+  v2d a0, b0;
+  auto fetch = [&](int k0) {
+    a0 = *(const v2d*)(Ab + (int64_t)lr * lda + k0 + lk);
+    b0 = *(const v2d*)(TB ? Bb + (int64_t)lr * ldb + k0 + lk : Bb + (int64_t)(k0 + lr) * ldb + lk);
+  };
+  if (klo < khi) fetch(klo);
+  for (int k0 = klo; k0 < khi; k0 += SB) {
+    const int sc = (lr + 8 * (lk >> 2)) & (SB - 1);  // element (k, col) lives at column (col + 8 (k >> 2)) & 31
+    As[lk][sc] = a0.x;
+    As[lk + 1][sc] = a0.y;
+    if (TB) {
+      Bs[lk][sc] = b0.x;
+      Bs[lk + 1][sc] = b0.y;
+    } else {
+      *(v2d*)&Bs[lr][lk] = b0;
+    }
+    __syncthreads();
+    if (k0 + SB < khi) fetch(k0 + SB);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k4 = kh * 4 + q, kr = k4 * 4 + (lane >> 4);
+      const double bv = Bs[kr][TB ? (fn * 16 + (lane & 15) + 8 * k4) & (SB - 1) : fn * 16 + (lane & 15)];
+      acc = mfma_f64(As[kr][(fm * 16 + (lane & 15) + 8 * k4) & (SB - 1)], bv, acc);
+    }
+    __syncthreads();
+  }
+  if (kh == 1) *(v4d*)&red[((w & 3) * 64 + lane) * 4] = acc;
+  __syncthreads();
+  if (kh == 0) {
+    const v4d o = *(const v4d*)&red[((w & 3) * 64 + lane) * 4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t row = (int64_t)tm * SB + fm * 16 + (lane >> 4) + 4 * r;
+      const int64_t col = (int64_t)tn * SB + fn * 16 + (lane & 15);
+      double* dst = C + row * ldc + col;
+      const double v = alpha * (acc[r] + o[r]);
+      *dst = (beta == 0.0) ? v : fma(beta, *dst, v);
+    }
+  }
+}
+
+template <bool TB>
+__global__ __launch_bounds__(512) void gemm_small_kernel(int m, int n, int k, double alpha,
+                                                         const double* __restrict__ A, int64_t lda,
+                                                         const double* __restrict__ B, int64_t ldb,
+                                                         double beta, double* __restrict__ C, int64_t ldc,
+                                                         int lower_only, int tri) {
+  __shared__ double As[SB][SLD];
+  __shared__ double Bs[SB][SLD];
+  __shared__ __attribute__((aligned(32))) double red[4 * 64 * 4];
+  gemm_small_body<TB>(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lower_only, tri, (int)blockIdx.x, As, Bs, red);
+}
+
+// how many live 64 x 64 tiles a product may have and still take the 32 x 32 form
+static int small_tile_limit() {
+  static const int v = getenv("TGP_GEMM_SMALL") ? atoi(getenv("TGP_GEMM_SMALL")) : 256;  // tuning aid
+  return v;
+}
+
 // Two INDEPENDENT products of a recursion node in one launch: A22 -= L21 L21^T (lower tiles) and
 // T = L21 W11 both need only L21; as two dependent launches the second waited for the first although each is
 // a latency-bound chain on a handful of CUs.  Workgroups [0, nt1) run the first problem, the rest the second.
@@ -491,6 +575,18 @@ __global__ __launch_bounds__(512) void gemm_dual_kernel(Gemm8Args p1 /* A B^T */
                       p2.tri, (int)blockIdx.x - nt1, As, Bs);
 }
 
+__global__ __launch_bounds__(512) void gemm_dual_small_kernel(Gemm8Args p1 /* A B^T */, int nt1, Gemm8Args p2 /* A B */) {
+  __shared__ double As[SB][SLD];
+  __shared__ double Bs[SB][SLD];
+  __shared__ __attribute__((aligned(32))) double red[4 * 64 * 4];
+  if ((int)blockIdx.x < nt1)
+    gemm_small_body<true>(p1.m, p1.n, p1.k, p1.alpha, p1.A, p1.lda, p1.B, p1.ldb, p1.beta, p1.C, p1.ldc, p1.lower_only,
+                          p1.tri, (int)blockIdx.x, As, Bs, red);
+  else
+    gemm_small_body<false>(p2.m, p2.n, p2.k, p2.alpha, p2.A, p2.lda, p2.B, p2.ldb, p2.beta, p2.C, p2.ldc, p2.lower_only,
+                           p2.tri, (int)blockIdx.x - nt1, As, Bs, red);
+}
+
 // node step 2 + 3:  A22 -= L21 L21^T (lower)  and  T = L21 W11 (W11 lower triangular: tri 2)
 void launch_node_pair(hipStream_t s, int s2, int s1, const double* L21, double* A22, const double* W11, double* T,
                       int64_t ld) {
@@ -498,6 +594,12 @@ void launch_node_pair(hipStream_t s, int s2, int s1, const double* L21, double* 
   Gemm8Args p2{s2, s1, s1, 1.0, L21, ld, W11, ld, 0.0, T, ld, 0, 2};
   const int t2 = s2 / GB, t1 = s1 / GB;
   const int nt1 = t2 * (t2 + 1) / 2, nt2 = t2 * t1;
+  if (nt1 + nt2 <= small_tile_limit()) {
+    const int u2 = s2 / SB, u1 = s1 / SB;
+    const int ns1 = u2 * (u2 + 1) / 2, ns2 = u2 * u1;
+    hipLaunchKernelGGL(gemm_dual_small_kernel, dim3((unsigned)(ns1 + ns2)), dim3(512), 0, s, p1, ns1, p2);
+    return;
+  }
   hipLaunchKernelGGL(gemm_dual_kernel, dim3((unsigned)(nt1 + nt2)), dim3(512), 0, s, p1, nt1, p2);
 }
 
@@ -643,6 +745,12 @@ void launch_gemm(hipStream_t s, bool tb, int m, int n, int k, double alpha, cons
     return;
   }
   dim3 grid(live_tiles(GB));
+  if ((int)grid.x <= small_tile_limit()) {
+    dim3 gs(live_tiles(SB));
+    if (tb) hipLaunchKernelGGL(gemm_small_kernel<true>, gs, dim3(512), 0, s, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lo, tri);
+    else hipLaunchKernelGGL(gemm_small_kernel<false>, gs, dim3(512), 0, s, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lo, tri);
+    return;
+  }
   if (tb) hipLaunchKernelGGL(gemm_kernel8<true>, grid, dim3(512), 0, s, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lo, tri);
   else hipLaunchKernelGGL(gemm_kernel8<false>, grid, dim3(512), 0, s, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lo, tri);
 }
