@@ -613,8 +613,13 @@ static int factorise(tgp_handle h, int64_t N, int64_t keep_rows) {
   launch_row_norms(s, h->d_Xs.as<double>(), h->d_xn.as<double>(), Npad, dp);
   if (keep_rows == 0) {
     launch_assemble_K(s, h->d_Xs.as<double>(), A, N, Npad, dp, h->kind, h->variance, h->noise);
-    HIPCHK(h, hipMemsetAsync(L, 0, nn, s));
-    HIPCHK(h, hipMemsetAsync(W, 0, nn, s));
+    if (h->zeroed_L != L || h->zeroed_W != W || h->zeroed_npad != Npad) {
+      HIPCHK(h, hipMemsetAsync(L, 0, nn, s));
+      HIPCHK(h, hipMemsetAsync(W, 0, nn, s));
+      h->zeroed_L = L;
+      h->zeroed_W = W;
+      h->zeroed_npad = Npad;
+    }
     static const bool timing = getenv("TGP_TIMING") != nullptr;  // development aid: enqueue vs execution time
     std::chrono::steady_clock::time_point tq0;
     if (timing) { (void)hipStreamSynchronize(s); tq0 = std::chrono::steady_clock::now(); }
@@ -633,8 +638,10 @@ static int factorise(tgp_handle h, int64_t N, int64_t keep_rows) {
     HIPCHK(h, h->s_grad.reserve((size_t)s2 * Npad * sizeof(double)));
     double* As = h->s_grad.as<double>() - (size_t)lo * Npad;
     launch_assemble_K(s, h->d_Xs.as<double>(), As, N, Npad, dp, h->kind, h->variance, h->noise, lo);
-    HIPCHK(h, hipMemsetAsync(L + (size_t)lo * Npad, 0, (size_t)s2 * Npad * sizeof(double), s));
-    HIPCHK(h, hipMemsetAsync(W + (size_t)lo * Npad, 0, (size_t)s2 * Npad * sizeof(double), s));
+    if (h->zeroed_L != L || h->zeroed_W != W || h->zeroed_npad != Npad) {  // (cannot happen: the append path keeps its buffers)
+      HIPCHK(h, hipMemsetAsync(L + (size_t)lo * Npad, 0, (size_t)s2 * Npad * sizeof(double), s));
+      HIPCHK(h, hipMemsetAsync(W + (size_t)lo * Npad, 0, (size_t)s2 * Npad * sizeof(double), s));
+    }
     double* A21 = As + (size_t)lo * Npad;
     double* L21 = L + (size_t)lo * Npad;
     double* A22 = As + (size_t)lo * Npad + lo;
@@ -740,6 +747,9 @@ int tgp_clone_from(tgp_handle dst, tgp_handle src) {
     HIPCHK(dst, copy(dst->d_err, src->d_err, Npad * sizeof(double)));
     dst->N = src->N;
     dst->Npad = src->Npad;
+    dst->zeroed_L = src->zeroed_L == src->d_L.p ? dst->d_L.p : nullptr;  // the copies carry the zeros along
+    dst->zeroed_W = src->zeroed_W == src->d_W.p ? dst->d_W.p : nullptr;
+    dst->zeroed_npad = src->zeroed_npad;
     HIPCHK(dst, hipStreamSynchronize(s));
     dst->have_data = true;
     dst->data_version = ++g_data_version;

@@ -72,6 +72,10 @@ struct tgp_handle_s {
   double variance = 1.0, noise = 1.0, mean_const = 0.0;
   std::vector<double> ls;  // [d]
   int64_t N = 0, Npad = 0;
+  // The factorisation only ever writes zeros above the diagonals of d_L / d_W and rewrites every block below them:
+  // the buffers are wiped once per (allocation, Npad), not on every update (2 x Npad^2 x 8 bytes of HBM writes)
+  const void *zeroed_L = nullptr, *zeroed_W = nullptr;
+  int64_t zeroed_npad = 0;
   int variant = 0;
   // arithmetic of the plain (non-joint) sweeps: TGP_PREC_F64, or TGP_PREC_I8X4 = W K* on the int8 matrix cores with
   // four digit planes per operand (tgp_set_precision); the planes of W are rebuilt lazily per factorisation

@@ -29,6 +29,7 @@
 // development aid (tools/ubench_leaf.hip): time stamps of thread 0 at the phase boundaries
 #ifndef TGP_LEAF_TICK
 #define TGP_LEAF_TICK(i)
+#define TGP_LEAF_TICKW(i)
 #endif
 
 namespace tgp {
@@ -226,7 +227,10 @@ __global__ __launch_bounds__(512) void leaf128_kernel(const double* __restrict__
   }
   if (tid < QB * NWORK * WSLOTS) {
     const int kb = tid / (NWORK * WSLOTS), wk = (tid / WSLOTS) % NWORK, u = tid % WSLOTS;
-    items[tid] = kb >= 1 ? make_work_item(kb, wk + NWORK * u) : WorkItem{};
+    // waves 4 and 5 (wk 2, 3) share the panel waves' SIMDs: they come last in the hand-out, so that they are the
+    // ones left without work when a panel has few items
+    const int rank = wk < 2 ? wk : (wk < 4 ? wk + 2 : wk - 2);
+    items[tid] = kb >= 1 ? make_work_item(kb, rank + NWORK * u) : WorkItem{};
   }
   __syncthreads();
   TGP_LEAF_TICK(0);
@@ -245,6 +249,8 @@ __global__ __launch_bounds__(512) void leaf128_kernel(const double* __restrict__
 #pragma unroll
       for (int u = 0; u < WSLOTS; ++u) {
         const v4i e0 = tab[2 * u], e1 = tab[2 * u + 1];  // per-lane copies of wave-uniform values
+        flags[u] = 0;
+        if (!(__builtin_amdgcn_readfirstlane(e1.z) & 4)) continue;  // no item in this slot (wave-uniform)
         const char* const pa = S8 + lane_a + e0.x;
         const char* const pb1 = S8 + (e0.z ? lane_o : lane_a) + e0.y;
         const int step = e0.z ? 4 * RB : 32;
