@@ -16,6 +16,7 @@ agg=collections.OrderedDict()
 for r in seg:
     k=(r[0].split('(')[0].replace('void ','').replace('tgp::','')[:34], r[3])
     a=agg.setdefault(k,[0,0.0]); a[0]+=1; a[1]+=r[2]-r[1]
+print("kernels with 256 workgroups, in order (us):", " ".join(f"{1e-3*(r[2]-r[1]):.0f}" for r in seg if r[3]==256))
 for k,v in sorted(agg.items(), key=lambda kv:-kv[1][1]):
     print(f"{k[0]:34s} wgs={k[1]:5d} n={v[0]:4d} avg={1e-3*v[1]/v[0]:7.1f} us  total={1e-3*v[1]:8.1f} us")
 PY
