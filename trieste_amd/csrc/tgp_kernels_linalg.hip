@@ -745,7 +745,10 @@ void launch_gemm(hipStream_t s, bool tb, int m, int n, int k, double alpha, cons
     return;
   }
   dim3 grid(live_tiles(GB));
-  if ((int)grid.x <= small_tile_limit()) {
+  // (not for lower_only: the 32 x 32 form would leave the upper-right quarter of the diagonal 64 x 64 blocks
+  // unwritten, and the callers of this entry point -- the NLML reduction over K^-1 -- read whole 64 x 64 tiles;
+  // the factor recursion, whose consumers read strictly the lower triangle, goes through launch_node_pair)
+  if (!lower_only && (int)grid.x <= small_tile_limit()) {
     dim3 gs(live_tiles(SB));
     if (tb) hipLaunchKernelGGL(gemm_small_kernel<true>, gs, dim3(512), 0, s, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lo, tri);
     else hipLaunchKernelGGL(gemm_small_kernel<false>, gs, dim3(512), 0, s, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lo, tri);
