@@ -317,10 +317,12 @@ void chol_inv(hipStream_t st, const FactorWs& f, int64_t lo, int64_t hi) {
   double* W11 = W + lo * ld + lo;
   double* A22 = A + mid * ld + mid;
   launch_gemm(st, true, s2, s1, s1, 1.0, A21, ld, W11, ld, 0.0, L21, ld, false, 1);
-  // A22 -= L21 L21^T and T = L21 W11 (into the dead A21) are independent: below the big-tile sizes they
-  // share one launch instead of queueing behind each other
+  // A22 -= L21 L21^T and T = L21 W11 (into the dead A21) are independent: they share one launch instead of queueing
+  // behind each other -- at every node size (the two grids fill each other's last, partly empty round of workgroups:
+  // N = 4096 update 2.79 -> 2.64 ms when the nodes >= 1024 joined in; running T on a CU-masked side stream underneath
+  // the right half's factorisation instead measured 2.72 ms)
   static const bool pair = getenv("TGP_NO_PAIR") == nullptr;  // A/B aid
-  const bool fused = pair && (int64_t)(s2 / 64) * (s1 / 64) < 512 && (int64_t)(s2 / 64) * (s2 / 64) < 512;
+  const bool fused = pair;
   if (fused) {
     launch_node_pair(st, s2, s1, L21, A22, W11, A21, ld);
   } else {
