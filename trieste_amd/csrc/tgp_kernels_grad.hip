@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void nlml_grad_kernel(ModelDev m, const double
   // G_ij dK_ij is symmetric: only the tiles on and below the diagonal are visited (K^-1 is produced for
   // those tiles only), off-diagonal ones count twice
   if (blockIdx.x > blockIdx.y) {
-    if (tid < m.d + 2) partial[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * NG_MAXP + tid] = 0.0;
+    if (tid < m.d + 2) partial[(int64_t)tid * gridDim.x * gridDim.y + (int64_t)blockIdx.y * gridDim.x + blockIdx.x] = 0.0;
     return;
   }
   const double sym = (blockIdx.x == blockIdx.y) ? 1.0 : 2.0;
@@ -332,24 +332,27 @@ __global__ __launch_bounds__(256) void nlml_grad_kernel(ModelDev m, const double
     if (tid < d) v *= -2.0 / m.ls[tid];
     else if (tid == d) v /= m.variance;
     const int64_t b = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
-    partial[b * NG_MAXP + tid] = v;
+    partial[(int64_t)tid * gridDim.x * gridDim.y + b] = v;  // [term][block]: the final reduction reads it coalesced
   }
 }
 
 // out[0] = nlml, out[1..d] = d/d lengthscale, out[d+1] = d/d variance, out[d+2] = d/d noise,
 // out[d+3] = d/d mean.  One workgroup; fixed summation order.
-__global__ __launch_bounds__(256) void nlml_final_kernel(ModelDev m, const double* __restrict__ L,
-                                                         const double* __restrict__ err,
-                                                         const double* __restrict__ partial, int64_t nblocks,
-                                                         double* __restrict__ out) {
-  __shared__ double red[4][NG_MAXP + 3];
+__global__ __launch_bounds__(1024) void nlml_final_kernel(ModelDev m, const double* __restrict__ L,
+                                                          const double* __restrict__ err,
+                                                          const double* __restrict__ partial, int64_t nblocks,
+                                                          double* __restrict__ out) {
+  // up to 1024 threads: the N diagonal entries of L are N separate cache lines and the block partials are d + 2 rows of
+  // `nblocks` values -- with 256 threads and a block-major layout this kernel walked them 16 deep per thread
+  // (100 us at N = 4096, as long as the N^2 pair reduction before it)
+  __shared__ double red[16][NG_MAXP + 3];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int d = m.d, np = d + 2;
   double acc[NG_MAXP + 3];
   for (int c = 0; c < np + 3; ++c) acc[c] = 0.0;
-  for (int64_t b = tid; b < nblocks; b += 256)
-    for (int c = 0; c < np; ++c) acc[c] += partial[b * NG_MAXP + c];
-  for (int64_t i = tid; i < m.N; i += 256) {
+  for (int c = 0; c < np; ++c)
+    for (int64_t b = tid; b < nblocks; b += blockDim.x) acc[c] += partial[(int64_t)c * nblocks + b];
+  for (int64_t i = tid; i < m.N; i += blockDim.x) {
     acc[np] += err[i] * m.alpha[i];
     acc[np + 1] += log(L[i * m.Npad + i]);
     acc[np + 2] += m.alpha[i];
@@ -360,7 +363,11 @@ __global__ __launch_bounds__(256) void nlml_final_kernel(ModelDev m, const doubl
   }
   __syncthreads();
   if (tid == 0) {
-    auto tot = [&](int c) { return (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]); };
+    auto tot = [&](int c) {
+      double t = 0.0;
+      for (int g = 0; g < (int)(blockDim.x >> 6); ++g) t += red[g][c];
+      return t;
+    };
     out[0] = 0.5 * tot(np) + tot(np + 1) + 0.5 * (double)m.N * 1.8378770664093453;  // log(2 pi)
     for (int c = 0; c < np; ++c) out[1 + c] = 0.5 * tot(c);
     out[1 + np] = -tot(np + 2);
@@ -369,7 +376,7 @@ __global__ __launch_bounds__(256) void nlml_final_kernel(ModelDev m, const doubl
 
 // value only (find_best_model_initialization compares losses, no gradient): no K^-1, no pair reduction
 void launch_nlml_value(hipStream_t s, const ModelDev& m, const double* L, const double* err, double* out) {
-  hipLaunchKernelGGL(nlml_final_kernel, dim3(1), dim3(256), 0, s, m, L, err, (const double*)nullptr, (int64_t)0, out);
+  hipLaunchKernelGGL(nlml_final_kernel, dim3(1), dim3(m.N > 1024 ? 1024 : 256), 0, s, m, L, err, (const double*)nullptr, (int64_t)0, out);
 }
 
 int64_t nlml_blocks(int64_t Npad) { return (Npad / 64) * (Npad / 64); }
@@ -385,7 +392,7 @@ void launch_nlml(hipStream_t s, const ModelDev& m, const double* Kinv, const dou
     case 16: hipLaunchKernelGGL(nlml_grad_kernel<16>, grid, dim3(256), 0, s, m, Kinv, partial); break;
     default: hipLaunchKernelGGL(nlml_grad_kernel<32>, grid, dim3(256), 0, s, m, Kinv, partial); break;
   }
-  hipLaunchKernelGGL(nlml_final_kernel, dim3(1), dim3(256), 0, s, m, L, err, partial, nlml_blocks(m.Npad), out);
+  hipLaunchKernelGGL(nlml_final_kernel, dim3(1), dim3(m.N > 1024 ? 1024 : 256), 0, s, m, L, err, partial, nlml_blocks(m.Npad), out);
 }
 
 }  // namespace tgp
