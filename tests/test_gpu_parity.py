@@ -873,3 +873,33 @@ def test_gibbon_repulsion_by_rank_m_update_equals_the_twin_sweep(cfg, monkeypatc
         ref3 = O.gibbon_quality_term(m3, v3, samples, noise) + 0.5 * w * (np.log(vt + noise) - np.log(v3 + noise))
         g3 = np.max((samples[None, :] - m3[:, None]) / np.sqrt(v3)[:, None], axis=1) <= 30.0
         assert_close(eng.acq_values("gibbon", 0.0, Xq)[g3], ref3[g3], rtol=1e-6, atol=sens[g3] * 10, what="foreign twin")
+
+
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N", [1, 15, 16, 17, 127, 128, 129, 255, 256, 257, 383, 384, 640])
+def test_factor_at_the_leaf_and_panel_boundaries(N):
+    """`update` around the sizes where the 128-leaf's structure changes (16-row panels, two-row-set panels, one vs
+    several leaves, padding rows inside a leaf): L, W = L^-1 and alpha against the oracle."""
+    rng = np.random.default_rng(100 + N)
+    d, noise = 3, 1e-3
+    X = rng.uniform(size=(N, d))
+    Y = np.sin(3.0 * X.sum(axis=1)) + 0.1 * rng.standard_normal(N)
+    ls = np.array([0.4, 0.5, 0.6])
+    eng = _engine("matern52", d, 1.3, ls, noise, 0.2, X, Y)
+    st = O.gpr_update("matern52", 1.3, ls, noise, 0.2, X, Y)
+    L, W, alpha = eng.get_factor()
+    floor = cancellation_floor(N, 1.3, noise)
+    assert_close(L, st.L, atol=floor, what="L")
+    assert np.array_equal(L, np.tril(L)) and np.array_equal(W, np.tril(W)), "zeros above the diagonals"
+    assert_close(W @ st.L, np.eye(N), rtol=0, atol=1e-9 * (1 + 1.3 / noise), what="W L = I")
+    import scipy.linalg as sla
+
+    oalpha = sla.cho_solve((st.L, True), st.err)
+    assert_close(alpha, oalpha, atol=floor * max(1.0, np.abs(oalpha).max()) / noise, what="alpha")
+    # a second, different factorisation in the same buffers (L / W are wiped once per allocation, not per update)
+    Y2 = np.cos(2.0 * X[:, 0]) - X[:, 1]
+    eng.set_data(X[::-1].copy(), Y2[::-1].copy())
+    st2 = O.gpr_update("matern52", 1.3, ls, noise, 0.2, X[::-1], Y2[::-1])
+    L2, W2, _ = eng.get_factor()
+    assert_close(L2, st2.L, atol=floor, what="L (second update)")
+    assert np.array_equal(L2, np.tril(L2)) and np.array_equal(W2, np.tril(W2))
