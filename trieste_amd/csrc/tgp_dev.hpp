@@ -44,28 +44,10 @@ __device__ __forceinline__ double fast_sqrt_pos(double x) {
   return g;
 }
 
-// sqrt(x) and 1/sqrt(x) together (x > 0, normal range): the coupled Goldschmidt pair of the routine
-// above, g -> sqrt(x), h -> 1 / (2 sqrt(x)); both within ~1 ulp.
-__device__ __forceinline__ void sqrt_and_rsqrt(double x, double& g_out, double& rs_out) {
-  const double y = __builtin_amdgcn_rsq(x);
-  double g = x * y, h = 0.5 * y;
-  double r = fma(-h, g, 0.5);
-  g = fma(g, r, g);
-  h = fma(h, r, h);
-  r = fma(-h, g, 0.5);
-  g = fma(g, r, g);
-  h = fma(h, r, h);
-  const double dd = fma(-g, g, x);
-  g = fma(dd, h, g);
-  r = fma(-h, g, 0.5);   // one more correction of h against the final g
-  h = fma(h, r, h);
-  g_out = g;
-  rs_out = h + h;
-}
-
-// The same pair with ONE coupled iteration (the pivot chain of the factor leaf is a serial dependency of the
-// whole wave: every dependent fp64 op costs ~10 cycles x 64 pivots x 64 leaves).  v_rsq_f64 delivers ~2^-26;
-// one Goldschmidt step squares that, the residual step on g brings sqrt(x) to ~1 ulp, 1/sqrt(x) to ~2 ulp.
+// sqrt(x) and 1/sqrt(x) together (x > 0, normal range): the coupled Goldschmidt pair g -> sqrt(x),
+// h -> 1 / (2 sqrt(x)) with ONE coupled iteration (the pivot chain of the 64-leaf is a serial dependency of its
+// wave).  v_rsq_f64 delivers ~2^-26; one Goldschmidt step squares that, the residual step on g brings sqrt(x) to
+// ~1 ulp, 1/sqrt(x) to ~2 ulp.
 __device__ __forceinline__ void sqrt_and_rsqrt_short(double x, double& g_out, double& rs_out) {
   const double y = __builtin_amdgcn_rsq(x);
   double g = x * y, h = 0.5 * y;

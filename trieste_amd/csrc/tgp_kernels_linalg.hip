@@ -92,84 +92,15 @@ void launch_assemble_K(hipStream_t s, const double* Xs, double* A, int64_t N, in
 }
 
 // ---------------------------------------------------------------------------------------------
-// Leaf: Cholesky factor L of a 64x64 diagonal block AND W = L^-1, one workgroup of 256 threads.
-// info: 0 = ok, else 1 + global index of the first non-positive pivot.
-//
-// Register-resident right-looking elimination.  Thread (i = tid >> 2, p = tid & 3) owns the 16
-// entries {A[i][p + 4m]} of row i of the (symmetric) trailing matrix and the same 16 entries of
-// row i of T, which starts as the identity and ends as L^-1 (T <- L_j^-1 T for j = 0..63 is the
-// same rank-1 update shape as the trailing update, so both ride on one broadcast per step).
-// Step j (fully unrolled, so every register index is static):
-//   owners of column j of A and of row j of T publish them through a double-buffered LDS strip,
-//   ONE barrier, then every thread applies
-//       A[i][k] -= A[i][j] A[k][j] / d_j   (k > j)        T[i][c] -= A[i][j] T[j][c] / d_j   (i > j, c <= j)
-//   and the owner of (i, j) overwrites its dead A register with L[i][j] = A[i][j] / sqrt(d_j).
-// 17 fused multiply-adds and ~10 LDS reads per thread per step; the upper triangle of A is updated
-// too (never read back) which removes every row/column predicate except "k > j" in one register.
-__global__ __launch_bounds__(256) void leaf_kernel(const double* __restrict__ A, double* __restrict__ L,
-                                                   double* __restrict__ W, int64_t ld, int64_t off,
-                                                   int* __restrict__ info) {
-  // strips are laid out [p][m] so that a thread's 16 entries are contiguous (b128 reads)
-  __shared__ __attribute__((aligned(16))) double colbuf[2][LEAF];
-  __shared__ __attribute__((aligned(16))) double rowbuf[2][LEAF];
-  const int tid = threadIdx.x;
-  const int i = tid >> 2, p = tid & 3;
-  double a[16], t[16], myrs = 1.0;
-#pragma unroll
-  for (int m = 0; m < 16; ++m) {
-    const int k = p + 4 * m;
-    // symmetric fill from the lower triangle (the upper one of the global block is not trusted)
-    a[m] = (k <= i) ? A[(off + i) * ld + off + k] : A[(off + k) * ld + off + i];
-    t[m] = (k == i) ? 1.0 : 0.0;
-  }
-#pragma unroll
-  for (int j = 0; j < LEAF; ++j) {
-    const int jm = j >> 2, jp = j & 3, bsel = j & 1;
-    if (p == jp) colbuf[bsel][(i & 3) * 16 + (i >> 2)] = a[jm];
-    if (i == j) {
-#pragma unroll
-      for (int m = 0; m <= jm; ++m) rowbuf[bsel][p * 16 + m] = t[m];
-    }
-    __syncthreads();
-    double dj = colbuf[bsel][jp * 16 + jm];
-    if (!(dj > 0.0)) {  // also catches NaN
-      if (tid == 0) atomicCAS(info, 0, (int)(off + j) + 1);
-      dj = 1.0;
-    }
-    double sd, rs;
-    sqrt_and_rsqrt(dj, sd, rs);  // ~15 instructions instead of the ~100 of three IEEE divisions + sqrt
-    const double inv = rs * rs;
-    const double lij = colbuf[bsel][(i & 3) * 16 + (i >> 2)];
-    const double f = lij * inv;
-    // trailing update of A, columns k = p + 4m > j
-#pragma unroll
-    for (int m = jm; m < 16; ++m) {
-      const double ck = colbuf[bsel][p * 16 + m];
-      const double upd = fma(-f, ck, a[m]);
-      a[m] = (m > jm || p > jp) ? upd : a[m];
-    }
-    if (p == jp) a[jm] = (i == j) ? sd : lij * rs;  // L[i][j] (rows i < j hold garbage, masked on store)
-    // T <- L_j^-1 T: rows i > j take -L[i][j] * (row j / sd) = -(lij / dj) * (unscaled row j); the
-    // 1/sd scaling of row j itself is deferred to the store (branch-free: no register-array copies).
-    const double ft = (i > j) ? f : 0.0;
-    myrs = (i == j) ? rs : myrs;
-#pragma unroll
-    for (int m = 0; m <= jm; ++m) t[m] = fma(-ft, rowbuf[bsel][p * 16 + m], t[m]);
-  }
-#pragma unroll
-  for (int m = 0; m < 16; ++m) {
-    const int k = p + 4 * m;
-    L[(off + i) * ld + off + k] = (k <= i) ? a[m] : 0.0;
-    W[(off + i) * ld + off + k] = (k <= i) ? t[m] * myrs : 0.0;
-  }
-}
-
 // ---------------------------------------------------------------------------------------------
-// Blocked form of the same leaf: 16-wide panels, the 64 x 64 block resident in LDS.
-//   per panel:  (1) wave 0 factors the 16 x 16 diagonal block AND inverts it with the register-resident
-//                   rank-1 scheme above at 1/4 scale (64 lanes, 4 + 4 entries each) -- a single wave, so its
-//                   16 pivot steps need no workgroup barrier (the 64-step form pays LDS round trip + barrier
-//                   per pivot: 0.34 us with the arithmetic removed);
+// 64 x 64 leaf (Cholesky factor L of a diagonal block AND W = L^-1, one workgroup of 256 threads; info: 0 = ok, else
+// 1 + global index of the first non-positive pivot).  Used for the odd 64-block of a node whose size is not a multiple
+// of 128 (rank-k appends, small joint covariances); everything else goes through the 128-leaf of tgp_kernels_leaf.hip.
+// 16-wide panels, the 64 x 64 block resident in LDS.
+//   per panel:  (1) wave 0 factors the 16 x 16 diagonal block AND inverts it with a register-resident rank-1
+//                   scheme (64 lanes, 4 + 4 entries each; column j of L and row j of the running inverse travel
+//                   through a double-buffered LDS strip) -- a single wave, so its 16 pivot steps need no workgroup
+//                   barrier;
 //               (2) panel  L_p = A_p W_d^T  (VALU, <= 48 x 16 outputs);
 //               (3) trailing update  A_22 -= L_p L_p^T  by MFMA (<= 6 tiles of 16 x 16, k = 16);
 //   then the blocked triangular inverse  W[bi][bk] = -W_d[bi] sum_j L[bi][j] W[j][bk]  by MFMA (the
@@ -321,9 +252,7 @@ __global__ __launch_bounds__(256) void leaf_blocked_kernel(const double* __restr
 
 void launch_leaf(hipStream_t s, const double* A, double* L, double* W, int64_t ld, int64_t off,
                  int* info) {
-  static const bool rank1 = getenv("TGP_LEAF_RANK1") != nullptr;  // A/B aid: the 64-step form (31 us; blocked: 25 us)
-  if (rank1) hipLaunchKernelGGL(leaf_kernel, dim3(1), dim3(256), 0, s, A, L, W, ld, off, info);
-  else hipLaunchKernelGGL(leaf_blocked_kernel, dim3(1), dim3(256), 0, s, A, L, W, ld, off, info);
+  hipLaunchKernelGGL(leaf_blocked_kernel, dim3(1), dim3(256), 0, s, A, L, W, ld, off, info);
 }
 
 // ---------------------------------------------------------------------------------------------
