@@ -166,6 +166,12 @@ struct WorkItem {
   int a1, b1, b1nat, o;       // block origins (bytes); b1nat: natural (1) or transposed (0) B operand
   int a2, b2, flags, pad;     // second product (natural B); flags: has2 | keep << 1 | valid << 2
 };
+// Workers are the waves 2 .. 7.  Measured alternatives (tools/ubench_leaf.hip; a panel alone takes ~4650 cycles):
+//   waves 2..7, four items each (this):     panel 5000-5700 (waves 4, 5 share the panel waves' SIMDs), workers done first;
+//   waves 2, 3, 6, 7 only, six items each:  panel 4400-4700, but the workers need ~6700 (one wave issues a float64
+//                                           MFMA only every ~128 cycles) and the panel waves wait 1300-3300 for them;
+//   twelve waves, workers 2,3,6,7,10,11:    panel 4700-5400, workers ~7000 (three waves per SIMD queue on its MFMA pipe);
+//   all of a worker's loads up front:       workers ~5300, panel 5800-6300 (more LDS traffic against the panel waves).
 constexpr int NWORK = 6, WSLOTS = 4;  // worker waves, items per worker and panel (<= 21 items per panel)
 
 __device__ __forceinline__ WorkItem make_work_item(int kb, int idx) {
