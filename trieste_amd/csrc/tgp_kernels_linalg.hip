@@ -753,17 +753,34 @@ void launch_row_norms(hipStream_t s, const double* Xs, double* xn, int64_t Npad,
   hipLaunchKernelGGL(row_norms_kernel, dim3((unsigned)((Npad + 255) / 256)), dim3(256), 0, s, Xs, xn, Npad, dp);
 }
 
-// one wave per row: y[i] = sum_{k in tri range} M[i][k] x[k]
+// one wave per row: y[i] = sum_{k in tri range} M[i][k] x[k].  The row is walked from a 16-byte aligned start
+// (entries outside the triangle are explicit zeros in both users, W and Wt) with two entries per lane and load and
+// four independent partial sums, so that eight loads per lane are in flight instead of one dependent chain.
 __global__ __launch_bounds__(256) void trmv_kernel(const double* __restrict__ Mx, int64_t ld, int64_t n,
                                                    const double* __restrict__ x, double* __restrict__ y,
                                                    int lower) {
   const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (i >= n) return;
-  const int64_t lo = lower ? 0 : i, hi = lower ? i + 1 : n;
-  double acc = 0.0;
-  for (int64_t k = lo + lane; k < hi; k += 64) acc = fma(Mx[i * ld + k], x[k], acc);
-  acc = wave_sum(acc);
+  const int64_t lo = lower ? 0 : (i & ~(int64_t)1), hi = lower ? ((i + 2) & ~(int64_t)1) : n;  // even bounds (n is even)
+  const double* row = Mx + i * ld;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int64_t k = lo + 2 * lane;
+  for (; k + 384 < hi; k += 512) {
+    const v2d m0 = *(const v2d*)(row + k), m1 = *(const v2d*)(row + k + 128);
+    const v2d m2 = *(const v2d*)(row + k + 256), m3 = *(const v2d*)(row + k + 384);
+    const v2d x0 = *(const v2d*)(x + k), x1 = *(const v2d*)(x + k + 128);
+    const v2d x2 = *(const v2d*)(x + k + 256), x3 = *(const v2d*)(x + k + 384);
+    a0 = fma(m0.y, x0.y, fma(m0.x, x0.x, a0));
+    a1 = fma(m1.y, x1.y, fma(m1.x, x1.x, a1));
+    a2 = fma(m2.y, x2.y, fma(m2.x, x2.x, a2));
+    a3 = fma(m3.y, x3.y, fma(m3.x, x3.x, a3));
+  }
+  for (; k < hi; k += 128) {
+    const v2d m0 = *(const v2d*)(row + k), x0 = *(const v2d*)(x + k);
+    a0 = fma(m0.y, x0.y, fma(m0.x, x0.x, a0));
+  }
+  double acc = wave_sum((a0 + a1) + (a2 + a3));
   if (lane == 0) y[i] = acc;
 }
 void launch_trmv(hipStream_t s, const double* Mx, int64_t ld, int64_t n, const double* x, double* y,
