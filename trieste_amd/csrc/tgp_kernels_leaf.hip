@@ -172,7 +172,8 @@ struct WorkItem {
 //                                           MFMA only every ~128 cycles) and the panel waves wait 1300-3300 for them;
 //   twelve waves, workers 2,3,6,7,10,11:    panel 4700-5400, workers ~7000 (three waves per SIMD queue on its MFMA pipe);
 //   all of a worker's loads up front:       workers ~5300, panel 5800-6300 (more LDS traffic against the panel waves).
-constexpr int NWORK = 6, WSLOTS = 4;  // worker waves, items per worker and panel (<= 21 items per panel)
+constexpr int NWORK = 6, WSLOTS = 4;  // worker waves, items per worker and panel (<= 22 items per panel)
+constexpr int SCRATCH_BLK = (0 * 16 * QS + 16 * 7) * 8;  // block (0, 7): the blocks above the block diagonal are never used
 
 __device__ __forceinline__ WorkItem make_work_item(int kb, int idx) {
   const int pb = kb - 1;
@@ -191,6 +192,10 @@ __device__ __forceinline__ WorkItem make_work_item(int kb, int idx) {
     } else {           // T[bi][pb-1] = -L[bi][pb-1] W_d[pb-1] - L[bi][pb] T[pb][pb-1]  (replaces the L block)
       it.a2 = blk(bi, pb - 1); it.b2 = blk(pb - 1, pb - 1); it.flags = 1 | 4;
     }
+  } else if (idx == ns + nt) {
+    // T~[kb][pb] = -L[kb][pb] W_d[pb], the one entry of row kb of T that no earlier step could prepare, into the
+    // scratch block: row kb's slot (kb, pb) still holds L[kb][pb], which this panel's other items read
+    it.a1 = blk(kb, pb); it.b1 = blk(pb, pb); it.b1nat = 1; it.o = SCRATCH_BLK; it.flags = 4;
   }
   return it;
 }
@@ -201,10 +206,11 @@ __device__ __forceinline__ WorkItem make_work_item(int kb, int idx) {
 //   [P kb]  waves 0, 1: panel kb (block column kb only).
 //           workers:    trailing updates of panel pb for block columns > kb;  contributions of source row pb to the
 //                       rows bi >= kb (columns c < pb), the one for c = pb - 1 fused with the initial term
-//                       -L[bi][pb-1] W_d[pb-1] that replaces the L block (nobody reads L[.][pb-1] any more).
+//                       -L[bi][pb-1] W_d[pb-1] that replaces the L block (nobody reads L[.][pb-1] any more);
+//                       T~[kb][pb] for [C kb].
 //   barrier
 //   [C kb]  one item per wave: trailing update of panel kb for block column kb + 1 (all the next panel needs), and
-//           row kb of T:  T[kb][c] = W_d[kb] T~[kb][c]  (c < pb),  T[kb][pb] = -W_d[kb] (L[kb][pb] W_d[pb]).
+//           row kb of T:  T[kb][c] = W_d[kb] T~[kb][c]  (T~[kb][pb] = -L[kb][pb] W_d[pb] comes from a worker, via a scratch block).
 //   barrier
 // so the critical path per panel is the panel itself, one 16 x 16 x 16 product and two barriers.
 __global__ __launch_bounds__(512) void leaf128_kernel(const double* __restrict__ A, double* __restrict__ L,
@@ -319,18 +325,12 @@ __global__ __launch_bounds__(512) void leaf128_kernel(const double* __restrict__
         double wd[4];
 #pragma unroll
         for (int k4 = 0; k4 < 4; ++k4) wd[k4] = ldsd(pwd + 32 * k4);
+        // T~[kb][c]: complete in its slot for c < pb; the last one, -L[kb][pb] W_d[pb], was left in the scratch block by a
+        // worker during the panel (the accumulator layout IS the natural B operand layout: entry r <-> k-group r)
+        const char* const px = (c < pb) ? (const char*)po : S8 + lane_o + SCRATCH_BLK;
         v4d x;
-        if (c < pb) {  // T~[kb][c], complete
 #pragma unroll
-          for (int r = 0; r < 4; ++r) x[r] = ldsd(po + 4 * RB * r);
-        } else {       // T~[kb][pb] = -L[kb][pb] W_d[pb]: the accumulator layout IS the natural B operand layout
-          const char* const pa = S8 + lane_a + blk(kb, pb);
-          const char* const pb1 = S8 + lane_o + blk(pb, pb);
-          x = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-          for (int k4 = 0; k4 < 4; ++k4) x = mfma_f64(ldsd(pa + 32 * k4), ldsd(pb1 + 4 * RB * k4), x);
-          x = -x;
-        }
+        for (int r = 0; r < 4; ++r) x[r] = ldsd(px + 4 * RB * r);
         v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int k4 = 0; k4 < 4; ++k4) acc = mfma_f64(wd[k4], x[k4], acc);
