@@ -376,9 +376,17 @@ int tgp_last_kernel_ms(tgp_handle h, double* ms, int* launches);
  *                 1e-5 |var| + cancellation floor at N = 4096; an EMULATED-precision option
  *                 for throughput, never the default and never what the float64 parity claims are made on.
  *   TGP_PREC_I8X5 the same with five digit planes (15 int8 products, truncation at 2^-40 of the scales): |var error|
- *                 <= 1.5e-3 x the parity tolerance at N = 4096 and below 1e-5 RELATIVE without any floor; d <= 16. */
-enum tgp_precision { TGP_PREC_F64 = 0, TGP_PREC_I8X4 = 1, TGP_PREC_I8X5 = 2 };
+ *                 <= 1.5e-3 x the parity tolerance at N = 4096 and below 1e-5 RELATIVE without any floor; d <= 16.
+ *   TGP_PREC_AUTO after every factorisation the engine measures max |W| and picks the cheapest of the three whose
+ *                 a-priori truncation budget on the variance, 2 x (2 s_f 2^-8P S' S_max sqrt(N / 6)) with
+ *                 S_max = 2 max |W|, S' = 2 s_f^2, fits under the cancellation floor of the parity tolerance
+ *                 (min(64 eps s_f^2 (1 + N s_f^2 / s^2), 1e-6 s_f^2)): four planes if it does, else five (d <= 16),
+ *                 else float64.  tgp_get_precision reports the choice. */
+enum tgp_precision { TGP_PREC_F64 = 0, TGP_PREC_I8X4 = 1, TGP_PREC_I8X5 = 2, TGP_PREC_AUTO = 3 };
 int tgp_set_precision(tgp_handle h, int precision);
+/* What was asked for, what is in effect for the current factorisation (never TGP_PREC_AUTO) and, under AUTO, the
+ * max |W_ik| the choice was made from (0 otherwise).  Under AUTO it needs data (TGP_ERR_STATE before tgp_set_data). */
+int tgp_get_precision(tgp_handle h, int* requested, int* effective, double* w_abs_max);
 /* Sweep launch policy knob for experiments and tests (0 = default): bit 0 = never use the row-group split of
  * small launches, bit 1 = always use it, bit 2 = joint mode on the first-generation kernel (64-column group slots;
  * dp = 32 always uses it), bit 3 = fused plain launches on the register-staged kernel instead of the LDS-DMA one.  Every setting computes the same arithmetic on every candidate. */

@@ -68,7 +68,8 @@ class TorchCpuSweep:
         pdf = torch.exp(-0.5 * z * z) / math.sqrt(2.0 * math.pi)
         return (eta - mean) * cdf + sd * pdf
 
-    def chunk_values(self, Xq_np, eta: float, improved: bool):
+    def chunk_mean_var(self, Xq_np, improved: bool = False):
+        """(mean [chunk], var [chunk]) of one chunk, reference interface.py:119-124 (clip at 1e-12 included)."""
         torch = self.torch
         Xq = torch.from_numpy(np.ascontiguousarray(Xq_np))
         Ks = self._kstar(Xq)                                                        # [N, chunk]
@@ -79,6 +80,10 @@ class TorchCpuSweep:
         else:
             A2 = torch.linalg.solve_triangular(self.L.T, A, upper=True)             # L^-T A
             mean = (A2.T @ self.err)[:, 0] + self.c
+        return mean, var
+
+    def chunk_values(self, Xq_np, eta: float, improved: bool):
+        mean, var = self.chunk_mean_var(Xq_np, improved)
         return self._ei(mean, var, eta)
 
     def sweep(self, Xq_np, eta: float, chunk: int, improved: bool = False):

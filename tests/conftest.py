@@ -62,3 +62,46 @@ def _seeded_host_draws():
     set_seed(20240916)
     yield
     set_seed(None)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Write the parity margins of this session (tests/util.py MARGINS): per comparison the observed worst error as
+    a fraction of its tolerance, worst first per test.  Goes to $TGP_MARGINS_FILE, else gpurun_out/parity_margins.txt
+    when GPU tests ran."""
+    try:
+        from tests.util import MARGINS
+    except Exception:
+        return
+    if not MARGINS:
+        return
+    path = os.environ.get("TGP_MARGINS_FILE")
+    if not path:
+        if not _has_gpu():
+            return
+        path = os.path.join(ROOT, "gpurun_out", "parity_margins.txt")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        agg = {}
+        for test, what, worst, rtol, atol, n in MARGINS:
+            key = (test, what, rtol, atol)
+            w, cnt, els = agg.get(key, (0.0, 0, 0))
+            agg[key] = (max(w, worst) if worst == worst else w, cnt + 1, els + n)
+        rows = sorted(agg.items(), key=lambda kv: (kv[0][0], -kv[1][0]))
+        summary = {}
+        for (test, what, rtol, atol), (w, cnt, els) in agg.items():
+            key = (test.split("[")[0], what)
+            sw, sc, se = summary.get(key, (0.0, 0, 0))
+            summary[key] = (max(sw, w), sc + cnt, se + els)
+        with open(path, "w") as f:
+            f.write("# observed worst |error| / tolerance per parity comparison (tolerance = rtol |ref| + atol); "
+                    "1.0 = the tolerance is fully used\n")
+            f.write(f"# {len(MARGINS)} comparisons\n# ---- summary: worst over the parametrisations of a test\n")
+            f.write(f"{'worst/tol':>10} {'calls':>6} {'elements':>10}  test :: what\n")
+            for (test, what), (w, cnt, els) in sorted(summary.items(), key=lambda kv: (kv[0][0], -kv[1][0])):
+                f.write(f"{w:10.3g} {cnt:6d} {els:10d}  {test} :: {what}\n")
+            f.write(f"# ---- every comparison ({len(agg)} rows)\n")
+            f.write(f"{'worst/tol':>10} {'rtol':>8} {'atol':>10} {'calls':>6} {'elements':>10}  test :: what\n")
+            for (test, what, rtol, atol), (w, cnt, els) in rows:
+                f.write(f"{w:10.3g} {rtol:8.1e} {atol:10.2e} {cnt:6d} {els:10d}  {test} :: {what}\n")
+    except OSError:
+        pass

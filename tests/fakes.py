@@ -111,8 +111,27 @@ class FakeEngine:
         pass
 
     def set_precision(self, precision="f64"):
-        if precision not in ("f64", "i8x4", "i8x5"):
+        if precision not in ("f64", "i8x4", "i8x5", "auto"):
             raise ValueError(f"unknown precision {precision!r}")
+        self._precision = precision
+
+    def get_precision(self):
+        """The engine's rule restated (csrc/tgp_api.hip resolve_precision): twice the truncation estimate of P digit
+        planes has to fit under the cancellation floor of the parity tolerance."""
+        req = getattr(self, "_precision", "f64")
+        if req != "auto":
+            return req, req, 0.0
+        st = self._st()
+        N, v, noise = st.X.shape[0], float(st.variance), float(st.noise)
+        W = np.linalg.inv(st.L)
+        wmax = float(np.abs(np.tril(W)).max())
+        floor = min(64.0 * np.finfo(float).eps * v * (1.0 + N * v / noise), 1e-6 * v)
+
+        def budget(planes):
+            return 2.0 * (2.0 * np.sqrt(v) * 2.0 ** (-8 * planes) * (2.0 * v) * (2.0 * wmax) * np.sqrt(N / 6.0))
+
+        eff = "i8x4" if budget(4) <= floor else ("i8x5" if self.d <= 16 and budget(5) <= floor else "f64")
+        return req, eff, wmax
 
     def clone_from(self, other):
         if not isinstance(other, FakeEngine):
@@ -397,6 +416,35 @@ class FakeGroup:
 
     def eta(self):
         return self.primary.eta()
+
+    def set_precision(self, precision="f64"):
+        for m in self.members:
+            m.set_precision(precision)
+
+    def set_variant(self, v):
+        for m in self.members:
+            m.set_variant(v)
+
+    def set_penalization(self, kind, pending=None, radius=None, scale=None):
+        for m in self.members:
+            m.set_penalization(kind, pending, radius, scale)
+
+    def set_min_value_samples(self, samples):
+        for m in self.members:
+            m.set_min_value_samples(samples)
+
+    def penalized(self, kind, pending, radius, scale):
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            self.set_penalization(kind, pending, radius, scale)
+            try:
+                yield self
+            finally:
+                self.set_penalization("none")
+
+        return scope()
 
     def set_candidates(self, points):
         self._cand = np.asarray(points, float)

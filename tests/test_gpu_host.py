@@ -355,7 +355,7 @@ def test_asynchronous_rules_on_gpu():
     Fantasizer / GIBBON) through an Ask-Tell loop on the real engine (rule.py:492-833)."""
     import trieste_amd.extras as A  # superset of trieste_amd.acquisition
     from trieste_amd import objectives as OBJ
-    from trieste_amd.ask_tell_optimization import AskTellOptimizer
+    from trieste_amd.ask_tell_optimization import AskTellOptimizerNoTraining as AskTellOptimizer
     from trieste_amd.data import Dataset
 
     for make in (lambda s: A.AsynchronousOptimization(A.BatchMonteCarloExpectedImprovement(256),
@@ -365,7 +365,7 @@ def test_asynchronous_rules_on_gpu():
                  lambda s: A.AsynchronousGreedy(A.GIBBON(s, grid_size=200))):
         space, data, model, st = _setup(n=40, noise=1e-2)
         rule = make(space)
-        loop = AskTellOptimizer(space, data, model, rule, fit_model=False)
+        loop = AskTellOptimizer(space, data, model, rule)
         p1 = loop.ask()
         p2 = loop.ask()
         q = p1.shape[0]
@@ -373,7 +373,7 @@ def test_asynchronous_rules_on_gpu():
         loop.tell(Dataset(p1, OBJ.scaled_branin(p1)))
         p3 = loop.ask()
         np.testing.assert_allclose(loop.acquisition_state.pending_points, np.concatenate([p2, p3]))
-        # fit_model=False: the loop leaves the model to its caller (reference bayesian_optimizer.py:828-834)
+        # AskTellOptimizerNoTraining leaves the model to its caller (ask_tell_optimization.py:749-757)
         assert model.engine.N == 40 and np.all((p3 >= 0) & (p3 <= 1))
 
 

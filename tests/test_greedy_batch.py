@@ -152,6 +152,48 @@ def test_ego_with_local_penalization_returns_a_diverse_batch(optimizer):
     assert pts2.shape == (4, 2)
 
 
+def test_local_penalization_on_a_multi_device_model_penalises_every_shard(monkeypatch):
+    """A model built with devices=[...] shards the fused sweeps over its group; the penalization is handle state and
+    has to reach EVERY member -- set on member 0 alone, the other shards are swept unpenalised and the greedy batch
+    repeats its first point (round-2 advisor finding).  Same batch as the single-device model, point for point."""
+    import trieste_amd.group as G
+    from tests.fakes import FakeGroup
+
+    monkeypatch.setattr(G, "GPEngineGroup", FakeGroup)
+    rng = np.random.default_rng(0)
+    x = rng.uniform(size=(15, 2))
+    data = Dataset(x, OBJ.scaled_branin(x))
+
+    class SeededBox(Box):  # the Lipschitz estimate samples the space: the same sample for both models
+        def sample(self, num_samples, seed=None):
+            return super().sample(num_samples, seed=123 if seed is None else seed)
+
+    space = SeededBox([0, 0], [1, 1])
+    single = M.GaussianProcessRegression(M.build_gpr(data, space, likelihood_variance=1e-3))
+    multi = M.GaussianProcessRegression(M.build_gpr(data, space, likelihood_variance=1e-3), devices=[0, 1, 2])
+    batches = []
+    for model in (single, multi):
+        opt = generate_random_search_optimizer(3000, seed=5, on_device=False)
+        rule = EfficientGlobalOptimization(LocalPenalization(space, num_samples=200), optimizer=opt, num_query_points=4)
+        batches.append(rule.acquire_single(space, model, data))
+    np.testing.assert_array_equal(batches[0], batches[1])
+    dist = np.linalg.norm(batches[1][:, None, :] - batches[1][None, :, :], axis=-1) + np.eye(4)
+    assert dist.min() > 1e-3
+    # the scope leaves no member penalised behind
+    assert all(m._pen is None for m in multi.group.members)
+    # and the fused arg-max of a penalised function is the single-device one on a table crossing the shard bounds
+    lp1 = LocalPenalization(space, num_samples=200)
+    lp3 = LocalPenalization(space, num_samples=200)
+    pend = batches[0][:2]
+    f1 = lp1.prepare_acquisition_function(single, data, pend)
+    f3 = lp3.prepare_acquisition_function(multi, data, pend)
+    pts = rng.uniform(size=(2999, 2))
+    a, b = f1.argmax(pts), f3.argmax(pts)
+    assert (a[0], a[1]) == (b[0], b[1])
+    for u, v in zip(f1.top_k(pts, 5), f3.top_k(pts, 5)):
+        np.testing.assert_array_equal(u, v)
+
+
 # ---- Fantasizer (reference test_greedy_batch.py:187-296) ------------------------------------------------
 def _sin_model():
     x = (np.arange(1, 6).reshape(-1, 1) / 5.0)

@@ -813,13 +813,44 @@ def test_history_records_hold_per_step_model_copies():
     sizes = [len(rec.models[OBJECTIVE].get_internal_data()) for rec in res.history]
     assert sizes == [8, 9, 10] and len(final.models[OBJECTIVE].get_internal_data()) == 11
     assert all(rec.models[OBJECTIVE] is not final.models[OBJECTIVE] for rec in res.history)
+    # a record holds the GPR record only: no engine (= no device memory) until the copy is first used
+    assert all("_engine" not in rec.models[OBJECTIVE].__dict__ for rec in res.history)
     assert all(rec.models[OBJECTIVE].engine is not final.models[OBJECTIVE].engine for rec in res.history)
     assert [rec.models[OBJECTIVE].engine.N for rec in res.history] == [8, 9, 10]
 
 
+def test_model_copies_are_lazy_and_keep_their_placement(monkeypatch):
+    """copy.deepcopy(model): host record only; the engine is rebuilt (and refactorised) on first use with the SAME
+    placement -- a devices=[...] model restored from the history is still sharded (round-2 advisor finding)."""
+    import copy
+
+    import trieste_amd.group as G
+    from tests.fakes import FakeGroup
+
+    monkeypatch.setattr(G, "GPEngineGroup", FakeGroup)
+    model, data = _model(n=9)
+    ref_mean = model.predict(data.query_points[:4])[0]
+    version = model.data_version
+    twin = copy.deepcopy(model)
+    assert "_engine" not in twin.__dict__ and "_group" not in twin.__dict__
+    np.testing.assert_allclose(twin.predict(data.query_points[:4])[0], ref_mean, rtol=1e-12)
+    assert twin.engine is not model.engine and twin.group is None and twin.data_version == version
+    x_new = np.array([[0.3, 0.3]])
+    twin.update(data + Dataset(x_new, OBJ.scaled_branin(x_new)))
+    assert twin.engine.N == 10 and model.engine.N == 9
+    gpr = M.build_gpr(data, Box([0.0, 0.0], [1.0, 1.0]), likelihood_variance=1e-3)
+    multi = M.GaussianProcessRegression(gpr, devices=[0, 1])
+    mt = copy.deepcopy(multi)
+    assert "_group" not in mt.__dict__
+    assert mt.group is not None and mt.group is not multi.group and len(mt.group.members) == 2
+    assert all(m.N == 9 for m in mt.group.members) and mt.engine is mt.group.primary
+
+
 def test_fit_model_false_leaves_the_models_alone():
-    """fit_model=False: neither optimize nor update (reference bayesian_optimizer.py:828-834,
-    AskTellOptimizerNoTraining.update_model)."""
+    """BayesianOptimizer fit_model=False: neither optimize nor update (reference bayesian_optimizer.py:828-834).
+    Ask-Tell: `fit_model` is the constructor's INITIAL fit only, `tell` always updates
+    (ask_tell_optimization.py:333-340, 716-718, 744-746); AskTellOptimizerNoTraining never touches the models
+    (:749-757)."""
     model, data = _model(n=8)
     box = Box([0.0, 0.0], [1.0, 1.0])
     rule = EfficientGlobalOptimization(optimizer=generate_random_search_optimizer(100, seed=1, on_device=False))
@@ -827,8 +858,19 @@ def test_fit_model_false_leaves_the_models_alone():
     res = bo.optimize(2, data, model, rule, fit_model=False, track_state=False)
     assert len(res.final_result.unwrap().datasets[OBJECTIVE]) == 10 and model.engine.N == 8
     at = AskTellOptimizer(box, data, model, rule, fit_model=False)
-    at.tell(Dataset(at.ask(), OBJ.scaled_branin(at.ask())))
-    assert model.engine.N == 8
+    assert model.engine.N == 8  # no initial fit ...
+    q = at.ask()
+    at.tell(Dataset(q, OBJ.scaled_branin(q)))
+    assert model.engine.N == 9  # ... but a pre-trained model handed over this way still sees the new observations
+    q2 = at.ask()
+    assert not np.allclose(q, q2)  # (it would keep proposing from stale data otherwise)
+    from trieste_amd.ask_tell_optimization import AskTellOptimizerNoTraining
+
+    model2, _ = _model(n=8)
+    nt = AskTellOptimizerNoTraining(box, data, model2, rule)
+    q = nt.ask()
+    nt.tell(Dataset(q, OBJ.scaled_branin(q)))
+    assert model2.engine.N == 8 and len(nt.dataset) == 9
 
 
 def test_multiple_optimism_lcb_accepts_flat_points_and_single_query_point():

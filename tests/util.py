@@ -29,12 +29,32 @@ def cancellation_floor(N: int, variance: float, noise: float) -> float:
     return min(64.0 * EPS * variance * cond, 1e-6 * variance)
 
 
+# ---- margins: observed worst error / tolerance of every parity comparison ------------------------------------------
+# Every assert_close (and every record_margin of a hand-written comparison) notes how much of its tolerance the
+# comparison used; tests/conftest.py writes the table at the end of the session (profiles/r03_parity_margins.txt is
+# one such table from a GPU run).  A tolerance multiplier is justified by its row here, not by habit.
+MARGINS = []  # (test id, what, worst error / tolerance, rtol, atol, elements)
+
+
+def record_margin(what, err, tol, rtol=float("nan"), atol=float("nan")):
+    err, tol = np.asarray(err, dtype=np.float64), np.asarray(tol, dtype=np.float64)
+    if err.size == 0:
+        return 0.0
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ratio = np.where(err == 0.0, 0.0, err / tol)
+    worst = float(np.nanmax(ratio)) if np.any(~np.isnan(ratio)) else float("nan")
+    test = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" (")[0]
+    MARGINS.append((test, what, worst, float(np.max(rtol)), float(np.max(atol)), int(err.size)))
+    return worst
+
+
 def assert_close(actual, desired, rtol=RTOL, atol=0.0, what=""):
     actual = np.asarray(actual, dtype=np.float64)
     desired = np.asarray(desired, dtype=np.float64)
     assert actual.shape == desired.shape, f"{what}: shape {actual.shape} vs {desired.shape}"
     err = np.abs(actual - desired)
     tol = rtol * np.abs(desired) + atol
+    record_margin(what, err, tol, rtol, atol)
     bad = ~(err <= tol)
     if np.any(bad):
         i = np.argmax(err - tol)

@@ -89,6 +89,7 @@ SIGNATURES = {
     "tgp_last_kernel_ms": (C.c_int, [_vp, _dp, C.POINTER(C.c_int)]),
     "tgp_set_variant": (C.c_int, [_vp, C.c_int]),
     "tgp_set_precision": (C.c_int, [_vp, C.c_int]),
+    "tgp_get_precision": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _dp]),
 }
 
 _lib = None
@@ -126,7 +127,7 @@ def load():
 
 
 MERGES = {"rccl": 0, "peer": 1}
-PRECISIONS = {"f64": 0, "i8x4": 1, "i8x5": 2}
+PRECISIONS = {"f64": 0, "i8x4": 1, "i8x5": 2, "auto": 3}
 
 
 def check(lib, handle, rc, group=False):

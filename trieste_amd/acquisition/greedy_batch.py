@@ -97,8 +97,12 @@ class PenalizedAcquisition:
                 and pen.kind in ("soft", "hard") and pen._engine is base._engine)
 
     def _scope(self):
-        pen = self._penalization
-        return self._base_acquisition_function._engine.penalized(pen.kind, *pen.parameters)
+        # a model with devices=[...] shards the base function's fused sweeps over its group: the penalization is
+        # state of the handle, so it goes to EVERY member (member 0 alone would leave the other shards unpenalised
+        # and the greedy batch would repeat its first point)
+        pen, base = self._penalization, self._base_acquisition_function
+        owner = base._group if getattr(base, "_group", None) is not None else base._engine
+        return owner.penalized(pen.kind, *pen.parameters)
 
     def __call__(self, x):
         if self._fused():

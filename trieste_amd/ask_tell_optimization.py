@@ -35,16 +35,19 @@ class AskTellOptimizer:
         self._acquisition_rule = acquisition_rule
         self._acquisition_state = acquisition_state  # of stateful rules (ask_tell_optimization.py:237)
         self._track_data = track_data
-        self._fit_model = fit_model
         # rules with regions (trust regions) set them up against the search space and see every new data set
         # (ask_tell_optimization.py:316-330; bayesian_optimizer.py:755-770)
         if hasattr(acquisition_rule, "initialize_subspaces"):
             acquisition_rule.initialize_subspaces(search_space)
         self._filter_datasets()
-        if fit_model:
+        if fit_model:  # the INITIAL fit only (ask_tell_optimization.py:221, 333-340); `tell` always updates
             for tag, model in self._models.items():
-                model.update(self._datasets[tag])
-                model.optimize(self._datasets[tag])
+                self.update_model(model, self._datasets[tag])
+
+    def update_model(self, model, dataset: Dataset) -> None:
+        """Refresh one model with its data set: update, then train (ask_tell_optimization.py:744-746)."""
+        model.update(dataset)
+        model.optimize(dataset)
 
     def __repr__(self) -> str:
         return (f"AskTellOptimizer({self._search_space!r}, {self._datasets!r}, {self._models!r}, "
@@ -102,7 +105,16 @@ class AskTellOptimizer:
         for tag, ds in new_data.items():
             self._datasets[tag] = (self._datasets[tag] + ds) if self._track_data else ds
         self._filter_datasets()
-        if self._fit_model:  # fit_model=False: the caller trains / updates the models (AskTellOptimizerNoTraining)
-            for tag, model in self._models.items():
-                model.update(self._datasets[tag])
-                model.optimize(self._datasets[tag])
+        # `fit_model` governs the constructor's initial fit only: a pre-trained model handed over with
+        # fit_model=False (the reference's from_record / from_state, :497) still has to see the new observations
+        # (ask_tell_optimization.py:716-718)
+        for tag, model in self._models.items():
+            self.update_model(model, self._datasets[tag])
+
+
+class AskTellOptimizerNoTraining(AskTellOptimizer):
+    """The Ask-Tell loop for models the caller trains and updates (ask_tell_optimization.py:749-757): neither the
+    constructor nor ``tell`` touches the models."""
+
+    def update_model(self, model, dataset: Dataset) -> None:
+        pass

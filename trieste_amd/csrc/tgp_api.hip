@@ -147,8 +147,46 @@ void apply_penalization(tgp_handle h, double* dvals, const double* dXq, int64_t 
 //   VARIANT_REG_STAGING (8): fused plain launches on the register-staged kernel instead of the LDS-DMA one
 constexpr int VARIANT_NO_SPLIT = 1, VARIANT_FORCE_SPLIT = 2, VARIANT_JOINT_V1 = 4, VARIANT_REG_STAGING = 8;
 
+// TGP_PREC_AUTO: once per factorisation pick the cheapest arithmetic whose a-priori truncation budget on the predictive
+// variance fits under the parity tolerance where that is tightest.  Budget (the same formula the
+// parity tests grant TGP_PREC_I8X4 explicitly, tests/util.py i8x4_variance_bound): both operands are cut at 2^-8P of
+// their scales (S_i = 2 max_k |W_ik|, S' = 2 s_f^2), which leaves  |d var| <~ 2 s_f 2^-8P S' S_max sqrt(N / 6)  on
+// var = s_f^2 - |W k*|^2; twice that is required to stay below the cancellation floor min(64 eps s_f^2 (1 + N s_f^2 /
+// s^2), 1e-6 s_f^2) -- the absolute part of the tolerance, all that is left of it where var -> 0.  Four planes if
+// that holds, else five (d <= 16), else float64.  One small reduction kernel + one 8-byte copy per factorisation.
+hipError_t resolve_precision(tgp_handle h) {
+  if (h->precision_req != TGP_PREC_AUTO) {
+    h->precision = h->precision_req;
+    return hipSuccess;
+  }
+  if (h->auto_version == h->data_version && h->data_version != 0) return hipSuccess;
+  hipError_t e;
+  if ((e = h->s_small.reserve(64)) != hipSuccess) return e;
+  double* slot = h->s_small.as<double>();
+  if ((e = hipMemsetAsync(slot, 0, sizeof(double), h->stream)) != hipSuccess) return e;
+  launch_w_absmax(h->stream, h->d_W.as<double>(), h->N, h->Npad, slot);
+  double wmax = 0.0;
+  if ((e = hipMemcpyAsync(&wmax, slot, sizeof(double), hipMemcpyDeviceToHost, h->stream)) != hipSuccess) return e;
+  if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return e;
+  const double v = h->variance, eps = 2.220446049250313e-16;
+  const double floor_ = std::min(64.0 * eps * v * (1.0 + (double)h->N * v / h->noise), 1e-6 * v);
+  auto budget = [&](int planes) {
+    return 2.0 * (2.0 * std::sqrt(v) * std::ldexp(1.0, -8 * planes) * (2.0 * v) * (2.0 * wmax) * std::sqrt((double)h->N / 6.0));
+  };
+  int pick = TGP_PREC_F64;
+  if (wmax > 0.0 && std::isfinite(wmax)) {
+    if (budget(4) <= floor_) pick = TGP_PREC_I8X4;
+    else if (h->dp <= 16 && budget(5) <= floor_) pick = TGP_PREC_I8X5;
+  }
+  h->w_abs_max = wmax;
+  h->precision = pick;
+  h->auto_version = h->data_version;
+  return hipSuccess;
+}
+
 // number of per-block winner slots a fused arg-max over `a` fills (one per candidate block of the kernel in use)
 int64_t sweep_blocks(tgp_handle h, const SweepArgs& a, bool joint) {
+  if (!joint) (void)resolve_precision(h);  // (an error here resurfaces from launch_sweep_timed)
   if (!joint && h->precision != TGP_PREC_F64) return (a.M + 63) / 64;
   return sweep_grid(a, joint);
 }
@@ -190,6 +228,7 @@ hipError_t launch_sweep_timed(tgp_handle h, const SweepArgs& a, bool joint) {
   hipError_t e;
   SweepArgs& am = const_cast<SweepArgs&>(a);
   am.split_g = 0;
+  if (!joint && (e = resolve_precision(h)) != hipSuccess) return e;
   if (!joint && h->precision != TGP_PREC_F64) return launch_sweep_i8_timed(h, am);
   if (joint && a.m.dp <= 16 && !(h->variant & VARIANT_JOINT_V1)) {
     // contiguously packed 128 x 256 tiles, Gram phase out of LDS (tgp_kernels_joint.inc)
@@ -547,17 +586,32 @@ int tgp_use_private_stream(tgp_handle h) {
 
 int tgp_set_precision(tgp_handle h, int precision) {
   if (!h) return TGP_ERR_ARG;
-  if (precision != TGP_PREC_F64 && precision != TGP_PREC_I8X4 && precision != TGP_PREC_I8X5)
+  if (precision != TGP_PREC_F64 && precision != TGP_PREC_I8X4 && precision != TGP_PREC_I8X5 && precision != TGP_PREC_AUTO)
     return fail(h, TGP_ERR_ARG, "unknown precision %d", precision);
   if (precision == TGP_PREC_I8X5 && h->dp > 16)
     return fail(h, TGP_ERR_ARG, "TGP_PREC_I8X5 supports input dimensions up to 16 (LDS), got %d", h->d);
-  h->precision = precision;
+  h->precision_req = precision;
+  h->precision = precision == TGP_PREC_AUTO ? TGP_PREC_F64 : precision;  // AUTO: resolved at the next plain sweep
+  h->auto_version = 0;
   return TGP_OK;
 }
 
 int tgp_set_variant(tgp_handle h, int variant) {
   if (!h) return TGP_ERR_ARG;
   h->variant = variant;
+  return TGP_OK;
+}
+
+int tgp_get_precision(tgp_handle h, int* requested, int* effective, double* w_abs_max) {
+  if (!h) return TGP_ERR_ARG;
+  if (int rc = set_device(h)) return rc;
+  if (h->precision_req == TGP_PREC_AUTO) {
+    if (!h->have_data) return fail(h, TGP_ERR_STATE, "TGP_PREC_AUTO is resolved per factorisation: call tgp_set_data first");
+    HIPCHK(h, resolve_precision(h));
+  }
+  if (requested) *requested = h->precision_req;
+  if (effective) *effective = h->precision;
+  if (w_abs_max) *w_abs_max = h->precision_req == TGP_PREC_AUTO ? h->w_abs_max : 0.0;
   return TGP_OK;
 }
 
@@ -1119,28 +1173,6 @@ int tgp_sample_joint(tgp_handle h, const double* Xq, int64_t n, const double* ep
   if (hinfo != 0)
     return fail(h, TGP_ERR_NOT_PD, "Cholesky of the joint posterior covariance failed at point %d: increase the jitter",
                 hinfo - 1);
-  return TGP_OK;
-}
-
-// Development aid (not part of include/tgp.h): time `reps` launches of the factor GEMM on scratch buffers.
-int tgp_debug_gemm(tgp_handle h, int m, int n, int k, int tb, int tri, int lower_only, int reps, double* ms) {
-  if (!h || !ms) return TGP_ERR_ARG;
-  if (int rc = set_device(h)) return rc;
-  const size_t ld = (size_t)std::max(std::max(m, n), k);
-  HIPCHK(h, h->s_grad.reserve(3 * ld * ld * sizeof(double)));
-  double* A = h->s_grad.as<double>();
-  double* B = A + ld * ld;
-  double* Cc = B + ld * ld;
-  HIPCHK(h, hipMemsetAsync(A, 0, 3 * ld * ld * sizeof(double), h->stream));
-  launch_gemm(h->stream, tb != 0, m, n, k, 1.0, A, ld, B, ld, 0.0, Cc, ld, lower_only != 0, tri);
-  (void)hipEventRecord(h->ev0, h->stream);
-  for (int r = 0; r < reps; ++r)
-    launch_gemm(h->stream, tb != 0, m, n, k, 1.0, A, ld, B, ld, 0.0, Cc, ld, lower_only != 0, tri);
-  (void)hipEventRecord(h->ev1, h->stream);
-  HIPCHK(h, hipEventSynchronize(h->ev1));
-  float f = 0.f;
-  HIPCHK(h, hipEventElapsedTime(&f, h->ev0, h->ev1));
-  *ms = (double)f / reps;
   return TGP_OK;
 }
 

@@ -246,6 +246,56 @@ int merge_and_fetch(tgp_group g, int V, int minimize, double* out_val, int64_t* 
   return TGP_OK;
 }
 
+// Group calls walk over the members' devices; the caller's current device (torch code in the same thread relies on
+// it) is put back when the entry point returns.
+struct DeviceGuard {
+  int dev = -1;
+  DeviceGuard() {
+    if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+  }
+  ~DeviceGuard() {
+    if (dev >= 0) (void)hipSetDevice(dev);
+    (void)hipGetLastError();
+  }
+};
+
+// First use of a fresh communicator: all-gather (member ordinal, device id) and check every member's copy before
+// any winner travels through it -- a mis-wired communicator (ranks permuted against the members' buffers) would
+// otherwise merge the right values under the wrong global indices without any error.
+int rccl_self_check(tgp_group g) {
+  const int n = g->n;
+  for (int i = 0; i < n; ++i) {
+    GHIP(g, hipSetDevice(g->devs[i]));
+    const double tag[2] = {(double)i, (double)g->devs[i]};
+    GHIP(g, hipMemcpyAsync(g->pair[i].p, tag, sizeof tag, hipMemcpyHostToDevice, g->h[i]->stream));
+    GHIP(g, hipStreamSynchronize(g->h[i]->stream));  // `tag` is a stack buffer
+  }
+  GNCCL(g, g->rccl.GroupStart());
+  for (int i = 0; i < n; ++i) {
+    if (hipSetDevice(g->devs[i]) != hipSuccess) {
+      (void)g->rccl.GroupEnd();
+      return gfail(g, TGP_ERR_HIP, "hipSetDevice(%d) failed", g->devs[i]);
+    }
+    const ncclResult_t r = g->rccl.AllGather(g->pair[i].p, g->gather[i].p, 2, ncclDouble, g->comms[i], g->h[i]->stream);
+    if (r != ncclSuccess) {
+      (void)g->rccl.GroupEnd();
+      return gfail(g, TGP_ERR_HIP, "ncclAllGather self-check (member %d): %s", i, g->rccl.GetErrorString(r));
+    }
+  }
+  GNCCL(g, g->rccl.GroupEnd());
+  std::vector<double> got(2 * (size_t)n);
+  for (int i = 0; i < n; ++i) {
+    GHIP(g, hipSetDevice(g->devs[i]));
+    GHIP(g, hipMemcpyAsync(got.data(), g->gather[i].p, got.size() * sizeof(double), hipMemcpyDeviceToHost, g->h[i]->stream));
+    GHIP(g, hipStreamSynchronize(g->h[i]->stream));
+    for (int j = 0; j < n; ++j)
+      if (got[2 * j] != (double)j || got[2 * j + 1] != (double)g->devs[j])
+        return gfail(g, TGP_ERR_HIP, "RCCL self-check: member %d received (%g, %g) in slot %d, expected (%d, %d)", i,
+                     got[2 * j], got[2 * j + 1], j, j, g->devs[j]);
+  }
+  return TGP_OK;
+}
+
 int need_candidates(tgp_group g) {
   if (g->M < 1) return gfail(g, TGP_ERR_STATE, "no resident candidates: call tgp_group_set_candidates / _sample_candidates");
   return TGP_OK;
@@ -262,6 +312,7 @@ int tgp_group_create(const int* device_ids, int n_dev, int d, int kernel_kind, i
   *out = nullptr;
   if (!device_ids || n_dev < 1 || n_dev > 64) return gfail(nullptr, TGP_ERR_ARG, "need 1..64 device ids");
   if (merge != TGP_MERGE_RCCL && merge != TGP_MERGE_PEER) return gfail(nullptr, TGP_ERR_ARG, "unknown merge %d", merge);
+  DeviceGuard guard;
   // A device may be listed more than once only as a TEST AID (TGP_GROUP_ALLOW_DUPLICATES=1, peer merge): several
   // members then share one GPU, which exercises the whole multi-member path -- worker threads, shards, per-member
   // streams, peer copies + events, the P-way merge -- on a single-GPU box.  RCCL needs distinct devices.
@@ -313,6 +364,7 @@ int tgp_group_create(const int* device_ids, int n_dev, int d, int kernel_kind, i
     }
     int cnt = 0;
     if (g->rccl.CommCount(g->comms[0], &cnt) == ncclSuccess) g->rccl_ranks = cnt;
+    if (int rc = rccl_self_check(g)) return bail(rc, g->err);
   }
   (void)hipGetLastError();
   *out = g;
@@ -321,6 +373,7 @@ int tgp_group_create(const int* device_ids, int n_dev, int d, int kernel_kind, i
 
 int tgp_group_destroy(tgp_group g) {
   if (!g) return TGP_OK;
+  DeviceGuard guard;
   for (size_t i = 0; i < g->h.size(); ++i) {
     (void)hipSetDevice(g->devs[i]);
     if (g->h[i] && g->h[i]->stream) (void)hipStreamSynchronize(g->h[i]->stream);
@@ -419,6 +472,7 @@ int tgp_group_sample_candidates(tgp_group g, uint64_t seed, int64_t M, const dou
 
 int tgp_group_acq_argmax(tgp_group g, int acq_kind, double param, double* best_val, int64_t* best_idx, double* best_x) {
   if (!g) return TGP_ERR_ARG;
+  DeviceGuard guard;
   if (int rc = need_candidates(g)) return rc;
   for (int i = 0; i < g->n; ++i) {  // enqueue only: the members' sweeps run concurrently on their devices
     const int64_t Mi = g->hi[i] - g->lo[i];
@@ -518,6 +572,7 @@ int tgp_group_traj_create(tgp_group g, const double* rff_W, const double* rff_b,
 
 int tgp_group_traj_destroy(tgp_group_traj t) {
   if (!t) return TGP_OK;
+  DeviceGuard guard;
   for (tgp_traj m : t->t)
     if (m) (void)tgp_traj_destroy(m);
   delete t;
@@ -526,6 +581,7 @@ int tgp_group_traj_destroy(tgp_group_traj t) {
 
 int tgp_group_traj_argmin(tgp_group_traj t, double* best_val, int64_t* best_idx) {
   if (!t) return TGP_ERR_ARG;
+  DeviceGuard guard;
   tgp_group g = t->g;
   if (int rc = need_candidates(g)) return rc;
   const int B = t->B;
@@ -544,6 +600,7 @@ int tgp_group_traj_argmin(tgp_group_traj t, double* best_val, int64_t* best_idx)
 
 int tgp_group_last_kernel_ms(tgp_group g, double* ms) {
   if (!g || !ms) return TGP_ERR_ARG;
+  DeviceGuard guard;
   double worst = 0.0;
   for (int i = 0; i < g->n; ++i) {
     double m = 0.0;

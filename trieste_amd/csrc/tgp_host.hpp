@@ -79,7 +79,10 @@ struct tgp_handle_s {
   int variant = 0;
   // arithmetic of the plain (non-joint) sweeps: TGP_PREC_F64, or TGP_PREC_I8X4 = W K* on the int8 matrix cores with
   // four digit planes per operand (tgp_set_precision); the planes of W are rebuilt lazily per factorisation
-  int precision = 0;
+  int precision = 0;      // the arithmetic in effect (never TGP_PREC_AUTO)
+  int precision_req = 0;  // what tgp_set_precision asked for; TGP_PREC_AUTO is resolved per factorisation
+  uint64_t auto_version = 0;  // data_version the AUTO choice was made for
+  double w_abs_max = 0.0;     // max |W_ik| of that factorisation (0: not measured)
   DevBuf d_wq, d_rs;
   uint64_t wq_version = 0;
   int wq_planes = 0;

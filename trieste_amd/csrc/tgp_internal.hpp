@@ -155,6 +155,7 @@ void launch_theta_tail(hipStream_t s, const double* mean, int64_t ldm, const dou
 void launch_traj_grad(hipStream_t s, const TrajDev& t, const double* Xq, int64_t nitems, double* val,
                       double* grad);
 void launch_w_digits(hipStream_t s, const double* W, int64_t N, int64_t Npad, double* rs, void* Wq, int planes);
+void launch_w_absmax(hipStream_t s, const double* W, int64_t N, int64_t Npad, double* out);  // *out zeroed before
 void launch_merge_winners(hipStream_t s, const double* gathered, int P, int V, int minimize, double* out);
 void launch_argmin_final_multi(hipStream_t s, const double* blk_val, const int64_t* blk_idx,
                                int64_t nblk, int B, double* out_val, int64_t* out_idx);

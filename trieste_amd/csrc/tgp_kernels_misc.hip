@@ -666,6 +666,26 @@ __global__ __launch_bounds__(256) void w_digits_kernel(const double* __restrict_
     for (int sdx = 0; sdx < NS; ++sdx) *(uint32_t*)(dst + sdx * plane) = p[sdx];
   }
 }
+// max |W_ik| over the N x N lower triangle -> *out (a non-negative double: its bit pattern orders like an unsigned
+// integer, so one 64-bit atomicMax per wave does the reduction).  *out must be zero before the launch.
+__global__ __launch_bounds__(256) void w_absmax_kernel(const double* __restrict__ W, int64_t N, int64_t Npad,
+                                                       unsigned long long* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  double amax = 0.0;
+  if (i < N) {
+    const double* row = W + i * Npad;
+    for (int64_t k = lane; k <= i; k += 64) amax = fmax(amax, fabs(row[k]));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) amax = fmax(amax, __shfl_xor(amax, o, 64));
+  if (lane == 0 && amax > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(amax));
+}
+void launch_w_absmax(hipStream_t s, const double* W, int64_t N, int64_t Npad, double* out) {
+  hipLaunchKernelGGL(w_absmax_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, W, N, Npad,
+                     (unsigned long long*)out);
+}
+
 void launch_w_digits(hipStream_t s, const double* W, int64_t N, int64_t Npad, double* rs, void* Wq, int planes) {
   if (planes == 5)
     hipLaunchKernelGGL(w_digits_kernel<5>, dim3((unsigned)(Npad / 32)), dim3(256), 0, s, W, N, Npad, rs, (unsigned char*)Wq);

@@ -73,9 +73,11 @@ def all_gather_winners(engine, pairs, minimize: bool = False, group=None):
     ``trajectory.argmin_pairs`` left on the device ([2] or [2, V]: values, then global indices as int64 bit
     patterns).  One all-gather of the pairs (RCCL on GPUs), the merge kernel of the engine
     (``tgp_merge_winners_async``: max value -- min if ``minimize`` --, min global index), and ONE device-to-host
-    copy: a single host synchronisation per sharded step instead of three.  The engine must queue its kernels on
-    torch's current stream (``engine.use_torch_stream()``) so that sweep, collective and merge are ordered.
-    Returns (values [V], global indices [V]) as numpy arrays; identity for a single process."""
+    copy: a single host synchronisation per sharded step instead of three.  Sweep, collective and merge are ordered
+    by the stream when the engine queues on torch's current stream (``engine.use_torch_stream()``, or the default
+    stream on both sides); an engine on a private stream is ordered here with host synchronisations instead (correct,
+    two more host waits).  Returns (values [V], global indices [V]) as numpy arrays; identity for a single process.
+    Raises ``ValueError`` when no shard produced a valid winner (every shard empty, or every value NaN)."""
     import torch
     import torch.distributed as dist
 
@@ -84,15 +86,23 @@ def all_gather_winners(engine, pairs, minimize: bool = False, group=None):
     t = t.reshape(2, V)
     active = dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if active else 1
+    unordered = active and t.is_cuda and getattr(engine, "on_private_stream", False)
     if active:
+        if unordered:
+            engine.synchronize()  # the pair is written on the engine's own stream: the collective must not read it early
         out = torch.empty((world, 2, V), dtype=torch.float64, device=t.device)
         dist.all_gather_into_tensor(out.view(-1), t.contiguous().view(-1), group=group)
+        if unordered:
+            torch.cuda.current_stream(t.device).synchronize()  # ... nor the merge kernel the gathered pairs
     else:
         out = t.reshape(1, 2, V)
     merged = engine.merge_winners(out, minimize)
     host = merged.cpu() if _is_tensor(merged) else torch.as_tensor(np.asarray(merged))
     host = host.reshape(2, V)
-    return host[0].numpy().copy(), host[1].contiguous().view(torch.int64).numpy().copy()
+    vals, idxs = host[0].numpy().copy(), host[1].contiguous().view(torch.int64).numpy().copy()
+    if np.any(idxs < 0):
+        raise ValueError("the sharded sweep produced no valid winner (every shard empty, or every value NaN)")
+    return vals, idxs
 
 
 def _is_tensor(x) -> bool:
@@ -139,6 +149,8 @@ def generate_sharded_discrete_optimizer(group=None, device=None):
         else:  # more ranks than points: an empty shard never wins
             val, idx = float("nan"), -1
         _, gi = all_gather_best(val, idx, group=group, device=device)
+        if int(gi[0]) < 0:
+            raise ValueError("the sharded sweep produced no valid winner (every shard empty, or every value NaN)")
         return points[int(gi[0])][None, :]
 
     return optimizer

@@ -85,22 +85,39 @@ class GPEngine:
 
         self._chk(self._lib.tgp_set_stream(self._h, C.c_void_p(
             torch.cuda.current_stream(self.device).cuda_stream)))
+        self._private_stream = False
 
     def use_private_stream(self):
         """Give this engine its own (non-blocking) stream, so that several engines driven from several
         host threads overlap on the GPU -- the latency-bound factorisation chain of one model leaves most
         of the chip idle (used by ``GaussianProcessRegression.find_best_model_initialization``)."""
         self._chk(self._lib.tgp_use_private_stream(self._h))
+        self._private_stream = True
+
+    @property
+    def on_private_stream(self) -> bool:
+        """True after ``use_private_stream``: nothing orders this engine's kernels against torch's streams."""
+        return bool(getattr(self, "_private_stream", False))
 
     def set_variant(self, v: int):
         self._chk(self._lib.tgp_set_variant(self._h, int(v)))
 
     def set_precision(self, precision: str = "f64"):
-        """Arithmetic of the plain sweeps: "f64" (default, the parity path) or "i8x4" -- W K* on the int8 matrix
-        cores with four 8-bit digit planes per operand (an emulated-precision throughput option, tgp_set_precision)."""
+        """Arithmetic of the plain sweeps (tgp_set_precision): "f64" (default, the parity path); "i8x4" / "i8x5" --
+        W K* on the int8 matrix cores with four / five 8-bit digit planes per operand (emulated-precision throughput
+        options: x5 holds the plain parity tolerance on every tested model, x4 only on well-conditioned ones);
+        "auto" -- after every factorisation the engine picks the cheapest of the three whose a-priori error bound
+        (from max|W|) fits inside the parity tolerance."""
         if precision not in _lib.PRECISIONS:
             raise ValueError(f"unknown precision {precision!r}; choose from {sorted(_lib.PRECISIONS)}")
         self._chk(self._lib.tgp_set_precision(self._h, _lib.PRECISIONS[precision]))
+
+    def get_precision(self):
+        """-> (requested, in effect, max |W| the "auto" choice was made from or 0.0): tgp_get_precision."""
+        req, eff, wmax = C.c_int(), C.c_int(), C.c_double()
+        self._chk(self._lib.tgp_get_precision(self._h, C.byref(req), C.byref(eff), C.byref(wmax)))
+        names = {v: k for k, v in _lib.PRECISIONS.items()}
+        return names[req.value], names[eff.value], wmax.value
 
     # -- model state -----------------------------------------------------------------------------
     def clone_from(self, other: "GPEngine") -> None:

@@ -112,6 +112,40 @@ class GPEngineGroup:
     def eta(self) -> float:
         return self.primary.eta()
 
+    # -- per-handle settings, replicated ------------------------------------------------------------------
+    # A sharded sweep runs on EVERY member, so whatever changes the values a member computes (arithmetic, launch
+    # policy, a penalization around pending points, the entropy tails' min-value samples) has to be set on all of
+    # them -- on member 0 alone the other shards would be swept with different settings.
+    def set_precision(self, precision: str = "f64") -> None:
+        for m in self.members:
+            m.set_precision(precision)
+
+    def set_variant(self, v: int) -> None:
+        for m in self.members:
+            m.set_variant(v)
+
+    def set_penalization(self, kind: str, pending=None, radius=None, scale=None) -> None:
+        for m in self.members:
+            m.set_penalization(kind, pending, radius, scale)
+
+    def set_min_value_samples(self, samples) -> None:
+        for m in self.members:
+            m.set_min_value_samples(samples)
+
+    def penalized(self, kind: str, pending, radius, scale):
+        """Context manager: the penalization is active on every member inside the block only."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            self.set_penalization(kind, pending, radius, scale)
+            try:
+                yield self
+            finally:
+                self.set_penalization("none")
+
+        return scope()
+
     # -- the sharded candidate table -----------------------------------------------------------------
     def set_candidates(self, points) -> None:
         """Scatter a host table [M, d] (e.g. ``DiscreteSearchSpace.points``) over the members."""

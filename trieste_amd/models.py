@@ -150,15 +150,33 @@ class GaussianProcessRegression:
         # devices=[...]: ONE process, one model replica per GPU (trieste_amd.group.GPEngineGroup over the C-ABI's
         # tgp_group_*): updates are replicated, the fused candidate sweeps of the acquisition functions shard over
         # the devices, everything else (predictions, gradients, fits) runs on member 0.  The BO loop is unchanged.
+        self._placement = (int(device), None if devices is None else [int(v) for v in devices])
+        self._attach_engine()
+        self._push()
+
+    def _attach_engine(self) -> None:
+        """Create the engine (or the group and its member 0) this model's placement asks for; no state yet."""
+        device, devices = self._placement
+        d, kind = self._model.data[0].shape[1], self._model.kernel.kind
         self._group = None
         if devices is not None:
             from .group import GPEngineGroup
 
-            self._group = GPEngineGroup(x.shape[1], model.kernel.kind, devices=devices)
+            self._group = GPEngineGroup(d, kind, devices=devices)
             self._engine = self._group.primary
         else:
-            self._engine = GPEngine(x.shape[1], model.kernel.kind, device=device)
-        self._push()
+            self._engine = GPEngine(d, kind, device=device)
+
+    def __getattr__(self, name):
+        # A deep copy (one per step in the BO history) holds the GPR record only; its engine -- same placement,
+        # devices=[...] included -- is built and factorised when the copy is first USED.
+        if name in ("_engine", "_group") and "_placement" in self.__dict__ and "_model" in self.__dict__:
+            version = self.__dict__.get("_data_version", 0)
+            self._attach_engine()
+            self._push()
+            self._data_version = version  # materialising a snapshot is not a change of state
+            return self.__dict__[name]
+        raise AttributeError(f"{type(self).__name__!r} object has no attribute {name!r}")
 
     def __repr__(self) -> str:
         return (f"GaussianProcessRegression({self._model!r}, {self._num_kernel_samples!r}, "
@@ -182,9 +200,11 @@ class GaussianProcessRegression:
         return getattr(self, "_data_version", 0)
 
     def __deepcopy__(self, memo):
-        """A copy that shares nothing with this model: its own GPR record and its own engine holding a copy of the
-        factorisation (``tgp_clone_from``).  What ``BayesianOptimizer(track_state=True)`` stores per step (the
-        reference deep-copies its models, bayesian_optimizer.py:745-760)."""
+        """A copy that shares nothing with this model: its own GPR record (data + hyper-parameters) and NO device
+        memory -- the engine of the copy (same placement, a ``devices=[...]`` model stays sharded) is created and
+        factorised on first use (``__getattr__``).  What ``BayesianOptimizer(track_state=True)`` stores per step
+        (the reference deep-copies its models, bayesian_optimizer.py:745-760): a history of T steps costs T host
+        records, not T x 3 N^2 x 8 bytes of HBM held to the end of the run."""
         import copy
 
         twin = type(self).__new__(type(self))
@@ -193,8 +213,6 @@ class GaussianProcessRegression:
             if name in ("_engine", "_eval_engines", "_group", "_cond_twin"):
                 continue
             setattr(twin, name, copy.deepcopy(value, memo))
-        twin._group = None  # the copy is a single-device model holding a copy of member 0's factorisation
-        twin._engine = self._engine.clone()
         return twin
 
     @property
