@@ -101,7 +101,7 @@ def torch_clamp0(torch, r2):
     return torch.clamp(r2, min=0.0)
 
 
-def best_thread_count(state, eta: float, d: int, improved: bool, probe: int = 4096) -> int:
+def best_thread_count(state, eta: float, d: int, improved: bool, probe: int = 2048) -> int:
     """MKL's triangular solves stop scaling (and regress) well before 256 hyper-threads: time one small chunk at
     every power-of-two fraction of the logical cores down to 16 and keep the fastest, so the baseline is the best
     this host can do rather than whatever the default thread count gives."""

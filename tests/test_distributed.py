@@ -269,6 +269,69 @@ def test_all_gather_winners_world_size_2_gloo():
         assert tv == wv and ti == wi
 
 
+def _ragged_worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import gp_oracle as O
+        from tests.fakes import FakeEngine, _pairs
+        from trieste_amd.distributed import all_gather_winners
+
+        X, Y = O.synthetic_problem(O.branin, 2, 30)
+        eng = FakeEngine(2, "matern52")
+        eng.set_hyper(1.0, O.default_lengthscales(2), 1e-3, 0.0)
+        eng.set_data(X, Y)
+        eta = eng.eta()
+        for M in (1003, 9, 3):  # M % 4 != 0; ceil(9 / 4) = 3 -> rank 3 is EMPTY; 3 points on 4 ranks -> ranks 3 empty, rows of 1
+            lo, hi = shard_range(M, rank, world)
+            if hi > lo:
+                Xq = eng.sample_box(5678, lo, hi - lo, 0.0, 1.0)
+                pair = eng.acq_argmax_pair("ei", eta, Xq, index_base=lo)
+            else:  # what the sharded optimizer contributes for an empty shard: (NaN, -1), which never wins
+                pair = _pairs([float("nan")], [-1])
+            gv, gi = all_gather_winners(eng, pair)
+            full = eng.sample_box(5678, 0, M, 0.0, 1.0)
+            v, i, _ = eng.acq_argmax("ei", eta, full)
+            q.put(("ragged", rank, M, (lo, hi), float(gv[0]), int(gi[0]), float(v), int(i)))
+        try:  # every shard empty / invalid: an error, not a silently wrong point
+            all_gather_winners(eng, _pairs([float("nan")], [-1]))
+            q.put(("allempty", rank, "no error"))
+        except ValueError as e:
+            q.put(("allempty", rank, str(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_all_gather_winners_world_size_4_gloo_ragged_and_empty_shards():
+    """SURVEY 8e at world size 4: a table that does not divide (1003), one with an EMPTY last shard (9 rows on 4
+    ranks: ceil = 3 -> rank 3 owns nothing) and one with fewer rows than ranks -- every rank ends with the unsharded
+    winner, bit for bit; no valid winner anywhere raises on every rank."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ragged_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=240) for _ in range(16)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ragged = [o for o in out if o[0] == "ragged"]
+    assert len(ragged) == 12
+    for _, rank, M, (lo, hi), gv, gi, v, i in ragged:
+        # (the numpy stand-in's BLAS rounds a 1-row shard differently from the 3-row table: last-ulp slack on the value;
+        # the engine's values do not depend on the launch shape -- tests/test_gpu_multi.py compares them bit for bit)
+        assert gi == i and abs(gv - v) <= 1e-12 * abs(v), (rank, M)
+    assert any(hi == lo for _, rank, M, (lo, hi), *_ in ragged if M == 9)   # the empty shard was exercised
+    empties = [o for o in out if o[0] == "allempty"]
+    assert len(empties) == 4 and all("no valid winner" in o[2] for o in empties)
+
+
 def test_all_gather_winners_single_process_is_the_merge_of_one():
     from tests.fakes import _pairs
     from trieste_amd.distributed import all_gather_winners

@@ -282,6 +282,8 @@ def test_bench_prints_the_ranks_it_ran(how):
     out = json.loads(line)
     assert out["n_gpus"] == want_n and out["config"]["rccl_ranks"] == want_ranks
     assert out["value"] > 0 and out["roofline"]["kernel_ms"] > 0
+    per_rank = out["config"]["kernel_ms_per_rank"]  # the load balance of a multi-GPU line: one entry per rank / member
+    assert len(per_rank) == want_n and all(t > 0 for t in per_rank)
 
 
 def test_model_with_devices_through_the_host_layer():

@@ -25,7 +25,8 @@ def shard_range(M: int, rank: int, world: int) -> Tuple[int, int]:
 
 def merge_best(vals: np.ndarray, idxs: np.ndarray, minimize: bool = False) -> Tuple[np.ndarray, np.ndarray]:
     """Merge per-rank winners.  vals/idxs: [world, V].  Larger value wins (smaller if
-    ``minimize``); ties go to the smaller global index; NaN / empty shards (idx < 0) never win."""
+    ``minimize``); ties go to the smaller global index; NaN / empty shards (idx < 0) never win.
+    No valid entry in a column: (NaN, -1), like the device kernel (csrc merge_winners_kernel)."""
     vals = np.asarray(vals, dtype=np.float64)
     idxs = np.asarray(idxs, dtype=np.int64)
     if vals.ndim == 1:
@@ -38,7 +39,8 @@ def merge_best(vals: np.ndarray, idxs: np.ndarray, minimize: bool = False) -> Tu
     win_idx = np.min(cand, axis=0)
     win_rank = np.argmin(cand, axis=0)
     win_val = vals[win_rank, np.arange(vals.shape[1])]
-    return win_val, win_idx
+    none = win_idx == np.iinfo(np.int64).max
+    return np.where(none, np.nan, win_val), np.where(none, -1, win_idx)
 
 
 def all_gather_best(val, idx, minimize: bool = False, group=None, device=None, force: bool = False):
