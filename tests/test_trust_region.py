@@ -12,7 +12,7 @@ from trieste_amd.extras import (BatchTrustRegionBox, BatchTrustRegionState, Disc
                                      EfficientGlobalOptimization, SingleObjectiveTrustRegionBox, TREGOBox, TURBOBox,
                                      generate_continuous_optimizer)
 from trieste_amd.acquisition.rule import AcquisitionRule
-from trieste_amd.ask_tell_optimization import AskTellOptimizer
+from trieste_amd.ask_tell_optimization import AskTellOptimizer, AskTellOptimizerNoTraining
 from trieste_amd.bayesian_optimizer import BayesianOptimizer
 from trieste_amd.data import OBJECTIVE, Dataset
 from trieste_amd.space import Box
@@ -216,8 +216,8 @@ def test_trego_through_the_loops_alternates_modes_and_improves():
     # Ask-Tell: two regions, one point each
     model2, data2 = _model(seed=1)
     regions = [SingleObjectiveTrustRegionBox(space) for _ in range(2)]
-    loop = AskTellOptimizer(space, data2, model2, BatchTrustRegionBox(regions, EfficientGlobalOptimization(optimizer=opt)),
-                            fit_model=False)
+    loop = AskTellOptimizerNoTraining(space, data2, model2,
+                                      BatchTrustRegionBox(regions, EfficientGlobalOptimization(optimizer=opt)))
     for _ in range(3):
         pts = loop.ask()
         assert pts.shape == (1, 2, 2)
@@ -225,7 +225,8 @@ def test_trego_through_the_loops_alternates_modes_and_improves():
             assert pts[0, v] in sub
         flat = pts.reshape(-1, 2)
         loop.tell(Dataset(flat, OBJ.scaled_branin(flat)))
-    # fit_model=False: the caller manages the model -- neither refitted nor updated (reference :828-834)
+    # AskTellOptimizerNoTraining: the caller manages the model -- neither refitted nor updated
+    # (reference ask_tell_optimization.py:749-757)
     assert len(loop.dataset) == 10 + 6 and model2.engine.N == 10
 
 
