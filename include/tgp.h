@@ -389,8 +389,29 @@ int tgp_set_precision(tgp_handle h, int precision);
 int tgp_get_precision(tgp_handle h, int* requested, int* effective, double* w_abs_max);
 /* Sweep launch policy knob for experiments and tests (0 = default): bit 0 = never use the row-group split of
  * small launches, bit 1 = always use it, bit 2 = joint mode on the first-generation kernel (64-column group slots;
- * dp = 32 always uses it), bit 3 = fused plain launches on the register-staged kernel instead of the LDS-DMA one.  Every setting computes the same arithmetic on every candidate. */
+ * dp = 32 always uses it), bit 3 = fused plain launches on the register-staged kernel instead of the LDS-DMA one, bit 4 =
+ * `update` through the recursion of dependent launches instead of the persistent task-DAG kernel.  Bits 0-3: every setting
+ * computes the same arithmetic on every candidate; bit 4: the same factor up to the rounding of another summation order. */
 int tgp_set_variant(tgp_handle h, int variant);
+
+
+/* ---- development / test aid (host only: no device is touched) -------------------------------------------------------
+ * The static task list of the persistent `update` kernel (csrc/tgp_kernels_dag.hip) for nb = Npad / 128 block rows of
+ * matrices with leading dimension ld: what tgp_set_data uploads for 512 <= Npad <= 16128.  tests/test_dag_plan.py
+ * executes it on numpy blocks (any valid interleaving gives L and W) and checks that every pair of tasks touching the
+ * same tile with a write among them is ordered by the flags.  Matrices: 0 = K + s I (tiles carry the partial sums),
+ * 1 = L, 2 = W.  flags: bit 0 = B operand natural (else transposed), bit 1 = add the tile already at c_off, bit 2 =
+ * negate the product.  dep[]: flag ids to wait for (0xffffffff = none); set: the task's own flag (= its position).
+ * Flag ids >= ntasks belong to the chain workgroup: ntasks + j = diagonal block j factored and inverted,
+ * ntasks + nb + j = L(j+1, j) stored.  chain_dep[2 j], chain_dep[2 j + 1]: what the chain waits for before the leaf
+ * of step j and before its L(j+1, j).  Returns TGP_OK, TGP_ERR_ARG, or TGP_ERR_SHAPE when cap < *ntasks (which is
+ * always set). */
+typedef struct {
+  uint32_t a_off, b_off, c_off, o_off, nk, flags;
+  uint8_t a_mat, b_mat, c_mat, o_mat;
+  uint32_t dep[3], set, pad;
+} tgp_dag_task;
+int tgp_dag_plan(int nb, int64_t ld, tgp_dag_task* tasks, int64_t cap, int64_t* ntasks, uint32_t* chain_dep);
 
 #ifdef __cplusplus
 }

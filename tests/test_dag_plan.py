@@ -1,0 +1,272 @@
+"""The static task list of the persistent `update` kernel (csrc/tgp_kernels_dag.hip, exported for tests through
+``tgp_dag_plan``), checked WITHOUT a GPU:
+
+* executed on numpy blocks -- chain steps and tile tasks interpreted exactly as the kernel defines them -- it produces
+  L = chol(A) and W = L^-1, in list order AND in random valid interleavings (a worker may only start a task whose
+  flags are up; the chain is its own worker);
+* every flag a task waits for belongs to an EARLIER task or to a chain step (what makes the in-order dispatch
+  deadlock-free whatever the residency);
+* every pair of accesses to the same tile with a write among them is ordered by the flags (happens-before through the
+  transitive closure): no data race, hence a schedule-independent -- bit-identical -- result.
+Reference: the factorisation behind trieste/models/gpflow/models.py:171-186 -> interface.py:108-112."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from trieste_amd import _lib
+
+T = 128
+NONE = 0xFFFFFFFF
+NN, BETA, NEG = 1, 2, 4
+
+
+class Task(C.Structure):
+    _fields_ = [("a_off", C.c_uint32), ("b_off", C.c_uint32), ("c_off", C.c_uint32), ("o_off", C.c_uint32),
+                ("nk", C.c_uint32), ("flags", C.c_uint32), ("a_mat", C.c_uint8), ("b_mat", C.c_uint8),
+                ("c_mat", C.c_uint8), ("o_mat", C.c_uint8), ("dep", C.c_uint32 * 3), ("set", C.c_uint32),
+                ("pad", C.c_uint32)]
+
+
+def plan(nb, ld=None):
+    lib = _lib.load()
+    ld = ld or nb * T
+    n = C.c_int64()
+    rc = lib.tgp_dag_plan(nb, ld, None, 0, C.byref(n), None)
+    assert rc == _lib.TGP_ERR_SHAPE and n.value >= 0
+    tasks = (Task * max(n.value, 1))()
+    chain = (C.c_uint32 * (2 * nb))()
+    assert lib.tgp_dag_plan(nb, ld, tasks, n.value, C.byref(n), chain) == _lib.TGP_OK
+    return [tasks[i] for i in range(n.value)], list(chain), ld
+
+
+def tile_of(off, ld):
+    r, c = divmod(off, ld)
+    assert r % T == 0 and c % T == 0
+    return r // T, c // T
+
+
+def accesses(t, ld):
+    """(reads, writes) of a bulk task as sets of (matrix, tile row, tile col)."""
+    reads, writes = set(), set()
+    ai, ak = tile_of(t.a_off, ld)
+    bi, bk = tile_of(t.b_off, ld)
+    for kt in range(t.nk):
+        reads.add((t.a_mat, ai, ak + kt))
+        reads.add((t.b_mat, bi + kt, bk) if t.flags & NN else (t.b_mat, bi, bk + kt))
+    if t.flags & BETA:
+        reads.add((t.c_mat,) + tile_of(t.c_off, ld))
+    writes.add((t.o_mat,) + tile_of(t.o_off, ld))
+    return reads, writes
+
+
+def chain_accesses(nb):
+    """per chain node (A(j) = diagonal step, B(j) = sub-diagonal step): reads, writes, flag it sets (relative)"""
+    out = []
+    for j in range(nb):
+        out.append(({(0, j, j)}, {(1, j, j), (2, j, j)}))                      # P(j,j) -> L_jj, W_jj (Lsub stays in LDS)
+        out.append(({(0, j + 1, j), (2, j, j)} if j + 1 < nb else set(), {(1, j + 1, j)} if j + 1 < nb else set()))
+    return out
+
+
+class Machine:
+    """numpy interpretation of the kernel's task semantics on an ld x ld workspace."""
+
+    def __init__(self, A, nb, tasks, chain, ld):
+        self.m = [A.copy(), np.zeros_like(A), np.zeros_like(A)]
+        self.nb, self.tasks, self.chain, self.ld = nb, tasks, chain, ld
+        self.flags = np.zeros(len(tasks) + 2 * nb, dtype=bool)
+        self.next_bulk = 0
+        self.chain_pos = 0  # 2 j (diagonal step of j) or 2 j + 1
+        self.lsub = None
+
+    def blk(self, mat, i, j):
+        return self.m[mat][i * T:(i + 1) * T, j * T:(j + 1) * T]
+
+    def ready(self, t):
+        return all(d == NONE or self.flags[d] for d in t.dep)
+
+    def run_bulk(self, idx):
+        t, ld = self.tasks[idx], self.ld
+        assert self.ready(t), f"task {idx} started before its flags"
+        ai, ak = tile_of(t.a_off, ld)
+        bi, bk = tile_of(t.b_off, ld)
+        acc = np.zeros((T, T))
+        for kt in range(t.nk):
+            a = self.blk(t.a_mat, ai, ak + kt)
+            acc += a @ self.blk(t.b_mat, bi + kt, bk) if t.flags & NN else a @ self.blk(t.b_mat, bi, bk + kt).T
+        cin = self.blk(t.c_mat, *tile_of(t.c_off, ld)).copy() if t.flags & BETA else 0.0
+        oi, oj = tile_of(t.o_off, ld)
+        self.m[t.o_mat][oi * T:(oi + 1) * T, oj * T:(oj + 1) * T] = cin + (-acc if t.flags & NEG else acc)
+        assert t.set == idx
+        self.flags[idx] = True
+
+    def chain_ready(self):
+        if self.chain_pos >= 2 * self.nb:
+            return False
+        d = self.chain[self.chain_pos]
+        return d == NONE or self.flags[d]
+
+    def run_chain(self):
+        j, part = divmod(self.chain_pos, 2)
+        nt = len(self.tasks)
+        if part == 0:
+            S = self.blk(0, j, j).copy()
+            if j > 0:
+                S -= self.lsub @ self.lsub.T
+            Ljj = np.linalg.cholesky(np.tril(S) + np.tril(S, -1).T)
+            self.m[1][j * T:(j + 1) * T, j * T:(j + 1) * T] = Ljj
+            self.m[2][j * T:(j + 1) * T, j * T:(j + 1) * T] = np.tril(np.linalg.inv(Ljj))  # (the leaf writes zeros above)
+            self.flags[nt + j] = True
+        elif j + 1 < self.nb:
+            assert self.flags[nt + j]
+            self.lsub = self.blk(0, j + 1, j) @ self.blk(2, j, j).T
+            self.m[1][(j + 1) * T:(j + 2) * T, j * T:(j + 1) * T] = self.lsub
+            self.flags[nt + self.nb + j] = True
+        self.chain_pos += 1
+
+    def done(self):
+        return self.next_bulk >= len(self.tasks) and self.chain_pos >= 2 * self.nb
+
+
+def spd(n, seed):
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(size=(n, 3))
+    d2 = ((X[:, None, :] - X[None, :, :]) ** 2).sum(-1)
+    return np.exp(-0.5 * d2 / 0.3 ** 2) + 1e-2 * np.eye(n)
+
+
+@pytest.mark.parametrize("nb", [1, 2, 4, 7])
+def test_plan_in_list_order_factors_and_inverts(nb):
+    tasks, chain, ld = plan(nb)
+    n = nb * T
+    A = spd(n, nb)
+    mc = Machine(A, nb, tasks, chain, ld)
+    while not mc.done():  # bulk workers pop in order; the chain runs whenever it can
+        if mc.chain_ready():
+            mc.run_chain()
+        elif mc.next_bulk < len(tasks) and mc.ready(tasks[mc.next_bulk]):
+            mc.run_bulk(mc.next_bulk)
+            mc.next_bulk += 1
+        else:
+            raise AssertionError(f"stuck: chain at {mc.chain_pos}, next bulk task {mc.next_bulk}")
+    L = np.tril(mc.m[1])
+    np.testing.assert_allclose(L @ L.T, A, rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(np.tril(mc.m[2]) @ L, np.eye(n), atol=1e-9)
+    np.testing.assert_array_equal(np.triu(mc.m[1], 1), 0.0)   # nothing is ever written above the diagonal
+    np.testing.assert_array_equal(np.triu(mc.m[2], 1), 0.0)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_plan_in_random_valid_interleavings_gives_the_same_bits(seed):
+    """Three workers with a window: any ready task among the next few popped ones may run, in any order against the
+    chain -- what different residencies / timings produce on the device.  Same L and W, bit for bit."""
+    nb = 5
+    tasks, chain, ld = plan(nb)
+    A = spd(nb * T, 11)
+    ref = Machine(A, nb, tasks, chain, ld)
+    while not ref.done():
+        if ref.chain_ready():
+            ref.run_chain()
+        else:
+            ref.run_bulk(ref.next_bulk)
+            ref.next_bulk += 1
+    rng = np.random.default_rng(seed)
+    mc = Machine(A, nb, tasks, chain, ld)
+    popped = []  # tasks handed to workers but not yet run
+    while not mc.done() or popped:
+        while len(popped) < 3 and mc.next_bulk < len(tasks):
+            popped.append(mc.next_bulk)
+            mc.next_bulk += 1
+        choices = [("b", i) for i in popped if mc.ready(tasks[i])] + ([("c", -1)] if mc.chain_ready() else [])
+        assert choices, "deadlock"
+        kind, i = choices[rng.integers(len(choices))]
+        if kind == "c":
+            mc.run_chain()
+        else:
+            mc.run_bulk(i)
+            popped.remove(i)
+    np.testing.assert_array_equal(mc.m[1], ref.m[1])
+    np.testing.assert_array_equal(mc.m[2], ref.m[2])
+
+
+@pytest.mark.parametrize("nb", [3, 8, 32])
+def test_flags_order_every_conflicting_pair_and_point_backwards(nb):
+    tasks, chain, ld = plan(nb, ld=max(nb * T, 4096) if nb == 32 else None)
+    nt = len(tasks)
+    # nodes: bulk tasks 0..nt-1, chain nodes nt + s (s = 2 j: diagonal step, 2 j + 1: sub-diagonal step)
+    def chain_node_of_flag(f):  # flag ids >= nt: WD(j) = nt + j -> node nt + 2 j; LSUB(j) = nt + nb + j -> node nt + 2 j + 1
+        return nt + 2 * (f - nt) if f < nt + nb else nt + 2 * (f - nt - nb) + 1
+    preds = [[] for _ in range(nt + 2 * nb)]
+    for i, t in enumerate(tasks):
+        assert t.set == i
+        for d in t.dep:
+            if d == NONE:
+                continue
+            assert d < nt + 2 * nb
+            if d < nt:
+                assert d < i, f"task {i} waits for the LATER task {d}: in-order dispatch could deadlock"
+                preds[i].append(d)
+            else:
+                preds[i].append(chain_node_of_flag(d))
+    for s in range(2 * nb):
+        if s > 0:
+            preds[nt + s].append(nt + s - 1)
+        if chain[s] != NONE:
+            assert chain[s] < nt
+            preds[nt + s].append(chain[s])
+    # a topological order exists in which chain nodes interleave: list order for bulk, chain node after its bulk deps
+    order, placed, cpos = [], [False] * (nt + 2 * nb), 0
+    for i in range(nt + 1):
+        while cpos < 2 * nb and all(placed[p] for p in preds[nt + cpos]):
+            order.append(nt + cpos)
+            placed[nt + cpos] = True
+            cpos += 1
+        if i < nt:
+            assert all(placed[p] for p in preds[i]), f"task {i} depends on a chain step that cannot have run yet"
+            order.append(i)
+            placed[i] = True
+    assert cpos == 2 * nb
+    # ancestors as bit sets
+    anc = [0] * (nt + 2 * nb)
+    for n in order:
+        a = 0
+        for p in preds[n]:
+            a |= anc[p] | (1 << p)
+        anc[n] = a
+    # per tile: readers and writers
+    acc = {}
+    ch = chain_accesses(nb)
+    for n in range(nt + 2 * nb):
+        r, w = accesses(tasks[n], ld) if n < nt else ch[n - nt]
+        for tile in r:
+            acc.setdefault(tile, []).append((n, False))
+        for tile in w:
+            acc.setdefault(tile, []).append((n, True))
+    for tile, lst in acc.items():
+        writers = [n for n, wr in lst if wr]
+        for wn in writers:
+            for n, _ in lst:
+                if n == wn:
+                    continue
+                assert (anc[wn] >> n) & 1 or (anc[n] >> wn) & 1, f"tile {tile}: nodes {wn} and {n} are not ordered"
+    # coverage: every product of the left-looking factorisation and of the inverse exactly once
+    seen = {}
+    for t in tasks:
+        oi, oj = tile_of(t.o_off, ld)
+        ai, ak = tile_of(t.a_off, ld)
+        if t.a_mat == 1 and t.b_mat == 1:      # G
+            for kt in range(t.nk):
+                seen[("G", oi, oj, ak + kt)] = seen.get(("G", oi, oj, ak + kt), 0) + 1
+        elif t.a_mat == 1 and t.b_mat == 2:    # X
+            for kt in range(t.nk):
+                seen[("X", oi, oj, ak + kt)] = seen.get(("X", oi, oj, ak + kt), 0) + 1
+    for j in range(nb):
+        for i in range(j, nb):
+            for k in range(j - 1 if i == j else j):
+                assert seen.get(("G", i, j, k)) == 1
+    for i in range(1, nb):
+        for c in range(i):
+            for k in range(c, i):
+                assert seen.get(("X", i, c, k)) == 1
+    assert sum(seen.values()) == len(seen)

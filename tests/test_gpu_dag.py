@@ -1,0 +1,149 @@
+"""`update` as one persistent launch (csrc/tgp_kernels_dag.hip; tgp_set_data for 512 <= Npad <= 16128) on the GPU:
+
+* L, W = L^-1 and alpha against numpy's Cholesky of the oracle's K + s I at the sizes where the task list changes
+  shape (1 ... 5 block rows with and without padding, a mid size, the headline N = 4096), both noise levels;
+* against the recursion of dependent launches it replaces (tgp_set_variant bit 4): the same factor up to rounding;
+* BIT-IDENTICAL run to run, across handles and after a different factorisation has used the same buffers -- the
+  result must not depend on which workgroup ran which task when (the replica contract of SURVEY 8e);
+* a matrix that is not positive definite is reported, not hung on.
+Reference: trieste/models/gpflow/models.py:171-186 -> interface.py:108-112 (K + s I, Cholesky, no jitter)."""
+import numpy as np
+import pytest
+
+from oracle import gp_oracle as O
+from tests.util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+NO_DAG = 16
+
+
+def _problem(N, d=4, kind="matern52", noise=1e-2, seed_obj=O.ackley):
+    X, Y = O.synthetic_problem(seed_obj, d, N)
+    ls = O.default_lengthscales(d)
+    c = float(np.mean(Y))
+    return X, Y, ls, c, kind, noise
+
+
+def _engine(X, Y, ls, c, kind, noise, variant=0):
+    from trieste_amd.engine import GPEngine
+
+    eng = GPEngine(X.shape[1], kind)
+    eng.set_variant(variant)
+    eng.set_hyper(1.0, ls, noise, c)
+    eng.set_data(X, Y)
+    return eng
+
+
+@pytest.mark.parametrize("N", [300, 512, 513, 640, 1000, 1536, 2049])
+@pytest.mark.parametrize("noise", [1e-2, 1e-5])
+def test_dag_update_matches_numpy_and_the_recursion(N, noise):
+    X, Y, ls, c, kind, _ = _problem(N, noise=noise)
+    st = O.gpr_update(kind, 1.0, ls, noise, c, X, Y)
+    eng = _engine(X, Y, ls, c, kind, noise)
+    L, W, alpha = eng.get_factor()
+    old = _engine(X, Y, ls, c, kind, noise, variant=NO_DAG)
+    L0, W0, alpha0 = old.get_factor()
+    scale = np.abs(st.L).max()
+    cond = 1.0 + N / noise
+    tol = 64 * np.finfo(float).eps * cond  # backward-stable factorisations differ by ~ eps cond(K)
+    assert_close(L, st.L, rtol=1e-9, atol=tol * scale, what=f"L vs numpy (N={N})")
+    assert_close(L, L0, rtol=1e-9, atol=tol * scale, what="L vs the recursion")
+    Wref = np.linalg.solve(st.L, np.eye(N))
+    assert_close(W, Wref, rtol=1e-7, atol=tol * np.abs(Wref).max() * 64, what="W vs numpy")
+    assert_close(W, W0, rtol=1e-7, atol=tol * np.abs(Wref).max() * 64, what="W vs the recursion")
+    assert np.abs(np.tril(W) @ np.tril(L) - np.eye(N)).max() < 1e-7
+    assert np.array_equal(np.triu(L, 1), np.zeros_like(L)) and np.array_equal(np.triu(W, 1), np.zeros_like(W))
+    assert_close(alpha, np.linalg.solve(st.L.T, np.linalg.solve(st.L, Y - c)), rtol=1e-6,
+                 atol=1e-6 * np.abs(alpha0).max(), what="alpha")
+    # the posterior through the new factor
+    Xq = np.random.default_rng(3).uniform(size=(257, X.shape[1]))
+    Xq[:7] = X[:7]
+    m, v = eng.predict(Xq)
+    m0, v0 = old.predict(Xq)
+    om, ov = O.predict(st, Xq)
+    from tests.util import cancellation_floor
+
+    floor = cancellation_floor(N, 1.0, noise)
+    assert_close(v, ov, atol=floor, what="var through the DAG factor")
+    assert_close(m, om, atol=floor * 10, what="mean through the DAG factor")
+    assert_close(v, v0, atol=floor, what="var: DAG vs recursion")
+
+
+def test_dag_update_is_bit_identical_run_to_run_and_across_handles():
+    X, Y, ls, c, kind, noise = _problem(4096, d=8)
+    a = _engine(X, Y, ls, c, kind, noise)
+    La, Wa, aa = a.get_factor()
+    for _ in range(3):  # the same handle, the same buffers
+        a.set_data(X, Y)
+        L, W, al = a.get_factor()
+        assert np.array_equal(L, La) and np.array_equal(W, Wa) and np.array_equal(al, aa)
+    b = _engine(X, Y, ls, c, kind, noise)  # another handle (other buffers, other task-list upload)
+    Lb, Wb, ab = b.get_factor()
+    assert np.array_equal(Lb, La) and np.array_equal(Wb, Wa) and np.array_equal(ab, aa)
+    # a different factorisation in between leaves nothing behind
+    X2, Y2, *_ = _problem(3000, d=8, seed_obj=O.hartmann_6 if False else O.ackley)
+    b.set_data(X2[:3000] * 0.9, Y2[:3000])
+    b.set_data(X, Y)
+    Lb, Wb, ab = b.get_factor()
+    assert np.array_equal(Lb, La) and np.array_equal(Wb, Wa) and np.array_equal(ab, aa)
+    # sanity at this size against numpy
+    st = O.gpr_update(kind, 1.0, ls, noise, c, X, Y)
+    assert_close(La, st.L, rtol=1e-9, atol=1e-9 * np.abs(st.L).max(), what="L at N = 4096")
+    assert np.abs(np.tril(Wa) @ np.tril(La) - np.eye(4096)).max() < 1e-8
+
+
+def test_dag_update_two_handles_concurrently_on_private_streams():
+    """Two persistent launches share the GPU (find_best_model_initialization drives several engines from several
+    threads): neither may depend on being fully resident."""
+    import threading
+
+    X, Y, ls, c, kind, noise = _problem(2048, d=6)
+    ref = _engine(X, Y, ls, c, kind, noise)
+    Lr, Wr, _ = ref.get_factor()
+    engs = [_engine(X, Y, ls, c, kind, noise) for _ in range(2)]
+    for e in engs:
+        e.use_private_stream()
+    errs = []
+
+    def work(e):
+        try:
+            for _ in range(5):
+                e.set_data(X, Y)
+        except Exception as ex:  # noqa: BLE001
+            errs.append(ex)
+
+    th = [threading.Thread(target=work, args=(e,)) for e in engs]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not errs, errs
+    for e in engs:
+        L, W, _ = e.get_factor()
+        assert np.array_equal(L, Lr) and np.array_equal(W, Wr)
+
+
+@pytest.mark.parametrize("where", ["first_block", "late_blocks"])
+def test_dag_update_reports_a_matrix_that_is_not_positive_definite(where):
+    """A breakdown fills the rest of the factor with NaN; every task still runs and raises its flag (no hang), the
+    breakdown is reported, and the handle is usable afterwards."""
+    from trieste_amd._lib import NotPositiveDefiniteError
+    from trieste_amd.engine import GPEngine
+
+    rng = np.random.default_rng(0)
+    N, d = 1024, 2
+    X = rng.uniform(size=(N, d))
+    if where == "first_block":
+        X[1] = X[0]                                   # pivot 1 is exactly zero
+    else:
+        X[600:] = 0.5 + 1e-13 * rng.standard_normal((N - 600, d))   # a numerically rank-one trailing block
+    Y = rng.standard_normal(N)
+    eng = GPEngine(d, "rbf")
+    eng.set_hyper(1.0, [0.3, 0.3], 1e-300, 0.0)      # (numerically) no noise
+    with pytest.raises(NotPositiveDefiniteError):
+        eng.set_data(X, Y)
+    eng.set_hyper(1.0, [0.3, 0.3], 1e-2, 0.0)         # the handle is usable afterwards
+    eng.set_data(X, Y)
+    L, W, _ = eng.get_factor()
+    assert np.isfinite(L).all() and np.abs(np.tril(W) @ np.tril(L) - np.eye(N)).max() < 1e-8

@@ -145,7 +145,8 @@ void apply_penalization(tgp_handle h, double* dvals, const double* dXq, int64_t 
 //   VARIANT_NO_SPLIT (1): never use the row-group split    VARIANT_FORCE_SPLIT (2): use it whenever Npad allows
 //   VARIANT_JOINT_V1 (4): joint mode on the first-generation kernel (64-column slots, Gram operands from L2)
 //   VARIANT_REG_STAGING (8): fused plain launches on the register-staged kernel instead of the LDS-DMA one
-constexpr int VARIANT_NO_SPLIT = 1, VARIANT_FORCE_SPLIT = 2, VARIANT_JOINT_V1 = 4, VARIANT_REG_STAGING = 8;
+//   VARIANT_NO_DAG (16): `update` through the recursion of dependent launches instead of the persistent task-DAG kernel
+constexpr int VARIANT_NO_SPLIT = 1, VARIANT_FORCE_SPLIT = 2, VARIANT_JOINT_V1 = 4, VARIANT_REG_STAGING = 8, VARIANT_NO_DAG = 16;
 
 // TGP_PREC_AUTO: once per factorisation pick the cheapest arithmetic whose a-priori truncation budget on the predictive
 // variance fits under the parity tolerance where that is tightest.  Budget (the same formula the
@@ -379,6 +380,50 @@ void chol_inv(tgp_handle h, int64_t lo, int64_t hi) {
                                h->d_info.as<int>()}, lo, hi);
 }
 
+// The whole factorisation + inverse as ONE persistent launch (tgp_kernels_dag.hip) for 512 <= Npad <= 16128 (tile
+// offsets in bytes fit 31 bits); the recursion above stays for everything else (small blocks, the append path, the
+// q x q / F x F factorisations of the samplers).  TGP_NO_DAG=1 forces the recursion (A/B aid, tests).
+bool dag_applies(tgp_handle h, int64_t Npad) {
+  static const bool off = getenv("TGP_NO_DAG") != nullptr;
+  return !off && !(h->variant & VARIANT_NO_DAG) && Npad >= 512 && Npad % 128 == 0 && Npad * Npad * 8 < (int64_t)0x7fffffff;
+}
+
+// -> TGP_OK / error; the launch's own error words are read back by dag_check after the stream has drained
+int chol_inv_dag(tgp_handle h) {
+  const int64_t Npad = h->Npad;
+  const int NB = (int)(Npad / 128);
+  if (h->dag_nb != NB || h->dag_ld != Npad) {
+    std::vector<DagTask> tasks;
+    std::vector<uint32_t> chain;
+    dag_build(NB, Npad, tasks, chain);
+    HIPCHK(h, h->d_dag_tasks.reserve(tasks.size() * sizeof(DagTask)));
+    HIPCHK(h, h->d_dag_chain.reserve(chain.size() * sizeof(uint32_t)));
+    HIPCHK(h, h->d_dag_flags.reserve((tasks.size() + 2 * (size_t)NB + 4) * sizeof(uint32_t)));
+    HIPCHK(h, hipMemcpyAsync(h->d_dag_tasks.p, tasks.data(), tasks.size() * sizeof(DagTask), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_dag_chain.p, chain.data(), chain.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // the host vectors die here
+    h->dag_nb = NB;
+    h->dag_ld = Npad;
+    h->dag_ntasks = (int)tasks.size();
+  }
+  const size_t nflags = (size_t)h->dag_ntasks + 2 * (size_t)NB;
+  HIPCHK(h, hipMemsetAsync(h->d_dag_flags.p, 0, (nflags + 4) * sizeof(uint32_t), h->stream));  // before EVERY launch
+  DagArgs a{};
+  a.Ap = h->d_A.as<double>();
+  a.Lp = h->d_L.as<double>();
+  a.Wp = h->d_W.as<double>();
+  a.ld = Npad;
+  a.NB = NB;
+  a.ntasks = h->dag_ntasks;
+  a.tasks = h->d_dag_tasks.as<DagTask>();
+  a.chain_dep = h->d_dag_chain.as<uint32_t>();
+  a.flags = h->d_dag_flags.as<uint32_t>();
+  a.ctrl = a.flags + nflags;
+  a.info = h->d_info.as<int>();
+  HIPCHK(h, launch_dag_update(h->stream, a, h->num_cu));
+  return TGP_OK;
+}
+
 // Products with few output tiles and a long k (N x P x N, P <= 128: gradients, cross-covariances): split k.
 int gemm_tall(tgp_handle h, bool tb, int m, int n, int k, double alpha, const double* A, int64_t lda,
               const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int tri) {
@@ -602,6 +647,19 @@ int tgp_set_variant(tgp_handle h, int variant) {
   return TGP_OK;
 }
 
+static_assert(sizeof(tgp_dag_task) == sizeof(tgp::DagTask), "tgp_dag_task mirrors tgp::DagTask");
+int tgp_dag_plan(int nb, int64_t ld, tgp_dag_task* tasks, int64_t cap, int64_t* ntasks, uint32_t* chain_dep) {
+  if (nb < 1 || nb > 126 || ld < (int64_t)nb * 128 || !ntasks) return TGP_ERR_ARG;
+  std::vector<tgp::DagTask> t;
+  std::vector<uint32_t> c;
+  tgp::dag_build(nb, ld, t, c);
+  *ntasks = (int64_t)t.size();
+  if (cap < (int64_t)t.size() || !tasks || !chain_dep) return TGP_ERR_SHAPE;
+  memcpy(tasks, t.data(), t.size() * sizeof(tgp::DagTask));
+  memcpy(chain_dep, c.data(), c.size() * sizeof(uint32_t));
+  return TGP_OK;
+}
+
 int tgp_get_precision(tgp_handle h, int* requested, int* effective, double* w_abs_max) {
   if (!h) return TGP_ERR_ARG;
   if (int rc = set_device(h)) return rc;
@@ -679,7 +737,12 @@ static int factorise(tgp_handle h, int64_t N, int64_t keep_rows) {
     static const bool timing = getenv("TGP_TIMING") != nullptr;  // development aid: enqueue vs execution time
     std::chrono::steady_clock::time_point tq0;
     if (timing) { (void)hipStreamSynchronize(s); tq0 = std::chrono::steady_clock::now(); }
-    chol_inv(h, 0, Npad);
+    const bool dag = dag_applies(h, Npad);
+    if (dag) {
+      if (int rc = chol_inv_dag(h)) return rc;
+    } else {
+      chol_inv(h, 0, Npad);
+    }
     if (timing) {
       const auto tq1 = std::chrono::steady_clock::now();
       (void)hipStreamSynchronize(s);
@@ -719,9 +782,18 @@ static int factorise(tgp_handle h, int64_t N, int64_t keep_rows) {
   launch_trmv(s, A, Npad, Npad, h->d_tmp2.as<double>(), h->d_alpha.as<double>(), false);
   // the padding rows of W carry the identity: alpha/tmp there are err_pad = 0 -> stay 0.
   int info = 0;
+  uint32_t dag_ctrl[4] = {0, 0, 0, 0};
+  const bool used_dag = keep_rows == 0 && dag_applies(h, Npad);
   HIPCHK(h, hipMemcpyAsync(&info, h->d_info.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  if (used_dag)
+    HIPCHK(h, hipMemcpyAsync(dag_ctrl, h->d_dag_flags.as<uint32_t>() + (size_t)h->dag_ntasks + 2 * (size_t)h->dag_nb,
+                             sizeof dag_ctrl, hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipStreamSynchronize(s));
   HIPCHK(h, hipGetLastError());
+  if (dag_ctrl[2] != 0)
+    return fail(h, TGP_ERR_HIP, "persistent update kernel gave up (code %u) waiting for flag %u of %d tasks + %d chain "
+                "steps: a workgroup did not become resident or a dependency is wrong", dag_ctrl[2], dag_ctrl[3],
+                h->dag_ntasks, 2 * h->dag_nb);
   if (info != 0)
     return fail(h, TGP_ERR_NOT_PD, "Cholesky failed: K + noise*I is not positive definite (pivot %d)",
                 info - 1);

@@ -105,6 +105,10 @@ struct tgp_handle_s {
   DevBuf d_repv;                   // [N + m][m]: the twin's last m rows of W as weight columns
   // scratch
   DevBuf s_ent, s_in, s_in2, s_out1, s_out2, s_out3, s_blkv, s_blki, s_small, s_kcache, s_aslab, s_grad, s_ks, s_part;
+  // `update` as one persistent launch: the task list of the current block count (tgp_kernels_dag.hip)
+  int dag_nb = 0, dag_ntasks = 0;
+  int64_t dag_ld = 0;
+  DevBuf d_dag_tasks, d_dag_chain, d_dag_flags;  // flags: [ntasks + 2 NB] flag words, then the 4 control words
   // timing of the dominant kernel
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double last_ms = 0.0;

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 namespace tgp {
 
 constexpr int SW_BN = 128;  // candidates per workgroup (sweep kernel)
@@ -154,6 +156,32 @@ void launch_theta_tail(hipStream_t s, const double* mean, int64_t ldm, const dou
                        double scale, double* theta, double* ws);
 void launch_traj_grad(hipStream_t s, const TrajDev& t, const double* Xq, int64_t nitems, double* val,
                       double* grad);
+// ---- `update` as one persistent launch (tgp_kernels_dag.hip) -----------------------------------------------------
+constexpr int DAG_MAT_A = 0, DAG_MAT_L = 1, DAG_MAT_W = 2;   // which matrix a tile offset refers to
+constexpr uint32_t DAG_NN = 1, DAG_BETA = 2, DAG_NEG = 4;     // B operand natural (else transposed); add Cin; negate
+struct DagTask {  // one 128 x 128 tile task: out = beta Cin + alpha sum_{kt < nk} A_kt B_kt(^T); 48 bytes
+  uint32_t a_off, b_off, c_off, o_off;  // element offsets of the first tiles (k tiles of A follow at +128; of B at
+                                        // +128 (transposed form) or +128 ld (natural form))
+  uint32_t nk, flags;
+  uint8_t a_mat, b_mat, c_mat, o_mat;
+  uint32_t dep[3];                      // flags to wait for (0xffffffff: none)
+  uint32_t set;                         // flag to raise when the tile is stored
+  uint32_t pad;
+};
+struct DagArgs {
+  double *Ap, *Lp, *Wp;        // K + s I (in; its tiles carry the partial sums P), L, W = L^-1; all ld x ld, row-major
+  int64_t ld;
+  int NB, ntasks;              // 128-blocks per side; bulk tasks
+  const DagTask* tasks;        // [ntasks] in dispatch order
+  const uint32_t* chain_dep;   // [2 NB] flag the chain workgroup waits for before step j's leaf / its L(j+1,j)
+  uint32_t* flags;             // [ntasks + 2 NB], zero at launch
+  uint32_t* ctrl;              // [4] arrival ticket, next task, error code, flag that timed out; zero at launch
+  int* info;                   // Cholesky breakdown report (1 + index of the first bad pivot)
+};
+void dag_build(int NB, int64_t ld, std::vector<DagTask>& tasks, std::vector<uint32_t>& chain_dep);
+hipError_t launch_dag_update(hipStream_t s, const DagArgs& a, int grid);
+size_t dag_lds_bytes();
+
 void launch_w_digits(hipStream_t s, const double* W, int64_t N, int64_t Npad, double* rs, void* Wq, int planes);
 void launch_w_absmax(hipStream_t s, const double* W, int64_t N, int64_t Npad, double* out);  // *out zeroed before
 void launch_merge_winners(hipStream_t s, const double* gathered, int P, int V, int minimize, double* out);

@@ -1,0 +1,643 @@
+// `update` as ONE persistent launch: Cholesky factor L of K + s I AND W = L^-1 as a static DAG of 128 x 128 tile tasks.
+//
+// Reference call site: gpflow's GPR posterior cache (tf.linalg.cholesky(K + s I)) reached from
+// trieste/models/gpflow/models.py:171-186 -> interface.py:108-112; called 10^2..10^3 times per BO step
+// through optimize_encoded (models.py:256-321), which is why its latency matters.
+//
+// The recursion of tgp_api.hip (chol_inv) is a chain of ~130 dependent launches at N = 4096 in which the only true
+// chain -- leaf(j) -> L(j+1,j) -> S(j+1,j+1) -> leaf(j+1) -- leaves 255 of 256 CUs idle a third of the time, and every
+// other product waits at launch boundaries it does not depend on.  Here:
+//   * one workgroup per CU, all resident; the first to arrive is the CHAIN workgroup, the others are BULK workers;
+//   * the chain workgroup walks the block diagonal: S = P(j,j) - L(j,j-1) L(j,j-1)^T (in LDS, operands never leave the
+//     CU), the 128-leaf (factor + inverse of the diagonal block, tgp_leaf_dev.inc), then L(j+1,j) = P(j+1,j) W_jj^T,
+//     which stays in LDS for the next step: no memory hand-off ON the chain, only flags going out;
+//   * everything else is a generic tile task  C = beta Cin + alpha sum_k A_k B_k(^T)  (k tiles of 128) executed by the
+//     bulk workers from ONE static list in a topological order (tools/dag_sim.py is the design model of it):
+//       G  P(i,j) -= sum_{k in burst} L(i,k) L(j,k)^T     left-looking bursts (<= 4 products per read-modify-write)
+//       T  L(i,j)  = P(i,j) W_jj^T                         i >= j + 2 (the chain does i = j + 1)
+//       X  V(i,c) += sum_{k in burst} L(i,k) W(k,c)        the inverse, row by row, V kept in W's own tile
+//       E  W(i,c)  = -W_ii V(i,c)
+//     a worker pops the next list index with one atomic, waits (relaxed agent-scope polls, bounded) for the <= 3 flags
+//     the task names -- always tasks earlier in the list or chain steps, so whatever the residency nothing can
+//     deadlock -- runs it and sets the task's own flag;
+//   * every tile has ONE writer at a time and every partial sum a fixed order: the result does not depend on the
+//     schedule (bit-identical run to run and across handles -- the replica contract of SURVEY 8e).
+// Memory model (MI355X_MICROARCH.md, "Workgroup dispatch ... visibility"): the L2s of the eight XCDs are not coherent
+// and a CU's L1 is never refreshed, so every tile that crosses workgroups inside the launch is WRITTEN write-through
+// (sc1 stores, every storing wave drains vmcnt, barrier, then ONE lane stores the flag) and READ past the L1 (sc1
+// loads / sc1 LDS-DMA); flags are relaxed agent-scope atomics, zeroed by a memset node before every launch.
+// GEMM tasks: 8 waves, wave tile 64 x 32 (the sweep kernel's), k chunks of 32 staged global -> LDS by
+// global_load_lds_dwordx4 (two stages, one barrier per chunk); a DMA image is lane-linear, so the row-major operand
+// tiles are stored four rows per KiB with the 16-byte granules of row q rotated by 4 q -- conflict-free ds_read_b64.
+#include <algorithm>
+#include <queue>
+#include <vector>
+
+#include "tgp_dev.hpp"
+#include "tgp_internal.hpp"
+
+namespace tgp {
+namespace {
+
+#include "tgp_leaf_dev.inc"
+
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) char lds_char;
+
+constexpr uint32_t NONE = 0xffffffffu;
+constexpr int TILE = 128, KC = 32;                       // tile side, k chunk
+constexpr int GROUP_B = 1024 + 16;                       // four operand rows of 32 doubles + 16 B pad
+constexpr int STAGE_A = (TILE / 4) * GROUP_B;            // 33 280 B: A tile chunk [128 rows][32 k]
+constexpr int BN_ROW = 1024 + 128;                       // NN B operand: one k row of 128 doubles + 128 B pad
+constexpr int STAGE_B = KC * BN_ROW;                     // 36 864 B (>= the NT layout's 33 280)
+constexpr int STAGE = STAGE_A + STAGE_B;                 // 70 144 B
+constexpr int OUT_LD = 130;                              // epilogue tile [128][130] doubles = 133 120 B
+constexpr int LEAF_BYTES = QN * QS * 8 + QB * NWORK * WSLOTS * (int)sizeof(WorkItem);  // 141 312 B
+constexpr int CTL_OFF = LEAF_BYTES;                      // four control words behind everything
+constexpr int DAG_LDS = LEAF_BYTES + 64;
+static_assert(2 * STAGE <= LEAF_BYTES && TILE * OUT_LD * 8 <= LEAF_BYTES, "LDS layout");
+constexpr unsigned SPIN_LIMIT = 1u << 22;                // ~1.2 us per poll: several seconds, then an error
+
+// error codes in ctrl[2]
+constexpr uint32_t DAG_ERR_TIMEOUT = 1;
+
+typedef __attribute__((address_space(1))) double gdouble;  // global memory, said so: no flat instructions
+#define DAG_LDS_DECL extern __shared__ __attribute__((aligned(16))) char dag_lds[]
+// Values that are the same in every lane but reach a non-inlined function through memory or VGPRs: back to SGPRs
+// (buffer resources and the `nn` branch want them there).
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+template <class P>
+__device__ __forceinline__ P* uniptr(P* p) {
+  const uint64_t v = (uint64_t)p;
+  const uint32_t lo = uni((uint32_t)v), hi = uni((uint32_t)(v >> 32));
+  return (P*)(((uint64_t)hi << 32) | lo);
+}
+
+__device__ __forceinline__ uint32_t ld_flag(const uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_flag(uint32_t* p, uint32_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// one lane: wait until flags[id] != 0; false on timeout or when another workgroup has raised the error word
+__device__ bool wait_flag(const DagArgs& a, uint32_t id) {
+  if (id == NONE) return true;
+  unsigned spins = 0;
+  while (ld_flag(a.flags + id) == 0) {
+    __builtin_amdgcn_s_sleep(8);
+    if ((++spins & 255u) == 0) {
+      if (ld_flag(a.ctrl + 2) != 0) return false;
+      if (spins > SPIN_LIMIT) {
+        st_flag(a.ctrl + 2, DAG_ERR_TIMEOUT);
+        st_flag(a.ctrl + 3, id);
+        return false;
+      }
+    }
+  }
+  return true;
+}
+
+__device__ __forceinline__ void glds16_sc1(const void* gsrc, uint32_t lds_dst_uniform) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst_uniform)
+      : "memory");
+}
+__device__ __forceinline__ void drain_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ double ld8_sc1(const double* p) {  // compiler-tracked 8-byte load past the L1
+  return __hip_atomic_load((const gdouble*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st16_sc1(double* p, v2d x) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+}
+
+// ---- generic tile task ----------------------------------------------------------------------------------------------
+struct TaskU {  // a task descriptor with every field in scalar registers
+  uint32_t a_off, b_off, c_off, o_off, nk, flags, a_mat, b_mat, c_mat, o_mat, set;
+};
+__device__ __attribute__((noinline)) void run_task(const DagArgs& a, uint32_t idx) {
+  DAG_LDS_DECL;
+  char* const lds = dag_lds;
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = w >> 2, wc = w & 3;  // wave tile: rows 64 wr .., columns 32 wc ..
+  const DagTask* const tp = uniptr(a.tasks) + uni(idx);
+  TaskU t;
+  t.a_off = uni(tp->a_off); t.b_off = uni(tp->b_off); t.c_off = uni(tp->c_off); t.o_off = uni(tp->o_off);
+  t.nk = uni(tp->nk); t.flags = uni(tp->flags);
+  t.a_mat = uni(tp->a_mat); t.b_mat = uni(tp->b_mat); t.c_mat = uni(tp->c_mat); t.o_mat = uni(tp->o_mat);
+  t.set = uni(tp->set);
+  double* const Ap = uniptr(a.Ap);
+  double* const Lp = uniptr(a.Lp);
+  double* const Wp = uniptr(a.Wp);
+  auto mat = [&](uint32_t m) { return m == DAG_MAT_A ? Ap : (m == DAG_MAT_L ? Lp : Wp); };
+  const int64_t ld = (int64_t)uni((uint32_t)a.ld);
+  const bool nn = (t.flags & DAG_NN) != 0;
+  const double* const Abase = mat(t.a_mat) + t.a_off;
+  const double* const Bbase = mat(t.b_mat) + t.b_off;
+  const int64_t bstep = nn ? (int64_t)TILE * ld : TILE;  // from one k tile of B to the next
+  const uint32_t lds0 = (uint32_t)(size_t)(lds_char*)lds;
+  const int nchunks = (int)t.nk * (TILE / KC);
+
+  // DMA sources of this lane: A group g = 4 w + u (rows 4 g + q), granule gp holds k = 2 ((gp - 4 q) & 15)
+  const int q = lane >> 4, gp = lane & 15;
+  const int64_t a_lane = (int64_t)q * ld + 2 * ((gp - 4 * q) & 15);
+  const int64_t bn_lane = 2 * lane;  // NN: one k row per instruction, 64 lanes x 2 columns
+
+  auto issue = [&](int c) {
+    const int kt = c >> 2, kk = (c & 3) * KC;
+    const uint32_t sa = lds0 + (uint32_t)((c & 1) * STAGE), sb = sa + STAGE_A;
+    const double* const At = Abase + (int64_t)kt * TILE + kk;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int g = 4 * w + u;
+      glds16_sc1(At + (int64_t)(4 * g) * ld + a_lane, sa + (uint32_t)(g * GROUP_B));
+    }
+    if (nn) {
+      const double* const Bt = Bbase + (int64_t)kt * bstep + (int64_t)kk * ld;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = 4 * w + u;
+        glds16_sc1(Bt + (int64_t)r * ld + bn_lane, sb + (uint32_t)(r * BN_ROW));
+      }
+    } else {
+      const double* const Bt = Bbase + (int64_t)kt * TILE + kk;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int g = 4 * w + u;
+        glds16_sc1(Bt + (int64_t)(4 * g) * ld + a_lane, sb + (uint32_t)(g * GROUP_B));
+      }
+    }
+  };
+
+  v4d acc[4][2];
+#pragma unroll
+  for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+    for (int bj = 0; bj < 2; ++bj) acc[bi][bj] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+  // operand read offsets of this lane inside a stage (row 16 b + lr, k = 4 k4 + lq)
+  const int lane_rows = (lr >> 2) * GROUP_B + (lr & 3) * 256 + (lq & 1) * 8;
+  const int c_lane = (lq >> 1) + 4 * (lr & 3);
+  const int bn_off = lq * BN_ROW + lr * 8;
+
+  issue(0);
+#pragma unroll 1
+  for (int c = 0; c < nchunks; ++c) {
+    drain_vm();        // this wave's share of chunk c has landed ...
+    __syncthreads();   // ... everyone's has, and everyone is done with the other stage (chunk c - 1)
+    if (c + 1 < nchunks) issue(c + 1);
+    const char* const sa = lds + (c & 1) * STAGE;
+    const char* const sb = sa + STAGE_A;
+#pragma unroll
+    for (int k4 = 0; k4 < KC / 4; ++k4) {
+      const int rot = ((2 * k4 + c_lane) & 15) << 4;
+      double av[4], bv[2];
+#pragma unroll
+      for (int bi = 0; bi < 4; ++bi) av[bi] = *(const double*)(sa + (16 * wr + 4 * bi) * GROUP_B + lane_rows + rot);
+      if (nn) {
+#pragma unroll
+        for (int bj = 0; bj < 2; ++bj) bv[bj] = *(const double*)(sb + 4 * k4 * BN_ROW + bn_off + (32 * wc + 16 * bj) * 8);
+      } else {
+#pragma unroll
+        for (int bj = 0; bj < 2; ++bj) bv[bj] = *(const double*)(sb + (8 * wc + 4 * bj) * GROUP_B + lane_rows + rot);
+      }
+#pragma unroll
+      for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < 2; ++bj) acc[bi][bj] = mfma_f64(av[bi], bv[bj], acc[bi][bj]);
+    }
+  }
+  __syncthreads();  // the stages are dead: the tile goes through LDS once, so that global traffic is 16 B per lane
+  double* const T = (double*)lds;
+#pragma unroll
+  for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+    for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        T[(64 * wr + 16 * bi + lq + 4 * r) * OUT_LD + 32 * wc + 16 * bj + lr] = acc[bi][bj][r];
+  __syncthreads();
+  {
+    const double alpha = (t.flags & DAG_NEG) ? -1.0 : 1.0;
+    const bool beta = (t.flags & DAG_BETA) != 0;
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(mat(t.c_mat), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(mat(t.o_mat), 0, 0x7fffffff, 0x00020000);
+    constexpr int NIT = TILE * TILE / 1024;  // 16 passes of 512 threads x 2 doubles
+    v2d cin[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e = tid + 512 * it, row = e >> 6, c2 = (e & 63) * 2;
+      cin[it] = (v2d){0.0, 0.0};
+      if (beta) {
+        const v4u raw = __builtin_amdgcn_raw_buffer_load_b128(rc, (int)(((int64_t)t.c_off + (int64_t)row * ld + c2) * 8), 0, 16);
+        cin[it] = __builtin_bit_cast(v2d, raw);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e = tid + 512 * it, row = e >> 6, c2 = (e & 63) * 2;
+      const v2d v = *(const v2d*)(T + row * OUT_LD + c2);
+      v2d o;
+      o.x = fma(alpha, v.x, cin[it].x);
+      o.y = fma(alpha, v.y, cin[it].y);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, o), ro,
+                                             (int)(((int64_t)t.o_off + (int64_t)row * ld + c2) * 8), 0, 16);
+    }
+  }
+  drain_vm();  // every storing wave drains its write-through stores, THEN the barrier, THEN one lane publishes
+  __syncthreads();
+  if (tid == 0) st_flag(uniptr(a.flags) + t.set, 1u);
+}
+
+// ---- the chain workgroup ------------------------------------------------------------------------------------------
+__device__ bool chain_wait(const DagArgs& a, uint32_t id, volatile uint32_t* ctl) {
+  if (threadIdx.x == 0) ctl[1] = wait_flag(a, id) ? 1u : 0u;
+  __syncthreads();
+  const bool ok = ctl[1] != 0;
+  __syncthreads();
+  return ok;
+}
+
+// Step j, part 1: S (LDS) = lower triangle of the diagonal tile with every earlier column subtracted.
+//   j == 0: the tile as the assembly kernel left it;
+//   j  > 0: P(j,j) - Lsub Lsub^T with Lsub = L(j,j-1) row-major in LDS (left there by part 3 of step j - 1).
+__device__ __attribute__((noinline)) void chain_diag(const DagArgs& a, int j) {
+  DAG_LDS_DECL;
+  double* const S = (double*)dag_lds;
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const char* const S8 = (const char*)S;
+  const int lane_a = (lr * QS + lq) * 8, lane_o = (lq * QS + lr) * 8;
+  j = __builtin_amdgcn_readfirstlane(j);
+  const int64_t ld = (int64_t)uni((uint32_t)a.ld), off = (int64_t)j * TILE;
+  const double* const Pd = uniptr(a.Ap) + off * ld + off;  // tile (j, j)
+  const int ld32 = (int)ld;  // (offsets inside a tile fit 32 bits: one address register per load instead of two)
+  if (j == 0) {
+    constexpr int NIT = QN * QN / 1024;
+    v2d x[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e = tid + 512 * it, i = e >> 6, c2 = (e & 63) * 2;
+      x[it] = (v2d){0.0, 0.0};
+      if (c2 <= i) x[it] = *(const v2d*)(Pd + (int64_t)i * ld + c2);  // written by the launch before this one
+      if (c2 + 1 > i) x[it].y = 0.0;
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e = tid + 512 * it, i = e >> 6, c2 = (e & 63) * 2;
+      *(v2d*)(S + i * QS + c2) = x[it];
+    }
+    __syncthreads();
+    return;
+  }
+  // The 36 lower fragments: block rows p and 7 - p make 9 fragments, n <= p: (p, n), n > p: (7 - p, n - p - 1); the
+  // pair of waves 2 p, 2 p + 1 splits them by parity (5 + 4).  Everything about a fragment is wave-uniform.
+  constexpr int NF = 5;
+  const int p = w >> 1, h = w & 1;
+  v4d acc[NF];
+  double pin[NF][4];
+  int fbi[NF], fbj[NF];
+  bool live[NF];
+#pragma unroll
+  for (int m = 0; m < NF; ++m) {
+    const int n = 2 * m + h;
+    live[m] = n < 9;
+    fbi[m] = n <= p ? p : 7 - p;
+    fbj[m] = n <= p ? n : (live[m] ? n - p - 1 : 0);
+  }
+#pragma unroll
+  for (int m = 0; m < NF; ++m) {
+    acc[m] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pin[m][r] = ld8_sc1(Pd + ((16 * fbi[m] + lq + 4 * r) * ld32 + 16 * fbj[m] + lr));
+  }
+#pragma unroll 1
+  for (int kb = 0; kb < QB; ++kb) {
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+#pragma unroll
+      for (int m = 0; m < NF; ++m) {
+        const double av = ldsd(S8 + lane_a + blk(fbi[m], kb) + 32 * k4);
+        const double bv = ldsd(S8 + lane_a + blk(fbj[m], kb) + 32 * k4);
+        acc[m] = mfma_f64(av, bv, acc[m]);
+      }
+    }
+  }
+  __syncthreads();  // everybody is done reading Lsub: S takes its place
+#pragma unroll
+  for (int m = 0; m < NF; ++m) {
+    if (!live[m]) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * fbi[m] + lq + 4 * r, col = 16 * fbj[m] + lr;
+      const double v = pin[m][r] - acc[m][r];
+      *(double*)((char*)S + lane_o + blk(fbi[m], fbj[m]) + 4 * RB * r) = (col <= row) ? v : 0.0;
+    }
+  }
+  __syncthreads();
+}
+
+// Step j, part 2: the 128-leaf on S (L_jj goes to global memory panel by panel, write-through), then W_jj = T.
+__device__ __attribute__((noinline)) void chain_leaf(const DagArgs& a, int j) {
+  DAG_LDS_DECL;
+  double* const S = (double*)dag_lds;
+  const WorkItem* const items = (const WorkItem*)(S + QN * QS);
+  const int tid = threadIdx.x;
+  j = __builtin_amdgcn_readfirstlane(j);
+  const int64_t ld = (int64_t)uni((uint32_t)a.ld), off = (int64_t)j * TILE;
+  double* const Wp = uniptr(a.Wp);
+  leaf_core<true>(S, items, uniptr(a.Lp), ld, off, uniptr(a.info));
+  constexpr int NPASS = QN * QN / 1024;
+#pragma unroll
+  for (int it = 0; it < NPASS; ++it) {
+    const int e = tid + 512 * it, i = e >> 6, c2 = (e & 63) * 2;
+    if ((c2 >> 4) <= (i >> 4)) st16_sc1(Wp + (off + i) * ld + off + c2, *(const v2d*)(S + i * QS + c2));
+  }
+  drain_vm();
+  __syncthreads();
+}
+
+// Step j, part 3: L(j+1,j) = P(j+1,j) W_jj^T.  Wave w owns rows 16 w .. of the tile, held transposed as natural B
+// operands; W_jj is read from S; the result replaces it there (row-major: the operand of the next step's part 1) and
+// goes to global memory write-through.
+__device__ __attribute__((noinline)) void chain_sub(const DagArgs& a, int j) {
+  DAG_LDS_DECL;
+  double* const S = (double*)dag_lds;
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const char* const S8 = (const char*)S;
+  const int lane_a = (lr * QS + lq) * 8;
+  j = __builtin_amdgcn_readfirstlane(j);
+  const int64_t ld = (int64_t)uni((uint32_t)a.ld), off = (int64_t)j * TILE;
+  const double* const Ps = uniptr(a.Ap) + (off + TILE) * ld + off;
+  double pb[QB][4];
+#pragma unroll
+  for (int kc = 0; kc < QB; ++kc)
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) pb[kc][k4] = ld8_sc1(Ps + ((16 * w + lr) * (int)ld + 16 * kc + 4 * k4 + lq));
+  v4d o[QB];
+#pragma unroll
+  for (int kb = 0; kb < QB; ++kb) {
+    o[kb] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kc = 0; kc <= kb; ++kc)
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) o[kb] = mfma_f64(ldsd(S8 + lane_a + blk(kb, kc) + 32 * k4), pb[kc][k4], o[kb]);
+  }
+  __syncthreads();  // W_jj has been read (and stored): S becomes Lsub, row-major
+#pragma unroll
+  for (int kb = 0; kb < QB; ++kb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) S[(16 * w + lr) * QS + 16 * kb + lq + 4 * r] = o[kb][r];
+  __syncthreads();
+  constexpr int NPASS = QN * QN / 1024;
+  double* const Ls = uniptr(a.Lp) + (off + TILE) * ld + off;
+#pragma unroll
+  for (int it = 0; it < NPASS; ++it) {
+    const int e = tid + 512 * it, i = e >> 6, c2 = (e & 63) * 2;
+    st16_sc1(Ls + (int64_t)i * ld + c2, *(const v2d*)(S + i * QS + c2));
+  }
+  drain_vm();
+  __syncthreads();
+}
+
+__device__ void run_chain(const DagArgs& a) {
+  DAG_LDS_DECL;
+  char* const lds = dag_lds;
+  double* const S = (double*)lds;
+  WorkItem* const items = (WorkItem*)(S + QN * QS);
+  volatile uint32_t* const ctl = (volatile uint32_t*)(lds + CTL_OFF);
+  const int tid = threadIdx.x;
+  leaf_build_items(items, tid);
+  const uint32_t WD = (uint32_t)a.ntasks, LSUB = (uint32_t)(a.ntasks + a.NB);
+#pragma unroll 1
+  for (int j = 0; j < a.NB; ++j) {
+    if (!chain_wait(a, a.chain_dep[2 * j], ctl)) return;
+    chain_diag(a, j);
+    chain_leaf(a, j);
+    if (tid == 0) st_flag(a.flags + WD + j, 1u);
+    if (j + 1 == a.NB) break;
+    if (!chain_wait(a, a.chain_dep[2 * j + 1], ctl)) return;
+    chain_sub(a, j);
+    if (tid == 0) st_flag(a.flags + LSUB + j, 1u);
+  }
+}
+
+__global__ __launch_bounds__(512) void dag_update_kernel(DagArgs a) {
+  DAG_LDS_DECL;
+  char* const lds = dag_lds;
+  volatile uint32_t* const ctl = (volatile uint32_t*)(lds + CTL_OFF);
+  const int tid = threadIdx.x;
+  if (tid == 0) ctl[0] = atomicAdd(a.ctrl + 0, 1u);  // arrival ticket: the first resident workgroup is the chain
+  __syncthreads();
+  const uint32_t role = ctl[0];
+  __syncthreads();
+  if (role == 0) {
+    run_chain(a);
+    return;
+  }
+#pragma unroll 1
+  for (;;) {
+    if (tid == 0) ctl[0] = atomicAdd(a.ctrl + 1, 1u);
+    __syncthreads();
+    const uint32_t idx = uni(ctl[0]);
+    if (idx >= (uint32_t)a.ntasks) return;
+    if (tid == 0) {
+      bool ok = true;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) ok = ok && wait_flag(a, a.tasks[idx].dep[d]);
+      ctl[1] = ok ? 1u : 0u;
+    }
+    __syncthreads();
+    if (ctl[1] == 0) return;
+    run_task(a, idx);
+  }
+}
+
+// ---- host: the task list ------------------------------------------------------------------------------------------
+struct HostTask {
+  DagTask t{};
+  std::vector<int> deps;   // producers (host task indices; chain steps are negative codes resolved below)
+  double ready = 0, need = 0;
+};
+
+std::vector<std::pair<int, int>> bursts(int lo, int hi, int burst) {  // long bursts first, the LAST (urgent) ones short
+  std::vector<std::pair<int, int>> out;
+  int k = lo;
+  while (k < hi) {
+    const int left = hi - k;
+    int n;
+    if (left <= 2) n = 1;
+    else if (left <= burst + 1) n = std::max(1, left - 2);
+    else n = burst;
+    out.emplace_back(k, k + n);
+    k += n;
+  }
+  return out;
+}
+
+}  // namespace
+
+// Build the static list for NB = Npad / 128 block rows: tasks in a topological order (Kahn's algorithm; among the
+// tasks whose producers are placed, the one that becomes ready at the earliest chain step goes first, ties by the step
+// its result is needed at -- tools/dag_sim.py compares orderings), dependencies as flag ids.
+// flag ids: task n -> n;  chain: W_jj / L_jj ready -> ntasks + j;  L(j+1,j) ready -> ntasks + NB + j.
+void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<uint32_t>& chain_dep) {
+  constexpr int BURST = 4;
+  constexpr int CH_WD = -1000000, CH_LSUB = -2000000;  // chain producers: CH_WD - j, CH_LSUB - j
+  std::vector<HostTask> ts;
+  std::vector<int> lastG((size_t)NB * NB, -1), Tid((size_t)NB * NB, -1), Eid((size_t)NB * NB, -1);
+  auto off = [&](int i, int j) { return (uint32_t)((int64_t)i * TILE * ld + (int64_t)j * TILE); };
+  auto Lprod = [&](int i, int k) {  // producer of tile L(i,k), i > k
+    return i == k + 1 ? CH_LSUB - k : Tid[(size_t)i * NB + k];
+  };
+  for (int j = 0; j < NB; ++j)
+    for (int i = j; i < NB; ++i) {
+      const int hi = i == j ? j - 1 : j;  // the chain adds column j - 1 to the diagonal tile itself
+      int prev = -1;
+      for (auto [k0, k1] : bursts(0, std::max(hi, 0), BURST)) {
+        HostTask h;
+        h.t.a_mat = DAG_MAT_L; h.t.a_off = off(i, k0);
+        h.t.b_mat = DAG_MAT_L; h.t.b_off = off(j, k0);
+        h.t.c_mat = h.t.o_mat = DAG_MAT_A; h.t.c_off = h.t.o_off = off(i, j);
+        h.t.nk = (uint32_t)(k1 - k0);
+        h.t.flags = DAG_BETA | DAG_NEG;
+        h.deps.push_back(Lprod(i, k1 - 1));
+        if (i != j) h.deps.push_back(Lprod(j, k1 - 1));
+        if (prev >= 0) h.deps.push_back(prev);
+        h.ready = k1 - 1;
+        h.need = i == j ? j : (i == j + 1 ? j - 0.5 : j);
+        prev = (int)ts.size();
+        ts.push_back(h);
+      }
+      lastG[(size_t)i * NB + j] = prev;
+      if (i >= j + 2) {  // L(i,j) = P(i,j) W_jj^T
+        HostTask h;
+        h.t.a_mat = DAG_MAT_A; h.t.a_off = off(i, j);
+        h.t.b_mat = DAG_MAT_W; h.t.b_off = off(j, j);
+        h.t.c_mat = h.t.o_mat = DAG_MAT_L; h.t.c_off = h.t.o_off = off(i, j);
+        h.t.nk = 1;
+        h.t.flags = 0;
+        h.deps.push_back(CH_WD - j);
+        if (prev >= 0) h.deps.push_back(prev);
+        h.ready = j;
+        h.need = j + 1;
+        Tid[(size_t)i * NB + j] = (int)ts.size();
+        ts.push_back(h);
+      }
+    }
+  for (int i = 1; i < NB; ++i)
+    for (int c = 0; c < i; ++c) {
+      int prev = -1;
+      for (auto [k0, k1] : bursts(c, i, BURST)) {  // V(i,c) += sum_k L(i,k) W(k,c),  W(c,c) = W_cc
+        HostTask h;
+        h.t.a_mat = DAG_MAT_L; h.t.a_off = off(i, k0);
+        h.t.b_mat = DAG_MAT_W; h.t.b_off = off(k0, c);
+        h.t.c_mat = h.t.o_mat = DAG_MAT_W; h.t.c_off = h.t.o_off = off(i, c);
+        h.t.nk = (uint32_t)(k1 - k0);
+        h.t.flags = DAG_NN | (prev >= 0 ? DAG_BETA : 0);
+        h.deps.push_back(Lprod(i, k1 - 1));
+        h.deps.push_back(k1 - 1 == c ? CH_WD - c : Eid[(size_t)(k1 - 1) * NB + c]);
+        if (prev >= 0) h.deps.push_back(prev);
+        h.ready = k1 - 1 + 0.5;
+        h.need = i;
+        prev = (int)ts.size();
+        ts.push_back(h);
+      }
+      HostTask h;  // W(i,c) = -W_ii V(i,c)
+      h.t.a_mat = DAG_MAT_W; h.t.a_off = off(i, i);
+      h.t.b_mat = DAG_MAT_W; h.t.b_off = off(i, c);
+      h.t.c_mat = h.t.o_mat = DAG_MAT_W; h.t.c_off = h.t.o_off = off(i, c);
+      h.t.nk = 1;
+      h.t.flags = DAG_NN | DAG_NEG;
+      h.deps.push_back(CH_WD - i);
+      h.deps.push_back(prev);
+      h.ready = i;
+      h.need = i + 1;
+      Eid[(size_t)i * NB + c] = (int)ts.size();
+      ts.push_back(h);
+    }
+  // chain steps as nodes of the same graph: A(j) = leaf (sets W_jj), B(j) = L(j+1,j)
+  const int nb = (int)ts.size();
+  auto chainA = [&](int j) { return nb + 2 * j; };
+  auto chainB = [&](int j) { return nb + 2 * j + 1; };
+  const int total = nb + 2 * NB;
+  std::vector<std::vector<int>> deps(total);
+  auto resolve = [&](int d) { return d <= CH_LSUB ? chainB(CH_LSUB - d) : (d <= CH_WD ? chainA(CH_WD - d) : d); };
+  for (int n = 0; n < nb; ++n)
+    for (int d : ts[n].deps) deps[n].push_back(resolve(d));
+  chain_dep.assign((size_t)2 * NB, NONE);
+  std::vector<int> chain_dep_host((size_t)2 * NB, -1);
+  for (int j = 0; j < NB; ++j) {
+    if (j > 0) deps[chainA(j)].push_back(chainB(j - 1));
+    if (lastG[(size_t)j * NB + j] >= 0) {
+      deps[chainA(j)].push_back(lastG[(size_t)j * NB + j]);
+      chain_dep_host[2 * j] = lastG[(size_t)j * NB + j];
+    }
+    deps[chainB(j)].push_back(chainA(j));
+    if (j + 1 < NB && lastG[(size_t)(j + 1) * NB + j] >= 0) {
+      deps[chainB(j)].push_back(lastG[(size_t)(j + 1) * NB + j]);
+      chain_dep_host[2 * j + 1] = lastG[(size_t)(j + 1) * NB + j];
+    }
+  }
+  std::vector<int> indeg(total, 0);
+  std::vector<std::vector<int>> users(total);
+  for (int n = 0; n < total; ++n)
+    for (int d : deps[n]) {
+      ++indeg[n];
+      users[d].push_back(n);
+    }
+  auto key = [&](int n) {
+    if (n >= nb) return std::make_pair((double)((n - nb) / 2) - 0.45 + 0.4 * ((n - nb) & 1), -1.0);
+    return std::make_pair(ts[n].ready, ts[n].need);
+  };
+  typedef std::pair<std::pair<double, double>, int> Item;
+  std::priority_queue<Item, std::vector<Item>, std::greater<Item>> heap;
+  for (int n = 0; n < total; ++n)
+    if (indeg[n] == 0) heap.push({key(n), n});
+  std::vector<int> place(total, -1);  // host index -> position among the bulk tasks
+  std::vector<int> order;
+  while (!heap.empty()) {
+    const int n = heap.top().second;
+    heap.pop();
+    if (n < nb) {
+      place[n] = (int)order.size();
+      order.push_back(n);
+    }
+    for (int u : users[n])
+      if (--indeg[u] == 0) heap.push({key(u), u});
+  }
+  const uint32_t WD = (uint32_t)nb, LSUB = (uint32_t)(nb + NB);
+  auto flag_of = [&](int d) -> uint32_t {
+    if (d <= CH_LSUB) return LSUB + (uint32_t)(CH_LSUB - d);
+    if (d <= CH_WD) return WD + (uint32_t)(CH_WD - d);
+    return (uint32_t)place[d];
+  };
+  out_tasks.resize(nb);
+  for (int p = 0; p < nb; ++p) {
+    const HostTask& h = ts[order[p]];
+    DagTask t = h.t;
+    t.dep[0] = t.dep[1] = t.dep[2] = NONE;
+    for (size_t d = 0; d < h.deps.size(); ++d) t.dep[d] = flag_of(h.deps[d]);
+    t.set = (uint32_t)p;
+    out_tasks[p] = t;
+  }
+  for (int s = 0; s < 2 * NB; ++s)
+    if (chain_dep_host[s] >= 0) chain_dep[s] = (uint32_t)place[chain_dep_host[s]];
+}
+
+size_t dag_lds_bytes() { return DAG_LDS; }
+
+hipError_t launch_dag_update(hipStream_t s, const DagArgs& a, int grid) {
+  hipError_t e = hipFuncSetAttribute((const void*)dag_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DAG_LDS);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(dag_update_kernel, dim3((unsigned)grid), dim3(512), DAG_LDS, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace tgp
