@@ -402,6 +402,9 @@ int tgp_set_variant(tgp_handle h, int variant);
  * same tile with a write among them is ordered by the flags.  Matrices: 0 = K + s I (tiles carry the partial sums),
  * 1 = L, 2 = W.  flags: bit 0 = B operand natural (else transposed), bit 1 = add the tile already at c_off, bit 2 =
  * negate the product.  dep[]: flag ids to wait for (0xffffffff = none); set: the task's own flag (= its position).
+ * tasks[0 .. *n_urgent) is the urgent list, the rest the bulk list: a worker takes the head of the urgent list if its
+ * flags are up, else the head of the bulk list if its flags are up; both lists are subsequences of one topological
+ * order of the whole graph, which is what makes that dispatch deadlock-free.
  * Flag ids >= ntasks belong to the chain workgroup: ntasks + j = diagonal block j factored and inverted,
  * ntasks + nb + j = L(j+1, j) stored.  chain_dep[2 j], chain_dep[2 j + 1]: what the chain waits for before the leaf
  * of step j and before its L(j+1, j).  Returns TGP_OK, TGP_ERR_ARG, or TGP_ERR_SHAPE when cap < *ntasks (which is
@@ -411,7 +414,8 @@ typedef struct {
   uint8_t a_mat, b_mat, c_mat, o_mat;
   uint32_t dep[3], set, pad;
 } tgp_dag_task;
-int tgp_dag_plan(int nb, int64_t ld, tgp_dag_task* tasks, int64_t cap, int64_t* ntasks, uint32_t* chain_dep);
+int tgp_dag_plan(int nb, int64_t ld, tgp_dag_task* tasks, int64_t cap, int64_t* ntasks, int64_t* n_urgent,
+                 uint32_t* chain_dep);
 
 #ifdef __cplusplus
 }

@@ -2,10 +2,11 @@
 ``tgp_dag_plan``), checked WITHOUT a GPU:
 
 * executed on numpy blocks -- chain steps and tile tasks interpreted exactly as the kernel defines them -- it produces
-  L = chol(A) and W = L^-1, in list order AND in random valid interleavings (a worker may only start a task whose
-  flags are up; the chain is its own worker);
-* every flag a task waits for belongs to an EARLIER task or to a chain step (what makes the in-order dispatch
-  deadlock-free whatever the residency);
+  L = chol(A) and W = L^-1, with the kernel's dispatch rule (dependency counters and ready queues: a worker only ever
+  receives a task whose producers have completed, urgent tasks first; the chain is its own worker) AND in random valid
+  interleavings;
+* the dependency graph (tasks + chain steps) is acyclic: with ready queues that is all it takes for the dispatch to be
+  deadlock-free whatever the residency;
 * every pair of accesses to the same tile with a write among them is ordered by the flags (happens-before through the
   transitive closure): no data race, hence a schedule-independent -- bit-identical -- result.
 Reference: the factorisation behind trieste/models/gpflow/models.py:171-186 -> interface.py:108-112."""
@@ -31,13 +32,14 @@ class Task(C.Structure):
 def plan(nb, ld=None):
     lib = _lib.load()
     ld = ld or nb * T
-    n = C.c_int64()
-    rc = lib.tgp_dag_plan(nb, ld, None, 0, C.byref(n), None)
+    n, nu = C.c_int64(), C.c_int64()
+    rc = lib.tgp_dag_plan(nb, ld, None, 0, C.byref(n), C.byref(nu), None)
     assert rc == _lib.TGP_ERR_SHAPE and n.value >= 0
     tasks = (Task * max(n.value, 1))()
     chain = (C.c_uint32 * (2 * nb))()
-    assert lib.tgp_dag_plan(nb, ld, tasks, n.value, C.byref(n), chain) == _lib.TGP_OK
-    return [tasks[i] for i in range(n.value)], list(chain), ld
+    assert lib.tgp_dag_plan(nb, ld, tasks, n.value, C.byref(n), C.byref(nu), chain) == _lib.TGP_OK
+    assert 0 <= nu.value <= n.value
+    return [tasks[i] for i in range(n.value)], list(chain), ld, nu.value
 
 
 def tile_of(off, ld):
@@ -72,11 +74,11 @@ def chain_accesses(nb):
 class Machine:
     """numpy interpretation of the kernel's task semantics on an ld x ld workspace."""
 
-    def __init__(self, A, nb, tasks, chain, ld):
+    def __init__(self, A, nb, tasks, chain, ld, nu):
         self.m = [A.copy(), np.zeros_like(A), np.zeros_like(A)]
-        self.nb, self.tasks, self.chain, self.ld = nb, tasks, chain, ld
+        self.nb, self.tasks, self.chain, self.ld, self.nu = nb, tasks, chain, ld, nu
         self.flags = np.zeros(len(tasks) + 2 * nb, dtype=bool)
-        self.next_bulk = 0
+        self.taken = np.zeros(len(tasks), dtype=bool)
         self.chain_pos = 0  # 2 j (diagonal step of j) or 2 j + 1
         self.lsub = None
 
@@ -125,8 +127,21 @@ class Machine:
             self.flags[nt + self.nb + j] = True
         self.chain_pos += 1
 
+    def acquire(self):
+        """the kernel's rule: a ready task of the urgent class if there is one, else a ready bulk task, else None
+        (the queues deliver in order of readiness; list order stands in for that here)"""
+        for lo, hi in ((0, self.nu), (self.nu, len(self.tasks))):
+            for i in range(lo, hi):
+                if not self.taken[i] and self.ready(self.tasks[i]):
+                    self.taken[i] = True
+                    return i
+        return None
+
+    def lists_done(self):
+        return bool(self.taken.all())
+
     def done(self):
-        return self.next_bulk >= len(self.tasks) and self.chain_pos >= 2 * self.nb
+        return self.lists_done() and self.chain_pos >= 2 * self.nb
 
 
 def spd(n, seed):
@@ -138,18 +153,17 @@ def spd(n, seed):
 
 @pytest.mark.parametrize("nb", [1, 2, 4, 7])
 def test_plan_in_list_order_factors_and_inverts(nb):
-    tasks, chain, ld = plan(nb)
+    tasks, chain, ld, nu = plan(nb)
     n = nb * T
     A = spd(n, nb)
-    mc = Machine(A, nb, tasks, chain, ld)
-    while not mc.done():  # bulk workers pop in order; the chain runs whenever it can
+    mc = Machine(A, nb, tasks, chain, ld, nu)
+    while not mc.done():  # one worker with the kernel's dispatch rule; the chain runs whenever it can
         if mc.chain_ready():
             mc.run_chain()
-        elif mc.next_bulk < len(tasks) and mc.ready(tasks[mc.next_bulk]):
-            mc.run_bulk(mc.next_bulk)
-            mc.next_bulk += 1
-        else:
-            raise AssertionError(f"stuck: chain at {mc.chain_pos}, next bulk task {mc.next_bulk}")
+            continue
+        i = mc.acquire()
+        assert i is not None, f"stuck: chain at {mc.chain_pos}, {int(mc.taken.sum())} of {len(tasks)} tasks taken"
+        mc.run_bulk(i)
     L = np.tril(mc.m[1])
     np.testing.assert_allclose(L @ L.T, A, rtol=1e-11, atol=1e-11)
     np.testing.assert_allclose(np.tril(mc.m[2]) @ L, np.eye(n), atol=1e-9)
@@ -162,23 +176,24 @@ def test_plan_in_random_valid_interleavings_gives_the_same_bits(seed):
     """Three workers with a window: any ready task among the next few popped ones may run, in any order against the
     chain -- what different residencies / timings produce on the device.  Same L and W, bit for bit."""
     nb = 5
-    tasks, chain, ld = plan(nb)
+    tasks, chain, ld, nu = plan(nb)
     A = spd(nb * T, 11)
-    ref = Machine(A, nb, tasks, chain, ld)
+    ref = Machine(A, nb, tasks, chain, ld, nu)
     while not ref.done():
         if ref.chain_ready():
             ref.run_chain()
         else:
-            ref.run_bulk(ref.next_bulk)
-            ref.next_bulk += 1
+            ref.run_bulk(ref.acquire())
     rng = np.random.default_rng(seed)
-    mc = Machine(A, nb, tasks, chain, ld)
-    popped = []  # tasks handed to workers but not yet run
+    mc = Machine(A, nb, tasks, chain, ld, nu)
+    popped = []  # tasks taken by workers (their flags were up) but not yet run
     while not mc.done() or popped:
-        while len(popped) < 3 and mc.next_bulk < len(tasks):
-            popped.append(mc.next_bulk)
-            mc.next_bulk += 1
-        choices = [("b", i) for i in popped if mc.ready(tasks[i])] + ([("c", -1)] if mc.chain_ready() else [])
+        while len(popped) < 3:
+            i = mc.acquire()
+            if i is None:
+                break
+            popped.append(i)
+        choices = [("b", i) for i in popped] + ([("c", -1)] if mc.chain_ready() else [])
         assert choices, "deadlock"
         kind, i = choices[rng.integers(len(choices))]
         if kind == "c":
@@ -192,7 +207,7 @@ def test_plan_in_random_valid_interleavings_gives_the_same_bits(seed):
 
 @pytest.mark.parametrize("nb", [3, 8, 32])
 def test_flags_order_every_conflicting_pair_and_point_backwards(nb):
-    tasks, chain, ld = plan(nb, ld=max(nb * T, 4096) if nb == 32 else None)
+    tasks, chain, ld, nu = plan(nb, ld=max(nb * T, 4096) if nb == 32 else None)
     nt = len(tasks)
     # nodes: bulk tasks 0..nt-1, chain nodes nt + s (s = 2 j: diagonal step, 2 j + 1: sub-diagonal step)
     def chain_node_of_flag(f):  # flag ids >= nt: WD(j) = nt + j -> node nt + 2 j; LSUB(j) = nt + nb + j -> node nt + 2 j + 1
@@ -205,7 +220,6 @@ def test_flags_order_every_conflicting_pair_and_point_backwards(nb):
                 continue
             assert d < nt + 2 * nb
             if d < nt:
-                assert d < i, f"task {i} waits for the LATER task {d}: in-order dispatch could deadlock"
                 preds[i].append(d)
             else:
                 preds[i].append(chain_node_of_flag(d))
@@ -215,18 +229,27 @@ def test_flags_order_every_conflicting_pair_and_point_backwards(nb):
         if chain[s] != NONE:
             assert chain[s] < nt
             preds[nt + s].append(chain[s])
-    # a topological order exists in which chain nodes interleave: list order for bulk, chain node after its bulk deps
-    order, placed, cpos = [], [False] * (nt + 2 * nb), 0
-    for i in range(nt + 1):
-        while cpos < 2 * nb and all(placed[p] for p in preds[nt + cpos]):
-            order.append(nt + cpos)
-            placed[nt + cpos] = True
-            cpos += 1
-        if i < nt:
-            assert all(placed[p] for p in preds[i]), f"task {i} depends on a chain step that cannot have run yet"
-            order.append(i)
-            placed[i] = True
-    assert cpos == 2 * nb
+    # the dependency graph is acyclic: Kahn's algorithm places every node
+    order_preds = [list(p) for p in preds]
+    indeg = [len(set(p)) for p in order_preds]
+    users = [[] for _ in range(nt + 2 * nb)]
+    for n, ps in enumerate(order_preds):
+        for q in set(ps):
+            users[q].append(n)
+    stack = [n for n in range(nt + 2 * nb) if indeg[n] == 0]
+    order = []
+    while stack:
+        n = stack.pop()
+        order.append(n)
+        for u in users[n]:
+            indeg[u] -= 1
+            if indeg[u] == 0:
+                stack.append(u)
+    assert len(order) == nt + 2 * nb, "the dependencies form a cycle"
+    # the urgent class: the last burst of every tile and the single-tile products T / E
+    for i, t in enumerate(tasks):
+        if t.a_mat != 1 or (t.a_mat == 1 and t.b_mat == 2 and False):
+            assert i < nu, f"task {i} (T / E) is not on the urgent list"
     # ancestors as bit sets
     anc = [0] * (nt + 2 * nb)
     for n in order:

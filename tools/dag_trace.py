@@ -1,0 +1,92 @@
+"""Development aid: summarise the time stamps of one persistent `update` (TGP_DAG_TRACE=<file> python tools/dag_trace.py N).
+Chain: per step the wait before the leaf, the diagonal product, the leaf (+ W store), the wait before L(j+1,j), the
+sub-diagonal product.  Tasks: wait for flags / run time per kind, workgroup utilisation over the launch."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+def main():
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    path = os.environ.get("TGP_DAG_TRACE", "/tmp/dag_trace.bin")
+    os.environ["TGP_DAG_TRACE"] = path
+    from trieste_amd import objectives as O
+    from trieste_amd.engine import GPEngine
+    import ctypes as C
+    from trieste_amd import _lib
+    X, Y = O.synthetic_problem(O.ackley, 8, N)
+    eng = GPEngine(8, "matern52")
+    eng.set_hyper(1.0, O.default_lengthscales(8), 1e-2, float(Y.mean()))
+    for _ in range(3):
+        eng.set_data(X, Y)
+    raw = np.fromfile(path, dtype=np.uint64)
+    NB, nt = int(raw[0]), int(raw[1])
+    ch = raw[2:2 + 32 * NB].reshape(NB, 32).astype(np.float64) * 1e-2      # us (100 MHz clock)
+    tk = raw[2 + 32 * NB:].reshape(nt, 4).astype(np.float64)
+    tk[:, :3] *= 1e-2
+    t0 = ch[0, 0]
+    end = max(ch[-1, 3], tk[:, 2].max())
+    print(f"N={N} NB={NB} tasks={nt}: launch span {end - t0:.1f} us; chain ends at {ch[-1, 3] - t0:.1f} us")
+    waitA, diag, leaf = ch[:, 1] - ch[:, 0], ch[:, 2] - ch[:, 1], ch[:, 3] - ch[:, 2]
+    waitB, sub = ch[:-1, 4] - ch[:-1, 3], ch[:-1, 5] - ch[:-1, 4]
+    print(f"chain per step (us): wait-diag {waitA.mean():.1f} (max {waitA.max():.1f})  diag {diag[1:].mean():.1f}  leaf {leaf.mean():.1f}  "
+          f"wait-sub {waitB.mean():.1f} (max {waitB.max():.1f})  sub {sub.mean():.1f};  step {np.diff(ch[:, 0]).mean():.1f}")
+    dm, sm = ch[1:, 6] - ch[1:, 1], ch[:-1, 7] - ch[:-1, 4]
+    print(f"  inside: diag entry..end of MFMA loop {dm.mean():.1f}, rest {(diag[1:] - dm).mean():.1f};  sub entry..end of MFMA {sm.mean():.1f}, rest {(sub - sm).mean():.1f}")
+    mid = slice(4, NB - 1)
+    print("  sub, per wave, relative to its entry (mean over steps): loads landed", np.round((ch[mid, 16:24] - ch[mid, 4:5]).mean(0), 1),
+          " MFMAs done", np.round((ch[mid, 8:16] - ch[mid, 4:5]).mean(0), 1))
+    print("  diag, per wave, MFMA loop done after entry:", np.round((ch[mid, 24:32] - ch[mid, 1:2]).mean(0), 1))
+    print("  first steps:", " | ".join(f"{a:.0f} {b:.0f} {c:.0f} {d:.0f} {e:.0f}" for a, b, c, d, e in
+                                      zip(waitA[:6], diag[:6], leaf[:6], waitB[:6], sub[:6])))
+    # task kinds from the plan
+    lib = _lib.load()
+
+    class Task(C.Structure):
+        _fields_ = [("a_off", C.c_uint32), ("b_off", C.c_uint32), ("c_off", C.c_uint32), ("o_off", C.c_uint32),
+                    ("nk", C.c_uint32), ("flags", C.c_uint32), ("a_mat", C.c_uint8), ("b_mat", C.c_uint8),
+                    ("c_mat", C.c_uint8), ("o_mat", C.c_uint8), ("dep", C.c_uint32 * 3), ("set", C.c_uint32),
+                    ("pad", C.c_uint32)]
+
+    ld = NB * 128
+    n_, nu_ = C.c_int64(), C.c_int64()
+    lib.tgp_dag_plan(NB, ld, None, 0, C.byref(n_), C.byref(nu_), None)
+    tarr = (Task * n_.value)()
+    carr = (C.c_uint32 * (2 * NB))()
+    lib.tgp_dag_plan(NB, ld, tarr, n_.value, C.byref(n_), C.byref(nu_), carr)
+    tasks, chain, nu = [tarr[i] for i in range(n_.value)], list(carr), nu_.value
+    kinds = []
+    for t in tasks:
+        if t.a_mat == 1 and t.b_mat == 1: kinds.append("G%d" % t.nk)
+        elif t.a_mat == 0: kinds.append("T")
+        elif t.a_mat == 1: kinds.append("X%d" % t.nk)
+        else: kinds.append("E")
+    kinds = np.array(kinds)
+    wait, run = tk[:, 1] - tk[:, 0], tk[:, 2] - tk[:, 1]
+    for k in sorted(set(kinds)):
+        m = kinds == k
+        print(f"  {k:3s} n={m.sum():5d}  run {run[m].mean():6.1f} us (min {run[m].min():.1f})  wait {wait[m].mean():6.1f} us (max {wait[m].max():.0f})")
+    # the chain's late inputs: who was late, and why
+    for jj in np.argsort(-waitB)[:3]:
+        dep = chain[2 * jj + 1]
+        if dep == 0xFFFFFFFF: continue
+        def line(i, ind="    "):
+            t = tasks[i]
+            return (f"{ind}task {i} {kinds[i]} out=({t.o_off // (ld * 128)},{(t.o_off % ld) // 128}) popped {tk[i,0]-t0:.0f} started {tk[i,1]-t0:.0f} "
+                    f"ended {tk[i,2]-t0:.0f} wg {int(tk[i,3])}")
+        print(f"  step {jj}: chain waited {waitB[jj]:.0f} us from {ch[jj,3]-t0:.0f} for")
+        print(line(dep))
+        for d in tasks[dep].dep:
+            if d == 0xFFFFFFFF: continue
+            if d < nt:
+                print(line(d, "      <- "))
+                for d2 in tasks[d].dep:
+                    if d2 != 0xFFFFFFFF and d2 < nt: print(line(d2, "          <- "))
+                    elif d2 != 0xFFFFFFFF: print(f"          <- chain flag {d2 - nt} (WD/LSUB) at {ch[(d2-nt) % NB, 3 if d2 - nt < NB else 6]-t0:.0f}")
+            else:
+                print(f"      <- chain flag {d - nt}")
+    busy = run.sum()
+    nwg = len(set(tk[:, 3].astype(int)))
+    print(f"bulk: {nwg} workgroups ran tasks; busy {busy:.0f} us = {busy / (nwg * (end - t0)):.2f} of (workgroups x span); "
+          f"waiting on flags {wait.sum():.0f} us")
+
+main()

@@ -395,19 +395,56 @@ int chol_inv_dag(tgp_handle h) {
   if (h->dag_nb != NB || h->dag_ld != Npad) {
     std::vector<DagTask> tasks;
     std::vector<uint32_t> chain;
-    dag_build(NB, Npad, tasks, chain);
+    int nu = 0;
+    std::vector<uint32_t> topo;
+    dag_build(NB, Npad, tasks, chain, nu, &topo);
+    h->dag_nu = nu;
+    // successor lists (CSR) over the nodes [tasks | W_jj events | L(j+1,j) events], dependency counters, and the
+    // image of the launch state: flags 0, control words (queue tails = the tasks ready from the start), counters,
+    // queues (initial entries, then "empty")
+    const size_t nt = tasks.size(), nnodes = nt + 2 * (size_t)NB;
+    std::vector<uint32_t> cnt(nt, 0), off(nnodes + 1, 0), succ;
+    for (size_t t = 0; t < nt; ++t)
+      for (uint32_t d : tasks[t].dep)
+        if (d != 0xffffffffu) {
+          ++cnt[t];
+          ++off[d + 1];
+        }
+    for (size_t n = 0; n < nnodes; ++n) off[n + 1] += off[n];
+    succ.resize(off[nnodes]);
+    {
+      std::vector<uint32_t> fill(off.begin(), off.end() - 1);
+      for (size_t t = 0; t < nt; ++t)
+        for (uint32_t d : tasks[t].dep)
+          if (d != 0xffffffffu) succ[fill[d]++] = (uint32_t)t;
+    }
+    const size_t state_words = nnodes + DAG_CTRL_WORDS + 2 * nt;
+    for (size_t t = 0; t < nt; ++t)
+      if (cnt[t] == 0) return fail(h, TGP_ERR_STATE, "task %zu of the update plan has no dependency", t);  // (cannot happen)
     HIPCHK(h, h->d_dag_tasks.reserve(tasks.size() * sizeof(DagTask)));
     HIPCHK(h, h->d_dag_chain.reserve(chain.size() * sizeof(uint32_t)));
-    HIPCHK(h, h->d_dag_flags.reserve((tasks.size() + 2 * (size_t)NB + 4) * sizeof(uint32_t)));
+    HIPCHK(h, h->d_dag_flags.reserve(state_words * sizeof(uint32_t)));
+    HIPCHK(h, h->d_dag_succ.reserve((2 * nt + off.size() + succ.size() + 1) * sizeof(uint32_t)));
+    uint32_t* const dsucc = h->d_dag_succ.as<uint32_t>();
     HIPCHK(h, hipMemcpyAsync(h->d_dag_tasks.p, tasks.data(), tasks.size() * sizeof(DagTask), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_dag_chain.p, chain.data(), chain.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(dsucc, cnt.data(), nt * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(dsucc + nt, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+    if (!succ.empty())
+      HIPCHK(h, hipMemcpyAsync(dsucc + nt + off.size(), succ.data(), succ.size() * sizeof(uint32_t), hipMemcpyHostToDevice,
+                               h->stream));
+    HIPCHK(h, hipMemcpyAsync(dsucc + nt + off.size() + succ.size(), topo.data(), nt * sizeof(uint32_t), hipMemcpyHostToDevice,
+                             h->stream));
+    h->dag_nsucc = succ.size();
     HIPCHK(h, hipStreamSynchronize(h->stream));  // the host vectors die here
     h->dag_nb = NB;
     h->dag_ld = Npad;
     h->dag_ntasks = (int)tasks.size();
+    h->dag_state_words = state_words;
   }
   const size_t nflags = (size_t)h->dag_ntasks + 2 * (size_t)NB;
-  HIPCHK(h, hipMemsetAsync(h->d_dag_flags.p, 0, (nflags + 4) * sizeof(uint32_t), h->stream));  // before EVERY launch
+  // flags, control words, counters and queues all start from zero, before EVERY launch
+  HIPCHK(h, hipMemsetAsync(h->d_dag_flags.p, 0, h->dag_state_words * sizeof(uint32_t), h->stream));
   DagArgs a{};
   a.Ap = h->d_A.as<double>();
   a.Lp = h->d_L.as<double>();
@@ -415,12 +452,52 @@ int chol_inv_dag(tgp_handle h) {
   a.ld = Npad;
   a.NB = NB;
   a.ntasks = h->dag_ntasks;
+  a.nu = h->dag_nu;
   a.tasks = h->d_dag_tasks.as<DagTask>();
   a.chain_dep = h->d_dag_chain.as<uint32_t>();
   a.flags = h->d_dag_flags.as<uint32_t>();
   a.ctrl = a.flags + nflags;
+  a.need = h->d_dag_succ.as<uint32_t>();
+  a.succ_off = a.need + h->dag_ntasks;
+  a.succ = a.succ_off + nflags + 1;
+  a.topo = a.succ + h->dag_nsucc;
   a.info = h->d_info.as<int>();
+  static const int fences = getenv("TGP_DAG_FENCES") ? atoi(getenv("TGP_DAG_FENCES")) : 0;  // experiments
+  a.fences = fences;
+  // development aid: TGP_DAG_TRACE=<file> -- time stamps of every chain phase and task of the LAST update, dumped as
+  // uint64 [NB][32] + [ntasks][4] after the stream has drained (tools/dag_trace.py reads it)
+  static const char* trace_path = getenv("TGP_DAG_TRACE");
+  const size_t trace_words = 32 * (size_t)NB + 4 * (size_t)h->dag_ntasks;
+  if (trace_path) {
+    HIPCHK(h, h->d_dag_trace.reserve(trace_words * 8));
+    HIPCHK(h, hipMemsetAsync(h->d_dag_trace.p, 0, trace_words * 8, h->stream));
+    a.trace = h->d_dag_trace.as<unsigned long long>();
+  }
   HIPCHK(h, launch_dag_update(h->stream, a, h->num_cu));
+  static const char* dump_path = getenv("TGP_DAG_DUMP");  // development aid: the A buffer (partial sums) after the launch
+  if (dump_path) {
+    std::vector<double> hostA((size_t)Npad * Npad);
+    HIPCHK(h, hipMemcpyAsync(hostA.data(), h->d_A.p, hostA.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (FILE* f = fopen(dump_path, "wb")) {
+      fwrite(hostA.data(), 8, hostA.size(), f);
+      HIPCHK(h, hipMemcpyAsync(hostA.data(), h->d_L.p, hostA.size() * 8, hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      fwrite(hostA.data(), 8, hostA.size(), f);
+      fclose(f);
+    }
+  }
+  if (trace_path) {
+    std::vector<unsigned long long> host(trace_words);
+    HIPCHK(h, hipMemcpyAsync(host.data(), h->d_dag_trace.p, trace_words * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (FILE* f = fopen(trace_path, "wb")) {
+      const unsigned long long hdr[2] = {(unsigned long long)NB, (unsigned long long)h->dag_ntasks};
+      fwrite(hdr, 8, 2, f);
+      fwrite(host.data(), 8, host.size(), f);
+      fclose(f);
+    }
+  }
   return TGP_OK;
 }
 
@@ -648,12 +725,15 @@ int tgp_set_variant(tgp_handle h, int variant) {
 }
 
 static_assert(sizeof(tgp_dag_task) == sizeof(tgp::DagTask), "tgp_dag_task mirrors tgp::DagTask");
-int tgp_dag_plan(int nb, int64_t ld, tgp_dag_task* tasks, int64_t cap, int64_t* ntasks, uint32_t* chain_dep) {
-  if (nb < 1 || nb > 126 || ld < (int64_t)nb * 128 || !ntasks) return TGP_ERR_ARG;
+int tgp_dag_plan(int nb, int64_t ld, tgp_dag_task* tasks, int64_t cap, int64_t* ntasks, int64_t* n_urgent,
+                 uint32_t* chain_dep) {
+  if (nb < 1 || nb > 126 || ld < (int64_t)nb * 128 || !ntasks || !n_urgent) return TGP_ERR_ARG;
   std::vector<tgp::DagTask> t;
   std::vector<uint32_t> c;
-  tgp::dag_build(nb, ld, t, c);
+  int nu = 0;
+  tgp::dag_build(nb, ld, t, c, nu);
   *ntasks = (int64_t)t.size();
+  *n_urgent = nu;
   if (cap < (int64_t)t.size() || !tasks || !chain_dep) return TGP_ERR_SHAPE;
   memcpy(tasks, t.data(), t.size() * sizeof(tgp::DagTask));
   memcpy(chain_dep, c.data(), c.size() * sizeof(uint32_t));

@@ -45,6 +45,7 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) char lds_char;
 
 constexpr uint32_t NONE = 0xffffffffu;
+constexpr int CT = 32;  // trace words per chain step (development aid)
 constexpr int TILE = 128, KC = 32;                       // tile side, k chunk
 constexpr int GROUP_B = 1024 + 16;                       // four operand rows of 32 doubles + 16 B pad
 constexpr int STAGE_A = (TILE / 4) * GROUP_B;            // 33 280 B: A tile chunk [128 rows][32 k]
@@ -90,12 +91,17 @@ __device__ bool wait_flag(const DagArgs& a, uint32_t id) {
       if (ld_flag(a.ctrl + 2) != 0) return false;
       if (spins > SPIN_LIMIT) {
         st_flag(a.ctrl + 2, DAG_ERR_TIMEOUT);
-        st_flag(a.ctrl + 3, id);
+        st_flag(a.ctrl + 3, 0x80000000u | id);
         return false;
       }
     }
   }
   return true;
+}
+
+// development aid: 100 MHz wall-clock stamps of the phase boundaries (one lane; only when a trace buffer is given)
+__device__ __forceinline__ void stamp(unsigned long long* slot) {
+  if (slot) *slot = wall_clock64();
 }
 
 __device__ __forceinline__ void glds16_sc1(const void* gsrc, uint32_t lds_dst_uniform) {
@@ -112,7 +118,100 @@ __device__ __forceinline__ double ld8_sc1(const double* p) {  // compiler-tracke
   return __hip_atomic_load((const gdouble*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void st16_sc1(double* p, v2d x) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");  // (data-register hazard)
+}
+
+// ---- dispatch: dependency counters and two ready queues ---------------------------------------------------------
+// Every tile task has a counter of unmet dependencies (tasks and chain events); whoever completes a node walks its
+// successor list (one lane per successor), decrements their counters and pushes the ones that reach zero into a ready
+// queue: the URGENT queue (the last burst of a tile and the triangular products T / E -- every block row runs its own
+// chain of them at the pace of the diagonal chain) or the BULK queue (the long prefix bursts).  A worker pops the
+// urgent queue first, then the bulk queue, and only ever receives a task it can run at once.  The chain workgroup
+// does not walk successor lists (that would sit on the critical path): it bumps `ev_pub`, and the next worker that
+// looks for work releases the event's successors.  Each task is pushed exactly once: the queues are plain arrays of
+// their final length, no wrap-around.  Measured on the way here (tools/dag_trace.py): ONE list popped in order with
+// the worker spinning on whatever it drew left urgent tasks unpopped behind hundreds of long bursts (the chain waited
+// 40 us every few steps); taking only the head of two lists serialised everything behind an unready head; a 64-entry
+// scan window from the first unclaimed entry still hid ready tasks behind unready ones.
+// The whole launch state starts as ZEROS (one memset node before every launch): counters count the dependencies MET
+// (a task is ready when that reaches its `need`), queue slots hold task id + 1 (0 = not written yet).
+constexpr uint32_t TASK_DONE = 0xfffffffeu, TASK_ERR = 0xfffffffdu, Q_EMPTY = 0u;
+// ctrl words
+constexpr int C_TICKET = 0, C_UHEAD = 1, C_ERR = 2, C_ERRINFO = 3, C_BHEAD = 4, C_UTAIL = 5, C_BTAIL = 6, C_EVPUB = 7,
+              C_EVREL = 8, C_DONE = 9;
+
+__device__ __forceinline__ uint32_t* dag_cnt(const DagArgs& a) { return a.ctrl + DAG_CTRL_WORDS; }
+__device__ __forceinline__ uint32_t* dag_queue(const DagArgs& a, bool urgent) {
+  return a.ctrl + DAG_CTRL_WORDS + a.ntasks + (urgent ? 0 : a.nu);
+}
+
+// all lanes of one wave: node (task or chain event) is complete -> its successors
+__device__ void release_node(const DagArgs& a, uint32_t node) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t beg = a.succ_off[node], end = a.succ_off[node + 1];
+  for (uint32_t i = beg + lane; i < end; i += 64) {
+    const uint32_t sct = a.succ[i];
+    if (atomicAdd(dag_cnt(a) + sct, 1u) + 1u == a.need[sct]) {
+      const bool urgent = sct < (uint32_t)a.nu;
+      const uint32_t pos = atomicAdd(a.ctrl + (urgent ? C_UTAIL : C_BTAIL), 1u);
+      st_flag(dag_queue(a, urgent) + pos, sct + 1u);
+    }
+  }
+}
+
+// All 64 lanes of ONE wave: the next task this workgroup runs (wave-uniform), TASK_DONE when every task has completed,
+// TASK_ERR on a timeout / when another workgroup has raised the error word.
+__device__ uint32_t acquire_task(const DagArgs& a) {
+  const uint32_t lane = threadIdx.x & 63;
+  unsigned spins = 0;
+  for (;;) {
+    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, w4 = 0, w5 = 0, w6 = 0;
+    if (lane == 0) {
+      w0 = ld_flag(a.ctrl + C_EVREL);
+      w1 = ld_flag(a.ctrl + C_EVPUB);
+      w2 = ld_flag(a.ctrl + C_UHEAD);
+      w3 = ld_flag(a.ctrl + C_UTAIL);
+      w4 = ld_flag(a.ctrl + C_BHEAD);
+      w5 = ld_flag(a.ctrl + C_BTAIL);
+      w6 = ld_flag(a.ctrl + C_DONE);
+    }
+    const uint32_t rel = uni(w0), pub = uni(w1), uh = uni(w2), ut = uni(w3), bh = uni(w4), bt = uni(w5), dn = uni(w6);
+    if (rel < pub) {  // a chain event nobody has released yet: event e -> W_jj ready (even) / L(j+1,j) stored (odd)
+      uint32_t won = 0;
+      if (lane == 0) won = atomicCAS(a.ctrl + C_EVREL, rel, rel + 1) == rel ? 1u : 0u;
+      if (uni(won)) release_node(a, (uint32_t)a.ntasks + ((rel & 1) ? (uint32_t)a.NB + (rel >> 1) : (rel >> 1)));
+      continue;
+    }
+    const bool urgent = uh < ut;
+    if (urgent || bh < bt) {
+      const uint32_t h = urgent ? uh : bh;
+      uint32_t won = 0;
+      if (lane == 0) won = atomicCAS(a.ctrl + (urgent ? C_UHEAD : C_BHEAD), h, h + 1) == h ? 1u : 0u;
+      if (!uni(won)) continue;
+      uint32_t v = Q_EMPTY;
+      if (lane == 0) {  // (the producer reserved the slot before writing it: a few hundred ns at most)
+        const uint32_t* const slot = dag_queue(a, urgent) + h;
+        while ((v = ld_flag(slot)) == Q_EMPTY) __builtin_amdgcn_s_sleep(1);
+        v -= 1u;
+        if (a.trace) a.trace[CT * a.NB + 4 * (size_t)v] = wall_clock64();
+      }
+      return uni(v);
+    }
+    if (dn >= (uint32_t)a.ntasks) return TASK_DONE;
+    __builtin_amdgcn_s_sleep(4);
+    if ((++spins & 255u) == 0) {
+      uint32_t err = 0;
+      if (lane == 0) err = ld_flag(a.ctrl + C_ERR);
+      if (uni(err)) return TASK_ERR;
+      if (spins > SPIN_LIMIT / 4) {
+        if (lane == 0) {
+          st_flag(a.ctrl + C_ERR, DAG_ERR_TIMEOUT);
+          st_flag(a.ctrl + C_ERRINFO, dn);
+        }
+        return TASK_ERR;
+      }
+    }
+  }
 }
 
 // ---- generic tile task ----------------------------------------------------------------------------------------------
@@ -251,6 +350,13 @@ __device__ __attribute__((noinline)) void run_task(const DagArgs& a, uint32_t id
   }
   drain_vm();  // every storing wave drains its write-through stores, THEN the barrier, THEN one lane publishes
   __syncthreads();
+  if (a.fences & 2) {
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+  }
   if (tid == 0) st_flag(uniptr(a.flags) + t.set, 1u);
 }
 
@@ -263,10 +369,18 @@ __device__ bool chain_wait(const DagArgs& a, uint32_t id, volatile uint32_t* ctl
   return ok;
 }
 
+// pass `it` (0..15) of the copy of Lsub = L(j,j-1) from LDS to global memory: 512 threads x 16 B, write-through
+__device__ __forceinline__ void push_lsub_pass(double* Ls, int64_t ld, const double* S, int it) {
+  const int e = threadIdx.x + 512 * it, i = e >> 6, c2 = (e & 63) * 2;
+  st16_sc1(Ls + (int64_t)i * ld + c2, *(const v2d*)(S + i * QS + c2));
+}
+
 // Step j, part 1: S (LDS) = lower triangle of the diagonal tile with every earlier column subtracted.
-//   j == 0: the tile as the assembly kernel left it;
+//   j == 0: the tile as the assembly kernel left it (nothing can be pending);
 //   j  > 0: P(j,j) - Lsub Lsub^T with Lsub = L(j,j-1) row-major in LDS (left there by part 3 of step j - 1).
-__device__ __attribute__((noinline)) void chain_diag(const DagArgs& a, int j) {
+// `pending`: the flag of L(j,j-1), which so far exists in LDS only: its 16 store passes are interleaved with the first 16
+// k steps of this product and the flag goes out at the product's barrier (NONE: already stored and published).
+__device__ __forceinline__ void chain_diag(const DagArgs& a, int j, uint32_t pending) {
   DAG_LDS_DECL;
   double* const S = (double*)dag_lds;
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
@@ -316,19 +430,41 @@ __device__ __attribute__((noinline)) void chain_diag(const DagArgs& a, int j) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) pin[m][r] = ld8_sc1(Pd + ((16 * fbi[m] + lq + 4 * r) * ld32 + 16 * fbj[m] + lr));
   }
-#pragma unroll 1
-  for (int kb = 0; kb < QB; ++kb) {
+  double* const Lprev = uniptr(a.Lp) + off * ld + (off - TILE);  // L(j, j-1)
+  const bool push = pending != NONE;
+  // 32 k steps; the operands of step t + 1 are fetched BEFORE the MFMAs of step t are issued (by hand: the asm stores
+  // of the interleaved copy are compiler barriers, hipcc would not hoist the reads across them)
+  double a_lo, a_hi, bv[NF];
+  auto fetch = [&](int t, double& lo, double& hi, double (&b)[NF]) {
+    const int kb = t >> 2, k4 = t & 3;
+    lo = ldsd(S8 + lane_a + blk(p, kb) + 32 * k4);        // the wave's two block rows
+    hi = ldsd(S8 + lane_a + blk(7 - p, kb) + 32 * k4);
 #pragma unroll
-    for (int k4 = 0; k4 < 4; ++k4) {
+    for (int m = 0; m < NF; ++m) b[m] = ldsd(S8 + lane_a + blk(fbj[m], kb) + 32 * k4);
+  };
+  fetch(0, a_lo, a_hi, bv);
 #pragma unroll
-      for (int m = 0; m < NF; ++m) {
-        const double av = ldsd(S8 + lane_a + blk(fbi[m], kb) + 32 * k4);
-        const double bv = ldsd(S8 + lane_a + blk(fbj[m], kb) + 32 * k4);
-        acc[m] = mfma_f64(av, bv, acc[m]);
-      }
+  for (int t = 0; t < 4 * QB; ++t) {
+    double n_lo = 0.0, n_hi = 0.0, nb[NF];
+    if (t + 1 < 4 * QB) fetch(t + 1, n_lo, n_hi, nb);
+    if (push && (t & 1) == 0) push_lsub_pass(Lprev, ld, S, t >> 1);  // 16 passes over 32 steps: under the ~20 GB/s a CU's write-through stores drain at
+#pragma unroll
+    for (int m = 0; m < NF; ++m) acc[m] = mfma_f64((2 * m + h) <= p ? a_lo : a_hi, bv[m], acc[m]);
+    if (t + 1 < 4 * QB) {
+      a_lo = n_lo;
+      a_hi = n_hi;
+#pragma unroll
+      for (int m = 0; m < NF; ++m) bv[m] = nb[m];
     }
   }
+  stamp((a.trace && tid == 0) ? a.trace + CT * j + 6 : nullptr);
+  stamp((a.trace && lane == 0) ? a.trace + CT * j + 24 + w : nullptr);
+  drain_vm();       // (the write-through stores of L(j,j-1) issued before this product: long landed)
   __syncthreads();  // everybody is done reading Lsub: S takes its place
+  if (tid == 0 && pending != NONE) {
+    st_flag(uniptr(a.flags) + pending, 1u);
+    atomicAdd(uniptr(a.ctrl) + C_EVPUB, 1u);  // event 2 (j - 1) + 1: some worker releases its successors
+  }
 #pragma unroll
   for (int m = 0; m < NF; ++m) {
     if (!live[m]) continue;
@@ -339,11 +475,12 @@ __device__ __attribute__((noinline)) void chain_diag(const DagArgs& a, int j) {
       *(double*)((char*)S + lane_o + blk(fbi[m], fbj[m]) + 4 * RB * r) = (col <= row) ? v : 0.0;
     }
   }
+  drain_vm();  // (lane 0's flag store and event count: no wave enters the leaf with a memory wait still ahead of it)
   __syncthreads();
 }
 
 // Step j, part 2: the 128-leaf on S (L_jj goes to global memory panel by panel, write-through), then W_jj = T.
-__device__ __attribute__((noinline)) void chain_leaf(const DagArgs& a, int j) {
+__device__ __forceinline__ void chain_leaf(const DagArgs& a, int j) {
   DAG_LDS_DECL;
   double* const S = (double*)dag_lds;
   const WorkItem* const items = (const WorkItem*)(S + QN * QS);
@@ -351,13 +488,10 @@ __device__ __attribute__((noinline)) void chain_leaf(const DagArgs& a, int j) {
   j = __builtin_amdgcn_readfirstlane(j);
   const int64_t ld = (int64_t)uni((uint32_t)a.ld), off = (int64_t)j * TILE;
   double* const Wp = uniptr(a.Wp);
-  leaf_core<true>(S, items, uniptr(a.Lp), ld, off, uniptr(a.info));
-  constexpr int NPASS = QN * QN / 1024;
-#pragma unroll
-  for (int it = 0; it < NPASS; ++it) {
-    const int e = tid + 512 * it, i = e >> 6, c2 = (e & 63) * 2;
-    if ((c2 >> 4) <= (i >> 4)) st16_sc1(Wp + (off + i) * ld + off + c2, *(const v2d*)(S + i * QS + c2));
-  }
+  // (measured and rejected: a worker wave pulling P(j+1,j) into the L2 during the leaf with dummy LDS-DMA loads -- the
+  // leaf slows down by 2.5 us and part 3's operand loads do not get faster: they are address-rate bound, not misses)
+  leaf_core<true>(S, items, uniptr(a.Lp), ld, off, uniptr(a.info), (lds_sync_t*)(lds_char*)(dag_lds + CTL_OFF + 32),
+                  Wp + off * ld + off);  // (stores W_jj as it goes)
   drain_vm();
   __syncthreads();
 }
@@ -365,7 +499,7 @@ __device__ __attribute__((noinline)) void chain_leaf(const DagArgs& a, int j) {
 // Step j, part 3: L(j+1,j) = P(j+1,j) W_jj^T.  Wave w owns rows 16 w .. of the tile, held transposed as natural B
 // operands; W_jj is read from S; the result replaces it there (row-major: the operand of the next step's part 1) and
 // goes to global memory write-through.
-__device__ __attribute__((noinline)) void chain_sub(const DagArgs& a, int j) {
+__device__ __forceinline__ void chain_sub(const DagArgs& a, int j) {
   DAG_LDS_DECL;
   double* const S = (double*)dag_lds;
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
@@ -375,11 +509,25 @@ __device__ __attribute__((noinline)) void chain_sub(const DagArgs& a, int j) {
   j = __builtin_amdgcn_readfirstlane(j);
   const int64_t ld = (int64_t)uni((uint32_t)a.ld), off = (int64_t)j * TILE;
   const double* const Ps = uniptr(a.Ap) + (off + TILE) * ld + off;
+  // The MFMA sums over k whatever order the two operands agree on: inside a 16-block lane (lq, lr) takes
+  // k = 4 lq + k4 (not 4 k4 + lq), so that its four B values P[16 w + lr][16 kc + 4 lq .. + 3] are 32 contiguous bytes
+  // -- two 16-byte loads per block instead of four scattered 8-byte ones (the operand loads of this product are
+  // address-rate bound and sit ON the chain).  The A operand W_jj(kb, kc) comes from LDS with the same k.
+  const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((double*)Ps, 0, 0x7fffffff, 0x00020000);
   double pb[QB][4];
 #pragma unroll
-  for (int kc = 0; kc < QB; ++kc)
-#pragma unroll
-    for (int k4 = 0; k4 < 4; ++k4) pb[kc][k4] = ld8_sc1(Ps + ((16 * w + lr) * (int)ld + 16 * kc + 4 * k4 + lq));
+  for (int kc = 0; kc < QB; ++kc) {
+    const int voff = ((16 * w + lr) * (int)ld + 16 * kc + 4 * lq) * 8;
+    const v4u lo = __builtin_amdgcn_raw_buffer_load_b128(rp, voff, 0, 16);
+    const v4u hi = __builtin_amdgcn_raw_buffer_load_b128(rp, voff + 16, 0, 16);
+    const v2d l2 = __builtin_bit_cast(v2d, lo), h2 = __builtin_bit_cast(v2d, hi);
+    pb[kc][0] = l2.x; pb[kc][1] = l2.y; pb[kc][2] = h2.x; pb[kc][3] = h2.y;
+  }
+  if (a.trace) {  // development aid: when did this wave's operand loads land?
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp(lane == 0 ? a.trace + CT * j + 16 + w : nullptr);
+  }
+  const int lane_ap = (lr * QS + 4 * lq) * 8;  // A operand with k = 4 lq + k4: + 8 k4
   v4d o[QB];
 #pragma unroll
   for (int kb = 0; kb < QB; ++kb) {
@@ -387,26 +535,21 @@ __device__ __attribute__((noinline)) void chain_sub(const DagArgs& a, int j) {
 #pragma unroll
     for (int kc = 0; kc <= kb; ++kc)
 #pragma unroll
-      for (int k4 = 0; k4 < 4; ++k4) o[kb] = mfma_f64(ldsd(S8 + lane_a + blk(kb, kc) + 32 * k4), pb[kc][k4], o[kb]);
+      for (int k4 = 0; k4 < 4; ++k4) o[kb] = mfma_f64(ldsd(S8 + lane_ap + blk(kb, kc) + 8 * k4), pb[kc][k4], o[kb]);
   }
+  stamp((a.trace && tid == 0) ? a.trace + CT * j + 7 : nullptr);
+  stamp((a.trace && lane == 0) ? a.trace + CT * j + 8 + w : nullptr);
   __syncthreads();  // W_jj has been read (and stored): S becomes Lsub, row-major
 #pragma unroll
   for (int kb = 0; kb < QB; ++kb)
 #pragma unroll
     for (int r = 0; r < 4; ++r) S[(16 * w + lr) * QS + 16 * kb + lq + 4 * r] = o[kb][r];
   __syncthreads();
-  constexpr int NPASS = QN * QN / 1024;
-  double* const Ls = uniptr(a.Lp) + (off + TILE) * ld + off;
-#pragma unroll
-  for (int it = 0; it < NPASS; ++it) {
-    const int e = tid + 512 * it, i = e >> 6, c2 = (e & 63) * 2;
-    st16_sc1(Ls + (int64_t)i * ld + c2, *(const v2d*)(S + i * QS + c2));
-  }
-  drain_vm();
-  __syncthreads();
+  // L(j+1,j) goes to global memory from here (LDS) UNDERNEATH the next step's diagonal product (chain_diag), which
+  // also publishes its flag -- pushing 128 KB of write-through stores costs this CU ~6 us when nothing hides it
 }
 
-__device__ void run_chain(const DagArgs& a) {
+__device__ __attribute__((noinline)) void run_chain(const DagArgs& a) {
   DAG_LDS_DECL;
   char* const lds = dag_lds;
   double* const S = (double*)lds;
@@ -414,17 +557,71 @@ __device__ void run_chain(const DagArgs& a) {
   volatile uint32_t* const ctl = (volatile uint32_t*)(lds + CTL_OFF);
   const int tid = threadIdx.x;
   leaf_build_items(items, tid);
+  if (tid == 0) *(lds_sync_t*)(lds_char*)(dag_lds + CTL_OFF + 32) = 0;  // the panel waves' hand-shake word (tgp_leaf_dev.inc)
   const uint32_t WD = (uint32_t)a.ntasks, LSUB = (uint32_t)(a.ntasks + a.NB);
+  uint32_t pending = NONE;  // flag of L(j,j-1): stores issued, not yet drained / published
+  // Before BLOCKING on a flag everything this workgroup owes must be out (whoever sets that flag may be waiting for
+  // it); when the flag is already up -- the usual case -- the pending publication stays deferred.
+  auto wait_for = [&](uint32_t id) -> bool {
+    if (id == NONE) return true;
+    if (tid == 0) ctl[1] = ld_flag(a.flags + id) != 0 ? 1u : 0u;
+    __syncthreads();
+    const bool up = ctl[1] != 0;
+    __syncthreads();
+    if (up) return true;
+    if (pending != NONE) {  // L(j,j-1) is still in LDS only: store it now
+      const int jj = (int)(pending - LSUB) + 1;
+      double* const Lprev = a.Lp + (int64_t)jj * TILE * a.ld + (int64_t)(jj - 1) * TILE;
+      for (int it = 0; it < QN * QN / 1024; ++it) push_lsub_pass(Lprev, a.ld, S, it);
+      drain_vm();
+      __syncthreads();
+      if (tid == 0) {
+        st_flag(a.flags + pending, 1u);
+        atomicAdd(a.ctrl + C_EVPUB, 1u);
+      }
+      pending = NONE;
+    }
+    return chain_wait(a, id, ctl);
+  };
 #pragma unroll 1
   for (int j = 0; j < a.NB; ++j) {
-    if (!chain_wait(a, a.chain_dep[2 * j], ctl)) return;
-    chain_diag(a, j);
+    unsigned long long* const tr = (a.trace && tid == 0) ? a.trace + CT * j : nullptr;
+    stamp(tr);
+    if (!wait_for(a.chain_dep[2 * j])) return;
+    stamp(tr ? tr + 1 : nullptr);
+    if (a.fences & 1) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __syncthreads();
+    }
+    if (a.fences & 8) {  // experiment: the chain reads its inputs ~5 us after it has seen their flag
+      const unsigned long long t0 = wall_clock64();
+      while (wall_clock64() - t0 < 500) __builtin_amdgcn_s_sleep(8);
+      __syncthreads();
+    }
+    chain_diag(a, j, pending);
+    pending = NONE;
+    stamp(tr ? tr + 2 : nullptr);
     chain_leaf(a, j);
-    if (tid == 0) st_flag(a.flags + WD + j, 1u);
+    if (tid == 0) {
+      st_flag(a.flags + WD + j, 1u);
+      atomicAdd(a.ctrl + C_EVPUB, 1u);  // event 2 j
+    }
+    stamp(tr ? tr + 3 : nullptr);
     if (j + 1 == a.NB) break;
-    if (!chain_wait(a, a.chain_dep[2 * j + 1], ctl)) return;
+    if (!wait_for(a.chain_dep[2 * j + 1])) return;
+    stamp(tr ? tr + 4 : nullptr);
+    if (a.fences & 1) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __syncthreads();
+    }
+    if (a.fences & 8) {
+      const unsigned long long t0 = wall_clock64();
+      while (wall_clock64() - t0 < 500) __builtin_amdgcn_s_sleep(8);
+      __syncthreads();
+    }
     chain_sub(a, j);
-    if (tid == 0) st_flag(a.flags + LSUB + j, 1u);
+    pending = LSUB + (uint32_t)j;
+    stamp(tr ? tr + 5 : nullptr);
   }
 }
 
@@ -433,7 +630,11 @@ __global__ __launch_bounds__(512) void dag_update_kernel(DagArgs a) {
   char* const lds = dag_lds;
   volatile uint32_t* const ctl = (volatile uint32_t*)(lds + CTL_OFF);
   const int tid = threadIdx.x;
-  if (tid == 0) ctl[0] = atomicAdd(a.ctrl + 0, 1u);  // arrival ticket: the first resident workgroup is the chain
+  if (a.fences & 16) {  // experiment: system-scope invalidate at kernel start (L2 lines left by earlier launches?)
+    asm volatile("buffer_inv sc0 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  if (tid == 0) ctl[0] = atomicAdd(a.ctrl + C_TICKET, 1u);  // arrival ticket: the first resident workgroup is the chain
   __syncthreads();
   const uint32_t role = ctl[0];
   __syncthreads();
@@ -443,19 +644,61 @@ __global__ __launch_bounds__(512) void dag_update_kernel(DagArgs a) {
   }
 #pragma unroll 1
   for (;;) {
-    if (tid == 0) ctl[0] = atomicAdd(a.ctrl + 1, 1u);
-    __syncthreads();
-    const uint32_t idx = uni(ctl[0]);
-    if (idx >= (uint32_t)a.ntasks) return;
-    if (tid == 0) {
-      bool ok = true;
-#pragma unroll
-      for (int d = 0; d < 3; ++d) ok = ok && wait_flag(a, a.tasks[idx].dep[d]);
-      ctl[1] = ok ? 1u : 0u;
+    if (a.fences & 32) {  // experiment: the first dispatcher -- ONE list popped in order, the worker waits for its flags
+      if (tid == 0) {
+        const uint32_t pos = atomicAdd(a.ctrl + C_UHEAD, 1u);
+        uint32_t got = TASK_DONE;
+        if (pos < (uint32_t)a.ntasks) {
+          got = a.topo[pos];
+          bool ok = true;
+          for (int d = 0; d < 3; ++d) ok = ok && wait_flag(a, a.tasks[got].dep[d]);
+          if (!ok) got = TASK_ERR;
+          else atomicAdd(dag_cnt(a) + got, a.need[got]);  // (keeps the start-once check below meaningful)
+        }
+        ctl[0] = got;
+      }
+    } else if (tid < 64) {
+      const uint32_t got = acquire_task(a);
+      if (tid == 0) ctl[0] = got;
     }
     __syncthreads();
-    if (ctl[1] == 0) return;
+    const uint32_t idx = uni(ctl[0]);
+    __syncthreads();
+    if (idx >= (uint32_t)a.ntasks) return;  // TASK_DONE / TASK_ERR
+    unsigned long long* const tr = (a.trace && tid == 0) ? a.trace + CT * a.NB + 4 * (size_t)idx : nullptr;
+    stamp(tr ? tr + 1 : nullptr);
+    if (tid == 0) {  // sanity: a task starts exactly once, with every dependency met
+      const uint32_t old = atomicAdd(dag_cnt(a) + idx, 0x10000u);
+      if (old != a.need[idx]) {
+        st_flag(a.ctrl + C_ERR, 3u);
+        st_flag(a.ctrl + C_ERRINFO, idx);
+      }
+    }
+    if (a.trace && tid == 0) {  // development aid: a task must never start before its producers' flags are up
+      for (int d = 0; d < 3; ++d) {
+        const uint32_t dep = a.tasks[idx].dep[d];
+        if (dep != NONE && ld_flag(a.flags + dep) == 0) {
+          st_flag(a.ctrl + C_ERR, 2u);
+          st_flag(a.ctrl + C_ERRINFO, idx);
+        }
+      }
+    }
+    if (a.fences & 1) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __syncthreads();
+    }
+    if (a.fences & 4) {  // experiment: start every task ~20 us late
+      const unsigned long long t0 = wall_clock64();
+      while (wall_clock64() - t0 < 2000) __builtin_amdgcn_s_sleep(16);
+      __syncthreads();
+    }
     run_task(a, idx);
+    stamp(tr ? tr + 2 : nullptr);
+    if (tr) tr[3] = blockIdx.x;
+    if (tid < 64 && !(a.fences & 32)) {  // the tile is stored and its flag is up (run_task): hand its successors on
+      release_node(a, idx);
+      if (tid == 0) atomicAdd(a.ctrl + C_DONE, 1u);
+    }
   }
 }
 
@@ -464,6 +707,7 @@ struct HostTask {
   DagTask t{};
   std::vector<int> deps;   // producers (host task indices; chain steps are negative codes resolved below)
   double ready = 0, need = 0;
+  bool urgent = false;     // the last burst of a tile, T, E: the per-row chains
 };
 
 std::vector<std::pair<int, int>> bursts(int lo, int hi, int burst) {  // long bursts first, the LAST (urgent) ones short
@@ -487,7 +731,8 @@ std::vector<std::pair<int, int>> bursts(int lo, int hi, int burst) {  // long bu
 // tasks whose producers are placed, the one that becomes ready at the earliest chain step goes first, ties by the step
 // its result is needed at -- tools/dag_sim.py compares orderings), dependencies as flag ids.
 // flag ids: task n -> n;  chain: W_jj / L_jj ready -> ntasks + j;  L(j+1,j) ready -> ntasks + NB + j.
-void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<uint32_t>& chain_dep) {
+void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<uint32_t>& chain_dep, int& n_urgent,
+               std::vector<uint32_t>* topo_out) {
   constexpr int BURST = 4;
   constexpr int CH_WD = -1000000, CH_LSUB = -2000000;  // chain producers: CH_WD - j, CH_LSUB - j
   std::vector<HostTask> ts;
@@ -512,6 +757,7 @@ void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<
         if (prev >= 0) h.deps.push_back(prev);
         h.ready = k1 - 1;
         h.need = i == j ? j : (i == j + 1 ? j - 0.5 : j);
+        h.urgent = k1 == hi;
         prev = (int)ts.size();
         ts.push_back(h);
       }
@@ -527,6 +773,7 @@ void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<
         if (prev >= 0) h.deps.push_back(prev);
         h.ready = j;
         h.need = j + 1;
+        h.urgent = true;
         Tid[(size_t)i * NB + j] = (int)ts.size();
         ts.push_back(h);
       }
@@ -546,6 +793,7 @@ void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<
         if (prev >= 0) h.deps.push_back(prev);
         h.ready = k1 - 1 + 0.5;
         h.need = i;
+        h.urgent = k1 == i;
         prev = (int)ts.size();
         ts.push_back(h);
       }
@@ -559,6 +807,7 @@ void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<
       h.deps.push_back(prev);
       h.ready = i;
       h.need = i + 1;
+      h.urgent = true;
       Eid[(size_t)i * NB + c] = (int)ts.size();
       ts.push_back(h);
     }
@@ -600,17 +849,27 @@ void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<
   std::priority_queue<Item, std::vector<Item>, std::greater<Item>> heap;
   for (int n = 0; n < total; ++n)
     if (indeg[n] == 0) heap.push({key(n), n});
-  std::vector<int> place(total, -1);  // host index -> position among the bulk tasks
-  std::vector<int> order;
+  std::vector<int> place(total, -1);  // host index -> position in the device array (urgent list, then bulk list)
+  std::vector<int> topo;              // the common topological order (bulk-side nodes only)
   while (!heap.empty()) {
     const int n = heap.top().second;
     heap.pop();
-    if (n < nb) {
-      place[n] = (int)order.size();
-      order.push_back(n);
-    }
+    if (n < nb) topo.push_back(n);
     for (int u : users[n])
       if (--indeg[u] == 0) heap.push({key(u), u});
+  }
+  std::vector<int> order;
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int n : topo)
+      if (ts[n].urgent == (pass == 0)) {
+        place[n] = (int)order.size();
+        order.push_back(n);
+      }
+    if (pass == 0) n_urgent = (int)order.size();
+  }
+  if (topo_out) {
+    topo_out->clear();
+    for (int n : topo) topo_out->push_back((uint32_t)place[n]);
   }
   const uint32_t WD = (uint32_t)nb, LSUB = (uint32_t)(nb + NB);
   auto flag_of = [&](int d) -> uint32_t {

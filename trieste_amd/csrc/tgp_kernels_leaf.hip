@@ -59,9 +59,11 @@ __global__ __launch_bounds__(512) void leaf128_kernel(const double* __restrict__
     }
   }
   leaf_build_items(items, tid);
+  lds_sync_t* const sync = (lds_sync_t*)(__attribute__((address_space(3))) char*)(items + QB * NWORK * WSLOTS);  // one word behind the table
+  if (tid == 0) *sync = 0;
   __syncthreads();
   TGP_LEAF_TICK(0);
-  leaf_core<false>(S, items, L, ld, off, info);
+  leaf_core<false>(S, items, L, ld, off, info, sync);
   // W = T: the 36 blocks on and below the block diagonal (everything above stays zero: tgp_api.hip keeps the upper
   // triangles of L and W zeroed); 2 entries per thread and pass
   {
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(512) void leaf128_kernel(const double* __restrict__
 }  // namespace
 
 void launch_leaf128(hipStream_t s, const double* A, double* L, double* W, int64_t ld, int64_t off, int* info) {
-  constexpr size_t shmem = (size_t)QN * QS * sizeof(double) + QB * NWORK * WSLOTS * sizeof(WorkItem);
+  constexpr size_t shmem = (size_t)QN * QS * sizeof(double) + QB * NWORK * WSLOTS * sizeof(WorkItem) + 64;
   // > 64 KiB of dynamic LDS is opt-in, per function and per device: set on every launch
   (void)hipFuncSetAttribute((const void*)leaf128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
   hipLaunchKernelGGL(leaf128_kernel, dim3(1), dim3(512), shmem, s, A, L, W, ld, off, info);
