@@ -390,21 +390,23 @@ int tgp_get_precision(tgp_handle h, int* requested, int* effective, double* w_ab
 /* Sweep launch policy knob for experiments and tests (0 = default): bit 0 = never use the row-group split of
  * small launches, bit 1 = always use it, bit 2 = joint mode on the first-generation kernel (64-column group slots;
  * dp = 32 always uses it), bit 3 = fused plain launches on the register-staged kernel instead of the LDS-DMA one, bit 4 =
- * `update` through the recursion of dependent launches instead of the persistent task-DAG kernel.  Bits 0-3: every setting
- * computes the same arithmetic on every candidate; bit 4: the same factor up to the rounding of another summation order. */
+ * `update` through the recursion of dependent launches instead of the persistent task-DAG kernel, bit 5 = the persistent
+ * kernel from Npad = 256 on (default: from 4096 on, where it is the faster one).  Bits 0-3: every setting computes the same
+ * arithmetic on every candidate; bits 4, 5: the same factor up to the rounding of another summation order. */
 int tgp_set_variant(tgp_handle h, int variant);
 
 
 /* ---- development / test aid (host only: no device is touched) -------------------------------------------------------
  * The static task list of the persistent `update` kernel (csrc/tgp_kernels_dag.hip) for nb = Npad / 128 block rows of
- * matrices with leading dimension ld: what tgp_set_data uploads for 512 <= Npad <= 16128.  tests/test_dag_plan.py
+ * matrices with leading dimension ld: what tgp_set_data uploads for 4096 <= Npad <= 16128.  tests/test_dag_plan.py
  * executes it on numpy blocks (any valid interleaving gives L and W) and checks that every pair of tasks touching the
  * same tile with a write among them is ordered by the flags.  Matrices: 0 = K + s I (tiles carry the partial sums),
  * 1 = L, 2 = W.  flags: bit 0 = B operand natural (else transposed), bit 1 = add the tile already at c_off, bit 2 =
  * negate the product.  dep[]: flag ids to wait for (0xffffffff = none); set: the task's own flag (= its position).
- * tasks[0 .. *n_urgent) is the urgent list, the rest the bulk list: a worker takes the head of the urgent list if its
- * flags are up, else the head of the bulk list if its flags are up; both lists are subsequences of one topological
- * order of the whole graph, which is what makes that dispatch deadlock-free.
+ * order[ntasks] (may be NULL): the DISPATCH order -- workers draw positions of it with one atomic and wait for the flags
+ * of what they drew; it is a topological order (every flag a task waits for belongs to a chain step or to a task
+ * earlier in it), which is what makes that dispatch deadlock-free whatever the residency.  tasks[0 .. *n_urgent) are the
+ * tasks on the per-row critical paths (the last burst of a tile and the single-tile products).
  * Flag ids >= ntasks belong to the chain workgroup: ntasks + j = diagonal block j factored and inverted,
  * ntasks + nb + j = L(j+1, j) stored.  chain_dep[2 j], chain_dep[2 j + 1]: what the chain waits for before the leaf
  * of step j and before its L(j+1, j).  Returns TGP_OK, TGP_ERR_ARG, or TGP_ERR_SHAPE when cap < *ntasks (which is
@@ -415,7 +417,7 @@ typedef struct {
   uint32_t dep[3], set, pad;
 } tgp_dag_task;
 int tgp_dag_plan(int nb, int64_t ld, tgp_dag_task* tasks, int64_t cap, int64_t* ntasks, int64_t* n_urgent,
-                 uint32_t* chain_dep);
+                 uint32_t* chain_dep, uint32_t* order);
 
 #ifdef __cplusplus
 }

@@ -2,11 +2,11 @@
 ``tgp_dag_plan``), checked WITHOUT a GPU:
 
 * executed on numpy blocks -- chain steps and tile tasks interpreted exactly as the kernel defines them -- it produces
-  L = chol(A) and W = L^-1, with the kernel's dispatch rule (dependency counters and ready queues: a worker only ever
-  receives a task whose producers have completed, urgent tasks first; the chain is its own worker) AND in random valid
-  interleavings;
-* the dependency graph (tasks + chain steps) is acyclic: with ready queues that is all it takes for the dispatch to be
-  deadlock-free whatever the residency;
+  L = chol(A) and W = L^-1, with the kernel's dispatch rule (workers draw the positions of ONE list in order and wait
+  for the flags of what they drew; the chain is its own worker) AND in random valid interleavings;
+* the dispatch order is a topological order -- every flag a task waits for belongs to a chain step or to a task EARLIER
+  in the list -- which makes the in-order dispatch deadlock-free whatever the residency; the dependency graph as a
+  whole (tasks + chain steps) is acyclic;
 * every pair of accesses to the same tile with a write among them is ordered by the flags (happens-before through the
   transitive closure): no data race, hence a schedule-independent -- bit-identical -- result.
 Reference: the factorisation behind trieste/models/gpflow/models.py:171-186 -> interface.py:108-112."""
@@ -33,13 +33,18 @@ def plan(nb, ld=None):
     lib = _lib.load()
     ld = ld or nb * T
     n, nu = C.c_int64(), C.c_int64()
-    rc = lib.tgp_dag_plan(nb, ld, None, 0, C.byref(n), C.byref(nu), None)
+    rc = lib.tgp_dag_plan(nb, ld, None, 0, C.byref(n), C.byref(nu), None, None)
     assert rc == _lib.TGP_ERR_SHAPE and n.value >= 0
     tasks = (Task * max(n.value, 1))()
     chain = (C.c_uint32 * (2 * nb))()
-    assert lib.tgp_dag_plan(nb, ld, tasks, n.value, C.byref(n), C.byref(nu), chain) == _lib.TGP_OK
+    order = (C.c_uint32 * max(n.value, 1))()
+    assert lib.tgp_dag_plan(nb, ld, tasks, n.value, C.byref(n), C.byref(nu), chain, order) == _lib.TGP_OK
     assert 0 <= nu.value <= n.value
+    ORDER[(nb, ld)] = [order[i] for i in range(n.value)]
     return [tasks[i] for i in range(n.value)], list(chain), ld, nu.value
+
+
+ORDER = {}  # (nb, ld) -> dispatch order of the last plan() call
 
 
 def tile_of(off, ld):
@@ -79,6 +84,8 @@ class Machine:
         self.nb, self.tasks, self.chain, self.ld, self.nu = nb, tasks, chain, ld, nu
         self.flags = np.zeros(len(tasks) + 2 * nb, dtype=bool)
         self.taken = np.zeros(len(tasks), dtype=bool)
+        self.order = ORDER[(nb, ld)]
+        self.pos = 0
         self.chain_pos = 0  # 2 j (diagonal step of j) or 2 j + 1
         self.lsub = None
 
@@ -128,13 +135,21 @@ class Machine:
         self.chain_pos += 1
 
     def acquire(self):
-        """the kernel's rule: a ready task of the urgent class if there is one, else a ready bulk task, else None
-        (the queues deliver in order of readiness; list order stands in for that here)"""
-        for lo, hi in ((0, self.nu), (self.nu, len(self.tasks))):
-            for i in range(lo, hi):
-                if not self.taken[i] and self.ready(self.tasks[i]):
-                    self.taken[i] = True
-                    return i
+        """the kernel's rule with ONE worker: the next position of the dispatch order, if its flags are up"""
+        if self.pos < len(self.order):
+            i = self.order[self.pos]
+            if self.ready(self.tasks[i]):
+                self.pos += 1
+                self.taken[i] = True
+                return i
+        return None
+
+    def acquire_any(self):
+        """a worker that drew some later position: any ready task not yet taken"""
+        for i in self.order:
+            if not self.taken[i] and self.ready(self.tasks[i]):
+                self.taken[i] = True
+                return i
         return None
 
     def lists_done(self):
@@ -189,7 +204,7 @@ def test_plan_in_random_valid_interleavings_gives_the_same_bits(seed):
     popped = []  # tasks taken by workers (their flags were up) but not yet run
     while not mc.done() or popped:
         while len(popped) < 3:
-            i = mc.acquire()
+            i = mc.acquire_any()
             if i is None:
                 break
             popped.append(i)
@@ -229,6 +244,14 @@ def test_flags_order_every_conflicting_pair_and_point_backwards(nb):
         if chain[s] != NONE:
             assert chain[s] < nt
             preds[nt + s].append(chain[s])
+    # the dispatch order: a permutation in which every task dependency points backwards
+    order = ORDER[(nb, ld)]
+    assert sorted(order) == list(range(nt))
+    where = {t: i for i, t in enumerate(order)}
+    for i, t in enumerate(tasks):
+        for d in t.dep:
+            if d != NONE and d < nt:
+                assert where[d] < where[i], f"task {i} waits for task {d}, which is dispatched AFTER it: deadlock"
     # the dependency graph is acyclic: Kahn's algorithm places every node
     order_preds = [list(p) for p in preds]
     indeg = [len(set(p)) for p in order_preds]

@@ -1,4 +1,5 @@
-"""`update` as one persistent launch (csrc/tgp_kernels_dag.hip; tgp_set_data for 512 <= Npad <= 16128) on the GPU:
+"""`update` as one persistent launch (csrc/tgp_kernels_dag.hip; tgp_set_data for 4096 <= Npad <= 16128, from Npad = 256 on
+with tgp_set_variant bit 5, which these tests set) on the GPU:
 
 * L, W = L^-1 and alpha against numpy's Cholesky of the oracle's K + s I at the sizes where the task list changes
   shape (1 ... 5 block rows with and without padding, a mid size, the headline N = 4096), both noise levels;
@@ -15,7 +16,7 @@ from tests.util import assert_close
 
 pytestmark = pytest.mark.gpu
 
-NO_DAG = 16
+NO_DAG, DAG_SMALL = 16, 32
 
 
 def _problem(N, d=4, kind="matern52", noise=1e-2, seed_obj=O.ackley):
@@ -25,7 +26,7 @@ def _problem(N, d=4, kind="matern52", noise=1e-2, seed_obj=O.ackley):
     return X, Y, ls, c, kind, noise
 
 
-def _engine(X, Y, ls, c, kind, noise, variant=0):
+def _engine(X, Y, ls, c, kind, noise, variant=DAG_SMALL):
     from trieste_amd.engine import GPEngine
 
     eng = GPEngine(X.shape[1], kind)
@@ -93,6 +94,21 @@ def test_dag_update_is_bit_identical_run_to_run_and_across_handles():
     assert np.abs(np.tril(Wa) @ np.tril(La) - np.eye(4096)).max() < 1e-8
 
 
+@pytest.mark.parametrize("N", [640, 1536])
+def test_dag_update_many_fresh_handles(N):
+    """Forty fresh handles in recycled device memory, every one a first update: the persistent kernel must not depend
+    on how its workgroups and waves happen to be timed (a race of the leaf's two panel waves, exposed by a faster
+    dispatcher, corrupted ~15 % of such updates before it was fixed)."""
+    X, Y, ls, c, kind, noise = _problem(N)
+    ref = _engine(X, Y, ls, c, kind, noise)
+    Lr, Wr, ar = ref.get_factor()
+    for _ in range(40):
+        e = _engine(X, Y, ls, c, kind, noise)
+        L, W, al = e.get_factor()
+        assert np.array_equal(L, Lr) and np.array_equal(W, Wr) and np.array_equal(al, ar)
+        e.close()
+
+
 def test_dag_update_two_handles_concurrently_on_private_streams():
     """Two persistent launches share the GPU (find_best_model_initialization drives several engines from several
     threads): neither may depend on being fully resident."""
@@ -140,6 +156,7 @@ def test_dag_update_reports_a_matrix_that_is_not_positive_definite(where):
         X[600:] = 0.5 + 1e-13 * rng.standard_normal((N - 600, d))   # a numerically rank-one trailing block
     Y = rng.standard_normal(N)
     eng = GPEngine(d, "rbf")
+    eng.set_variant(DAG_SMALL)
     eng.set_hyper(1.0, [0.3, 0.3], 1e-300, 0.0)      # (numerically) no noise
     with pytest.raises(NotPositiveDefiniteError):
         eng.set_data(X, Y)

@@ -22,7 +22,7 @@ class Task(C.Structure):
                 ("nk", C.c_uint32), ("flags", C.c_uint32), ("a_mat", C.c_uint8), ("b_mat", C.c_uint8),
                 ("c_mat", C.c_uint8), ("o_mat", C.c_uint8), ("dep", C.c_uint32 * 3), ("set", C.c_uint32), ("pad", C.c_uint32)]
 for attempt in range(60):
-    eng = GPEngine(d, "matern52"); eng.set_hyper(1.0, ls, 1e-2, float(Y.mean()))
+    eng = GPEngine(d, "matern52"); eng.set_variant(32); eng.set_hyper(1.0, ls, 1e-2, float(Y.mean()))
     failed = False
     try:
         eng.set_data(X, Y)
@@ -39,9 +39,9 @@ for attempt in range(60):
     tk = raw[2 + 32 * NB:].reshape(nt, 4).astype(np.int64)
     ld = NB * 128
     n_, nu_ = C.c_int64(), C.c_int64()
-    lib.tgp_dag_plan(NB, ld, None, 0, C.byref(n_), C.byref(nu_), None)
+    lib.tgp_dag_plan(NB, ld, None, 0, C.byref(n_), C.byref(nu_), None, None)
     tarr = (Task * n_.value)(); carr = (C.c_uint32 * (2 * NB))()
-    lib.tgp_dag_plan(NB, ld, tarr, n_.value, C.byref(n_), C.byref(nu_), carr)
+    lib.tgp_dag_plan(NB, ld, tarr, n_.value, C.byref(n_), C.byref(nu_), carr, None)
     t0 = ch[0, 0]
     print(f"attempt {attempt} FAILED; NB={NB} tasks={nt}")
     bad = 0

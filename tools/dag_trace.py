@@ -15,6 +15,7 @@ def main():
     from trieste_amd import _lib
     X, Y = O.synthetic_problem(O.ackley, 8, N)
     eng = GPEngine(8, "matern52")
+    eng.set_variant(32)
     eng.set_hyper(1.0, O.default_lengthscales(8), 1e-2, float(Y.mean()))
     for _ in range(3):
         eng.set_data(X, Y)
@@ -49,10 +50,10 @@ def main():
 
     ld = NB * 128
     n_, nu_ = C.c_int64(), C.c_int64()
-    lib.tgp_dag_plan(NB, ld, None, 0, C.byref(n_), C.byref(nu_), None)
+    lib.tgp_dag_plan(NB, ld, None, 0, C.byref(n_), C.byref(nu_), None, None)
     tarr = (Task * n_.value)()
     carr = (C.c_uint32 * (2 * NB))()
-    lib.tgp_dag_plan(NB, ld, tarr, n_.value, C.byref(n_), C.byref(nu_), carr)
+    lib.tgp_dag_plan(NB, ld, tarr, n_.value, C.byref(n_), C.byref(nu_), carr, None)
     tasks, chain, nu = [tarr[i] for i in range(n_.value)], list(carr), nu_.value
     kinds = []
     for t in tasks:

@@ -1,4 +1,3 @@
 #!/bin/bash
 set -u; OUT=$PWD/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
-for n in ${1:-4096}; do timeout 200 python tools/dag_trace.py $n 2>&1 | grep -v amdgpu.ids > $OUT/dag_trace_$n.txt; done
-echo "== dag tests"; timeout 900 python -m pytest tests/test_gpu_dag.py -m gpu -x -q 2>&1 | tail -3
+for x in 0.5 1.1 1.6; do echo "== xshift $x"; TGP_DAG_XSHIFT=$x timeout 60 python tools/dag_trace.py 4096 2>&1 | grep -v amdgpu.ids | head -2; TGP_DAG_XSHIFT=$x timeout 90 python tools/bench_update.py 4096 8192 2>&1 | grep update; done

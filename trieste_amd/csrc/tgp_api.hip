@@ -146,7 +146,9 @@ void apply_penalization(tgp_handle h, double* dvals, const double* dXq, int64_t 
 //   VARIANT_JOINT_V1 (4): joint mode on the first-generation kernel (64-column slots, Gram operands from L2)
 //   VARIANT_REG_STAGING (8): fused plain launches on the register-staged kernel instead of the LDS-DMA one
 //   VARIANT_NO_DAG (16): `update` through the recursion of dependent launches instead of the persistent task-DAG kernel
-constexpr int VARIANT_NO_SPLIT = 1, VARIANT_FORCE_SPLIT = 2, VARIANT_JOINT_V1 = 4, VARIANT_REG_STAGING = 8, VARIANT_NO_DAG = 16;
+//   VARIANT_DAG_SMALL (32): the persistent kernel from Npad = 256 on (default: from 4096 on, where it wins)
+constexpr int VARIANT_NO_SPLIT = 1, VARIANT_FORCE_SPLIT = 2, VARIANT_JOINT_V1 = 4, VARIANT_REG_STAGING = 8, VARIANT_NO_DAG = 16,
+              VARIANT_DAG_SMALL = 32;
 
 // TGP_PREC_AUTO: once per factorisation pick the cheapest arithmetic whose a-priori truncation budget on the predictive
 // variance fits under the parity tolerance where that is tightest.  Budget (the same formula the
@@ -380,12 +382,15 @@ void chol_inv(tgp_handle h, int64_t lo, int64_t hi) {
                                h->d_info.as<int>()}, lo, hi);
 }
 
-// The whole factorisation + inverse as ONE persistent launch (tgp_kernels_dag.hip) for 512 <= Npad <= 16128 (tile
+// The whole factorisation + inverse as ONE persistent launch (tgp_kernels_dag.hip) for 4096 <= Npad <= 16128 (below:
+// 0.33 / 0.57 / 1.07 ms against the recursion's 0.24 / 0.45 / 0.98 ms at N = 512 / 1024 / 2048; tgp_set_variant bit 5
+// lowers the bound to 256 -- the tests use it; tile
 // offsets in bytes fit 31 bits); the recursion above stays for everything else (small blocks, the append path, the
 // q x q / F x F factorisations of the samplers).  TGP_NO_DAG=1 forces the recursion (A/B aid, tests).
 bool dag_applies(tgp_handle h, int64_t Npad) {
   static const bool off = getenv("TGP_NO_DAG") != nullptr;
-  return !off && !(h->variant & VARIANT_NO_DAG) && Npad >= 512 && Npad % 128 == 0 && Npad * Npad * 8 < (int64_t)0x7fffffff;
+  const int64_t min_n = (h->variant & VARIANT_DAG_SMALL) ? 256 : 4096;  // (measured: below 4096 the recursion wins)
+  return !off && !(h->variant & VARIANT_NO_DAG) && Npad >= min_n && Npad % 128 == 0 && Npad * Npad * 8 < (int64_t)0x7fffffff;
 }
 
 // -> TGP_OK / error; the launch's own error words are read back by dag_check after the stream has drained
@@ -418,7 +423,9 @@ int chol_inv_dag(tgp_handle h) {
         for (uint32_t d : tasks[t].dep)
           if (d != 0xffffffffu) succ[fill[d]++] = (uint32_t)t;
     }
-    const size_t state_words = nnodes + DAG_CTRL_WORDS + 2 * nt;
+    // flags, control, counters, ticket queue (tasks + events + wake tokens + exits), urgent side queue
+    h->dag_qcap = 2 * nt + 2 * (size_t)NB + (size_t)h->num_cu + 64;
+    const size_t state_words = nnodes + DAG_CTRL_WORDS + nt + h->dag_qcap + (nt + 2 * (size_t)NB + 64);
     for (size_t t = 0; t < nt; ++t)
       if (cnt[t] == 0) return fail(h, TGP_ERR_STATE, "task %zu of the update plan has no dependency", t);  // (cannot happen)
     HIPCHK(h, h->d_dag_tasks.reserve(tasks.size() * sizeof(DagTask)));
@@ -453,6 +460,7 @@ int chol_inv_dag(tgp_handle h) {
   a.NB = NB;
   a.ntasks = h->dag_ntasks;
   a.nu = h->dag_nu;
+  a.qcap = (int)h->dag_qcap;
   a.tasks = h->d_dag_tasks.as<DagTask>();
   a.chain_dep = h->d_dag_chain.as<uint32_t>();
   a.flags = h->d_dag_flags.as<uint32_t>();
@@ -462,8 +470,8 @@ int chol_inv_dag(tgp_handle h) {
   a.succ = a.succ_off + nflags + 1;
   a.topo = a.succ + h->dag_nsucc;
   a.info = h->d_info.as<int>();
-  static const int fences = getenv("TGP_DAG_FENCES") ? atoi(getenv("TGP_DAG_FENCES")) : 0;  // experiments
-  a.fences = fences;
+  static const int tickets = getenv("TGP_DAG_TICKETS") ? atoi(getenv("TGP_DAG_TICKETS")) : 0;  // A/B aid (dispatcher)
+  a.tickets = tickets;
   // development aid: TGP_DAG_TRACE=<file> -- time stamps of every chain phase and task of the LAST update, dumped as
   // uint64 [NB][32] + [ntasks][4] after the stream has drained (tools/dag_trace.py reads it)
   static const char* trace_path = getenv("TGP_DAG_TRACE");
@@ -726,17 +734,18 @@ int tgp_set_variant(tgp_handle h, int variant) {
 
 static_assert(sizeof(tgp_dag_task) == sizeof(tgp::DagTask), "tgp_dag_task mirrors tgp::DagTask");
 int tgp_dag_plan(int nb, int64_t ld, tgp_dag_task* tasks, int64_t cap, int64_t* ntasks, int64_t* n_urgent,
-                 uint32_t* chain_dep) {
+                 uint32_t* chain_dep, uint32_t* order) {
   if (nb < 1 || nb > 126 || ld < (int64_t)nb * 128 || !ntasks || !n_urgent) return TGP_ERR_ARG;
   std::vector<tgp::DagTask> t;
-  std::vector<uint32_t> c;
+  std::vector<uint32_t> c, topo;
   int nu = 0;
-  tgp::dag_build(nb, ld, t, c, nu);
+  tgp::dag_build(nb, ld, t, c, nu, &topo);
   *ntasks = (int64_t)t.size();
   *n_urgent = nu;
   if (cap < (int64_t)t.size() || !tasks || !chain_dep) return TGP_ERR_SHAPE;
   memcpy(tasks, t.data(), t.size() * sizeof(tgp::DagTask));
   memcpy(chain_dep, c.data(), c.size() * sizeof(uint32_t));
+  if (order) memcpy(order, topo.data(), topo.size() * sizeof(uint32_t));
   return TGP_OK;
 }
 

@@ -109,7 +109,7 @@ struct tgp_handle_s {
   int dag_nb = 0, dag_ntasks = 0, dag_nu = 0;
   int64_t dag_ld = 0;
   DevBuf d_dag_tasks, d_dag_chain, d_dag_flags, d_dag_trace, d_dag_succ;
-  size_t dag_state_words = 0, dag_nsucc = 0;  // flags: [ntasks + 2 NB] flag words, control words, counters, queues (DagArgs), zeroed per launch
+  size_t dag_state_words = 0, dag_nsucc = 0, dag_qcap = 0;  // flags: [ntasks + 2 NB] flag words, control words, counters, queues (DagArgs), zeroed per launch
   // timing of the dominant kernel
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double last_ms = 0.0;

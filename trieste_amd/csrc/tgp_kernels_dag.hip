@@ -121,28 +121,51 @@ __device__ __forceinline__ void st16_sc1(double* p, v2d x) {
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");  // (data-register hazard)
 }
 
-// ---- dispatch: dependency counters and two ready queues ---------------------------------------------------------
-// Every tile task has a counter of unmet dependencies (tasks and chain events); whoever completes a node walks its
-// successor list (one lane per successor), decrements their counters and pushes the ones that reach zero into a ready
-// queue: the URGENT queue (the last burst of a tile and the triangular products T / E -- every block row runs its own
-// chain of them at the pace of the diagonal chain) or the BULK queue (the long prefix bursts).  A worker pops the
-// urgent queue first, then the bulk queue, and only ever receives a task it can run at once.  The chain workgroup
-// does not walk successor lists (that would sit on the critical path): it bumps `ev_pub`, and the next worker that
-// looks for work releases the event's successors.  Each task is pushed exactly once: the queues are plain arrays of
-// their final length, no wrap-around.  Measured on the way here (tools/dag_trace.py): ONE list popped in order with
-// the worker spinning on whatever it drew left urgent tasks unpopped behind hundreds of long bursts (the chain waited
-// 40 us every few steps); taking only the head of two lists serialised everything behind an unready head; a 64-entry
-// scan window from the first unclaimed entry still hid ready tasks behind unready ones.
-// The whole launch state starts as ZEROS (one memset node before every launch): counters count the dependencies MET
-// (a task is ready when that reaches its `need`), queue slots hold task id + 1 (0 = not written yet).
-constexpr uint32_t TASK_DONE = 0xfffffffeu, TASK_ERR = 0xfffffffdu, Q_EMPTY = 0u;
-// ctrl words
-constexpr int C_TICKET = 0, C_UHEAD = 1, C_ERR = 2, C_ERRINFO = 3, C_BHEAD = 4, C_UTAIL = 5, C_BTAIL = 6, C_EVPUB = 7,
-              C_EVREL = 8, C_DONE = 9;
+// ---- dispatch: dependency counters and ONE ready queue with tickets --------------------------------------------
+// Every tile task has a counter of met dependencies (tasks and chain events); whoever completes a node walks its
+// successor list (one lane per successor), bumps their counters and pushes the ones that are complete into the ready
+// queue: slot = atomicAdd(tail), then the slot is written.  A worker draws a TICKET (atomicAdd(head)) and waits for
+// ITS slot: every idle worker polls a word of its own, a pushed task wakes exactly the longest-waiting worker, and a
+// worker only ever receives a task it can run at once.  The chain workgroup does not walk successor lists (that would
+// sit on the critical path): it pushes the event itself as a pseudo task, and the worker that draws it releases the
+// event's successors.  The worker that completes the last task pushes one EXIT token per worker.  Every entry is
+// pushed exactly once: the queue is a plain array of its final length, no wrap-around; all of it starts as zeros.
+// Measured on the way here (tools/dag_trace.py, N = 4096): ONE list popped in order with the worker spinning on
+// whatever it drew left urgent tasks unpopped behind hundreds of long bursts (the chain waited 40 us every few
+// steps); non-blocking pops from shared head / tail words with idle workers polling them -- even ONE shared hint word
+// with back-off -- is a thundering herd on a cache line: every push woke ~130 workers and the launch ran 6 x slower,
+// chain included.
+// PRIORITY (built, measured, switched off: SIDE_QUEUE): in the ticket queue a chain event or an urgent task (the last
+// burst of a tile, T, E: every block row runs its own chain of them at the pace of the diagonal chain) waits behind
+// every bulk burst pushed before it whenever all workers are busy.  With SIDE_QUEUE an urgent entry goes to the ticket
+// queue only while workers are WAITING there (head > tail: it wakes one at once), otherwise to a small side queue that
+// every worker looks at before it draws its next ticket (a WAKE token follows it if waiters appear between the two
+// looks, so that it cannot be stranded).  N = 4096: the chain's waits 9.8 -> 8.3 us per step (2.19 -> 2.16 ms);
+// N = 8192, where every worker is always busy and every task boundary now reads and compare-and-swaps the side
+// queue's two words: 8.4 -> 16.4 ms.  Off.
+constexpr bool SIDE_QUEUE = false;
+constexpr uint32_t TASK_DONE = 0xfffffffeu, TASK_ERR = 0xfffffffdu, Q_EMPTY = 0u, Q_EXIT = 0xffffffffu, Q_WAKE = 0xfffffffcu;
+// ctrl words: [0, 32) rare (ticket, error, done count); heads and tails on cache lines of their own
+constexpr int C_TICKET = 0, C_ERR = 2, C_ERRINFO = 3, C_DONE = 9, C_HEAD = 32, C_TAIL = 64, C_PHEAD = 96, C_PTAIL = 100;
+static_assert(DAG_CTRL_WORDS >= 128, "control block");
 
 __device__ __forceinline__ uint32_t* dag_cnt(const DagArgs& a) { return a.ctrl + DAG_CTRL_WORDS; }
-__device__ __forceinline__ uint32_t* dag_queue(const DagArgs& a, bool urgent) {
-  return a.ctrl + DAG_CTRL_WORDS + a.ntasks + (urgent ? 0 : a.nu);
+__device__ __forceinline__ uint32_t* dag_queue(const DagArgs& a) { return a.ctrl + DAG_CTRL_WORDS + a.ntasks; }
+__device__ __forceinline__ uint32_t* dag_pqueue(const DagArgs& a) { return dag_queue(a) + a.qcap; }
+
+__device__ __forceinline__ void push_ticket(const DagArgs& a, uint32_t code) {
+  const uint32_t pos = atomicAdd(a.ctrl + C_TAIL, 1u);
+  st_flag(dag_queue(a) + pos, code);
+}
+// code = node + 1 (a task, or a chain event: node >= ntasks), or Q_EXIT
+__device__ __forceinline__ void push_ready(const DagArgs& a, uint32_t code, bool urgent) {
+  if (SIDE_QUEUE && urgent && (int)(ld_flag(a.ctrl + C_HEAD) - ld_flag(a.ctrl + C_TAIL)) <= 0) {  // nobody is waiting for a ticket
+    const uint32_t pos = atomicAdd(a.ctrl + C_PTAIL, 1u);
+    st_flag(dag_pqueue(a) + pos, code);
+    if ((int)(ld_flag(a.ctrl + C_HEAD) - ld_flag(a.ctrl + C_TAIL)) > 0) push_ticket(a, Q_WAKE);
+    return;
+  }
+  push_ticket(a, code);
 }
 
 // all lanes of one wave: node (task or chain event) is complete -> its successors
@@ -151,66 +174,55 @@ __device__ void release_node(const DagArgs& a, uint32_t node) {
   const uint32_t beg = a.succ_off[node], end = a.succ_off[node + 1];
   for (uint32_t i = beg + lane; i < end; i += 64) {
     const uint32_t sct = a.succ[i];
-    if (atomicAdd(dag_cnt(a) + sct, 1u) + 1u == a.need[sct]) {
-      const bool urgent = sct < (uint32_t)a.nu;
-      const uint32_t pos = atomicAdd(a.ctrl + (urgent ? C_UTAIL : C_BTAIL), 1u);
-      st_flag(dag_queue(a, urgent) + pos, sct + 1u);
-    }
+    if (atomicAdd(dag_cnt(a) + sct, 1u) + 1u == a.need[sct]) push_ready(a, sct + 1u, sct < (uint32_t)a.nu);
   }
 }
 
-// All 64 lanes of ONE wave: the next task this workgroup runs (wave-uniform), TASK_DONE when every task has completed,
-// TASK_ERR on a timeout / when another workgroup has raised the error word.
+// All 64 lanes of ONE wave: the next task this workgroup runs (wave-uniform), TASK_DONE on an EXIT token, TASK_ERR on
+// a timeout / when another workgroup has raised the error word.
 __device__ uint32_t acquire_task(const DagArgs& a) {
   const uint32_t lane = threadIdx.x & 63;
-  unsigned spins = 0;
   for (;;) {
-    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, w4 = 0, w5 = 0, w6 = 0;
-    if (lane == 0) {
-      w0 = ld_flag(a.ctrl + C_EVREL);
-      w1 = ld_flag(a.ctrl + C_EVPUB);
-      w2 = ld_flag(a.ctrl + C_UHEAD);
-      w3 = ld_flag(a.ctrl + C_UTAIL);
-      w4 = ld_flag(a.ctrl + C_BHEAD);
-      w5 = ld_flag(a.ctrl + C_BTAIL);
-      w6 = ld_flag(a.ctrl + C_DONE);
-    }
-    const uint32_t rel = uni(w0), pub = uni(w1), uh = uni(w2), ut = uni(w3), bh = uni(w4), bt = uni(w5), dn = uni(w6);
-    if (rel < pub) {  // a chain event nobody has released yet: event e -> W_jj ready (even) / L(j+1,j) stored (odd)
-      uint32_t won = 0;
-      if (lane == 0) won = atomicCAS(a.ctrl + C_EVREL, rel, rel + 1) == rel ? 1u : 0u;
-      if (uni(won)) release_node(a, (uint32_t)a.ntasks + ((rel & 1) ? (uint32_t)a.NB + (rel >> 1) : (rel >> 1)));
-      continue;
-    }
-    const bool urgent = uh < ut;
-    if (urgent || bh < bt) {
-      const uint32_t h = urgent ? uh : bh;
-      uint32_t won = 0;
-      if (lane == 0) won = atomicCAS(a.ctrl + (urgent ? C_UHEAD : C_BHEAD), h, h + 1) == h ? 1u : 0u;
-      if (!uni(won)) continue;
-      uint32_t v = Q_EMPTY;
-      if (lane == 0) {  // (the producer reserved the slot before writing it: a few hundred ns at most)
-        const uint32_t* const slot = dag_queue(a, urgent) + h;
-        while ((v = ld_flag(slot)) == Q_EMPTY) __builtin_amdgcn_s_sleep(1);
-        v -= 1u;
-        if (a.trace) a.trace[CT * a.NB + 4 * (size_t)v] = wall_clock64();
+    uint32_t v = Q_EMPTY, st = 0;
+    if (SIDE_QUEUE && lane == 0) {
+      for (;;) {  // the side queue of urgent entries first
+        const uint32_t ph = ld_flag(a.ctrl + C_PHEAD);
+        if ((int)(ld_flag(a.ctrl + C_PTAIL) - ph) <= 0) break;
+        if (atomicCAS(a.ctrl + C_PHEAD, ph, ph + 1) != ph) continue;
+        const uint32_t* const slot = dag_pqueue(a) + ph;
+        while ((v = ld_flag(slot)) == Q_EMPTY) __builtin_amdgcn_s_sleep(1);  // (reserved before written: a moment)
+        break;
       }
-      return uni(v);
     }
-    if (dn >= (uint32_t)a.ntasks) return TASK_DONE;
-    __builtin_amdgcn_s_sleep(4);
-    if ((++spins & 255u) == 0) {
-      uint32_t err = 0;
-      if (lane == 0) err = ld_flag(a.ctrl + C_ERR);
-      if (uni(err)) return TASK_ERR;
-      if (spins > SPIN_LIMIT / 4) {
-        if (lane == 0) {
-          st_flag(a.ctrl + C_ERR, DAG_ERR_TIMEOUT);
-          st_flag(a.ctrl + C_ERRINFO, dn);
+    if (uni(v) == Q_EMPTY && lane == 0) {
+      const uint32_t t = atomicAdd(a.ctrl + C_HEAD, 1u);
+      const uint32_t* const slot = dag_queue(a) + t;
+      unsigned spins = 0;
+      int nap = 1;
+      while ((v = ld_flag(slot)) == Q_EMPTY) {
+        for (int z = 0; z < nap; ++z) __builtin_amdgcn_s_sleep(8);
+        if (nap < 8) ++nap;
+        if ((++spins & 63u) == 0) {
+          if (ld_flag(a.ctrl + C_ERR) != 0) { st = 1; break; }
+          if (spins > SPIN_LIMIT / 4) {
+            st_flag(a.ctrl + C_ERR, DAG_ERR_TIMEOUT);
+            st_flag(a.ctrl + C_ERRINFO, t);
+            st = 1;
+            break;
+          }
         }
-        return TASK_ERR;
       }
     }
+    if (uni(st)) return TASK_ERR;
+    v = uni(v);
+    if (v == Q_EXIT) return TASK_DONE;
+    if (v == Q_WAKE) continue;  // an urgent entry went to the side queue while this worker was waiting here
+    v -= 1u;
+    if (v < (uint32_t)a.ntasks) {
+      if (a.trace && lane == 0) a.trace[CT * a.NB + 4 * (size_t)v] = wall_clock64();
+      return v;
+    }
+    release_node(a, v);  // a chain event: hand its successors on, then draw again
   }
 }
 
@@ -350,13 +362,6 @@ __device__ __attribute__((noinline)) void run_task(const DagArgs& a, uint32_t id
   }
   drain_vm();  // every storing wave drains its write-through stores, THEN the barrier, THEN one lane publishes
   __syncthreads();
-  if (a.fences & 2) {
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-  }
   if (tid == 0) st_flag(uniptr(a.flags) + t.set, 1u);
 }
 
@@ -463,7 +468,7 @@ __device__ __forceinline__ void chain_diag(const DagArgs& a, int j, uint32_t pen
   __syncthreads();  // everybody is done reading Lsub: S takes its place
   if (tid == 0 && pending != NONE) {
     st_flag(uniptr(a.flags) + pending, 1u);
-    atomicAdd(uniptr(a.ctrl) + C_EVPUB, 1u);  // event 2 (j - 1) + 1: some worker releases its successors
+    if (a.tickets) push_ready(a, pending + 1u, true);  // the event as a pseudo task: the worker that draws it releases the successors
   }
 #pragma unroll
   for (int m = 0; m < NF; ++m) {
@@ -577,7 +582,7 @@ __device__ __attribute__((noinline)) void run_chain(const DagArgs& a) {
       __syncthreads();
       if (tid == 0) {
         st_flag(a.flags + pending, 1u);
-        atomicAdd(a.ctrl + C_EVPUB, 1u);
+        if (a.tickets) push_ready(a, pending + 1u, true);
       }
       pending = NONE;
     }
@@ -589,36 +594,18 @@ __device__ __attribute__((noinline)) void run_chain(const DagArgs& a) {
     stamp(tr);
     if (!wait_for(a.chain_dep[2 * j])) return;
     stamp(tr ? tr + 1 : nullptr);
-    if (a.fences & 1) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      __syncthreads();
-    }
-    if (a.fences & 8) {  // experiment: the chain reads its inputs ~5 us after it has seen their flag
-      const unsigned long long t0 = wall_clock64();
-      while (wall_clock64() - t0 < 500) __builtin_amdgcn_s_sleep(8);
-      __syncthreads();
-    }
     chain_diag(a, j, pending);
     pending = NONE;
     stamp(tr ? tr + 2 : nullptr);
     chain_leaf(a, j);
     if (tid == 0) {
       st_flag(a.flags + WD + j, 1u);
-      atomicAdd(a.ctrl + C_EVPUB, 1u);  // event 2 j
+      if (a.tickets) push_ready(a, WD + (uint32_t)j + 1u, true);
     }
     stamp(tr ? tr + 3 : nullptr);
     if (j + 1 == a.NB) break;
     if (!wait_for(a.chain_dep[2 * j + 1])) return;
     stamp(tr ? tr + 4 : nullptr);
-    if (a.fences & 1) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      __syncthreads();
-    }
-    if (a.fences & 8) {
-      const unsigned long long t0 = wall_clock64();
-      while (wall_clock64() - t0 < 500) __builtin_amdgcn_s_sleep(8);
-      __syncthreads();
-    }
     chain_sub(a, j);
     pending = LSUB + (uint32_t)j;
     stamp(tr ? tr + 5 : nullptr);
@@ -630,10 +617,6 @@ __global__ __launch_bounds__(512) void dag_update_kernel(DagArgs a) {
   char* const lds = dag_lds;
   volatile uint32_t* const ctl = (volatile uint32_t*)(lds + CTL_OFF);
   const int tid = threadIdx.x;
-  if (a.fences & 16) {  // experiment: system-scope invalidate at kernel start (L2 lines left by earlier launches?)
-    asm volatile("buffer_inv sc0 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
   if (tid == 0) ctl[0] = atomicAdd(a.ctrl + C_TICKET, 1u);  // arrival ticket: the first resident workgroup is the chain
   __syncthreads();
   const uint32_t role = ctl[0];
@@ -644,9 +627,9 @@ __global__ __launch_bounds__(512) void dag_update_kernel(DagArgs a) {
   }
 #pragma unroll 1
   for (;;) {
-    if (a.fences & 32) {  // experiment: the first dispatcher -- ONE list popped in order, the worker waits for its flags
+    if (!a.tickets) {  // ONE list popped in order, the worker waits for the flags of what it drew
       if (tid == 0) {
-        const uint32_t pos = atomicAdd(a.ctrl + C_UHEAD, 1u);
+        const uint32_t pos = atomicAdd(a.ctrl + C_HEAD, 1u);
         uint32_t got = TASK_DONE;
         if (pos < (uint32_t)a.ntasks) {
           got = a.topo[pos];
@@ -683,21 +666,15 @@ __global__ __launch_bounds__(512) void dag_update_kernel(DagArgs a) {
         }
       }
     }
-    if (a.fences & 1) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      __syncthreads();
-    }
-    if (a.fences & 4) {  // experiment: start every task ~20 us late
-      const unsigned long long t0 = wall_clock64();
-      while (wall_clock64() - t0 < 2000) __builtin_amdgcn_s_sleep(16);
-      __syncthreads();
-    }
     run_task(a, idx);
     stamp(tr ? tr + 2 : nullptr);
     if (tr) tr[3] = blockIdx.x;
-    if (tid < 64 && !(a.fences & 32)) {  // the tile is stored and its flag is up (run_task): hand its successors on
+    if (tid < 64 && (a.tickets)) {  // the tile is stored and its flag is up (run_task): hand its successors on
       release_node(a, idx);
-      if (tid == 0) atomicAdd(a.ctrl + C_DONE, 1u);
+      uint32_t last = 0;
+      if (tid == 0) last = atomicAdd(a.ctrl + C_DONE, 1u) + 1u == (uint32_t)a.ntasks ? 1u : 0u;
+      if (uni(last))  // the last task: one EXIT token per worker (every workgroup but the chain's draws exactly one)
+        for (uint32_t i = tid; i + 1 < gridDim.x; i += 64) push_ticket(a, Q_EXIT);
     }
   }
 }
