@@ -167,13 +167,19 @@ def test_auto_precision_stays_inside_the_plain_tolerance(cfg):
     print(f"[margin] auto {cfg[0]}: picked {eff} (max|W| = {wmax:.3g}); var error / plain tolerance = {worst:.4f}")
     assert_close(var, ov, atol=floor, what="var under auto")
     assert_close(mean, om, atol=floor * 10, what="mean under auto")
-    # a new factorisation re-decides: much more noise -> better conditioned -> never a more expensive arithmetic
-    order = {"i8x4": 0, "i8x5": 1, "f64": 2}
+    # a new factorisation re-decides, by the same rule, from ITS max |W| and ITS floor (more noise: smaller |W|, but
+    # also a smaller cancellation floor -- the choice can go either way)
     eng.set_hyper(1.0, O.default_lengthscales(d), 0.5, float(st.mean_const))
     X, Y = O.synthetic_problem(obj, d, N)
     eng.set_data(X, Y)
     _, eff2, wmax2 = eng.get_precision()
-    assert wmax2 < wmax and order[eff2] <= order[eff]
+    floor2 = cancellation_floor(N, 1.0, 0.5)
+
+    def budget2(planes):
+        return 2.0 * (2.0 * 2.0 ** (-8 * planes) * 2.0 * (2.0 * wmax2) * np.sqrt(N / 6.0))
+
+    want2 = "i8x4" if budget2(4) <= floor2 else ("i8x5" if d <= 16 and budget2(5) <= floor2 else "f64")
+    assert wmax2 < wmax and eff2 == want2, (eff2, want2, wmax2, floor2)
     eng.set_precision("f64")
     assert eng.get_precision() == ("f64", "f64", 0.0)
 
