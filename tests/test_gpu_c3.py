@@ -30,7 +30,7 @@ def test_fused_sweep_at_n4096_matches_the_cpu_restatement(noise):
     st = O.gpr_update(KIND, 1.0, ls, noise, c, X, Y)
     floor = cancellation_floor(N, 1.0, noise)
     eta = eng.eta()
-    assert_close(eta, O.eta_min_mean(st), atol=floor * 10, what="eta")
+    assert_close(eta, O.eta_min_mean(st), atol=floor, what="eta")
 
     Xq = eng.sample_box(5678, 0, M, 0.0, 1.0)
     host = P.sample_box(5678, 0, M, np.zeros(D), np.ones(D))
@@ -45,13 +45,13 @@ def test_fused_sweep_at_n4096_matches_the_cpu_restatement(noise):
     sw = TorchCpuSweep(st)
     oracle_vals = np.concatenate([sw.chunk_values(host[s:s + 16384], eta, improved=False).numpy()
                                   for s in range(0, M, 16384)])
-    tol = 1e-5 * np.abs(oracle_vals) + floor * 10
+    tol = 1e-5 * np.abs(oracle_vals) + floor
     err = np.abs(vals - oracle_vals)
-    worst = record_margin("EI, all 131109 values vs the CPU restatement", err, tol, 1e-5, floor * 10)
+    worst = record_margin("EI, all 131109 values vs the CPU restatement", err, tol, 1e-5, floor)
     print(f"[margin] c3 noise={noise:g}: EI worst error / tolerance = {worst:.3g}")
     assert np.all(err <= tol), (int(np.argmax(err - tol)), float(err.max()))
     oi = int(np.argmax(oracle_vals))
-    band = 1e-5 * oracle_vals[oi] + floor * 10
+    band = 1e-5 * oracle_vals[oi] + floor
     assert idx == oi or abs(oracle_vals[oi] - oracle_vals[idx]) <= band, (idx, oi)
     assert abs(val - oracle_vals[oi]) <= band
 

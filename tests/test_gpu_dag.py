@@ -67,7 +67,7 @@ def test_dag_update_matches_numpy_and_the_recursion(N, noise):
 
     floor = cancellation_floor(N, 1.0, noise)
     assert_close(v, ov, atol=floor, what="var through the DAG factor")
-    assert_close(m, om, atol=floor * 10, what="mean through the DAG factor")
+    assert_close(m, om, atol=floor, what="mean through the DAG factor")
     assert_close(v, v0, atol=floor, what="var: DAG vs recursion")
 
 

@@ -50,7 +50,7 @@ def test_c2_hartmann6_rbf_n1024_one_million_candidates():
     sl = Xq[:400].cpu().numpy()
     om, ov = O.predict(st, sl)
     assert_close(vals[:400].cpu().numpy(), O.expected_improvement(om, ov, eta),
-                 atol=cancellation_floor(1024, 1.0, 1e-2) * 10, what="EI slice")
+                 atol=cancellation_floor(1024, 1.0, 1e-2), what="EI slice")
     # shard-consistent candidate generation: rows [lo, hi) regenerated == slice of the whole
     lo, hi = 123_457, 123_457 + 1000
     np.testing.assert_array_equal(eng.sample_box(5678, lo, hi - lo, 0.0, 1.0).cpu().numpy(), Xq[lo:hi].cpu().numpy())
@@ -74,7 +74,7 @@ def test_c4_batch_mc_ei_q50_s512_n2048():
     np.testing.assert_array_equal(eng.qei(Xg[perm], eps, eta, 1e-6), full[perm])
     st = O.gpr_update("matern52", 1.0, ls, 1e-2, c, X, Y)
     want = O.batch_mc_ei(st, Xg[:6], eps, eta, 1e-6)
-    assert_close(full[:6], want, atol=cancellation_floor(2048, 1.0, 1e-2) * 100, what="qEI vs oracle")
+    assert_close(full[:6], want, atol=cancellation_floor(2048, 1.0, 1e-2), what="qEI vs oracle")
     jm, jc = eng.predict_joint(Xg[:3])
     om, oc = O.predict_joint(st, Xg[:3])
     assert_close(jm, om, atol=1e-8, what="joint mean")

@@ -38,21 +38,21 @@ def test_engine_matches_mpmath_goldens(c):
     assert_close(alpha, c["alpha"], atol=floor * ascale / min(noise, 1.0), what="alpha")
     Xq = np.array(c["Xq"])
     mean, var = eng.predict(Xq)
-    assert_close(mean, c["mean"], atol=floor * 10, what="mean")
+    assert_close(mean, c["mean"], atol=floor, what="mean")
     assert_close(var, c["var"], atol=floor, what="var")
-    assert_close(eng.predict_mean(Xq), c["mean"], atol=floor * 10, what="predict_mean")
-    assert_close(eng.eta(), c["eta"], atol=floor * 10, what="eta")
+    assert_close(eng.predict_mean(Xq), c["mean"], atol=floor, what="predict_mean")
+    assert_close(eng.eta(), c["eta"], atol=floor, what="eta")
     if noise >= 1e-3:  # well conditioned: acquisition values end to end
         assert_close(eng.acq_values("ei", c["eta"], Xq), c["ei"], atol=floor, what="ei")
         assert_close(eng.acq_values("pi", c["eta"], Xq), c["pi"], atol=max(floor, 1e-300) * 1e3, what="pi")
-        assert_close(eng.acq_values("nlcb", 1.96, Xq), c["nlcb"], atol=floor * 10, what="nlcb")
+        assert_close(eng.acq_values("nlcb", 1.96, Xq), c["nlcb"], atol=floor, what="nlcb")
         assert_close(eng.acq_values("aei", c["eta"], Xq), c["aei"], atol=floor, what="aei")
         assert_close(eng.qei(np.array(c["Xg"]), np.array(c["eps"]), c["eta"], c["jitter"]), c["qei"],
-                     atol=floor * 10, what="qei")
+                     atol=floor, what="qei")
     n1, n2 = len(c["cov12"]), len(c["cov12"][0])
     assert_close(eng.cov_between(Xq[:n1], Xq[n1:n1 + n2]), c["cov12"], atol=floor, what="cov12")
     jm, jc = eng.predict_joint(np.array(c["Xg"]))
-    assert_close(jm, c["joint_mean"], atol=floor * 10, what="joint mean")
+    assert_close(jm, c["joint_mean"], atol=floor, what="joint mean")
     assert_close(jc, c["joint_cov"], atol=floor, what="joint cov")
     traj = eng.trajectory(np.array(c["rff_W"]), np.array(c["rff_b"]), np.array(c["traj_w"]),
                           np.array(c["traj_xi"]))
@@ -111,16 +111,16 @@ def test_sweep_matches_oracle(cfg, variant):
     assert_close(mean, om, atol=floor * 10, what="mean")
     assert_close(var, ov, atol=floor, what="var")
     eta = eng.eta()
-    assert_close(eta, O.eta_min_mean(st), atol=floor * 10, what="eta")
+    assert_close(eta, O.eta_min_mean(st), atol=floor, what="eta")
     ei = eng.acq_values("ei", eta, Xq)
     oei = O.expected_improvement(om, ov, eta)
-    assert_close(ei, oei, atol=floor * 10, what="ei")
+    assert_close(ei, oei, atol=floor, what="ei")
     # fused arg-max == arg-max of the engine's own values (first index on ties); its value agrees with the
     # oracle's maximum and its INDEX with the oracle's arg-max (up to the tolerance band)
     val, idx, x = eng.acq_argmax("ei", eta, Xq)
     assert idx == int(np.argmax(ei)) and val == ei[idx]
-    assert_close(val, np.max(oei), atol=floor * 10, what="max ei")
-    assert _oracle_argmax_agrees(idx, oei, 1e-5 * np.max(oei) + floor * 10), (idx, int(np.argmax(oei)))
+    assert_close(val, np.max(oei), atol=floor, what="max ei")
+    assert _oracle_argmax_agrees(idx, oei, 1e-5 * np.max(oei) + floor), (idx, int(np.argmax(oei)))
     np.testing.assert_array_equal(x, Xq[idx])
     # top-k == stable descending sort of the engine's values
     k = 17
@@ -259,13 +259,13 @@ def test_joint_and_qei_match_oracle(cfg, variant):
         Xg[0, 0] = X[0]
         jm, jc = eng.predict_joint(Xg)
         om, oc = O.predict_joint(st, Xg)
-        assert_close(jm, om, atol=floor * 10, what=f"joint mean q={q}")
+        assert_close(jm, om, atol=floor, what=f"joint mean q={q}")
         assert_close(jc, oc, atol=floor, what=f"joint cov q={q}")
         eps = rng.normal(size=(q, S))
         eta = O.eta_min_mean(st)
         got = eng.qei(Xg, eps, eta, 1e-6)
         want = O.batch_mc_ei(st, Xg, eps, eta, 1e-6)
-        assert_close(got, want, atol=floor * 10, what=f"qei q={q}")
+        assert_close(got, want, atol=floor, what=f"qei q={q}")
     # q = 1 qEI with many draws is close to analytic EI (reference test_function.py:1359-1371)
 
 
@@ -337,7 +337,7 @@ def test_headline_size_properties():
     om, ov = O.predict(st, Xq)
     gm, gv = eng.predict(Xq)
     floor = cancellation_floor(N, 1.0, noise)
-    assert_close(gm, om, atol=floor * 10, what="mean vs oracle")
+    assert_close(gm, om, atol=floor, what="mean vs oracle")
     assert_close(gv, ov, atol=floor, what="var vs oracle")
     # (4) far field: var -> variance, mean -> c, EI underflows to exactly 0 (tf semantics)
     far = 10.0 + rng.uniform(size=(4, d))
@@ -359,7 +359,7 @@ def test_acq_value_and_gradient_match_oracle(cfg):
         val, grad = eng.acq_value_grad(acq, par, Xq)
         oval, ograd = O.acq_value_and_grad(st, acq, par, Xq)
         floor = cancellation_floor(N, 1.0, noise)
-        assert_close(val, oval, atol=floor * 10, what=f"{acq} value")
+        assert_close(val, oval, atol=floor, what=f"{acq} value")
         # gradients of the variance inherit the cancellation floor times |d k / dx| ~ 1 / lengthscale
         gscale = np.abs(ograd).max() + 1e-300
         assert_close(grad, ograd, rtol=1e-5, atol=max(floor * 1e3, 1e-9 * gscale), what=f"{acq} gradient")
@@ -396,10 +396,10 @@ def test_covariance_between_points_matches_oracle(cfg):
         assert_close(cov, O.covariance_between_points(st, X1, X2), atol=floor * 10, what=f"cov {p1}x{p2}")
         assert_close(eng.cov_between(X2, X1), cov.T, rtol=1e-12, atol=floor, what="cov symmetry")
     _, var_raw = O.predict(st, Xq[:70], clip=False)
-    assert_close(np.diag(eng.cov_between(Xq[:70], Xq[:70])), var_raw, atol=floor * 10, what="diag == raw variance")
+    assert_close(np.diag(eng.cov_between(Xq[:70], Xq[:70])), var_raw, atol=floor, what="diag == raw variance")
     # training inputs with themselves: K - K (K + noise I)^-1 K, tiny for tiny noise
     Xt = X[:33]
-    assert_close(eng.cov_between(Xt, Xt), O.covariance_between_points(st, Xt, Xt), atol=floor * 10, what="cov at data")
+    assert_close(eng.cov_between(Xt, Xt), O.covariance_between_points(st, Xt, Xt), atol=floor, what="cov at data")
 
 
 @pytest.mark.parametrize("cfg", CONFIGS, ids=[c[0] for c in CONFIGS])
@@ -518,9 +518,9 @@ def test_append_data_equals_full_refactorisation(cfg):
         assert_close(aa, af, rtol=1e-7, atol=floor * ascale / min(noise, 1.0), what="alpha append == full")
         ma, va = eng.predict(Xq)
         mo, vo = O.predict(sto, Xq)
-        assert_close(ma, mo, atol=floor * 10, what="mean after append")
+        assert_close(ma, mo, atol=floor, what="mean after append")
         assert_close(va, vo, atol=floor, what="var after append")
-        assert_close(eng.eta(), O.eta_min_mean(sto), atol=floor * 10, what="eta after append")
+        assert_close(eng.eta(), O.eta_min_mean(sto), atol=floor, what="eta after append")
     # a hyper-parameter change invalidates the factor: append must refuse until set_data is called again
     eng.set_hyper(1.1, ls, noise, c)
     with pytest.raises(RuntimeError):
@@ -572,10 +572,10 @@ def test_greedy_batch_pieces_match_mpmath_goldens(c):
     twin = eng.clone()
     twin.append_data(pend, np.array(c["fant_y"]))
     fm, fv = twin.predict(Xq)
-    assert_close(fm, c["fant_mean"], atol=floor * 10 / min(noise, 1.0) ** 0.5, what="fantasized mean")
+    assert_close(fm, c["fant_mean"], atol=floor / min(noise, 1.0) ** 0.5, what="fantasized mean")
     assert_close(fv, np.maximum(np.array(c["fant_var_raw"]), 1e-12), atol=floor, what="fantasized var")
     mean, var = eng.predict(Xq)  # the source is untouched
-    assert_close(mean, c["mean"], atol=floor * 10, what="base mean after clone")
+    assert_close(mean, c["mean"], atol=floor, what="base mean after clone")
     assert_close(var, c["var"], atol=floor, what="base var after clone")
     assert eng.N == N and twin.N == N + pend.shape[0]
 
@@ -612,7 +612,7 @@ def test_penalized_sweeps_match_oracle(cfg, kind):
     np.testing.assert_array_equal(ti, oi_)
     np.testing.assert_array_equal(tv, ov_)
     oval, ograd = O.penalized_value_and_grad(st, "ei", eta, kind, pending, radius, scale, Xq[:64])
-    assert_close(gv, oval, atol=floor * 10, what="penalized value")
+    assert_close(gv, oval, atol=floor, what="penalized value")
     gscale = np.abs(ograd).max() + 1e-300
     assert_close(gg, ograd, rtol=1e-5, atol=max(floor * 1e3, 1e-9 * gscale), what="penalized gradient")
     assert np.all(np.isfinite(gg))
@@ -650,15 +650,15 @@ def test_clone_then_append_is_the_fantasized_posterior(cfg):
     sto = O.fantasized_state(st, pend, O.predict(st, pend)[0])
     fm, fv = twin.predict(Xq)
     om, ov = O.predict(sto, Xq)
-    assert_close(fm, om, atol=floor * 10, what="fantasized mean")
+    assert_close(fm, om, atol=floor, what="fantasized mean")
     assert_close(fv, ov, atol=floor, what="fantasized var")
     if noise >= 1e-3:
         cm, cv = O.conditional_predict_f(st, Xq, pend, O.predict(st, pend)[0])
-        assert_close(fm, cm, atol=floor * 100, what="== conditional_predict_f mean")
-        assert_close(fv, np.maximum(cv, 1e-12), atol=floor * 10, what="== conditional_predict_f var")
+        assert_close(fm, cm, atol=floor, what="== conditional_predict_f mean")
+        assert_close(fv, np.maximum(cv, 1e-12), atol=floor, what="== conditional_predict_f var")
     assert_close(fm, m0, atol=max(floor * 1e4, 1e-6), what="kriging believer keeps the mean")  # test_greedy_batch.py:233-257
     assert np.all(fv <= v0 + floor)  # :260-296
-    assert_close(twin.eta(), O.eta_min_mean(sto), atol=floor * 10, what="fantasized eta")
+    assert_close(twin.eta(), O.eta_min_mean(sto), atol=floor, what="fantasized eta")
     np.testing.assert_array_equal(eng.predict(Xq)[0], m0)
     assert eng.N == N and twin.N == N + 6
     twin.clone_from(eng)  # reset
@@ -799,7 +799,7 @@ def test_append_with_split_k_products_equals_full_refactorisation(N0):
     Xq = np.random.default_rng(1).uniform(size=(300, d))
     ma, va = eng.predict(Xq)
     mo, vo = O.predict(sto, Xq)
-    assert_close(ma, mo, atol=floor * 10, what="mean after append")
+    assert_close(ma, mo, atol=floor, what="mean after append")
     assert_close(va, vo, atol=floor, what="var after append")
 
 
