@@ -402,7 +402,7 @@ int chol_inv_dag(tgp_handle h) {
     std::vector<uint32_t> chain;
     int nu = 0;
     std::vector<uint32_t> topo;
-    dag_build(NB, Npad, tasks, chain, nu, &topo);
+    dag_build(NB, Npad, tasks, chain, nu, &topo, h->num_cu - 1);
     h->dag_nu = nu;
     // successor lists (CSR) over the nodes [tasks | W_jj events | L(j+1,j) events], dependency counters, and the
     // image of the launch state: flags 0, control words (queue tails = the tasks ready from the start), counters,

@@ -189,7 +189,7 @@ struct DagArgs {
   unsigned long long* trace;   // development aid (TGP_DAG_TRACE): [NB][8] chain + [ntasks][4] task time stamps, or null
 };
 void dag_build(int NB, int64_t ld, std::vector<DagTask>& tasks, std::vector<uint32_t>& chain_dep, int& n_urgent,
-               std::vector<uint32_t>* topo_out = nullptr);
+               std::vector<uint32_t>* topo_out = nullptr, int workers = 255);
 hipError_t launch_dag_update(hipStream_t s, const DagArgs& a, int grid);
 size_t dag_lds_bytes();
 

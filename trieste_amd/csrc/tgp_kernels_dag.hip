@@ -633,6 +633,7 @@ __global__ __launch_bounds__(512) void dag_update_kernel(DagArgs a) {
         uint32_t got = TASK_DONE;
         if (pos < (uint32_t)a.ntasks) {
           got = a.topo[pos];
+          if (a.trace) a.trace[CT * a.NB + 4 * (size_t)got] = wall_clock64();  // development aid: drawn (before the wait)
           bool ok = true;
           for (int d = 0; d < 3; ++d) ok = ok && wait_flag(a, a.tasks[got].dep[d]);
           if (!ok) got = TASK_ERR;
@@ -704,12 +705,11 @@ std::vector<std::pair<int, int>> bursts(int lo, int hi, int burst) {  // long bu
 
 }  // namespace
 
-// Build the static list for NB = Npad / 128 block rows: tasks in a topological order (Kahn's algorithm; among the
-// tasks whose producers are placed, the one that becomes ready at the earliest chain step goes first, ties by the step
-// its result is needed at -- tools/dag_sim.py compares orderings), dependencies as flag ids.
+// Build the static list for NB = Npad / 128 block rows: tasks, their dispatch order (a topological order: the start
+// order of a simulated launch, see below), dependencies as flag ids.
 // flag ids: task n -> n;  chain: W_jj / L_jj ready -> ntasks + j;  L(j+1,j) ready -> ntasks + NB + j.
 void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<uint32_t>& chain_dep, int& n_urgent,
-               std::vector<uint32_t>* topo_out) {
+               std::vector<uint32_t>* topo_out, int workers) {
   constexpr int BURST = 4;
   constexpr int CH_WD = -1000000, CH_LSUB = -2000000;  // chain producers: CH_WD - j, CH_LSUB - j
   std::vector<HostTask> ts;
@@ -818,22 +818,71 @@ void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<
       ++indeg[n];
       users[d].push_back(n);
     }
-  auto key = [&](int n) {
-    if (n >= nb) return std::make_pair((double)((n - nb) / 2) - 0.45 + 0.4 * ((n - nb) & 1), -1.0);
-    return std::make_pair(ts[n].ready, ts[n].need);
-  };
-  typedef std::pair<std::pair<double, double>, int> Item;
-  std::priority_queue<Item, std::vector<Item>, std::greater<Item>> heap;
-  for (int n = 0; n < total; ++n)
-    if (indeg[n] == 0) heap.push({key(n), n});
+  // Dispatch order = the start order of a LIST-SCHEDULING SIMULATION of the launch (highest level first): `workers`
+  // workgroups draw, whenever one is free, the ready task with the longest remaining path to the end of the
+  // factorisation; the chain steps run on their own workgroup.  Durations are the measured ones (tools/dag_trace.py,
+  // us): a product 6.5 + 19 per k tile (+ 1.5 until its flag is seen), diag + leaf 44, L(j+1,j) 14.5.  The kernel's
+  // workers then draw this list IN ORDER and wait for the flags of what they drew: as long as the model is roughly
+  // right a task is drawn about when it becomes ready, and what the chain needs next is never queued behind the pile
+  // of first bursts whose results are needed twenty steps later (the earlier order -- by the step a task becomes ready
+  // at -- left the chain waiting 50 us every fourth step at N = 4096 and 70 us per step at N = 8192).
+  std::vector<double> dur(total), tail(total, 0.0);
+  for (int n = 0; n < nb; ++n) dur[n] = 8.0 + 19.0 * ts[n].t.nk;
+  for (int j = 0; j < NB; ++j) {
+    dur[chainA(j)] = j == 0 ? 31.0 : 45.0;
+    dur[chainB(j)] = j + 1 < NB ? 15.0 : 0.0;
+  }
+  std::vector<int> full;  // any topological order of all nodes
+  {
+    std::vector<int> deg = indeg, stack;
+    for (int n = 0; n < total; ++n)
+      if (deg[n] == 0) stack.push_back(n);
+    while (!stack.empty()) {
+      const int n = stack.back();
+      stack.pop_back();
+      full.push_back(n);
+      for (int u : users[n])
+        if (--deg[u] == 0) stack.push_back(u);
+    }
+  }
+  for (auto it = full.rbegin(); it != full.rend(); ++it) {
+    double t = 0.0;
+    for (int u : users[*it]) t = std::max(t, tail[u]);
+    tail[*it] = t + dur[*it];
+  }
   std::vector<int> place(total, -1);  // host index -> position in the device array (urgent list, then bulk list)
-  std::vector<int> topo;              // the common topological order (bulk-side nodes only)
-  while (!heap.empty()) {
-    const int n = heap.top().second;
-    heap.pop();
-    if (n < nb) topo.push_back(n);
-    for (int u : users[n])
-      if (--indeg[u] == 0) heap.push({key(u), u});
+  std::vector<int> topo;              // the dispatch order (bulk-side nodes only)
+  {
+    typedef std::pair<double, int> Ev;
+    std::priority_queue<Ev, std::vector<Ev>, std::greater<Ev>> events;  // (finish time, node)
+    std::priority_queue<Ev> ready;                                     // (tail, -index): longest remaining path first
+    std::vector<int> deg = indeg;
+    int free_workers = std::max(1, workers);
+    double now = 0.0;
+    auto release = [&](int n) {
+      if (n >= nb) events.push({now + dur[n], n});  // a chain step starts the moment its producers are done
+      else ready.push({tail[n], -n});
+    };
+    for (int n = 0; n < total; ++n)
+      if (deg[n] == 0) release(n);
+    for (;;) {
+      while (free_workers > 0 && !ready.empty()) {
+        const int n = -ready.top().second;
+        ready.pop();
+        topo.push_back(n);
+        events.push({now + dur[n], n});
+        --free_workers;
+      }
+      if (events.empty()) break;
+      now = events.top().first;
+      while (!events.empty() && events.top().first <= now) {
+        const int n = events.top().second;
+        events.pop();
+        if (n < nb) ++free_workers;
+        for (int u : users[n])
+          if (--deg[u] == 0) release(u);
+      }
+    }
   }
   std::vector<int> order;
   for (int pass = 0; pass < 2; ++pass) {
