@@ -3,13 +3,13 @@
 # bench workload.   usage: tools/gpu_profile.sh <round> <workload> [extra bench args]
 # (counters are collected in their own runs with --kernel-trace only, as the pool requires)
 set -u
-ROUND=${1:-r02}; W=${2:-headline}; shift 2 || true
+ROUND=${1:-r03}; W=${2:-headline}; shift 2 || true
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
 WL=$W; EXTRA=""
 if [ "$W" = i8 ]; then WL=headline; EXTRA="--precision i8x4"; fi   # the split-precision line of the headline workload
-B="python $PWD/bench.py --workload $WL $EXTRA --no-cpu-baseline --no-acquire $*"
+B="python $PWD/bench.py --workload $WL $EXTRA --no-cpu-baseline --no-acquire --no-secondary $*"
 T=${ROUND}_${W}
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/prof_${T}_stats -o stats -- $B --steps 3 --warmup 1 > $OUT/prof_${T}_stats.log 2>&1 ); echo "$W stats rc=$?"
 ( cd /tmp && rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/prof_${T}_fetch -o fetch -- $B --steps 1 --warmup 0 > $OUT/prof_${T}_fetch.log 2>&1 ); echo "$W fetch rc=$?"
