@@ -510,69 +510,115 @@ void launch_sample_box(hipStream_t s, uint64_t seed, int64_t first, int64_t M, i
 }
 
 // ---------------------------------------------------------------------------------------------
-// Batch Monte-Carlo EI tail, one workgroup per group of q points:
+// Batch Monte-Carlo EI tail, ONE WAVE per group of q points (a 64-thread workgroup: no s_barrier anywhere):
 //   Lq = chol(cov + jitter I);  samples_s = mean + Lq eps[:, s];  out = mean_s max(eta - min_j, 0)
 // == BatchReparametrizationSampler.sample (sampler.py:278-287) + batch_monte_carlo_expected_
 // improvement.__call__ (function.py:1183-1186).  (SURVEY K2 batched, K8.)
-__global__ __launch_bounds__(256) void qei_tail_kernel(const double* __restrict__ mean,
-                                                       const double* __restrict__ cov, int64_t G, int q,
-                                                       const double* __restrict__ eps, int S, double eta,
-                                                       double jitter, double* __restrict__ out,
-                                                       double* __restrict__ samples_out,
-                                                       int* __restrict__ info) {
-  __shared__ double Lq[MAX_Q][MAX_Q + 1];
-  __shared__ double mu[MAX_Q];
-  __shared__ double red[4];
+// Round 2's form (one 256-thread workgroup per group, three barriers per pivot, eps re-read from L2 for every (j, k))
+// took 33 ms for C4's 10^5 groups, 7 % of the step; its arithmetic is kept operation for operation:
+//  * factorisation: lane i owns row i, kept in its own LDS row (odd row stride: conflict-free); the pivot and the
+//    multiplier l_kj reach every lane through v_readlane (-> a scalar operand of the FMA), so no lane ever reads
+//    another lane's LDS data: no barrier, no fence, and the compiler is free to pipeline the row updates.  Entries
+//    right of the diagonal are updated along with the rest (never read);
+//  * samples: lane = sample; the q base draws of a sample sit in registers (loops unrolled to the template bound QP,
+//    left by wave-uniform branches), L_jk comes from LDS as a broadcast read (one read + one FMA per term, q(q+1)/2
+//    terms), RG rows at a time: independent FMA chains hide the f64 latency.
+template <int QP>
+__global__ __launch_bounds__(64, 2) void qei_tail_kernel(const double* __restrict__ mean,
+                                                         const double* __restrict__ cov, int64_t G, int q,
+                                                         const double* __restrict__ eps, int S, double eta,
+                                                         double jitter, double* __restrict__ out,
+                                                         double* __restrict__ samples_out,
+                                                         int* __restrict__ info) {
+  extern __shared__ double qei_lds[];
   const int64_t g = blockIdx.x;
-  const int tid = threadIdx.x;
-  for (int e = tid; e < q * q; e += 256) {
-    const int i = e / q, j = e % q;
-    Lq[i][j] = cov[(g * q + i) * q + j] + (i == j ? jitter : 0.0);
+  const int lane = threadIdx.x;
+  const int ldq = q | 1;  // odd row stride
+  double* const Ls = qei_lds;       // [q][ldq] (+ QP of slack: the last row group reads, and drops, rows beyond q)
+  double* const mu = qei_lds + q * ldq + QP;
+  auto bcast = [](double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+  };
+  const bool live = lane < q;
+  double* const Lrow = Ls + (live ? lane : 0) * ldq;
+  if (live) {
+    const double* const crow = cov + (g * q + lane) * q;
+    for (int k = 0; k < q; ++k) Lrow[k] = crow[k] + (k == lane ? jitter : 0.0);
+    mu[lane] = mean[g * q + lane];
   }
-  if (tid < q) mu[tid] = mean[g * q + tid];
-  // right-looking Cholesky in LDS (q <= 64)
   for (int j = 0; j < q; ++j) {
-    __syncthreads();
-    double dj = Lq[j][j];
+    const double x = Lrow[j];
+    double dj = bcast(x, j);
     if (!(dj > 0.0)) {
-      if (tid == 0) atomicCAS(info, 0, (int)(g % 2000000000) + 1);
+      if (lane == 0) atomicCAS(info, 0, (int)(g % 2000000000) + 1);
       dj = 1.0;
     }
     const double sd = sqrt(dj);
-    __syncthreads();
-    if (tid < q) {
-      if (tid == j) Lq[j][j] = sd;
-      else if (tid > j) Lq[tid][j] = Lq[tid][j] / sd;
-    }
-    __syncthreads();
-    const int i = tid >> 2;
-    if (i > j && i < q) {
-      const double lij = Lq[i][j];
-      for (int k = j + 1 + (tid & 3); k <= i; k += 4) Lq[i][k] = fma(-lij, Lq[k][j], Lq[i][k]);
+    const double lij = lane == j ? sd : x / sd;
+    const bool below = live && lane > j;
+    if (live && lane >= j) Lrow[j] = lij;
+    const double nl = -lij;
+    for (int k = j + 1; k < q; ++k) {
+      const double lkj = bcast(lij, k);
+      if (below) Lrow[k] = fma(nl, lkj, Lrow[k]);
     }
   }
-  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // from here on every lane reads every row
+  constexpr int RG = 2;
   double acc = 0.0;
-  for (int s = tid; s < S; s += 256) {
+  for (int s0 = 0; s0 < S; s0 += 64) {
+    const int s = s0 + lane;
+    const bool valid = s < S;
+    double er[QP];
+#pragma unroll
+    for (int k = 0; k < QP; ++k) er[k] = (k < q && valid) ? eps[(int64_t)k * S + s] : 0.0;
     double mn = INFINITY;
-    for (int j = 0; j < q; ++j) {
-      double v = mu[j];
-      for (int k = 0; k <= j; ++k) v = fma(Lq[j][k], eps[(int64_t)k * S + s], v);
-      if (samples_out) samples_out[(g * S + s) * q + j] = v;  // [G][S][q]
-      mn = fmin(mn, v);
+#pragma unroll
+    for (int j0 = 0; j0 < QP; j0 += RG) {
+      if (j0 < q) {  // (wave-uniform)
+        double v[RG];
+        const double* Lj[RG];
+#pragma unroll
+        for (int r = 0; r < RG; ++r) {
+          const int j = j0 + r < q ? j0 + r : q - 1;
+          Lj[r] = Ls + j * ldq;
+          v[r] = mu[j];
+        }
+#pragma unroll
+        for (int k = 0; k < j0 + RG; ++k)
+#pragma unroll
+          for (int r = 0; r < RG; ++r)
+            if (k <= j0 + r) v[r] = fma(Lj[r][k], er[k], v[r]);
+#pragma unroll
+        for (int r = 0; r < RG; ++r)
+          if (j0 + r < q) {
+            if (samples_out && valid) samples_out[(g * S + s) * q + j0 + r] = v[r];  // [G][S][q]
+            mn = fmin(mn, v[r]);
+          }
+      }
     }
-    acc += fmax(eta - mn, 0.0);
+    if (valid) acc += fmax(eta - mn, 0.0);
   }
   acc = wave_sum(acc);
-  if ((tid & 63) == 0) red[tid >> 6] = acc;
-  __syncthreads();
-  if (tid == 0 && out) out[g] = (red[0] + red[1] + red[2] + red[3]) / (double)S;
+  if (lane == 0 && out) out[g] = acc / (double)S;
+}
+template <int QP>
+static void launch_qei_tail_qp(hipStream_t s, const double* mean, const double* cov, int64_t G, int q,
+                               const double* eps, int S, double eta, double jitter, double* out,
+                               double* samples_out, int* info) {
+  const size_t lds = (size_t)(q * (q | 1) + QP + q) * sizeof(double);
+  hipLaunchKernelGGL(qei_tail_kernel<QP>, dim3((unsigned)G), dim3(64), lds, s, mean, cov, G, q, eps, S, eta, jitter,
+                     out, samples_out, info);
 }
 void launch_qei_tail(hipStream_t s, const double* mean, const double* cov, int64_t G, int q,
                      const double* eps, int S, double eta, double jitter, double* out, double* samples_out,
                      int* info) {
-  hipLaunchKernelGGL(qei_tail_kernel, dim3((unsigned)G), dim3(256), 0, s, mean, cov, G, q, eps, S, eta,
-                     jitter, out, samples_out, info);
+  if (q <= 8) launch_qei_tail_qp<8>(s, mean, cov, G, q, eps, S, eta, jitter, out, samples_out, info);
+  else if (q <= 16) launch_qei_tail_qp<16>(s, mean, cov, G, q, eps, S, eta, jitter, out, samples_out, info);
+  else if (q <= 32) launch_qei_tail_qp<32>(s, mean, cov, G, q, eps, S, eta, jitter, out, samples_out, info);
+  else launch_qei_tail_qp<MAX_Q>(s, mean, cov, G, q, eps, S, eta, jitter, out, samples_out, info);
 }
 
 // final arg-min over per-workgroup partials for B trajectories: one workgroup per trajectory.
