@@ -94,6 +94,25 @@ def test_dag_update_is_bit_identical_run_to_run_and_across_handles():
     assert np.abs(np.tril(Wa) @ np.tril(La) - np.eye(4096)).max() < 1e-8
 
 
+def test_dag_update_at_n8200_ragged_padding():
+    """The persistent kernel where it is throughput-bound (66 block rows, 36 000 tasks), with N not a multiple of the
+    tile: L against numpy's factor of the oracle's K + s I, W L = I."""
+    N = 8200
+    X, Y, ls, c, kind, noise = _problem(N, d=8)
+    eng = _engine(X, Y, ls, c, kind, noise, variant=0)   # the default policy picks the persistent form here
+    L, W, alpha = eng.get_factor()
+    K = O.kernel_matrix(kind, 1.0, ls, X, X) + noise * np.eye(N)
+    Lref = np.linalg.cholesky(K)
+    assert_close(L, Lref, rtol=1e-9, atol=1e-9 * np.abs(Lref).max(), what="L at N = 8200")
+    R = np.tril(W) @ np.tril(L)
+    assert np.abs(R - np.eye(N)).max() < 1e-8
+    assert_close(alpha, np.linalg.solve(Lref.T, np.linalg.solve(Lref, Y - c)), rtol=1e-6,
+                 atol=1e-6 * np.abs(alpha).max(), what="alpha at N = 8200")
+    eng.set_data(X, Y)
+    L2, W2, a2 = eng.get_factor()
+    assert np.array_equal(L2, L) and np.array_equal(W2, W) and np.array_equal(a2, alpha)
+
+
 @pytest.mark.parametrize("N", [640, 1536])
 def test_dag_update_many_fresh_handles(N):
     """Forty fresh handles in recycled device memory, every one a first update: the persistent kernel must not depend
