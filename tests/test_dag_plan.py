@@ -166,7 +166,7 @@ def spd(n, seed):
     return np.exp(-0.5 * d2 / 0.3 ** 2) + 1e-2 * np.eye(n)
 
 
-@pytest.mark.parametrize("nb", [1, 2, 4, 7])
+@pytest.mark.parametrize("nb", [1, 2, 4, 7, 49])  # (49: bursts of 8 k tiles)
 def test_plan_in_list_order_factors_and_inverts(nb):
     tasks, chain, ld, nu = plan(nb)
     n = nb * T
@@ -220,7 +220,7 @@ def test_plan_in_random_valid_interleavings_gives_the_same_bits(seed):
     np.testing.assert_array_equal(mc.m[2], ref.m[2])
 
 
-@pytest.mark.parametrize("nb", [3, 8, 32])
+@pytest.mark.parametrize("nb", [3, 8, 32, 50, 90])  # (50, 90: bursts of 8 and 16 k tiles)
 def test_flags_order_every_conflicting_pair_and_point_backwards(nb):
     tasks, chain, ld, nu = plan(nb, ld=max(nb * T, 4096) if nb == 32 else None)
     nt = len(tasks)

@@ -33,6 +33,7 @@
 #include <queue>
 #include <vector>
 
+#include <cstdlib>
 #include "tgp_dev.hpp"
 #include "tgp_internal.hpp"
 
@@ -304,23 +305,31 @@ __device__ __attribute__((noinline)) void run_task(const DagArgs& a, uint32_t id
     if (c + 1 < nchunks) issue(c + 1);
     const char* const sa = lds + (c & 1) * STAGE;
     const char* const sb = sa + STAGE_A;
-#pragma unroll
-    for (int k4 = 0; k4 < KC / 4; ++k4) {
+    // operands of k step k4 + 1 are fetched BEFORE the MFMAs of step k4 are issued (the scheduling barriers keep hipcc
+    // from sinking the reads back below them): with two waves per SIMD an exposed LDS round trip per k step costs ~10 %
+    double av[2][4], bv[2][2];
+    auto fetch = [&](int k4, double (&fa)[4], double (&fb)[2]) {
       const int rot = ((2 * k4 + c_lane) & 15) << 4;
-      double av[4], bv[2];
 #pragma unroll
-      for (int bi = 0; bi < 4; ++bi) av[bi] = *(const double*)(sa + (16 * wr + 4 * bi) * GROUP_B + lane_rows + rot);
+      for (int bi = 0; bi < 4; ++bi) fa[bi] = *(const double*)(sa + (16 * wr + 4 * bi) * GROUP_B + lane_rows + rot);
       if (nn) {
 #pragma unroll
-        for (int bj = 0; bj < 2; ++bj) bv[bj] = *(const double*)(sb + 4 * k4 * BN_ROW + bn_off + (32 * wc + 16 * bj) * 8);
+        for (int bj = 0; bj < 2; ++bj) fb[bj] = *(const double*)(sb + 4 * k4 * BN_ROW + bn_off + (32 * wc + 16 * bj) * 8);
       } else {
 #pragma unroll
-        for (int bj = 0; bj < 2; ++bj) bv[bj] = *(const double*)(sb + (8 * wc + 4 * bj) * GROUP_B + lane_rows + rot);
+        for (int bj = 0; bj < 2; ++bj) fb[bj] = *(const double*)(sb + (8 * wc + 4 * bj) * GROUP_B + lane_rows + rot);
       }
+    };
+    fetch(0, av[0], bv[0]);
+#pragma unroll
+    for (int k4 = 0; k4 < KC / 4; ++k4) {
+      if (k4 + 1 < KC / 4) fetch(k4 + 1, av[(k4 + 1) & 1], bv[(k4 + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int bi = 0; bi < 4; ++bi)
 #pragma unroll
-        for (int bj = 0; bj < 2; ++bj) acc[bi][bj] = mfma_f64(av[bi], bv[bj], acc[bi][bj]);
+        for (int bj = 0; bj < 2; ++bj) acc[bi][bj] = mfma_f64(av[k4 & 1][bi], bv[k4 & 1][bj], acc[bi][bj]);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   __syncthreads();  // the stages are dead: the tile goes through LDS once, so that global traffic is 16 B per lane
@@ -710,7 +719,10 @@ std::vector<std::pair<int, int>> bursts(int lo, int hi, int burst) {  // long bu
 // flag ids: task n -> n;  chain: W_jj / L_jj ready -> ntasks + j;  L(j+1,j) ready -> ntasks + NB + j.
 void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<uint32_t>& chain_dep, int& n_urgent,
                std::vector<uint32_t>* topo_out, int workers) {
-  constexpr int BURST = 4;
+  // k tiles per product: longer bursts amortise a task's fixed ~8 us (N = 8192 is throughput-bound: 8.0 -> 7.65 ms with
+  // 8), shorter ones keep the scheduling fine where the chain is the bound (N = 4096: 1.91 ms with 4, 2.08 with 8)
+  static const int burst_env = getenv("TGP_DAG_BURST") ? atoi(getenv("TGP_DAG_BURST")) : 0;  // development aid
+  const int BURST = burst_env > 0 ? burst_env : (NB >= 88 ? 16 : (NB >= 48 ? 8 : 4));  // (N = 12288: 24.7 -> 23.7 ms with 16)
   constexpr int CH_WD = -1000000, CH_LSUB = -2000000;  // chain producers: CH_WD - j, CH_LSUB - j
   std::vector<HostTask> ts;
   std::vector<int> lastG((size_t)NB * NB, -1), Tid((size_t)NB * NB, -1), Eid((size_t)NB * NB, -1);
