@@ -403,46 +403,16 @@ int chol_inv_dag(tgp_handle h) {
     int nu = 0;
     std::vector<uint32_t> topo;
     dag_build(NB, Npad, tasks, chain, nu, &topo, h->num_cu - 1);
-    h->dag_nu = nu;
-    // successor lists (CSR) over the nodes [tasks | W_jj events | L(j+1,j) events], dependency counters, and the
-    // image of the launch state: flags 0, control words (queue tails = the tasks ready from the start), counters,
-    // queues (initial entries, then "empty")
-    const size_t nt = tasks.size(), nnodes = nt + 2 * (size_t)NB;
-    std::vector<uint32_t> cnt(nt, 0), off(nnodes + 1, 0), succ;
-    for (size_t t = 0; t < nt; ++t)
-      for (uint32_t d : tasks[t].dep)
-        if (d != 0xffffffffu) {
-          ++cnt[t];
-          ++off[d + 1];
-        }
-    for (size_t n = 0; n < nnodes; ++n) off[n + 1] += off[n];
-    succ.resize(off[nnodes]);
-    {
-      std::vector<uint32_t> fill(off.begin(), off.end() - 1);
-      for (size_t t = 0; t < nt; ++t)
-        for (uint32_t d : tasks[t].dep)
-          if (d != 0xffffffffu) succ[fill[d]++] = (uint32_t)t;
-    }
-    // flags, control, counters, ticket queue (tasks + events + wake tokens + exits), urgent side queue
-    h->dag_qcap = 2 * nt + 2 * (size_t)NB + (size_t)h->num_cu + 64;
-    const size_t state_words = nnodes + DAG_CTRL_WORDS + nt + h->dag_qcap + (nt + 2 * (size_t)NB + 64);
-    for (size_t t = 0; t < nt; ++t)
-      if (cnt[t] == 0) return fail(h, TGP_ERR_STATE, "task %zu of the update plan has no dependency", t);  // (cannot happen)
+    // launch state: flags (tasks, then the chain's 2 NB events), control words, per-task start counts
+    const size_t nt = tasks.size();
+    const size_t state_words = nt + 2 * (size_t)NB + DAG_CTRL_WORDS + nt;
     HIPCHK(h, h->d_dag_tasks.reserve(tasks.size() * sizeof(DagTask)));
     HIPCHK(h, h->d_dag_chain.reserve(chain.size() * sizeof(uint32_t)));
     HIPCHK(h, h->d_dag_flags.reserve(state_words * sizeof(uint32_t)));
-    HIPCHK(h, h->d_dag_succ.reserve((2 * nt + off.size() + succ.size() + 1) * sizeof(uint32_t)));
-    uint32_t* const dsucc = h->d_dag_succ.as<uint32_t>();
+    HIPCHK(h, h->d_dag_topo.reserve((nt + 1) * sizeof(uint32_t)));
     HIPCHK(h, hipMemcpyAsync(h->d_dag_tasks.p, tasks.data(), tasks.size() * sizeof(DagTask), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_dag_chain.p, chain.data(), chain.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(dsucc, cnt.data(), nt * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(dsucc + nt, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-    if (!succ.empty())
-      HIPCHK(h, hipMemcpyAsync(dsucc + nt + off.size(), succ.data(), succ.size() * sizeof(uint32_t), hipMemcpyHostToDevice,
-                               h->stream));
-    HIPCHK(h, hipMemcpyAsync(dsucc + nt + off.size() + succ.size(), topo.data(), nt * sizeof(uint32_t), hipMemcpyHostToDevice,
-                             h->stream));
-    h->dag_nsucc = succ.size();
+    HIPCHK(h, hipMemcpyAsync(h->d_dag_topo.p, topo.data(), nt * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));  // the host vectors die here
     h->dag_nb = NB;
     h->dag_ld = Npad;
@@ -450,7 +420,7 @@ int chol_inv_dag(tgp_handle h) {
     h->dag_state_words = state_words;
   }
   const size_t nflags = (size_t)h->dag_ntasks + 2 * (size_t)NB;
-  // flags, control words, counters and queues all start from zero, before EVERY launch
+  // flags, control words and start counts all start from zero, before EVERY launch
   HIPCHK(h, hipMemsetAsync(h->d_dag_flags.p, 0, h->dag_state_words * sizeof(uint32_t), h->stream));
   DagArgs a{};
   a.Ap = h->d_A.as<double>();
@@ -459,19 +429,12 @@ int chol_inv_dag(tgp_handle h) {
   a.ld = Npad;
   a.NB = NB;
   a.ntasks = h->dag_ntasks;
-  a.nu = h->dag_nu;
-  a.qcap = (int)h->dag_qcap;
   a.tasks = h->d_dag_tasks.as<DagTask>();
   a.chain_dep = h->d_dag_chain.as<uint32_t>();
+  a.topo = h->d_dag_topo.as<uint32_t>();
   a.flags = h->d_dag_flags.as<uint32_t>();
   a.ctrl = a.flags + nflags;
-  a.need = h->d_dag_succ.as<uint32_t>();
-  a.succ_off = a.need + h->dag_ntasks;
-  a.succ = a.succ_off + nflags + 1;
-  a.topo = a.succ + h->dag_nsucc;
   a.info = h->d_info.as<int>();
-  static const int tickets = getenv("TGP_DAG_TICKETS") ? atoi(getenv("TGP_DAG_TICKETS")) : 0;  // A/B aid (dispatcher)
-  a.tickets = tickets;
   // development aid: TGP_DAG_TRACE=<file> -- time stamps of every chain phase and task of the LAST update, dumped as
   // uint64 [NB][32] + [ntasks][4] after the stream has drained (tools/dag_trace.py reads it)
   static const char* trace_path = getenv("TGP_DAG_TRACE");

@@ -159,7 +159,7 @@ void launch_traj_grad(hipStream_t s, const TrajDev& t, const double* Xq, int64_t
 // ---- `update` as one persistent launch (tgp_kernels_dag.hip) -----------------------------------------------------
 constexpr int DAG_MAT_A = 0, DAG_MAT_L = 1, DAG_MAT_W = 2;   // which matrix a tile offset refers to
 constexpr uint32_t DAG_NN = 1, DAG_BETA = 2, DAG_NEG = 4;     // B operand natural (else transposed); add Cin; negate
-constexpr int DAG_CTRL_WORDS = 128;
+constexpr int DAG_CTRL_WORDS = 64;
 struct DagTask {  // one 128 x 128 tile task: out = beta Cin + alpha sum_{kt < nk} A_kt B_kt(^T); 48 bytes
   uint32_t a_off, b_off, c_off, o_off;  // element offsets of the first tiles (k tiles of A follow at +128; of B at
                                         // +128 (transposed form) or +128 ld (natural form))
@@ -172,21 +172,15 @@ struct DagTask {  // one 128 x 128 tile task: out = beta Cin + alpha sum_{kt < n
 struct DagArgs {
   double *Ap, *Lp, *Wp;        // K + s I (in; its tiles carry the partial sums P), L, W = L^-1; all ld x ld, row-major
   int64_t ld;
-  int NB, ntasks, nu;          // 128-blocks per side; tile tasks; tasks [0, nu) are the urgent ones
-  int qcap;                    // capacity of the ticket queue (the urgent side queue follows it)
-  const DagTask* tasks;        // [ntasks]: the urgent list [0, nu), then the bulk list, each in dispatch order
+  int NB, ntasks;              // 128-blocks per side; tile tasks
+  const DagTask* tasks;        // [ntasks]
   const uint32_t* chain_dep;   // [2 NB] flag the chain workgroup waits for before step j's leaf / its L(j+1,j)
+  const uint32_t* topo;        // [ntasks] dispatch order: task indices in a topological order (dag_build)
   uint32_t* flags;             // [ntasks + 2 NB], zero at launch
-  uint32_t* ctrl;              // [DAG_CTRL_WORDS] control words (ticket, queue head / tail, done count, error), then
-                               // [ntasks] dependency counters, then the ready queue [ntasks + 2 NB + grid];
-                               // ALL ZERO at launch (memset before every launch)
-  const uint32_t* need;        // [ntasks] number of dependencies of each task
-  const uint32_t* topo;        // [ntasks] the tasks in one topological order (experiments)
-  const uint32_t* succ_off;    // [ntasks + 2 NB + 1] successor lists (CSR) of tasks and chain events
-  const uint32_t* succ;
+  uint32_t* ctrl;              // [DAG_CTRL_WORDS] control words (arrival ticket, error, list head), then [ntasks]
+                               // start counts; ALL ZERO at launch (memset before every launch)
   int* info;                   // Cholesky breakdown report (1 + index of the first bad pivot)
-  int tickets;                 // 0: in-order list (default); 1: dependency counters + ticket queue (TGP_DAG_TICKETS=1, A/B aid)
-  unsigned long long* trace;   // development aid (TGP_DAG_TRACE): [NB][8] chain + [ntasks][4] task time stamps, or null
+  unsigned long long* trace;   // development aid (TGP_DAG_TRACE): [NB][32] chain + [ntasks][4] task time stamps, or null
 };
 void dag_build(int NB, int64_t ld, std::vector<DagTask>& tasks, std::vector<uint32_t>& chain_dep, int& n_urgent,
                std::vector<uint32_t>* topo_out = nullptr, int workers = 255);

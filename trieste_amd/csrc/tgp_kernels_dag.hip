@@ -13,7 +13,7 @@
 //     which stays in LDS for the next step: no memory hand-off ON the chain, only flags going out;
 //   * everything else is a generic tile task  C = beta Cin + alpha sum_k A_k B_k(^T)  (k tiles of 128) executed by the
 //     bulk workers from ONE static list in a topological order (tools/dag_sim.py is the design model of it):
-//       G  P(i,j) -= sum_{k in burst} L(i,k) L(j,k)^T     left-looking bursts (<= 4 products per read-modify-write)
+//       G  P(i,j) -= sum_{k in burst} L(i,k) L(j,k)^T     left-looking bursts (4 / 8 / 16 products per read-modify-write)
 //       T  L(i,j)  = P(i,j) W_jj^T                         i >= j + 2 (the chain does i = j + 1)
 //       X  V(i,c) += sum_{k in burst} L(i,k) W(k,c)        the inverse, row by row, V kept in W's own tile
 //       E  W(i,c)  = -W_ii V(i,c)
@@ -122,110 +122,18 @@ __device__ __forceinline__ void st16_sc1(double* p, v2d x) {
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");  // (data-register hazard)
 }
 
-// ---- dispatch: dependency counters and ONE ready queue with tickets --------------------------------------------
-// Every tile task has a counter of met dependencies (tasks and chain events); whoever completes a node walks its
-// successor list (one lane per successor), bumps their counters and pushes the ones that are complete into the ready
-// queue: slot = atomicAdd(tail), then the slot is written.  A worker draws a TICKET (atomicAdd(head)) and waits for
-// ITS slot: every idle worker polls a word of its own, a pushed task wakes exactly the longest-waiting worker, and a
-// worker only ever receives a task it can run at once.  The chain workgroup does not walk successor lists (that would
-// sit on the critical path): it pushes the event itself as a pseudo task, and the worker that draws it releases the
-// event's successors.  The worker that completes the last task pushes one EXIT token per worker.  Every entry is
-// pushed exactly once: the queue is a plain array of its final length, no wrap-around; all of it starts as zeros.
-// Measured on the way here (tools/dag_trace.py, N = 4096): ONE list popped in order with the worker spinning on
-// whatever it drew left urgent tasks unpopped behind hundreds of long bursts (the chain waited 40 us every few
-// steps); non-blocking pops from shared head / tail words with idle workers polling them -- even ONE shared hint word
-// with back-off -- is a thundering herd on a cache line: every push woke ~130 workers and the launch ran 6 x slower,
-// chain included.
-// PRIORITY (built, measured, switched off: SIDE_QUEUE): in the ticket queue a chain event or an urgent task (the last
-// burst of a tile, T, E: every block row runs its own chain of them at the pace of the diagonal chain) waits behind
-// every bulk burst pushed before it whenever all workers are busy.  With SIDE_QUEUE an urgent entry goes to the ticket
-// queue only while workers are WAITING there (head > tail: it wakes one at once), otherwise to a small side queue that
-// every worker looks at before it draws its next ticket (a WAKE token follows it if waiters appear between the two
-// looks, so that it cannot be stranded).  N = 4096: the chain's waits 9.8 -> 8.3 us per step (2.19 -> 2.16 ms);
-// N = 8192, where every worker is always busy and every task boundary now reads and compare-and-swaps the side
-// queue's two words: 8.4 -> 16.4 ms.  Off.
-constexpr bool SIDE_QUEUE = false;
-constexpr uint32_t TASK_DONE = 0xfffffffeu, TASK_ERR = 0xfffffffdu, Q_EMPTY = 0u, Q_EXIT = 0xffffffffu, Q_WAKE = 0xfffffffcu;
-// ctrl words: [0, 32) rare (ticket, error, done count); heads and tails on cache lines of their own
-constexpr int C_TICKET = 0, C_ERR = 2, C_ERRINFO = 3, C_DONE = 9, C_HEAD = 32, C_TAIL = 64, C_PHEAD = 96, C_PTAIL = 100;
-static_assert(DAG_CTRL_WORDS >= 128, "control block");
+// ---- dispatch ---------------------------------------------------------------------------------------------------
+// Workers draw tasks from ONE list in order (atomicAdd on a head word) and wait for the flags of what they drew.  The
+// list is a topological order (dag_build: the start order of a simulated launch), so whatever is at the head can run
+// once the tasks before it have: no deadlock at any residency, no scheduler state.  The dispatchers tried before it
+// (two lists, a claim window, dependency counters + ready queues with polling workers, a ticket FIFO, a side queue for
+// urgent tasks) are recorded in tools/legacy_kernels/dag_dispatch_tickets.inc and DESIGN.md section 4.4.
+constexpr uint32_t TASK_DONE = 0xfffffffeu, TASK_ERR = 0xfffffffdu;
+// ctrl words: [0, 32) rare (arrival ticket, error, error info); the list head on a cache line of its own
+constexpr int C_TICKET = 0, C_ERR = 2, C_ERRINFO = 3, C_HEAD = 32;
+static_assert(DAG_CTRL_WORDS >= 64, "control block");
 
-__device__ __forceinline__ uint32_t* dag_cnt(const DagArgs& a) { return a.ctrl + DAG_CTRL_WORDS; }
-__device__ __forceinline__ uint32_t* dag_queue(const DagArgs& a) { return a.ctrl + DAG_CTRL_WORDS + a.ntasks; }
-__device__ __forceinline__ uint32_t* dag_pqueue(const DagArgs& a) { return dag_queue(a) + a.qcap; }
-
-__device__ __forceinline__ void push_ticket(const DagArgs& a, uint32_t code) {
-  const uint32_t pos = atomicAdd(a.ctrl + C_TAIL, 1u);
-  st_flag(dag_queue(a) + pos, code);
-}
-// code = node + 1 (a task, or a chain event: node >= ntasks), or Q_EXIT
-__device__ __forceinline__ void push_ready(const DagArgs& a, uint32_t code, bool urgent) {
-  if (SIDE_QUEUE && urgent && (int)(ld_flag(a.ctrl + C_HEAD) - ld_flag(a.ctrl + C_TAIL)) <= 0) {  // nobody is waiting for a ticket
-    const uint32_t pos = atomicAdd(a.ctrl + C_PTAIL, 1u);
-    st_flag(dag_pqueue(a) + pos, code);
-    if ((int)(ld_flag(a.ctrl + C_HEAD) - ld_flag(a.ctrl + C_TAIL)) > 0) push_ticket(a, Q_WAKE);
-    return;
-  }
-  push_ticket(a, code);
-}
-
-// all lanes of one wave: node (task or chain event) is complete -> its successors
-__device__ void release_node(const DagArgs& a, uint32_t node) {
-  const uint32_t lane = threadIdx.x & 63;
-  const uint32_t beg = a.succ_off[node], end = a.succ_off[node + 1];
-  for (uint32_t i = beg + lane; i < end; i += 64) {
-    const uint32_t sct = a.succ[i];
-    if (atomicAdd(dag_cnt(a) + sct, 1u) + 1u == a.need[sct]) push_ready(a, sct + 1u, sct < (uint32_t)a.nu);
-  }
-}
-
-// All 64 lanes of ONE wave: the next task this workgroup runs (wave-uniform), TASK_DONE on an EXIT token, TASK_ERR on
-// a timeout / when another workgroup has raised the error word.
-__device__ uint32_t acquire_task(const DagArgs& a) {
-  const uint32_t lane = threadIdx.x & 63;
-  for (;;) {
-    uint32_t v = Q_EMPTY, st = 0;
-    if (SIDE_QUEUE && lane == 0) {
-      for (;;) {  // the side queue of urgent entries first
-        const uint32_t ph = ld_flag(a.ctrl + C_PHEAD);
-        if ((int)(ld_flag(a.ctrl + C_PTAIL) - ph) <= 0) break;
-        if (atomicCAS(a.ctrl + C_PHEAD, ph, ph + 1) != ph) continue;
-        const uint32_t* const slot = dag_pqueue(a) + ph;
-        while ((v = ld_flag(slot)) == Q_EMPTY) __builtin_amdgcn_s_sleep(1);  // (reserved before written: a moment)
-        break;
-      }
-    }
-    if (uni(v) == Q_EMPTY && lane == 0) {
-      const uint32_t t = atomicAdd(a.ctrl + C_HEAD, 1u);
-      const uint32_t* const slot = dag_queue(a) + t;
-      unsigned spins = 0;
-      int nap = 1;
-      while ((v = ld_flag(slot)) == Q_EMPTY) {
-        for (int z = 0; z < nap; ++z) __builtin_amdgcn_s_sleep(8);
-        if (nap < 8) ++nap;
-        if ((++spins & 63u) == 0) {
-          if (ld_flag(a.ctrl + C_ERR) != 0) { st = 1; break; }
-          if (spins > SPIN_LIMIT / 4) {
-            st_flag(a.ctrl + C_ERR, DAG_ERR_TIMEOUT);
-            st_flag(a.ctrl + C_ERRINFO, t);
-            st = 1;
-            break;
-          }
-        }
-      }
-    }
-    if (uni(st)) return TASK_ERR;
-    v = uni(v);
-    if (v == Q_EXIT) return TASK_DONE;
-    if (v == Q_WAKE) continue;  // an urgent entry went to the side queue while this worker was waiting here
-    v -= 1u;
-    if (v < (uint32_t)a.ntasks) {
-      if (a.trace && lane == 0) a.trace[CT * a.NB + 4 * (size_t)v] = wall_clock64();
-      return v;
-    }
-    release_node(a, v);  // a chain event: hand its successors on, then draw again
-  }
-}
+__device__ __forceinline__ uint32_t* dag_cnt(const DagArgs& a) { return a.ctrl + DAG_CTRL_WORDS; }  // [ntasks] start counts
 
 // ---- generic tile task ----------------------------------------------------------------------------------------------
 struct TaskU {  // a task descriptor with every field in scalar registers
@@ -477,7 +385,6 @@ __device__ __forceinline__ void chain_diag(const DagArgs& a, int j, uint32_t pen
   __syncthreads();  // everybody is done reading Lsub: S takes its place
   if (tid == 0 && pending != NONE) {
     st_flag(uniptr(a.flags) + pending, 1u);
-    if (a.tickets) push_ready(a, pending + 1u, true);  // the event as a pseudo task: the worker that draws it releases the successors
   }
 #pragma unroll
   for (int m = 0; m < NF; ++m) {
@@ -589,10 +496,7 @@ __device__ __attribute__((noinline)) void run_chain(const DagArgs& a) {
       for (int it = 0; it < QN * QN / 1024; ++it) push_lsub_pass(Lprev, a.ld, S, it);
       drain_vm();
       __syncthreads();
-      if (tid == 0) {
-        st_flag(a.flags + pending, 1u);
-        if (a.tickets) push_ready(a, pending + 1u, true);
-      }
+      if (tid == 0) st_flag(a.flags + pending, 1u);
       pending = NONE;
     }
     return chain_wait(a, id, ctl);
@@ -607,10 +511,7 @@ __device__ __attribute__((noinline)) void run_chain(const DagArgs& a) {
     pending = NONE;
     stamp(tr ? tr + 2 : nullptr);
     chain_leaf(a, j);
-    if (tid == 0) {
-      st_flag(a.flags + WD + j, 1u);
-      if (a.tickets) push_ready(a, WD + (uint32_t)j + 1u, true);
-    }
+    if (tid == 0) st_flag(a.flags + WD + j, 1u);
     stamp(tr ? tr + 3 : nullptr);
     if (j + 1 == a.NB) break;
     if (!wait_for(a.chain_dep[2 * j + 1])) return;
@@ -636,23 +537,17 @@ __global__ __launch_bounds__(512) void dag_update_kernel(DagArgs a) {
   }
 #pragma unroll 1
   for (;;) {
-    if (!a.tickets) {  // ONE list popped in order, the worker waits for the flags of what it drew
-      if (tid == 0) {
-        const uint32_t pos = atomicAdd(a.ctrl + C_HEAD, 1u);
-        uint32_t got = TASK_DONE;
-        if (pos < (uint32_t)a.ntasks) {
-          got = a.topo[pos];
-          if (a.trace) a.trace[CT * a.NB + 4 * (size_t)got] = wall_clock64();  // development aid: drawn (before the wait)
-          bool ok = true;
-          for (int d = 0; d < 3; ++d) ok = ok && wait_flag(a, a.tasks[got].dep[d]);
-          if (!ok) got = TASK_ERR;
-          else atomicAdd(dag_cnt(a) + got, a.need[got]);  // (keeps the start-once check below meaningful)
-        }
-        ctl[0] = got;
+    if (tid == 0) {  // the next entry of the list; wait for the flags of what was drawn
+      const uint32_t pos = atomicAdd(a.ctrl + C_HEAD, 1u);
+      uint32_t got = TASK_DONE;
+      if (pos < (uint32_t)a.ntasks) {
+        got = a.topo[pos];
+        if (a.trace) a.trace[CT * a.NB + 4 * (size_t)got] = wall_clock64();  // development aid: drawn (before the wait)
+        bool ok = true;
+        for (int d = 0; d < 3; ++d) ok = ok && wait_flag(a, a.tasks[got].dep[d]);
+        if (!ok) got = TASK_ERR;
       }
-    } else if (tid < 64) {
-      const uint32_t got = acquire_task(a);
-      if (tid == 0) ctl[0] = got;
+      ctl[0] = got;
     }
     __syncthreads();
     const uint32_t idx = uni(ctl[0]);
@@ -660,9 +555,9 @@ __global__ __launch_bounds__(512) void dag_update_kernel(DagArgs a) {
     if (idx >= (uint32_t)a.ntasks) return;  // TASK_DONE / TASK_ERR
     unsigned long long* const tr = (a.trace && tid == 0) ? a.trace + CT * a.NB + 4 * (size_t)idx : nullptr;
     stamp(tr ? tr + 1 : nullptr);
-    if (tid == 0) {  // sanity: a task starts exactly once, with every dependency met
-      const uint32_t old = atomicAdd(dag_cnt(a) + idx, 0x10000u);
-      if (old != a.need[idx]) {
+    if (tid == 0) {  // sanity: a task starts exactly once
+      const uint32_t old = atomicAdd(dag_cnt(a) + idx, 1u);
+      if (old != 0u) {
         st_flag(a.ctrl + C_ERR, 3u);
         st_flag(a.ctrl + C_ERRINFO, idx);
       }
@@ -679,13 +574,6 @@ __global__ __launch_bounds__(512) void dag_update_kernel(DagArgs a) {
     run_task(a, idx);
     stamp(tr ? tr + 2 : nullptr);
     if (tr) tr[3] = blockIdx.x;
-    if (tid < 64 && (a.tickets)) {  // the tile is stored and its flag is up (run_task): hand its successors on
-      release_node(a, idx);
-      uint32_t last = 0;
-      if (tid == 0) last = atomicAdd(a.ctrl + C_DONE, 1u) + 1u == (uint32_t)a.ntasks ? 1u : 0u;
-      if (uni(last))  // the last task: one EXIT token per worker (every workgroup but the chain's draws exactly one)
-        for (uint32_t i = tid; i + 1 < gridDim.x; i += 64) push_ticket(a, Q_EXIT);
-    }
   }
 }
 
