@@ -292,9 +292,16 @@ __device__ bool chain_wait(const DagArgs& a, uint32_t id, volatile uint32_t* ctl
 }
 
 // pass `it` (0..15) of the copy of Lsub = L(j,j-1) from LDS to global memory: 512 threads x 16 B, write-through
-__device__ __forceinline__ void push_lsub_pass(double* Ls, int64_t ld, const double* S, int it) {
+__device__ __forceinline__ v2d push_lsub_read(const double* S, int it) {
   const int e = threadIdx.x + 512 * it, i = e >> 6, c2 = (e & 63) * 2;
-  st16_sc1(Ls + (int64_t)i * ld + c2, *(const v2d*)(S + i * QS + c2));
+  return *(const v2d*)(S + i * QS + c2);
+}
+__device__ __forceinline__ void push_lsub_store(double* Ls, int64_t ld, v2d x, int it) {
+  const int e = threadIdx.x + 512 * it, i = e >> 6, c2 = (e & 63) * 2;
+  st16_sc1(Ls + (int64_t)i * ld + c2, x);
+}
+__device__ __forceinline__ void push_lsub_pass(double* Ls, int64_t ld, const double* S, int it) {
+  push_lsub_store(Ls, ld, push_lsub_read(S, it), it);
 }
 
 // Step j, part 1: S (LDS) = lower triangle of the diagonal tile with every earlier column subtracted.
@@ -334,7 +341,9 @@ __device__ __forceinline__ void chain_diag(const DagArgs& a, int j, uint32_t pen
   // The 36 lower fragments: block rows p and 7 - p make 9 fragments, n <= p: (p, n), n > p: (7 - p, n - p - 1); the
   // pair of waves 2 p, 2 p + 1 splits them by parity (5 + 4).  Everything about a fragment is wave-uniform.
   constexpr int NF = 5;
-  const int p = w >> 1, h = w & 1;
+  // (waves w and w + 4 share a SIMD: one of them takes the five-fragment half of its pair, the other the four-fragment
+  // half -- nine fragments per SIMD instead of ten and eight)
+  const int p = w >> 1, h = (w ^ (w >> 2)) & 1;
   v4d acc[NF];
   double pin[NF][4];
   int fbi[NF], fbj[NF];
@@ -357,6 +366,7 @@ __device__ __forceinline__ void chain_diag(const DagArgs& a, int j, uint32_t pen
   // 32 k steps; the operands of step t + 1 are fetched BEFORE the MFMAs of step t are issued (by hand: the asm stores
   // of the interleaved copy are compiler barriers, hipcc would not hoist the reads across them)
   double a_lo, a_hi, bv[NF];
+  v2d pv = {0.0, 0.0};
   auto fetch = [&](int t, double& lo, double& hi, double (&b)[NF]) {
     const int kb = t >> 2, k4 = t & 3;
     lo = ldsd(S8 + lane_a + blk(p, kb) + 32 * k4);        // the wave's two block rows
@@ -369,7 +379,10 @@ __device__ __forceinline__ void chain_diag(const DagArgs& a, int j, uint32_t pen
   for (int t = 0; t < 4 * QB; ++t) {
     double n_lo = 0.0, n_hi = 0.0, nb[NF];
     if (t + 1 < 4 * QB) fetch(t + 1, n_lo, n_hi, nb);
-    if (push && (t & 1) == 0) push_lsub_pass(Lprev, ld, S, t >> 1);  // 16 passes over 32 steps: under the ~20 GB/s a CU's write-through stores drain at
+    // 16 store passes over 32 steps (under the ~20 GB/s a CU's write-through stores drain at); a pass reads its 16 bytes
+    // from LDS in an even step and stores them in the next one: the store never waits for an LDS round trip
+    if (push && (t & 1) == 0) pv = push_lsub_read(S, t >> 1);
+    if (push && (t & 1) == 1) push_lsub_store(Lprev, ld, pv, t >> 1);
 #pragma unroll
     for (int m = 0; m < NF; ++m) acc[m] = mfma_f64((2 * m + h) <= p ? a_lo : a_hi, bv[m], acc[m]);
     if (t + 1 < 4 * QB) {
