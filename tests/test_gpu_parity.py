@@ -254,7 +254,9 @@ def test_joint_and_qei_match_oracle(cfg, variant):
     eng = _engine(kind, d, 1.0, ls, noise, c, X, Y, variant)
     rng = np.random.default_rng(7)
     for q, G, S in ((1, 9, 8), (1, 600, 4), (3, 50, 16), (3, 171, 4), (5, 11, 32), (50, 7, 64), (50, 5, 8), (64, 3, 8),
-                    (64, 9, 4), (17, 6, 8), (17, 31, 4), (33, 15, 4)):
+                    (64, 9, 4), (17, 6, 8), (17, 31, 4), (33, 15, 4),
+                    # the qEI tail's template bounds (8 / 16 / 32 / 64 base draws in registers) and ragged sample sets
+                    (8, 5, 70), (9, 4, 8), (16, 3, 130), (32, 3, 65)):
         Xg = rng.uniform(size=(G, q, d))
         Xg[0, 0] = X[0]
         jm, jc = eng.predict_joint(Xg)
