@@ -14,19 +14,24 @@ namespace tgp {
 
 constexpr int TRAJ_MAXB = 16;
 
-template <int KIND, int DP, int BP>
+// PER_TRAJ: logical item = (candidate j, trajectory b) with its own input row (BP = 1); else item = j and the BP
+// accumulators are the trajectories.  EXACT: B == BP -- the accumulator updates carry no test of b against B.  Both are
+// template parameters because as run-time tests they sat INSIDE the two inner loops as wave-uniform branches, each
+// update with a scalar load and a wait of its own (round 2's form: ~60 issued instructions per kernel evaluation for
+// 45 of arithmetic).
+template <int KIND, int DP, int BP, bool EXACT, bool PER_TRAJ>
 __global__ __launch_bounds__(256) void traj_eval_kernel(TrajDev t, const double* __restrict__ Xq,
-                                                        int64_t M, int per_traj, int rff_only,
+                                                        int64_t M, int rff_only,
                                                         double* __restrict__ out,
                                                         double* __restrict__ blk_val,
                                                         int64_t* __restrict__ blk_idx,
                                                         int64_t index_base) {
-  // per_traj: logical item = (candidate j, trajectory b) with its own input row; else item = j.
+  static_assert(!PER_TRAJ || BP == 1, "one accumulator per (candidate, trajectory) item");
   const int B = t.B, d = t.m.d;
   const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t nitems = per_traj ? M * B : M;
+  const int64_t nitems = PER_TRAJ ? M * B : M;
   const bool valid = item < nitems;
-  const int myb = per_traj ? (int)(item % B) : 0;
+  const int myb = PER_TRAJ ? (int)(item % B) : 0;
   double xq[DP];
   double nb = 0.0;
 #pragma unroll
@@ -41,18 +46,18 @@ __global__ __launch_bounds__(256) void traj_eval_kernel(TrajDev t, const double*
   const cptr W = as_const(t.rffW);
   const cptr bb = as_const(t.rffb);
   const cptr ws = as_const(t.ws);
-#pragma unroll 2
+#pragma unroll 1  // (two features per iteration need > 100 SGPRs: the spill reloads cost more than the interleaving gains)
   for (int f = 0; f < t.F; ++f) {
     double arg = bb[f];
 #pragma unroll
     for (int c = 0; c < DP; ++c) arg = fma(xq[c], W[(int64_t)f * DP + c], arg);
     const double ph = fast_cos(arg);
-    if (per_traj) {
+    if (PER_TRAJ) {
       acc[0] = fma(ph, t.ws[(int64_t)f * B + myb], acc[0]);
     } else {
 #pragma unroll
       for (int b = 0; b < BP; ++b)
-        if (b < B) acc[b] = fma(ph, ws[(int64_t)f * B + b], acc[b]);
+        if (EXACT || b < B) acc[b] = fma(ph, ws[(int64_t)f * (EXACT ? BP : B) + b], acc[b]);
     }
   }
   if (rff_only == 0 || rff_only == 3) {
@@ -67,32 +72,32 @@ __global__ __launch_bounds__(256) void traj_eval_kernel(TrajDev t, const double*
       for (int c = 0; c < DP; ++c) dot = fma(xq[c], xs[k * DP + c], dot);
       const double r2 = fmax(fma(-2.0, dot, nb + xn[k]), 0.0);
       const double kv = kernel_from_r2<KIND>(r2, variance);
-      if (per_traj) {
+      if (PER_TRAJ) {
         acc[0] = fma(kv, t.v[k * B + myb], acc[0]);
       } else {
 #pragma unroll
         for (int b = 0; b < BP; ++b)
-          if (b < B) acc[b] = fma(kv, vv[k * B + b], acc[b]);
+          if (EXACT || b < B) acc[b] = fma(kv, vv[k * (EXACT ? BP : B) + b], acc[b]);
       }
     }
   }
   // 1: bare projection Phi w; 2: RFF trajectory (+ mean); 3: bare kernel sums sum_k k(x, X_k) v[k][b]
   const double c0 = (rff_only == 1 || rff_only == 3) ? 0.0 : t.m.mean_const;
   if (out && valid) {
-    if (per_traj) out[item] = acc[0] + c0;
+    if (PER_TRAJ) out[item] = acc[0] + c0;
     else {
 #pragma unroll
       for (int b = 0; b < BP; ++b)
-        if (b < B) out[item * B + b] = acc[b] + c0;
+        if (EXACT || b < B) out[item * B + b] = acc[b] + c0;
     }
   }
-  if (blk_val) {  // per-workgroup arg-min per trajectory (shared-input mode only)
+  if (!PER_TRAJ && blk_val) {  // per-workgroup arg-min per trajectory (shared-input mode only)
     __shared__ double wv[4][TRAJ_MAXB];
     __shared__ int64_t wi[4][TRAJ_MAXB];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
     for (int b = 0; b < BP; ++b) {
-      if (b < B) {
+      if (EXACT || b < B) {
         double v = valid ? -(acc[b] + c0) : -INFINITY;  // arg-min == arg-max of the negation
         if (v != v) v = -INFINITY;
         int64_t i = valid ? index_base + item : INT64_MAX;
@@ -124,10 +129,15 @@ static void launch_traj_bp(hipStream_t s, const TrajDev& t, const double* Xq, in
                            int rff_only, double* out, double* bv, int64_t* bi, int64_t base) {
   const int64_t nitems = per_traj ? M * t.B : M;
   dim3 g((unsigned)((nitems + 255) / 256)), b(256);
-  const int B = per_traj ? 1 : t.B;
-  if (B <= 1) hipLaunchKernelGGL((traj_eval_kernel<KIND, DP, 1>), g, b, 0, s, t, Xq, M, per_traj, rff_only, out, bv, bi, base);
-  else if (B <= 4) hipLaunchKernelGGL((traj_eval_kernel<KIND, DP, 4>), g, b, 0, s, t, Xq, M, per_traj, rff_only, out, bv, bi, base);
-  else hipLaunchKernelGGL((traj_eval_kernel<KIND, DP, 16>), g, b, 0, s, t, Xq, M, per_traj, rff_only, out, bv, bi, base);
+#define TGP_TRAJ_LAUNCH(BP, EXACT, PT) \
+  hipLaunchKernelGGL((traj_eval_kernel<KIND, DP, BP, EXACT, PT>), g, b, 0, s, t, Xq, M, rff_only, out, bv, bi, base)
+  if (per_traj) TGP_TRAJ_LAUNCH(1, true, true);
+  else if (t.B == 1) TGP_TRAJ_LAUNCH(1, true, false);
+  else if (t.B == 4) TGP_TRAJ_LAUNCH(4, true, false);
+  else if (t.B < 4) TGP_TRAJ_LAUNCH(4, false, false);
+  else if (t.B == 16) TGP_TRAJ_LAUNCH(16, true, false);
+  else TGP_TRAJ_LAUNCH(16, false, false);
+#undef TGP_TRAJ_LAUNCH
 }
 
 template <int KIND>
