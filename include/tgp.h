@@ -394,6 +394,12 @@ int tgp_get_precision(tgp_handle h, int* requested, int* effective, double* w_ab
  * kernel from Npad = 256 on (default: from 4096 on, where it is the faster one).  Bits 0-3: every setting computes the same
  * arithmetic on every candidate; bits 4, 5: the same factor up to the rounding of another summation order. */
 int tgp_set_variant(tgp_handle h, int variant);
+/* `update` on SEVERAL handles at once (the prior draws of a hyper-parameter fit: reference models.py:294-321 evaluates
+ * them one after the other): the persistent update kernel of a handle takes 1 / n of the compute units (n = 1 ... 16, default
+ * 1), so that n handles factorising concurrently on private streams run side by side instead of queueing for the whole
+ * device -- one factorisation at N = 4096 keeps only half of the GPU's workgroups busy.  The factor does not depend on n,
+ * bit for bit. */
+int tgp_set_update_concurrency(tgp_handle h, int n);
 
 
 /* ---- development / test aid (host only: no device is touched) -------------------------------------------------------

@@ -110,6 +110,10 @@ class FakeEngine:
     def set_variant(self, v):
         pass
 
+    def set_update_concurrency(self, n=1):
+        if not 1 <= int(n) <= 16:
+            raise ValueError("update concurrency must be 1 ... 16")
+
     def set_precision(self, precision="f64"):
         if precision not in ("f64", "i8x4", "i8x5", "auto"):
             raise ValueError(f"unknown precision {precision!r}")

@@ -159,6 +159,47 @@ def test_dag_update_two_handles_concurrently_on_private_streams():
         assert np.array_equal(L, Lr) and np.array_equal(W, Wr)
 
 
+def test_update_concurrency_shares_the_gpu_and_keeps_the_bits():
+    """tgp_set_update_concurrency: the persistent kernel on 1 / n of the compute units (another dispatch order, fewer
+    workers) gives the same factor bit for bit, alone and with n handles factorising side by side."""
+    import threading
+
+    X, Y, ls, c, kind, noise = _problem(2048, d=6)
+    ref = _engine(X, Y, ls, c, kind, noise)
+    Lr, Wr, ar = ref.get_factor()
+    for n in (2, 8, 16):
+        e = _engine(X, Y, ls, c, kind, noise)
+        e.set_update_concurrency(n)
+        e.set_data(X, Y)
+        L, W, al = e.get_factor()
+        assert np.array_equal(L, Lr) and np.array_equal(W, Wr) and np.array_equal(al, ar), n
+        e.close()
+    with pytest.raises(ValueError):
+        ref.set_update_concurrency(0)
+    engs = [_engine(X, Y, ls, c, kind, noise) for _ in range(4)]
+    for e in engs:
+        e.use_private_stream()
+        e.set_update_concurrency(4)
+    errs = []
+
+    def work(e):
+        try:
+            for _ in range(6):
+                e.set_data(X, Y)
+        except Exception as ex:  # noqa: BLE001
+            errs.append(ex)
+
+    th = [threading.Thread(target=work, args=(e,)) for e in engs]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not errs, errs
+    for e in engs:
+        L, W, _ = e.get_factor()
+        assert np.array_equal(L, Lr) and np.array_equal(W, Wr)
+
+
 @pytest.mark.parametrize("where", ["first_block", "late_blocks"])
 def test_dag_update_reports_a_matrix_that_is_not_positive_definite(where):
     """A breakdown fills the rest of the factor with NaN; every task still runs and raises its flag (no hang), the

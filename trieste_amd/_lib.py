@@ -88,6 +88,7 @@ SIGNATURES = {
     "tgp_group_last_kernel_ms": (C.c_int, [_vp, _dp]),
     "tgp_last_kernel_ms": (C.c_int, [_vp, _dp, C.POINTER(C.c_int)]),
     "tgp_set_variant": (C.c_int, [_vp, C.c_int]),
+    "tgp_set_update_concurrency": (C.c_int, [_vp, C.c_int]),
     "tgp_set_precision": (C.c_int, [_vp, C.c_int]),
     "tgp_get_precision": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _dp]),
     "tgp_dag_plan": (C.c_int, [C.c_int, C.c_int64, _vp, C.c_int64, _ip, _ip, _vp, _vp]),

@@ -397,12 +397,14 @@ bool dag_applies(tgp_handle h, int64_t Npad) {
 int chol_inv_dag(tgp_handle h) {
   const int64_t Npad = h->Npad;
   const int NB = (int)(Npad / 128);
-  if (h->dag_nb != NB || h->dag_ld != Npad) {
+  // workgroups of the launch: all compute units, or this handle's share of them (tgp_set_update_concurrency)
+  const int grid = std::max(std::min(32, h->num_cu), h->num_cu / std::max(1, h->update_share));
+  if (h->dag_nb != NB || h->dag_ld != Npad || h->dag_grid != grid) {
     std::vector<DagTask> tasks;
     std::vector<uint32_t> chain;
     int nu = 0;
     std::vector<uint32_t> topo;
-    dag_build(NB, Npad, tasks, chain, nu, &topo, h->num_cu - 1);
+    dag_build(NB, Npad, tasks, chain, nu, &topo, grid - 1);  // (the dispatch order is simulated for this many workers)
     // launch state: flags (tasks, then the chain's 2 NB events), control words, per-task start counts
     const size_t nt = tasks.size();
     const size_t state_words = nt + 2 * (size_t)NB + DAG_CTRL_WORDS + nt;
@@ -416,6 +418,7 @@ int chol_inv_dag(tgp_handle h) {
     HIPCHK(h, hipStreamSynchronize(h->stream));  // the host vectors die here
     h->dag_nb = NB;
     h->dag_ld = Npad;
+    h->dag_grid = grid;
     h->dag_ntasks = (int)tasks.size();
     h->dag_state_words = state_words;
   }
@@ -444,7 +447,7 @@ int chol_inv_dag(tgp_handle h) {
     HIPCHK(h, hipMemsetAsync(h->d_dag_trace.p, 0, trace_words * 8, h->stream));
     a.trace = h->d_dag_trace.as<unsigned long long>();
   }
-  HIPCHK(h, launch_dag_update(h->stream, a, h->num_cu));
+  HIPCHK(h, launch_dag_update(h->stream, a, grid));
   static const char* dump_path = getenv("TGP_DAG_DUMP");  // development aid: the A buffer (partial sums) after the launch
   if (dump_path) {
     std::vector<double> hostA((size_t)Npad * Npad);
@@ -692,6 +695,13 @@ int tgp_set_precision(tgp_handle h, int precision) {
 int tgp_set_variant(tgp_handle h, int variant) {
   if (!h) return TGP_ERR_ARG;
   h->variant = variant;
+  return TGP_OK;
+}
+
+int tgp_set_update_concurrency(tgp_handle h, int n) {
+  if (!h) return TGP_ERR_ARG;
+  if (n < 1 || n > 16) return fail(h, TGP_ERR_ARG, "update concurrency must be 1 ... 16, got %d", n);
+  h->update_share = n;
   return TGP_OK;
 }
 

@@ -106,7 +106,8 @@ struct tgp_handle_s {
   // scratch
   DevBuf s_ent, s_in, s_in2, s_out1, s_out2, s_out3, s_blkv, s_blki, s_small, s_kcache, s_aslab, s_grad, s_ks, s_part;
   // `update` as one persistent launch: the task list of the current block count (tgp_kernels_dag.hip)
-  int dag_nb = 0, dag_ntasks = 0;
+  int dag_nb = 0, dag_ntasks = 0, dag_grid = 0;
+  int update_share = 1;  // tgp_set_update_concurrency: the persistent update kernel takes num_cu / update_share workgroups
   int64_t dag_ld = 0;
   DevBuf d_dag_tasks, d_dag_chain, d_dag_flags, d_dag_trace, d_dag_topo;
   size_t dag_state_words = 0;  // d_dag_flags: [ntasks + 2 NB] flag words, control words, start counts (DagArgs), zeroed per launch

@@ -102,6 +102,12 @@ class GPEngine:
     def set_variant(self, v: int):
         self._chk(self._lib.tgp_set_variant(self._h, int(v)))
 
+    def set_update_concurrency(self, n: int = 1):
+        """``update`` on ``n`` engines at once (tgp_set_update_concurrency): this engine's persistent update kernel takes
+        1 / n of the compute units, so that n engines factorising concurrently on private streams run side by side.
+        The factor does not depend on n."""
+        self._chk(self._lib.tgp_set_update_concurrency(self._h, int(n)))
+
     def set_precision(self, precision: str = "f64"):
         """Arithmetic of the plain sweeps (tgp_set_precision): "f64" (default, the parity path); "i8x4" / "i8x5" --
         W K* on the int8 matrix cores with four / five 8-bit digit planes per operand (emulated-precision throughput

@@ -477,6 +477,8 @@ class GaussianProcessRegression:
                              with_gradient=False)[0]
 
     MAX_PARALLEL_EVALUATIONS = 8
+    PERSISTENT_UPDATE_FROM = 4096      # padded size from which `update` is the persistent kernel (tgp_api.hip: dag_applies)
+    PERSISTENT_UPDATE_WORKERS = 2
 
     def _evaluation_engines(self, count: int):
         """Worker engines (own device buffers, own HIP stream) for concurrent loss evaluations."""
@@ -513,8 +515,18 @@ class GaussianProcessRegression:
         if not draws:
             return
         workers = min(self.MAX_PARALLEL_EVALUATIONS, len(draws))
-        engines = self._evaluation_engines(workers)
         x, y = self._model.data
+        if x.shape[0] > self.PERSISTENT_UPDATE_FROM - 256:
+            # from here on `update` is one persistent launch that owns the compute units it runs on: side by side means
+            # sharing them (tgp_set_update_concurrency), and its tile products stream enough memory that more than
+            # PERSISTENT_UPDATE_WORKERS at once lose again (N = 4096: 1.97 ms alone, 1.33 per update with two, 2.15 with four)
+            workers = min(workers, self.PERSISTENT_UPDATE_WORKERS)
+            share = workers
+        else:
+            share = 1  # the recursion of small dependent launches: any number of them interleave
+        engines = self._evaluation_engines(workers)
+        for eng in engines:
+            eng.set_update_concurrency(share)
         y0 = np.ascontiguousarray(y[:, 0])
 
         def evaluate(w):  # worker w takes draws w, w + workers, ...
