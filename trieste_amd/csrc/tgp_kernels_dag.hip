@@ -763,37 +763,87 @@ void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<
     for (int u : users[*it]) t = std::max(t, tail[u]);
     tail[*it] = t + dur[*it];
   }
+  // earliest start with unlimited workers -> slack of a node against the critical path
+  std::vector<double> est(total, 0.0);
+  double span = 0.0;
+  for (int n : full) {
+    for (int d : deps[n]) est[n] = std::max(est[n], est[d] + dur[d]);
+    span = std::max(span, est[n] + tail[n]);
+  }
   std::vector<int> place(total, -1);  // host index -> position in the device array (urgent list, then bulk list)
   std::vector<int> topo;              // the dispatch order (bulk-side nodes only)
   {
+    // A task enters the simulation when its ready time is KNOWN, i.e. when all its producers have started (chain steps
+    // need no worker: they start when ready).  A free worker takes the candidate with the longest remaining path among
+    // the tasks that are ready -- and among the near-critical ones (slack < SLACK_CRIT) that will be within LOOK us:
+    // it then waits for the flags, which is exactly what the kernel's worker does with an entry it drew too early.  So
+    // the list carries the chain's next operands a little AHEAD of their turn and a worker is already parked on them when
+    // their producers finish (without this a critical T or G task waited ~13 us for the next worker to come free,
+    // twice per step early in the factorisation).  Every producer of a task is still listed before it.
+    constexpr double LOOK = 12.0, SLACK_CRIT = 40.0;
     typedef std::pair<double, int> Ev;
-    std::priority_queue<Ev, std::vector<Ev>, std::greater<Ev>> events;  // (finish time, node)
-    std::priority_queue<Ev> ready;                                     // (tail, -index): longest remaining path first
-    std::vector<int> deg = indeg;
+    std::priority_queue<Ev, std::vector<Ev>, std::greater<Ev>> cand_crit, cand_norm;  // (ready time, node)
+    std::priority_queue<double, std::vector<double>, std::greater<double>> busy;      // workers' free times
+    std::priority_queue<Ev> avail;                                                    // (tail, -node)
+    std::vector<int> pend = indeg;  // producers not yet started
+    std::vector<double> ready_at(total, 0.0);
     int free_workers = std::max(1, workers);
     double now = 0.0;
-    auto release = [&](int n) {
-      if (n >= nb) events.push({now + dur[n], n});  // a chain step starts the moment its producers are done
-      else ready.push({tail[n], -n});
+    std::vector<std::pair<int, double>> work;  // (node, finish time) whose users are to be told
+    auto known = [&](int n) {
+      if (n >= nb) work.emplace_back(n, ready_at[n] + dur[n]);
+      else (span - est[n] - tail[n] < SLACK_CRIT ? cand_crit : cand_norm).push({ready_at[n], n});
+    };
+    auto started = [&](int n0, double f0) {
+      work.emplace_back(n0, f0);
+      while (!work.empty()) {
+        const auto [n, f] = work.back();
+        work.pop_back();
+        for (int u : users[n]) {
+          ready_at[u] = std::max(ready_at[u], f);
+          if (--pend[u] == 0) known(u);
+        }
+      }
     };
     for (int n = 0; n < total; ++n)
-      if (deg[n] == 0) release(n);
-    for (;;) {
-      while (free_workers > 0 && !ready.empty()) {
-        const int n = -ready.top().second;
-        ready.pop();
-        topo.push_back(n);
-        events.push({now + dur[n], n});
-        --free_workers;
+      if (indeg[n] == 0) {
+        known(n);
+        while (!work.empty()) {  // (a chain step without producers: step 0's leaf)
+          const auto [c, f] = work.back();
+          work.pop_back();
+          started(c, f);
+        }
       }
-      if (events.empty()) break;
-      now = events.top().first;
-      while (!events.empty() && events.top().first <= now) {
-        const int n = events.top().second;
-        events.pop();
-        if (n < nb) ++free_workers;
-        for (int u : users[n])
-          if (--deg[u] == 0) release(u);
+    for (;;) {
+      while (!cand_crit.empty() && cand_crit.top().first <= now + LOOK) {
+        avail.push({tail[cand_crit.top().second], -cand_crit.top().second});
+        cand_crit.pop();
+      }
+      while (!cand_norm.empty() && cand_norm.top().first <= now) {
+        avail.push({tail[cand_norm.top().second], -cand_norm.top().second});
+        cand_norm.pop();
+      }
+      if (free_workers > 0 && !avail.empty()) {
+        const int n = -avail.top().second;
+        avail.pop();
+        const double f = std::max(now, ready_at[n]) + dur[n];
+        topo.push_back(n);
+        busy.push(f);
+        --free_workers;
+        started(n, f);
+        continue;
+      }
+      double next = 1e300;
+      if (!busy.empty()) next = std::min(next, busy.top());
+      if (free_workers > 0) {
+        if (!cand_crit.empty()) next = std::min(next, cand_crit.top().first - LOOK);
+        if (!cand_norm.empty()) next = std::min(next, cand_norm.top().first);
+      }
+      if (next >= 1e300) break;
+      now = std::max(now, next);
+      while (!busy.empty() && busy.top() <= now) {
+        busy.pop();
+        ++free_workers;
       }
     }
   }
