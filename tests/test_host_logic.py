@@ -520,6 +520,25 @@ def test_find_best_model_initialization_never_gets_worse():
     assert model.training_loss() <= before + 1e-9
 
 
+def test_find_best_model_initialization_shares_the_gpu_between_its_workers(monkeypatch):
+    """Below the size where `update` is one persistent launch the draws go to up to MAX_PARALLEL_EVALUATIONS engines with
+    whole-device launches (small dependent launches interleave by themselves); from that size on to
+    PERSISTENT_UPDATE_WORKERS engines, each told to take its share of the compute units (tgp_set_update_concurrency)."""
+    from tests.fakes import FakeEngine
+
+    calls = []
+    monkeypatch.setattr(FakeEngine, "set_update_concurrency", lambda self, n=1: calls.append(int(n)))
+    model, data = _model(n=25, noise=1e-3)
+    model.find_best_model_initialization(12, seed=1)
+    assert calls and set(calls) == {1} and len(calls) == min(model.MAX_PARALLEL_EVALUATIONS, 12)
+    calls.clear()
+    monkeypatch.setattr(type(model), "PERSISTENT_UPDATE_FROM", 256)   # pretend 25 points are "large"
+    before = model.training_loss()
+    model.find_best_model_initialization(12, seed=2)
+    assert calls == [model.PERSISTENT_UPDATE_WORKERS] * model.PERSISTENT_UPDATE_WORKERS
+    assert model.training_loss() <= before + 1e-9
+
+
 # ---- SURVEY 8(f) rank 3/4: sibling tails, continuous Thompson sampling, fantasising ------------------
 def test_augmented_ei_builder_penalises_low_variance_and_updates():
     """reference test_function.py (AEI cases): raises without a noise-aware model / dataset, equals
