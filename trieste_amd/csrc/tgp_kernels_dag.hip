@@ -414,7 +414,9 @@ __device__ __forceinline__ void chain_diag(const DagArgs& a, int j, uint32_t pen
 }
 
 // Step j, part 2: the 128-leaf on S (L_jj goes to global memory panel by panel, write-through), then W_jj = T.
-__device__ __forceinline__ void chain_leaf(const DagArgs& a, int j) {
+// `peek`: the flag the chain waits for next -- lane 0 looks at it before this part's closing barrier, which then also
+// hands the answer round (returned: the flag was up, the usual case; saves the two barriers of a wait of its own).
+__device__ __forceinline__ bool chain_leaf(const DagArgs& a, int j, uint32_t peek) {
   DAG_LDS_DECL;
   double* const S = (double*)dag_lds;
   const WorkItem* const items = (const WorkItem*)(S + QN * QS);
@@ -427,13 +429,16 @@ __device__ __forceinline__ void chain_leaf(const DagArgs& a, int j) {
   leaf_core<true>(S, items, uniptr(a.Lp), ld, off, uniptr(a.info), (lds_sync_t*)(lds_char*)(dag_lds + CTL_OFF + 32),
                   Wp + off * ld + off);  // (stores W_jj as it goes)
   drain_vm();
+  volatile uint32_t* const ctl = (volatile uint32_t*)(dag_lds + CTL_OFF);
+  if (tid == 0) ctl[1] = (peek == NONE || ld_flag(uniptr(a.flags) + peek) != 0) ? 1u : 0u;
   __syncthreads();
+  return ctl[1] != 0;
 }
 
 // Step j, part 3: L(j+1,j) = P(j+1,j) W_jj^T.  Wave w owns rows 16 w .. of the tile, held transposed as natural B
 // operands; W_jj is read from S; the result replaces it there (row-major: the operand of the next step's part 1) and
 // goes to global memory write-through.
-__device__ __forceinline__ void chain_sub(const DagArgs& a, int j) {
+__device__ __forceinline__ bool chain_sub(const DagArgs& a, int j, uint32_t peek) {
   DAG_LDS_DECL;
   double* const S = (double*)dag_lds;
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
@@ -478,9 +483,12 @@ __device__ __forceinline__ void chain_sub(const DagArgs& a, int j) {
   for (int kb = 0; kb < QB; ++kb)
 #pragma unroll
     for (int r = 0; r < 4; ++r) S[(16 * w + lr) * QS + 16 * kb + lq + 4 * r] = o[kb][r];
+  volatile uint32_t* const ctl = (volatile uint32_t*)(dag_lds + CTL_OFF);
+  if (tid == 0) ctl[1] = (peek == NONE || ld_flag(uniptr(a.flags) + peek) != 0) ? 1u : 0u;
   __syncthreads();
   // L(j+1,j) goes to global memory from here (LDS) UNDERNEATH the next step's diagonal product (chain_diag), which
   // also publishes its flag -- pushing 128 KB of write-through stores costs this CU ~6 us when nothing hides it
+  return ctl[1] != 0;
 }
 
 __device__ __attribute__((noinline)) void run_chain(const DagArgs& a) {
@@ -514,22 +522,24 @@ __device__ __attribute__((noinline)) void run_chain(const DagArgs& a) {
     }
     return chain_wait(a, id, ctl);
   };
+  bool diag_up = false;  // the flag step j's diagonal product needs was seen up at the end of step j - 1
 #pragma unroll 1
   for (int j = 0; j < a.NB; ++j) {
     unsigned long long* const tr = (a.trace && tid == 0) ? a.trace + CT * j : nullptr;
     stamp(tr);
-    if (!wait_for(a.chain_dep[2 * j])) return;
+    if (!diag_up && !wait_for(a.chain_dep[2 * j])) return;
     stamp(tr ? tr + 1 : nullptr);
     chain_diag(a, j, pending);
     pending = NONE;
     stamp(tr ? tr + 2 : nullptr);
-    chain_leaf(a, j);
+    const bool last = j + 1 == a.NB;
+    const bool sub_up = chain_leaf(a, j, last ? NONE : a.chain_dep[2 * j + 1]);
     if (tid == 0) st_flag(a.flags + WD + j, 1u);
     stamp(tr ? tr + 3 : nullptr);
-    if (j + 1 == a.NB) break;
-    if (!wait_for(a.chain_dep[2 * j + 1])) return;
+    if (last) break;
+    if (!sub_up && !wait_for(a.chain_dep[2 * j + 1])) return;
     stamp(tr ? tr + 4 : nullptr);
-    chain_sub(a, j);
+    diag_up = chain_sub(a, j, a.chain_dep[2 * j + 2]);
     pending = LSUB + (uint32_t)j;
     stamp(tr ? tr + 5 : nullptr);
   }
