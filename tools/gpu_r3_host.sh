@@ -1,5 +1,3 @@
 #!/bin/bash
 set -u; OUT=$PWD/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
-timeout 300 python tools/bench_update_share.py 4096 2>&1 | grep -v amdgpu.ids
-timeout 300 python tools/bench_bo_step.py 4096 2>&1 | grep -v amdgpu.ids
-timeout 300 python tools/bench_bo_step.py 1000 2>&1 | grep -v amdgpu.ids
+for S in 0 16 32; do echo "== spare $S"; TGP_DAG_SPARE=$S timeout 120 python tools/bench_update_share.py 4096 2>&1 | grep -v amdgpu.ids; done
