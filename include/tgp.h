@@ -162,6 +162,14 @@ int tgp_get_sizes(tgp_handle h, int64_t* N, int* d);
  * GaussianProcessRegression.optimize_encoded (models/gpflow/models.py:256-292); priors and
  * parameter transforms are host-side scalars. */
 int tgp_nlml(tgp_handle h, double* value, double* grad);
+/* TRIAL evaluation: the value tgp_nlml(h, value, NULL) would return after tgp_set_hyper + tgp_set_data with the data
+ * already on the device (tgp_set_data has run once on this handle) at the CURRENT hyper-parameters -- what
+ * find_best_model_initialization does for every prior draw (reference models.py:294-321: assign the draw, evaluate
+ * training_loss).  From N = 3841 on only the Cholesky factor is built (half the tile products of an update, so that more
+ * trial handles run side by side: tgp_set_update_concurrency), err^T K^-1 err comes from a block forward substitution.
+ * The handle is left WITHOUT a posterior: queries fail with TGP_ERR_STATE until the next tgp_set_data.  NOT_PD as for
+ * tgp_set_data. */
+int tgp_nlml_trial(tgp_handle h, double* value);
 /* Read back the cache (tests / checkpoint-free restore checks): any pointer may be NULL.
  * L [N,N] lower (upper = 0), Winv [N,N] = L^-1, alpha [N].  `where` applies to all three. */
 int tgp_get_factor(tgp_handle h, double* L, double* Winv, double* alpha, int where);
@@ -423,7 +431,7 @@ typedef struct {
   uint32_t dep[3], set, pad;
 } tgp_dag_task;
 int tgp_dag_plan(int nb, int64_t ld, tgp_dag_task* tasks, int64_t cap, int64_t* ntasks, int64_t* n_urgent,
-                 uint32_t* chain_dep, uint32_t* order);
+                 uint32_t* chain_dep, uint32_t* order, int flags /* bit 0: the factor only (tgp_nlml_trial's plan) */);
 
 #ifdef __cplusplus
 }

@@ -235,6 +235,7 @@ class FakeEngine:
         if Y.shape[0] != X.shape[0]:
             raise ValueError("Y must hold N observations")
         v, ls, s2, c = self._hyper
+        self._xy = (X, Y)
         try:
             self.state = O.gpr_update(self.kernel, v, ls, s2, c, X, Y)
         except np.linalg.LinAlgError as e:
@@ -261,6 +262,23 @@ class FakeEngine:
     def nlml(self, with_gradient=True):
         v, g = O.nlml_and_grad(self._st())
         return (v, g) if with_gradient else (v, None)
+
+    def nlml_trial(self):
+        """tgp_nlml_trial: the likelihood at the current hyper-parameters over the data of the last set_data; no
+        posterior is left behind."""
+        if self._hyper is None:
+            raise RuntimeError("tgp_set_hyper must be called before tgp_nlml_trial")
+        if getattr(self, "_xy", None) is None:
+            raise RuntimeError("no data on the device: call tgp_set_data once first")
+        v, ls, s2, c = self._hyper
+        try:
+            st = O.gpr_update(self.kernel, v, ls, s2, c, *self._xy)
+        except np.linalg.LinAlgError as e:
+            from trieste_amd._lib import NotPositiveDefiniteError
+
+            raise NotPositiveDefiniteError(str(e))
+        self.state, self.N = None, 0
+        return O.nlml_and_grad(st)[0]
 
     def get_factor(self):
         st = self._st()

@@ -29,16 +29,16 @@ class Task(C.Structure):
                 ("pad", C.c_uint32)]
 
 
-def plan(nb, ld=None):
+def plan(nb, ld=None, flags=0):
     lib = _lib.load()
     ld = ld or nb * T
     n, nu = C.c_int64(), C.c_int64()
-    rc = lib.tgp_dag_plan(nb, ld, None, 0, C.byref(n), C.byref(nu), None, None)
+    rc = lib.tgp_dag_plan(nb, ld, None, 0, C.byref(n), C.byref(nu), None, None, flags)
     assert rc == _lib.TGP_ERR_SHAPE and n.value >= 0
     tasks = (Task * max(n.value, 1))()
     chain = (C.c_uint32 * (2 * nb))()
     order = (C.c_uint32 * max(n.value, 1))()
-    assert lib.tgp_dag_plan(nb, ld, tasks, n.value, C.byref(n), C.byref(nu), chain, order) == _lib.TGP_OK
+    assert lib.tgp_dag_plan(nb, ld, tasks, n.value, C.byref(n), C.byref(nu), chain, order, flags) == _lib.TGP_OK
     assert 0 <= nu.value <= n.value
     ORDER[(nb, ld)] = [order[i] for i in range(n.value)]
     return [tasks[i] for i in range(n.value)], list(chain), ld, nu.value
@@ -184,6 +184,42 @@ def test_plan_in_list_order_factors_and_inverts(nb):
     np.testing.assert_allclose(np.tril(mc.m[2]) @ L, np.eye(n), atol=1e-9)
     np.testing.assert_array_equal(np.triu(mc.m[1], 1), 0.0)   # nothing is ever written above the diagonal
     np.testing.assert_array_equal(np.triu(mc.m[2], 1), 0.0)
+
+
+@pytest.mark.parametrize("nb", [2, 5, 9])
+def test_factor_only_plan_builds_the_factor_and_the_diagonal_inverses(nb):
+    """The plan of tgp_nlml_trial (flags bit 0): no task of the inverse -- about half the products -- L complete, W
+    holding exactly its diagonal tiles W_jj = L_jj^-1 (what the T tasks and the block forward substitution need)."""
+    full, _, _, _ = plan(nb)
+    tasks, chain, ld, nu = plan(nb, flags=1)
+    assert len(tasks) < len(full) and all(t.o_mat != 2 for t in tasks)   # 2 = DAG_MAT_W: nobody writes W but the chain
+    n = nb * T
+    A = spd(n, 40 + nb)
+    mc = Machine(A, nb, tasks, chain, ld, nu)
+    while not mc.done():
+        if mc.chain_ready():
+            mc.run_chain()
+            continue
+        i = mc.acquire()
+        assert i is not None
+        mc.run_bulk(i)
+    L = np.tril(mc.m[1])
+    np.testing.assert_allclose(L @ L.T, A, rtol=1e-11, atol=1e-11)
+    W = mc.m[2]
+    for j in range(nb):
+        blk = slice(j * T, (j + 1) * T)
+        np.testing.assert_allclose(np.tril(W[blk, blk]) @ L[blk, blk], np.eye(T), atol=1e-9)
+        W[blk, blk] = 0.0
+    np.testing.assert_array_equal(W, 0.0)
+    # the block forward substitution the trial evaluation runs on it: z = L^-1 r from L and the W_jj alone
+    r = np.random.default_rng(nb).standard_normal(n)
+    Wd = mc.m[2]
+    z = np.zeros(n)
+    for i in range(nb):
+        bi = slice(i * T, (i + 1) * T)
+        acc = r[bi] - L[bi, : i * T] @ z[: i * T]
+        z[bi] = np.tril(np.linalg.inv(L[bi, bi])) @ acc
+    np.testing.assert_allclose(L @ z, r, atol=1e-9)
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2])

@@ -200,6 +200,62 @@ def test_update_concurrency_shares_the_gpu_and_keeps_the_bits():
         assert np.array_equal(L, Lr) and np.array_equal(W, Wr)
 
 
+@pytest.mark.parametrize("N,variant", [(300, 0), (640, DAG_SMALL), (2049, DAG_SMALL), (4096, 0)])
+def test_trial_evaluation_matches_the_likelihood_of_a_full_update(N, variant):
+    """tgp_nlml_trial (factor-only launch + block forward substitution where the persistent kernel applies, a full update
+    below): the same value as set_data + nlml(value only) and as the oracle, at several hyper-parameter draws on the data
+    already on the device; no posterior is left behind; a later set_data gives the usual factor bit for bit."""
+    from trieste_amd._lib import TgpError
+
+    X, Y, ls, c, kind, noise = _problem(N, d=5)
+    ref = _engine(X, Y, ls, c, kind, noise, variant=variant)
+    Lr, Wr, ar = ref.get_factor()
+    eng = _engine(X, Y, ls, c, kind, noise, variant=variant)
+    rng = np.random.default_rng(N)
+    for trial in range(4):
+        ls_t = ls * np.exp(0.3 * rng.standard_normal(len(ls)))
+        var_t, noise_t, c_t = float(np.exp(0.2 * rng.standard_normal())), noise * (1.0 + trial), c + 0.1 * trial
+        ref.set_hyper(var_t, ls_t, noise_t, c_t)
+        ref.set_data(X, Y)
+        want = ref.nlml(False)[0]
+        eng.set_hyper(var_t, ls_t, noise_t, c_t)
+        got = eng.nlml_trial()
+        assert abs(got - want) <= 1e-9 * abs(want) + 1e-9 * N, (trial, got, want)
+        st = O.gpr_update(kind, var_t, ls_t, noise_t, c_t, X, Y)
+        assert abs(got - O.nlml_and_grad(st)[0]) <= 1e-8 * abs(want) + 1e-8 * N
+        assert eng.nlml_trial() == got                      # the same bits again
+    if variant == DAG_SMALL or N >= 4096:                  # factor only: nothing to query afterwards
+        with pytest.raises(RuntimeError):                   # TGP_ERR_STATE
+            eng.predict(X[:3])
+    eng.set_hyper(1.0, ls, noise, c)
+    eng.set_data(X, Y)
+    L, W, al = eng.get_factor()
+    assert np.array_equal(L, Lr) and np.array_equal(W, Wr) and np.array_equal(al, ar)
+    fresh = _engine(X, Y, ls, c, kind, noise, variant=variant)
+    fresh.close()
+
+
+def test_trial_evaluation_needs_data_and_reports_a_breakdown():
+    from trieste_amd._lib import NotPositiveDefiniteError, TgpError
+    from trieste_amd.engine import GPEngine
+
+    eng = GPEngine(2, "rbf")
+    eng.set_variant(DAG_SMALL)
+    eng.set_hyper(1.0, [0.3, 0.3], 1e-2, 0.0)
+    with pytest.raises(RuntimeError):                       # TGP_ERR_STATE: nothing uploaded yet
+        eng.nlml_trial()
+    rng = np.random.default_rng(0)
+    X = rng.uniform(size=(1024, 2))
+    X[600:] = 0.5 + 1e-13 * rng.standard_normal((424, 2))
+    Y = rng.standard_normal(1024)
+    eng.set_data(X, Y)
+    eng.set_hyper(1.0, [0.3, 0.3], 1e-300, 0.0)
+    with pytest.raises(NotPositiveDefiniteError):
+        eng.nlml_trial()
+    eng.set_hyper(1.0, [0.3, 0.3], 1e-2, 0.0)
+    assert np.isfinite(eng.nlml_trial())
+
+
 @pytest.mark.parametrize("where", ["first_block", "late_blocks"])
 def test_dag_update_reports_a_matrix_that_is_not_positive_definite(where):
     """A breakdown fills the rest of the factor with NaN; every task still runs and raises its flag (no hang), the

@@ -39,9 +39,9 @@ for attempt in range(60):
     tk = raw[2 + 32 * NB:].reshape(nt, 4).astype(np.int64)
     ld = NB * 128
     n_, nu_ = C.c_int64(), C.c_int64()
-    lib.tgp_dag_plan(NB, ld, None, 0, C.byref(n_), C.byref(nu_), None, None)
+    lib.tgp_dag_plan(NB, ld, None, 0, C.byref(n_), C.byref(nu_), None, None, 0)
     tarr = (Task * n_.value)(); carr = (C.c_uint32 * (2 * NB))()
-    lib.tgp_dag_plan(NB, ld, tarr, n_.value, C.byref(n_), C.byref(nu_), carr, None)
+    lib.tgp_dag_plan(NB, ld, tarr, n_.value, C.byref(n_), C.byref(nu_), carr, None, 0)
     t0 = ch[0, 0]
     print(f"attempt {attempt} FAILED; NB={NB} tasks={nt}")
     bad = 0

@@ -50,10 +50,10 @@ def main():
 
     ld = NB * 128
     n_, nu_ = C.c_int64(), C.c_int64()
-    lib.tgp_dag_plan(NB, ld, None, 0, C.byref(n_), C.byref(nu_), None, None)
+    lib.tgp_dag_plan(NB, ld, None, 0, C.byref(n_), C.byref(nu_), None, None, 0)
     tarr = (Task * n_.value)()
     carr = (C.c_uint32 * (2 * NB))()
-    lib.tgp_dag_plan(NB, ld, tarr, n_.value, C.byref(n_), C.byref(nu_), carr, None)
+    lib.tgp_dag_plan(NB, ld, tarr, n_.value, C.byref(n_), C.byref(nu_), carr, None, 0)
     tasks, chain, nu = [tarr[i] for i in range(n_.value)], list(carr), nu_.value
     kinds = []
     for t in tasks:

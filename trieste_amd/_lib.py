@@ -40,6 +40,7 @@ SIGNATURES = {
     "tgp_penalization_values": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int]),
     "tgp_get_sizes": (C.c_int, [_vp, _ip, C.POINTER(C.c_int)]),
     "tgp_nlml": (C.c_int, [_vp, _dp, _vp]),
+    "tgp_nlml_trial": (C.c_int, [_vp, _dp]),
     "tgp_get_factor": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int]),
     "tgp_predict": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, C.c_int]),
     "tgp_predict_mean": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int]),
@@ -91,7 +92,7 @@ SIGNATURES = {
     "tgp_set_update_concurrency": (C.c_int, [_vp, C.c_int]),
     "tgp_set_precision": (C.c_int, [_vp, C.c_int]),
     "tgp_get_precision": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _dp]),
-    "tgp_dag_plan": (C.c_int, [C.c_int, C.c_int64, _vp, C.c_int64, _ip, _ip, _vp, _vp]),
+    "tgp_dag_plan": (C.c_int, [C.c_int, C.c_int64, _vp, C.c_int64, _ip, _ip, _vp, _vp, C.c_int]),
 }
 
 _lib = None

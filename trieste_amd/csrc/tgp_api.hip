@@ -394,17 +394,17 @@ bool dag_applies(tgp_handle h, int64_t Npad) {
 }
 
 // -> TGP_OK / error; the launch's own error words are read back by dag_check after the stream has drained
-int chol_inv_dag(tgp_handle h) {
+int chol_inv_dag(tgp_handle h, bool factor_only = false) {
   const int64_t Npad = h->Npad;
   const int NB = (int)(Npad / 128);
   // workgroups of the launch: all compute units, or this handle's share of them (tgp_set_update_concurrency)
   const int grid = std::max(std::min(32, h->num_cu), h->num_cu / std::max(1, h->update_share));
-  if (h->dag_nb != NB || h->dag_ld != Npad || h->dag_grid != grid) {
+  if (h->dag_nb != NB || h->dag_ld != Npad || h->dag_grid != grid || h->dag_factor_only != factor_only) {
     std::vector<DagTask> tasks;
     std::vector<uint32_t> chain;
     int nu = 0;
     std::vector<uint32_t> topo;
-    dag_build(NB, Npad, tasks, chain, nu, &topo, grid - 1);  // (the dispatch order is simulated for this many workers)
+    dag_build(NB, Npad, tasks, chain, nu, &topo, grid - 1, !factor_only);  // (the dispatch order is simulated for this many workers)
     // launch state: flags (tasks, then the chain's 2 NB events), control words, per-task start counts
     const size_t nt = tasks.size();
     const size_t state_words = nt + 2 * (size_t)NB + DAG_CTRL_WORDS + nt;
@@ -419,6 +419,7 @@ int chol_inv_dag(tgp_handle h) {
     h->dag_nb = NB;
     h->dag_ld = Npad;
     h->dag_grid = grid;
+    h->dag_factor_only = factor_only;
     h->dag_ntasks = (int)tasks.size();
     h->dag_state_words = state_words;
   }
@@ -707,12 +708,12 @@ int tgp_set_update_concurrency(tgp_handle h, int n) {
 
 static_assert(sizeof(tgp_dag_task) == sizeof(tgp::DagTask), "tgp_dag_task mirrors tgp::DagTask");
 int tgp_dag_plan(int nb, int64_t ld, tgp_dag_task* tasks, int64_t cap, int64_t* ntasks, int64_t* n_urgent,
-                 uint32_t* chain_dep, uint32_t* order) {
+                 uint32_t* chain_dep, uint32_t* order, int flags) {
   if (nb < 1 || nb > 126 || ld < (int64_t)nb * 128 || !ntasks || !n_urgent) return TGP_ERR_ARG;
   std::vector<tgp::DagTask> t;
   std::vector<uint32_t> c, topo;
   int nu = 0;
-  tgp::dag_build(nb, ld, t, c, nu, &topo);
+  tgp::dag_build(nb, ld, t, c, nu, &topo, 255, (flags & 1) == 0);
   *ntasks = (int64_t)t.size();
   *n_urgent = nu;
   if (cap < (int64_t)t.size() || !tasks || !chain_dep) return TGP_ERR_SHAPE;
@@ -762,7 +763,10 @@ int tgp_set_hyper(tgp_handle h, double variance, const double* lengthscales, dou
 // rows/columns [0, keep_rows) of L and W are still valid (same inputs, same hyper-parameters) and only
 // the tail block is refactorised -- one node step of the recursion with the split at keep_rows:
 // L21 = A21 W11^T, A22 -= L21 L21^T, factor A22, W21 = -W22 (L21 W11): O((N - keep) N^2) instead of O(N^3).
-static int factorise(tgp_handle h, int64_t N, int64_t keep_rows) {
+// `trial_value` non-null (keep_rows == 0): a TRIAL evaluation of the likelihood at the current hyper-parameters -- where
+// the persistent kernel applies only the factor is built (no inverse), z = L^-1 err by block forward substitution and
+// *trial_value = 1/2 |z|^2 + sum log L_ii + N/2 log 2 pi; the handle is left WITHOUT a posterior (have_data false).
+static int factorise(tgp_handle h, int64_t N, int64_t keep_rows, double* trial_value = nullptr) {
   const int64_t Npad = ((N + NPAD_MULT - 1) / NPAD_MULT) * NPAD_MULT;
   const size_t nn = (size_t)Npad * Npad * sizeof(double);
   const int d = h->d, dp = h->dp;
@@ -801,7 +805,7 @@ static int factorise(tgp_handle h, int64_t N, int64_t keep_rows) {
     if (timing) { (void)hipStreamSynchronize(s); tq0 = std::chrono::steady_clock::now(); }
     const bool dag = dag_applies(h, Npad);
     if (dag) {
-      if (int rc = chol_inv_dag(h)) return rc;
+      if (int rc = chol_inv_dag(h, trial_value != nullptr)) return rc;
     } else {
       chol_inv(h, 0, Npad);
     }
@@ -838,14 +842,32 @@ static int factorise(tgp_handle h, int64_t N, int64_t keep_rows) {
   }
   // err = Y - c (zero padded)  -- gpflow GPRPosterior._precompute: err = Y - mean_function(X)
   launch_center(s, h->d_Y.as<double>(), h->mean_const, h->d_err.as<double>(), N, Npad);
-  // Wt (into A, dead now) = masked transpose of W; alpha = Wt (W err)
-  launch_transpose_mask(s, W, A, N, Npad);
-  launch_trmv(s, W, Npad, Npad, h->d_err.as<double>(), h->d_tmp2.as<double>(), true);
-  launch_trmv(s, A, Npad, Npad, h->d_tmp2.as<double>(), h->d_alpha.as<double>(), false);
-  // the padding rows of W carry the identity: alpha/tmp there are err_pad = 0 -> stay 0.
+  const bool used_dag = keep_rows == 0 && dag_applies(h, Npad);
+  const bool factor_only = trial_value != nullptr && used_dag;
+  double* trial_out = nullptr;
+  if (factor_only) {
+    // z (into the alpha buffer) = L^-1 err; the value kernel's err . alpha is then |z|^2
+    uint32_t* const tflags = h->d_tmp1.as<uint32_t>();  // [Npad / 128] words of the Npad doubles
+    HIPCHK(h, hipMemsetAsync(tflags, 0, (size_t)(Npad / 128) * sizeof(uint32_t), s));
+    launch_block_trsv(s, L, W, Npad, (int)(Npad / 128), h->d_err.as<double>(), h->d_alpha.as<double>(), tflags);
+    HIPCHK(h, h->s_small.reserve(64 + (MAX_D + 8) * sizeof(double)));
+    trial_out = h->s_small.as<double>() + 8;
+    launch_nlml_value(s, model_dev(h), L, h->d_alpha.as<double>(), trial_out);
+  } else {
+    // Wt (into A, dead now) = masked transpose of W; alpha = Wt (W err)
+    launch_transpose_mask(s, W, A, N, Npad);
+    launch_trmv(s, W, Npad, Npad, h->d_err.as<double>(), h->d_tmp2.as<double>(), true);
+    launch_trmv(s, A, Npad, Npad, h->d_tmp2.as<double>(), h->d_alpha.as<double>(), false);
+    // the padding rows of W carry the identity: alpha/tmp there are err_pad = 0 -> stay 0.
+    if (trial_value) {  // (below the persistent kernel's sizes a trial is a full update)
+      HIPCHK(h, h->s_small.reserve(64 + (MAX_D + 8) * sizeof(double)));
+      trial_out = h->s_small.as<double>() + 8;
+      launch_nlml_value(s, model_dev(h), L, h->d_err.as<double>(), trial_out);
+    }
+  }
   int info = 0;
   uint32_t dag_ctrl[4] = {0, 0, 0, 0};
-  const bool used_dag = keep_rows == 0 && dag_applies(h, Npad);
+  if (trial_out) HIPCHK(h, hipMemcpyAsync(trial_value, trial_out, sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipMemcpyAsync(&info, h->d_info.p, sizeof(int), hipMemcpyDeviceToHost, s));
   if (used_dag)
     HIPCHK(h, hipMemcpyAsync(dag_ctrl, h->d_dag_flags.as<uint32_t>() + (size_t)h->dag_ntasks + 2 * (size_t)h->dag_nb,
@@ -859,9 +881,18 @@ static int factorise(tgp_handle h, int64_t N, int64_t keep_rows) {
   if (info != 0)
     return fail(h, TGP_ERR_NOT_PD, "Cholesky failed: K + noise*I is not positive definite (pivot %d)",
                 info - 1);
-  h->have_data = true;
+  h->have_data = !factor_only;  // (a factor-only trial leaves no posterior behind)
   h->data_version = ++g_data_version;
   return TGP_OK;
+}
+
+int tgp_nlml_trial(tgp_handle h, double* value) {
+  if (!h || !value) return TGP_ERR_ARG;
+  if (!h->have_hyper) return fail(h, TGP_ERR_STATE, "tgp_set_hyper must be called before tgp_nlml_trial");
+  if (!h->have_xy) return fail(h, TGP_ERR_STATE, "no data on the device: call tgp_set_data once first");
+  if (int rc = set_device(h)) return rc;
+  h->have_data = false;
+  return factorise(h, h->N, 0, value);
 }
 
 int tgp_set_data(tgp_handle h, const double* X, const double* Y, int64_t N, int where) {
@@ -877,6 +908,7 @@ int tgp_set_data(tgp_handle h, const double* X, const double* Y, int64_t N, int 
   const hipMemcpyKind kindcp = where == TGP_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
   HIPCHK(h, hipMemcpyAsync(h->d_X.p, X, (size_t)N * d * sizeof(double), kindcp, h->stream));
   HIPCHK(h, hipMemcpyAsync(h->d_Y.p, Y, (size_t)N * sizeof(double), kindcp, h->stream));
+  h->have_xy = true;
   return factorise(h, N, 0);
 }
 

@@ -69,6 +69,7 @@ struct tgp_handle_s {
   std::string err;
   // hyper-parameters
   bool have_hyper = false, have_data = false;
+  bool have_xy = false;  // X, Y are on the device (tgp_set_data has run): tgp_nlml_trial may re-factorise them
   double variance = 1.0, noise = 1.0, mean_const = 0.0;
   std::vector<double> ls;  // [d]
   int64_t N = 0, Npad = 0;
@@ -107,6 +108,7 @@ struct tgp_handle_s {
   DevBuf s_ent, s_in, s_in2, s_out1, s_out2, s_out3, s_blkv, s_blki, s_small, s_kcache, s_aslab, s_grad, s_ks, s_part;
   // `update` as one persistent launch: the task list of the current block count (tgp_kernels_dag.hip)
   int dag_nb = 0, dag_ntasks = 0, dag_grid = 0;
+  bool dag_factor_only = false;
   int update_share = 1;  // tgp_set_update_concurrency: the persistent update kernel takes num_cu / update_share workgroups
   int64_t dag_ld = 0;
   DevBuf d_dag_tasks, d_dag_chain, d_dag_flags, d_dag_trace, d_dag_topo;

@@ -183,7 +183,10 @@ struct DagArgs {
   unsigned long long* trace;   // development aid (TGP_DAG_TRACE): [NB][32] chain + [ntasks][4] task time stamps, or null
 };
 void dag_build(int NB, int64_t ld, std::vector<DagTask>& tasks, std::vector<uint32_t>& chain_dep, int& n_urgent,
-               std::vector<uint32_t>* topo_out = nullptr, int workers = 255);
+               std::vector<uint32_t>* topo_out = nullptr, int workers = 255, bool with_inverse = true);
+// z = L^-1 r over 128-blocks from L and the diagonal inverses in W; flags: [NB] words, zero at launch
+void launch_block_trsv(hipStream_t s, const double* L, const double* W, int64_t ld, int NB, const double* r, double* z,
+                       uint32_t* flags);
 hipError_t launch_dag_update(hipStream_t s, const DagArgs& a, int grid);
 size_t dag_lds_bytes();
 

@@ -628,8 +628,9 @@ std::vector<std::pair<int, int>> bursts(int lo, int hi, int burst) {  // long bu
 // Build the static list for NB = Npad / 128 block rows: tasks, their dispatch order (a topological order: the start
 // order of a simulated launch, see below), dependencies as flag ids.
 // flag ids: task n -> n;  chain: W_jj / L_jj ready -> ntasks + j;  L(j+1,j) ready -> ntasks + NB + j.
+// `with_inverse` false: the factor only (no X / E tasks: W keeps its diagonal tiles W_jj, which the T tasks need).
 void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<uint32_t>& chain_dep, int& n_urgent,
-               std::vector<uint32_t>* topo_out, int workers) {
+               std::vector<uint32_t>* topo_out, int workers, bool with_inverse) {
   // k tiles per product: longer bursts amortise a task's fixed ~8 us (N = 8192 is throughput-bound: 8.0 -> 7.65 ms with
   // 8), shorter ones keep the scheduling fine where the chain is the bound (N = 4096: 1.91 ms with 4, 2.08 with 8)
   static const int burst_env = getenv("TGP_DAG_BURST") ? atoi(getenv("TGP_DAG_BURST")) : 0;  // development aid
@@ -678,7 +679,7 @@ void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<
         ts.push_back(h);
       }
     }
-  for (int i = 1; i < NB; ++i)
+  for (int i = 1; with_inverse && i < NB; ++i)
     for (int c = 0; c < i; ++c) {
       int prev = -1;
       for (auto [k0, k1] : bursts(c, i, BURST)) {  // V(i,c) += sum_k L(i,k) W(k,c),  W(c,c) = W_cc
@@ -890,6 +891,61 @@ void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<
 }
 
 size_t dag_lds_bytes() { return DAG_LDS; }
+
+namespace {
+// z = L^-1 r by block forward substitution over the 128-blocks, given the diagonal inverses W_jj (what a factor-only
+// launch leaves in W): workgroup i owns block row i, adds L(i,k) z_k to its sum as the z_k appear (one flag per block,
+// same hand-over as the tile tasks: write-through store, drain, barrier, flag) and then publishes z_i = W_ii (r_i - sum).
+// Workgroups are dispatched in index order and wait only for lower indices: no deadlock whatever the residency.
+// A wait that times out poisons z_i with NaN (the caller sees a NaN likelihood).
+__global__ __launch_bounds__(256) void block_trsv_kernel(const double* __restrict__ L, const double* __restrict__ W,
+                                                         int64_t ld, const double* __restrict__ r,
+                                                         double* z, uint32_t* flags) {
+  __shared__ double zk[TILE], part[2][TILE], t[TILE];
+  __shared__ uint32_t ok;
+  const int i = blockIdx.x, tid = threadIdx.x, row = tid & (TILE - 1), half = tid >> 7;
+  const double* const Lrow = L + ((int64_t)i * TILE + row) * ld + half * (TILE / 2);
+  double s = 0.0;
+  bool good = true;
+  for (int k = 0; k < i; ++k) {
+    if (tid == 0) {
+      unsigned spins = 0;
+      while (ld_flag(flags + k) == 0 && ++spins < SPIN_LIMIT) __builtin_amdgcn_s_sleep(4);
+      ok = spins < SPIN_LIMIT ? 1u : 0u;
+    }
+    __syncthreads();
+    good = good && ok != 0;
+    if (tid < TILE) zk[tid] = ld8_sc1(z + (int64_t)k * TILE + tid);
+    __syncthreads();
+    const double* const lp = Lrow + (int64_t)k * TILE;
+#pragma unroll 8
+    for (int c = 0; c < TILE / 2; ++c) s = fma(lp[c], zk[half * (TILE / 2) + c], s);
+  }
+  part[half][row] = s;
+  __syncthreads();
+  if (tid < TILE) t[tid] = r[(int64_t)i * TILE + tid] - (part[0][tid] + part[1][tid]);
+  __syncthreads();
+  const double* const wp = W + ((int64_t)i * TILE + row) * ld + (int64_t)i * TILE + half * (TILE / 2);
+  double acc = 0.0;  // (W_ii carries explicit zeros right of its diagonal)
+#pragma unroll 8
+  for (int c = 0; c < TILE / 2; ++c) acc = fma(wp[c], t[half * (TILE / 2) + c], acc);
+  __syncthreads();
+  part[half][row] = acc;
+  __syncthreads();
+  if (tid < TILE) {
+    const double v = good ? part[0][tid] + part[1][tid] : __builtin_nan("");
+    __hip_atomic_store((gdouble*)(z + (int64_t)i * TILE + tid), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  drain_vm();
+  __syncthreads();
+  if (tid == 0) st_flag(flags + i, 1u);
+}
+}  // namespace
+
+void launch_block_trsv(hipStream_t s, const double* L, const double* W, int64_t ld, int NB, const double* r, double* z,
+                       uint32_t* flags) {
+  hipLaunchKernelGGL(block_trsv_kernel, dim3((unsigned)NB), dim3(256), 0, s, L, W, ld, r, z, flags);
+}
 
 hipError_t launch_dag_update(hipStream_t s, const DagArgs& a, int grid) {
   hipError_t e = hipFuncSetAttribute((const void*)dag_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DAG_LDS);

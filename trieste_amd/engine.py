@@ -242,6 +242,14 @@ class GPEngine:
         self._chk(self._lib.tgp_nlml(self._h, C.byref(v), g.ctypes.data))
         return v.value, g
 
+    def nlml_trial(self) -> float:
+        """The value ``nlml(False)`` would give after ``set_data`` with the data already on the device, at the current
+        hyper-parameters (tgp_nlml_trial: the factor only from N = 3841 on).  Leaves the engine WITHOUT a posterior --
+        for the throw-away evaluations of a fit's prior draws."""
+        v = C.c_double()
+        self._chk(self._lib.tgp_nlml_trial(self._h, C.byref(v)))
+        return v.value
+
     def get_factor(self):
         """(L, W = L^-1, alpha) as numpy arrays (tests / diagnostics)."""
         n = self.N

@@ -478,7 +478,7 @@ class GaussianProcessRegression:
 
     MAX_PARALLEL_EVALUATIONS = 8
     PERSISTENT_UPDATE_FROM = 4096      # padded size from which `update` is the persistent kernel (tgp_api.hip: dag_applies)
-    PERSISTENT_UPDATE_WORKERS = 2
+    PERSISTENT_UPDATE_WORKERS = 3      # (trial evaluations build the factor only: three fit side by side; HIP maps streams onto four queues)
 
     def _evaluation_engines(self, count: int):
         """Worker engines (own device buffers, own HIP stream) for concurrent loss evaluations."""
@@ -519,7 +519,8 @@ class GaussianProcessRegression:
         if x.shape[0] > self.PERSISTENT_UPDATE_FROM - 256:
             # from here on `update` is one persistent launch that owns the compute units it runs on: side by side means
             # sharing them (tgp_set_update_concurrency), and its tile products stream enough memory that more than
-            # PERSISTENT_UPDATE_WORKERS at once lose again (N = 4096: 1.97 ms alone, 1.33 per update with two, 2.15 with four)
+            # PERSISTENT_UPDATE_WORKERS at once lose again (N = 4096, full updates: 1.97 ms alone, 1.29 per update with
+            # two, 1.25 with three, 2.15 with four)
             workers = min(workers, self.PERSISTENT_UPDATE_WORKERS)
             share = workers
         else:
@@ -531,11 +532,17 @@ class GaussianProcessRegression:
 
         def evaluate(w):  # worker w takes draws w, w + workers, ...
             out = []
+            eng, uploaded = engines[w], False
             for ls, var in draws[w::workers]:
                 try:
-                    engines[w].set_hyper(var, ls, noise, c)
-                    engines[w].set_data(x, y0)
-                    out.append(engines[w].nlml(False)[0] + self._log_prior(ls, var)[0])
+                    eng.set_hyper(var, ls, noise, c)
+                    if uploaded:  # a trial evaluation on the data already there: no posterior is built (tgp_nlml_trial)
+                        value = eng.nlml_trial()
+                    else:
+                        eng.set_data(x, y0)
+                        uploaded = True
+                        value = eng.nlml(False)[0]
+                    out.append(value + self._log_prior(ls, var)[0])
                 except ArithmeticError:
                     out.append(1e100)
             return out
