@@ -132,6 +132,26 @@ def cpu_baseline(w, budget_s=4.5):
                       f"(features [chunk, F+N] materialised per chunk of {chunk}), {el:.1f} s"}
 
 
+def end_to_end_fit_ms(X, Y, w):
+    """Informational (outside the timed region): one ``GaussianProcessRegression.optimize`` -- the MAP fit of a BO step
+    (prior draws as trial evaluations, then L-BFGS-B: ~110 factorisations at N train) -- through the reference-shaped
+    host API.  -> {"ms": ..., "nfev": ...} or a "failed: ..." string."""
+    try:
+        import trieste_amd.models as M
+        from trieste_amd.data import Dataset
+        from trieste_amd.space import Box
+
+        d = w["d"]
+        data = Dataset(X, Y[:, None])
+        model = M.GaussianProcessRegression(M.build_gpr(data, Box([0.0] * d, [1.0] * d), likelihood_variance=w["noise"]))
+        model.optimize(data)  # warm-up (creates the worker engines, allocations)
+        t0 = time.perf_counter()
+        res = model.optimize(data)
+        return {"ms": (time.perf_counter() - t0) * 1e3, "nfev": int(getattr(res, "nfev", -1))}
+    except Exception as e:  # never let the informational figure break the bench line
+        return f"failed: {type(e).__name__}: {e}"
+
+
 def end_to_end_acquire_ms(X, Y, w):
     """Informational (outside the timed region, SURVEY 8d "end-to-end acquire time"): one
     EfficientGlobalOptimization().acquire on the same model through the reference-shaped host API."""
@@ -504,6 +524,7 @@ def main():
                                     "f64_equivalent_TFLOPs": achieved})
         if nshards == 1 and not args.no_acquire and kind == "ei":
             out["config"]["acquire_ms"] = end_to_end_acquire_ms(X, Y, w)
+            out["config"]["fit"] = end_to_end_fit_ms(X, Y, w)
         if (nshards == 1 and not args.no_secondary and args.workload == "headline" and args.precision == "f64"
                 and not args.m_per_gpu and not group_mode):
             # every other workload of BASELINE.json's configs in the same driver-timed run: few steps each, same pricing
