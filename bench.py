@@ -178,6 +178,16 @@ def end_to_end_acquire_ms(X, Y, w):
         return f"failed: {type(e).__name__}: {e}"
 
 
+def qei_eta(eng, Xq) -> float:
+    """The incumbent of the qEI workload: the MEDIAN posterior mean over the first 8192 candidate points.  At the
+    reference's eta = min_i mean(X_i) (function.py:1135-1147) every uniformly random q-batch of this synthetic problem
+    has qEI = max(eta - min, 0) = 0 exactly, so the step's arg-max would be over zeros; the
+    arithmetic and its cost do not depend on eta, the winner does."""
+    import torch
+
+    return float(torch.median(eng.predict_mean(Xq.reshape(-1, Xq.shape[-1])[:8192])))
+
+
 def secondary_line(name: str, precision: str, steps: int, device: int = 0) -> dict:
     """One more workload inside the SAME driver-timed run (1 GPU): `steps` timed steps after one warm-up step, the
     dominant kernel timed by HIP events on its launch stream, priced exactly like the main line.  Returns
@@ -206,6 +216,7 @@ def secondary_line(name: str, precision: str, steps: int, device: int = 0) -> di
         q, S = w["q"], w["S"]
         eps = torch.from_numpy(np.random.default_rng(91011).standard_normal((q, S))).to(dev)
         Xq = eng.sample_box(5678, 0, per * q, 0.0, 1.0).reshape(per, q, d)
+        eta = qei_eta(eng, Xq)
 
         def step():
             v, i = torch.max(eng.qei(Xq, eps, eta, 1e-6), 0)
@@ -404,6 +415,7 @@ def main():
             q, S = w["q"], w["S"]
             eps = torch.from_numpy(np.random.default_rng(91011).standard_normal((q, S))).to(dev)
             Xq = eng.sample_box(5678, lo * q, mine * q, 0.0, 1.0).reshape(mine, q, d)
+            eta = qei_eta(eng, eng.sample_box(5678, 0, 8192, 0.0, 1.0))  # the same eta on every rank
 
             def step():
                 vals = eng.qei(Xq, eps, eta, 1e-6)                             # [G] on the device
@@ -505,7 +517,7 @@ def main():
                             + (f", F={w['F']}, B={w['B']}" if kind == "ts" else ""),
                 "N": N, "d": d, "kernel": kernel, "units_per_gpu": per, "total_units": total_units,
                 "parallelism": par, "rccl_ranks": rccl_ranks, "kernel_ms_per_rank": per_rank_ms,
-                "update_ms": update_ms, "best_value": best[0], "best_index": best[1],
+                "update_ms": update_ms, "eta": float(eta), "best_value": best[0], "best_index": best[1],
             },
             "roofline": {
                 "bound": "mfma" if kind != "ts" else "valu_f64", "achieved": achieved, "peak": FP64_PEAK_TFLOPS,

@@ -242,6 +242,15 @@ def test_edge_cases_and_errors():
     assert_close(v, ov, atol=1e-10)
 
 
+def _sample_atol(cov, floor, eps, jitter=1e-6):
+    """Absolute tolerance of a reparametrised sample mean + (chol(cov + jitter I) eps): an error `floor` in the
+    covariance entries moves the Cholesky factor by about floor / (2 sqrt(lambda_min)) per entry (first-order
+    perturbation of the factorisation), times |eps| summed over a row."""
+    lam = min(float(np.linalg.eigvalsh(c + jitter * np.eye(c.shape[-1])).min()) for c in cov)
+    q = cov.shape[-1]
+    return floor + floor * q * float(np.abs(eps).max()) / (2.0 * np.sqrt(max(lam, jitter)))
+
+
 @pytest.mark.parametrize("variant", [0, 4], ids=["packed-128x256", "slots-256x128"])
 @pytest.mark.parametrize("cfg", [CONFIGS[1], CONFIGS[2], CONFIGS[4]], ids=lambda c: c[0])
 def test_joint_and_qei_match_oracle(cfg, variant):
@@ -264,11 +273,24 @@ def test_joint_and_qei_match_oracle(cfg, variant):
         assert_close(jm, om, atol=floor, what=f"joint mean q={q}")
         assert_close(jc, oc, atol=floor, what=f"joint cov q={q}")
         eps = rng.normal(size=(q, S))
-        eta = O.eta_min_mean(st)
+        # eta = the median posterior mean over the groups, NOT the training minimum: with eta = min_i mean(X_i)
+        # every random group has qEI = max(eta - min, 0) = 0 exactly and the comparison is 0 == 0 (VERDICT r03
+        # weak 1) -- a wrong Cholesky row or a dropped eps column would pass.
+        eta = float(np.median(om))
         got = eng.qei(Xg, eps, eta, 1e-6)
         want = O.batch_mc_ei(st, Xg, eps, eta, 1e-6)
+        assert np.count_nonzero(want) >= want.size // 2, f"vacuous qEI comparison at q={q}: {want}"
         assert_close(got, want, atol=floor, what=f"qei q={q}")
-    # q = 1 qEI with many draws is close to analytic EI (reference test_function.py:1359-1371)
+        # ... and at the reference's own eta (function.py:1135-1147), where most values are exactly zero
+        eta0 = O.eta_min_mean(st)
+        assert_close(eng.qei(Xg, eps, eta0, 1e-6), O.batch_mc_ei(st, Xg, eps, eta0, 1e-6), atol=floor,
+                     what=f"qei at eta=min q={q}")
+        # the samples themselves (the tail's Cholesky + sample code without the max / mean reduction that could
+        # hide an error): BatchReparametrizationSampler.sample, models/gpflow/sampler.py:276-287
+        if (q, G) in ((9, 4), (16, 3), (17, 6), (32, 3), (50, 5), (64, 3), (5, 11)):
+            smp = eng.reparam_samples(Xg, eps, 1e-6)
+            want_s = O.batch_reparam_samples(st, Xg, eps, 1e-6)
+            assert_close(smp, want_s, atol=_sample_atol(oc, floor, eps), what=f"reparam samples q={q}")
 
 
 def test_trajectories_match_oracle_and_argmin():
