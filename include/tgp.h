@@ -379,22 +379,26 @@ int tgp_last_kernel_ms(tgp_handle h, double* ms, int* launches);
  *   TGP_PREC_F64  (default) W K* on the float64 matrix cores -- the parity path;
  *   TGP_PREC_I8X4 W K* on the int8 matrix cores with both operands split error-free into four signed 8-bit digit
  *                 planes (Ozaki scheme: 10 int8 products with exact int32 accumulation stand in for one float64
- *                 product; truncation at 2^-32 of each row / column scale).  K* generation, mean, column norms,
- *                 acquisition tail and arg-max stay float64.  Measured |var error| <= 0.4 x the parity tolerance
- *                 1e-5 |var| + cancellation floor at N = 4096; an EMULATED-precision option
- *                 for throughput, never the default and never what the float64 parity claims are made on.
- *   TGP_PREC_I8X5 the same with five digit planes (15 int8 products, truncation at 2^-40 of the scales): |var error|
- *                 <= 1.5e-3 x the parity tolerance at N = 4096 and below 1e-5 RELATIVE without any floor; d <= 16.
- *   TGP_PREC_AUTO after every factorisation the engine measures max |W| and picks the cheapest of the three whose
- *                 a-priori truncation budget on the variance, 2 x (2 s_f 2^-8P S' S_max sqrt(N / 6)) with
- *                 S_max = 2 max |W|, S' = 2 s_f^2, fits under the cancellation floor of the parity tolerance
- *                 (min(64 eps s_f^2 (1 + N s_f^2 / s^2), 1e-6 s_f^2)): four planes if it does, else five (d <= 16),
- *                 else float64.  tgp_get_precision reports the choice. */
+ *                 product; row / column scales S_i = (1 + 2^-7) max_k |W_ik|, S' = (1 + 2^-7) s_f^2; what is lost
+ *                 are the digit pairs below 2^-32 of S_i S').  K* generation, mean, column norms, acquisition tail
+ *                 and arg-max stay float64.  An EMULATED-precision option for throughput: no per-result guarantee,
+ *                 never the default and never what the float64 parity claims are made on.
+ *   TGP_PREC_I8X5 the same with five digit planes (15 int8 products, digit pairs below 2^-40 dropped); d <= 16.
+ *   TGP_PREC_AUTO the split-precision sweep WITH an a-posteriori repair: the int8 kernel prices every candidate's own
+ *                 truncation error on the variance (8 standard deviations of  2 2^-32.8 S' sqrt(sum_i c_i^2 S_i^2 (i+1)),
+ *                 c = W k*), every candidate whose bound exceeds the parity tolerance 1e-5 var + min(64 eps s_f^2
+ *                 (1 + N s_f^2 / s^2), 1e-6 s_f^2) -- and, in a fused arg-max, every candidate whose value interval
+ *                 reaches the best lower bound -- is recomputed by the float64 kernel in the same call.  Results are
+ *                 inside the parity tolerance candidate by candidate and the arg-max (value and index) is the
+ *                 float64 sweep's.  The engine starts on four planes and moves to five (d <= 16), then to float64,
+ *                 when a sweep had to recompute more than 5 % of its candidates; tgp_set_hyper / tgp_set_precision
+ *                 restart the ladder.  N <= 16384 (int32 accumulators), float64 above. */
 enum tgp_precision { TGP_PREC_F64 = 0, TGP_PREC_I8X4 = 1, TGP_PREC_I8X5 = 2, TGP_PREC_AUTO = 3 };
 int tgp_set_precision(tgp_handle h, int precision);
-/* What was asked for, what is in effect for the current factorisation (never TGP_PREC_AUTO) and, under AUTO, the
- * max |W_ik| the choice was made from (0 otherwise).  Under AUTO it needs data (TGP_ERR_STATE before tgp_set_data). */
-int tgp_get_precision(tgp_handle h, int* requested, int* effective, double* w_abs_max);
+/* What was asked for, what the next plain sweep will run (never TGP_PREC_AUTO) and, under AUTO, the fraction of its
+ * candidates the last completed sweep recomputed in float64 (-1: none yet / not AUTO).  Under AUTO it needs data
+ * (TGP_ERR_STATE before tgp_set_data) and synchronises the handle's stream. */
+int tgp_get_precision(tgp_handle h, int* requested, int* effective, double* repaired_fraction);
 /* Sweep launch policy knob for experiments and tests (0 = default): bit 0 = never use the row-group split of
  * small launches, bit 1 = always use it, bit 2 = joint mode on the first-generation kernel (64-column group slots;
  * dp = 32 always uses it), bit 3 = fused plain launches on the register-staged kernel instead of the LDS-DMA one, bit 4 =

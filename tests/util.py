@@ -65,11 +65,12 @@ def assert_close(actual, desired, rtol=RTOL, atol=0.0, what=""):
 
 
 def i8x4_variance_bound(N: int, variance: float, w_abs_max: float) -> float:
-    """Absolute error budget of the split-precision sweep (TGP_PREC_I8X4, csrc/tgp_kernels_sweep_i8.inc) on the
-    predictive variance, ON TOP of the parity tolerance: both operands are truncated at 2^-32 of their scale
-    (S_i = 2 max_k |W_ik| per row of W, S' = 2 variance for K*) and the digit pairs s + s' >= 4 are dropped, which
-    leaves an error of rms 2^-32 S_i S' sqrt(i / 3) on c_i = (W k*)_i (sum of i independent terms); with
-    var = variance - |c|^2, |c| <= sqrt(variance):  |d var| ~ 2 |c| 2^-32 S' S_max sqrt(N / 6).  Twice that
-    estimate is used as the budget (observed: 0.2 .. 0.5 of it); DESIGN.md section 4.5."""
-    s_max = 2.0 * w_abs_max
-    return 2.0 * (2.0 * np.sqrt(variance) * 2.0 ** -32 * (2.0 * variance) * s_max * np.sqrt(N / 6.0))
+    """Absolute error budget of the PLAIN split-precision sweep (TGP_PREC_I8X4 without the repair of TGP_PREC_AUTO;
+    csrc/tgp_kernels_sweep_i8.inc) on the predictive variance, ON TOP of the parity tolerance: the digit pairs below
+    2^-32 of S_i S' are dropped (S_i = (1 + 2^-7) max_k |W_ik| per row of W, S' = (1 + 2^-7) variance for K*), which
+    leaves an error of rms 2^-32.8 S_i S' sqrt(i + 1) on c_i = (W k*)_i; with var = variance - |c|^2,
+    |c| <= sqrt(variance):  |d var| ~ 2 |c| 2^-32.8 S' S_max sqrt(N) a priori (every row at the largest scale).  Twice
+    that estimate is the budget; DESIGN.md section 4.5, tools/ozaki_tight.py."""
+    tight = 1.0 + 2.0 ** -7
+    s_max = tight * w_abs_max
+    return 2.0 * (2.0 * np.sqrt(variance) * 2.0 ** -32.8 * (tight * variance) * s_max * np.sqrt(float(N)))

@@ -82,8 +82,15 @@ struct tgp_handle_s {
   // four digit planes per operand (tgp_set_precision); the planes of W are rebuilt lazily per factorisation
   int precision = 0;      // the arithmetic in effect (never TGP_PREC_AUTO)
   int precision_req = 0;  // what tgp_set_precision asked for; TGP_PREC_AUTO is resolved per factorisation
-  uint64_t auto_version = 0;  // data_version the AUTO choice was made for
-  double w_abs_max = 0.0;     // max |W_ik| of that factorisation (0: not measured)
+  // TGP_PREC_AUTO: the split-precision sweep with the a-posteriori repair, on a ladder 0: four planes, 1: five planes,
+  // 2: float64 (tgp_api.hip resolve_precision); a rung is left when a sweep had to recompute too many candidates
+  bool repair = false;        // the sweeps of the arithmetic in effect run with the repair
+  int auto_level = 0;
+  uint64_t auto_epoch = 1;    // bumps whenever the rung changes or the ladder restarts: stale reports are ignored
+  bool auto_pinned = false;   // resolved by sweep_blocks for the call in progress
+  int64_t* rep_host = nullptr;  // pinned: {count, M, epoch, -} of the last completed repaired sweep
+  int64_t rep_last_M = 0, rep_last_count = 0;
+  DevBuf s_rep, s_rep_stats;
   DevBuf d_wq, d_rs;
   uint64_t wq_version = 0;
   int wq_planes = 0;

@@ -58,7 +58,18 @@ struct SweepArgs {
   int split_g;            // 0/1: off
   int split_ib[9];
   double* part;           // [blocks][split_g][2][128]
+  // a-posteriori repair of the split-precision sweep (TGP_PREC_AUTO, tgp_api.hip sweep_i8_repaired): the int8
+  // kernel prices every candidate's own truncation error on the variance,
+  //     e_var = rep_scale sqrt(sum_i c_i^2 S_i^2 (i + 1)),  rep_scale = K_SIGMA 2 2^-32.8 S' (four planes),
+  // and leaves rep_ub[j] = +inf where e_var exceeds 1e-5 var + rep_floor (the candidate is recomputed in float64),
+  // else the upper end of its acquisition value's interval; the block winners then carry the LOWER ends.
+  double* rep_ub;         // [M] or null (null: the plain emulated-precision sweep, no bounds)
+  double rep_scale, rep_floor;
+  const int64_t* M_dev;   // SPLIT instantiation + combine kernel: the candidate count lives on the device (the
+                          // repair pass over the flagged candidates is enqueued without a host round trip)
 };
+constexpr double I8_TIGHT = 1.0078125;  // digit-plane scales S_i = I8_TIGHT max_k |W_ik|, S' = I8_TIGHT variance: the
+                                        // balanced digits reach |q| <= 0x7f7f7f7f = 0.99609 2^31 > 2^31 / I8_TIGHT
 void launch_sweep_combine(hipStream_t s, const SweepArgs& a, int64_t nblk);
 
 // ---- linalg (tgp_kernels_linalg.hip) ----
@@ -190,7 +201,20 @@ void launch_block_trsv(hipStream_t s, const double* L, const double* W, int64_t 
 hipError_t launch_dag_update(hipStream_t s, const DagArgs& a, int grid);
 size_t dag_lds_bytes();
 
+// rs: [2][Npad] -- row scales S_i, then the row weights S_i^2 (i + 1) of the a-posteriori error model
 void launch_w_digits(hipStream_t s, const double* W, int64_t N, int64_t Npad, double* rs, void* Wq, int planes);
+// ---- a-posteriori repair of the split-precision sweep (tgp_kernels_misc.hip) ----
+// stats [4]: {count (zeroed here), M, tag, 0}
+void launch_repair_begin(hipStream_t s, int64_t* stats, int64_t M, int64_t tag);
+// list [<= M]: indices j with ub[j] == +inf or ub[j] >= *L (L null: only +inf); count = stats[0]
+void launch_repair_flag(hipStream_t s, const double* ub, int64_t M, const double* L, int64_t* list, int64_t* stats);
+void launch_repair_gather(hipStream_t s, const double* Xq, int d, const int64_t* list, const int64_t* count, int64_t cap,
+                          double* Xg);
+void launch_repair_scatter(hipStream_t s, const int64_t* list, const int64_t* count, int64_t cap, const double* rmean,
+                           const double* rvar, const double* racq, double* mean, double* var, double* acq);
+// per-slot (max value, min index) partials of vals [M] (NaN never wins) into blk_val / blk_idx [nslots]
+void launch_values_argmax(hipStream_t s, const double* vals, int64_t M, int64_t index_base, double* blk_val,
+                          int64_t* blk_idx, int64_t nslots);
 void launch_w_absmax(hipStream_t s, const double* W, int64_t N, int64_t Npad, double* out);  // *out zeroed before
 void launch_merge_winners(hipStream_t s, const double* gathered, int P, int V, int minimize, double* out);
 void launch_argmin_final_multi(hipStream_t s, const double* blk_val, const int64_t* blk_idx,

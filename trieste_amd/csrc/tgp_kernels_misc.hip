@@ -93,45 +93,50 @@ __global__ __launch_bounds__(128) void sweep_combine_kernel(SweepArgs a) {
   __shared__ double bvs[2];
   __shared__ int64_t bis[2];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int64_t blk = blockIdx.x, cj = blk * 128 + tid;
-  double val = -INFINITY;
-  int64_t gidx = INT64_MAX;
-  if (cj < a.M) {
-    double m = 0.0, sq = 0.0;
-    for (int g = 0; g < a.split_g; ++g) {
-      const double* pp = a.part + ((size_t)blk * a.split_g + g) * 256;
-      m += pp[tid];
-      sq += pp[128 + tid];
-    }
-    const double mean = m + a.m.mean_const;
-    const double var = fmax(a.m.variance - sq, VAR_FLOOR);
-    if (a.mean_out) a.mean_out[cj] = mean;
-    if (a.var_out) a.var_out[cj] = var;
-    if (a.acq_kind >= 0) {
-      const double v = acq_tail(a.acq_kind, a.acq_param, mean, var, a.m.noise);
-      if (a.acq_out) a.acq_out[cj] = v;
-      if (!(v != v)) {
-        val = v;
-        gidx = a.index_base + cj;
+  const int64_t M = a.M_dev ? *a.M_dev : a.M;  // repair pass: the count of flagged candidates lives on the device
+  const int64_t nblk = (M + 127) / 128;
+  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int64_t cj = blk * 128 + tid;
+    double val = -INFINITY;
+    int64_t gidx = INT64_MAX;
+    if (cj < M) {
+      double m = 0.0, sq = 0.0;
+      for (int g = 0; g < a.split_g; ++g) {
+        const double* pp = a.part + ((size_t)blk * a.split_g + g) * 256;
+        m += pp[tid];
+        sq += pp[128 + tid];
+      }
+      const double mean = m + a.m.mean_const;
+      const double var = fmax(a.m.variance - sq, VAR_FLOOR);
+      if (a.mean_out) a.mean_out[cj] = mean;
+      if (a.var_out) a.var_out[cj] = var;
+      if (a.acq_kind >= 0) {
+        const double v = acq_tail(a.acq_kind, a.acq_param, mean, var, a.m.noise);
+        if (a.acq_out) a.acq_out[cj] = v;
+        if (!(v != v)) {
+          val = v;
+          gidx = a.index_base + cj;
+        }
       }
     }
-  }
-  if (a.blk_val) {
-    wave_argmax(val, gidx);
-    if (lane == 0) {
-      bvs[w] = val;
-      bis[w] = gidx;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      double v0 = bvs[0];
-      int64_t i0 = bis[0];
-      if (better(bvs[1], bis[1], v0, i0)) {
-        v0 = bvs[1];
-        i0 = bis[1];
+    if (a.blk_val) {
+      wave_argmax(val, gidx);
+      if (lane == 0) {
+        bvs[w] = val;
+        bis[w] = gidx;
       }
-      a.blk_val[blk] = v0;
-      a.blk_idx[blk] = i0;
+      __syncthreads();
+      if (tid == 0) {
+        double v0 = bvs[0];
+        int64_t i0 = bis[0];
+        if (better(bvs[1], bis[1], v0, i0)) {
+          v0 = bvs[1];
+          i0 = bis[1];
+        }
+        a.blk_val[blk] = v0;
+        a.blk_idx[blk] = i0;
+      }
+      __syncthreads();
     }
   }
 }
@@ -687,8 +692,14 @@ __global__ __launch_bounds__(256) void w_digits_kernel(const double* __restrict_
   amax = fmax(amax, __shfl_xor(amax, 1, 64));
   amax = fmax(amax, __shfl_xor(amax, 2, 64));
   amax = fmax(amax, __shfl_xor(amax, 4, 64));
-  const double S = amax > 0.0 ? 2.0 * amax : 1.0;
-  if (c == 0) rs[i] = S;
+  // tight scale: the balanced digits of rint(x / S 2^(8 NS - 1)) reach 0.99609 2^(8 NS - 1) (0x7f7f..7f), so
+  // S = (1 + 2^-7) max |W_ik| is enough -- half the scale of rounds 2 / 3, and the dominant error of the scheme (the
+  // dropped digit pairs s + s' = NS) is proportional to S_i S'
+  const double S = amax > 0.0 ? I8_TIGHT * amax : 1.0;
+  if (c == 0) {
+    rs[i] = S;
+    rs[Npad + i] = i < N ? S * S * (double)(i + 1) : 0.0;  // weight of row i in the error model (SweepArgs::rep_ub)
+  }
   const double to_fixed = (NS == 4 ? 2147483648.0 : 549755813888.0) / S;  // 2^(8 NS - 1) / S
   const size_t plane = (size_t)Npad * (size_t)Npad;
   for (int64_t kb = 0; kb < kb_end; ++kb) {
@@ -698,7 +709,7 @@ __global__ __launch_bounds__(256) void w_digits_kernel(const double* __restrict_
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int64_t k = kb * 32 + 4 * c + j;
-      long long q = (i < N && k < N) ? (long long)rint(row[k] * to_fixed) : 0;  // |.| <= 2^(8 NS - 2)
+      long long q = (i < N && k < N) ? (long long)rint(row[k] * to_fixed) : 0;  // |.| <= 2^(8 NS - 1) / I8_TIGHT
 #pragma unroll
       for (int sdx = NS - 1; sdx > 0; --sdx) {
         const int dg = (int)((q + 128) & 255) - 128;
@@ -765,6 +776,120 @@ __global__ void merge_winners_kernel(const double* __restrict__ gathered, int P,
   out[v] = braw;
   ((int64_t*)out)[V + v] = bi == INT64_MAX ? -1 : bi;
 }
+// ---------------------------------------------------------------------------------------------
+// A-posteriori repair of the split-precision sweep (tgp_api.hip sweep_i8_repaired).  The int8
+// kernel leaves ub [M]: +inf where the candidate's own truncation bound exceeds the parity tolerance, else the upper
+// end of the interval its acquisition value lies in; *L = the largest LOWER end over the sweep.  Whatever could still
+// be the float64 arg-max (ub >= L) and whatever violates the tolerance goes on a list, is recomputed by the float64
+// sweep (SPLIT instantiation, count on the device) and scattered back.
+__global__ void repair_begin_kernel(int64_t* stats, int64_t M, int64_t tag) {
+  stats[0] = 0;
+  stats[1] = M;
+  stats[2] = tag;
+  stats[3] = 0;
+}
+void launch_repair_begin(hipStream_t s, int64_t* stats, int64_t M, int64_t tag) {
+  hipLaunchKernelGGL(repair_begin_kernel, dim3(1), dim3(1), 0, s, stats, M, tag);
+}
+__global__ __launch_bounds__(256) void repair_flag_kernel(const double* __restrict__ ub, int64_t M, const double* L,
+                                                          int64_t* __restrict__ list, int64_t* stats) {
+  const double Lv = L ? *L : INFINITY;
+  const int lane = threadIdx.x & 63;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < M; i0 += stride) {
+    const int64_t i = i0 + threadIdx.x;
+    bool flag = false;
+    if (i < M) {
+      const double u = ub[i];
+      flag = u == INFINITY || (Lv > -INFINITY && Lv < INFINITY && u >= Lv);
+    }
+    // wave-aggregated append: one atomic per wave
+    const unsigned long long mask = __ballot(flag);
+    if (mask) {
+      const int n = __popcll(mask);
+      unsigned long long base = 0;
+      if (lane == __ffsll((long long)mask) - 1) base = atomicAdd((unsigned long long*)stats, (unsigned long long)n);
+      base = __shfl((long long)base, __ffsll((long long)mask) - 1, 64);
+      if (flag) list[base + __popcll(mask & ((1ull << lane) - 1ull))] = i;
+    }
+  }
+}
+void launch_repair_flag(hipStream_t s, const double* ub, int64_t M, const double* L, int64_t* list, int64_t* stats) {
+  const int64_t blocks = std::min<int64_t>((M + 255) / 256, 1024);
+  hipLaunchKernelGGL(repair_flag_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ub, M, L, list, stats);
+}
+__global__ __launch_bounds__(256) void repair_gather_kernel(const double* __restrict__ Xq, int d,
+                                                            const int64_t* __restrict__ list, const int64_t* count,
+                                                            double* __restrict__ Xg) {
+  const int64_t n = *count * d;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const int64_t r = e / d;
+    Xg[e] = Xq[list[r] * d + (e - r * d)];
+  }
+}
+void launch_repair_gather(hipStream_t s, const double* Xq, int d, const int64_t* list, const int64_t* count, int64_t cap,
+                          double* Xg) {
+  const int64_t blocks = std::min<int64_t>((cap * d + 255) / 256, 1024);
+  hipLaunchKernelGGL(repair_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, s, Xq, d, list, count, Xg);
+}
+__global__ __launch_bounds__(256) void repair_scatter_kernel(const int64_t* __restrict__ list, const int64_t* count,
+                                                             const double* rmean, const double* rvar, const double* racq,
+                                                             double* mean, double* var, double* acq) {
+  const int64_t n = *count;
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256) {
+    const int64_t j = list[r];
+    if (mean) mean[j] = rmean[r];
+    if (var) var[j] = rvar[r];
+    if (acq) acq[j] = racq[r];
+  }
+}
+void launch_repair_scatter(hipStream_t s, const int64_t* list, const int64_t* count, int64_t cap, const double* rmean,
+                           const double* rvar, const double* racq, double* mean, double* var, double* acq) {
+  const int64_t blocks = std::min<int64_t>((cap + 255) / 256, 1024);
+  hipLaunchKernelGGL(repair_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, s, list, count, rmean, rvar, racq, mean,
+                     var, acq);
+}
+__global__ __launch_bounds__(256) void values_argmax_kernel(const double* __restrict__ vals, int64_t M, int64_t index_base,
+                                                            double* blk_val, int64_t* blk_idx, int64_t nslots) {
+  __shared__ double sv[4];
+  __shared__ int64_t si[4];
+  double v = -INFINITY;
+  int64_t i = INT64_MAX;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < M; t += (int64_t)gridDim.x * 256) {
+    const double x = vals[t];
+    if (!(x != x) && better(x, index_base + t, v, i)) {
+      v = x;
+      i = index_base + t;
+    }
+  }
+  wave_argmax(v, i);
+  if ((threadIdx.x & 63) == 0) {
+    sv[threadIdx.x >> 6] = v;
+    si[threadIdx.x >> 6] = i;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (better(sv[w], si[w], v, i)) {
+        v = sv[w];
+        i = si[w];
+      }
+    blk_val[blockIdx.x] = v;
+    blk_idx[blockIdx.x] = i;
+  }
+  // the slots beyond the grid carry "nothing found"
+  for (int64_t t = (int64_t)gridDim.x + (int64_t)blockIdx.x * 256 + threadIdx.x; t < nslots; t += (int64_t)gridDim.x * 256) {
+    blk_val[t] = -INFINITY;
+    blk_idx[t] = INT64_MAX;
+  }
+}
+void launch_values_argmax(hipStream_t s, const double* vals, int64_t M, int64_t index_base, double* blk_val,
+                          int64_t* blk_idx, int64_t nslots) {
+  const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((M + 255) / 256, 256), nslots));
+  hipLaunchKernelGGL(values_argmax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, vals, M, index_base, blk_val, blk_idx,
+                     nslots);
+}
+
 void launch_merge_winners(hipStream_t s, const double* gathered, int P, int V, int minimize, double* out) {
   hipLaunchKernelGGL(merge_winners_kernel, dim3((unsigned)((V + 63) / 64)), dim3(64), 0, s, gathered, P, V,
                      minimize, out);

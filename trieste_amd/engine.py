@@ -112,18 +112,21 @@ class GPEngine:
         """Arithmetic of the plain sweeps (tgp_set_precision): "f64" (default, the parity path); "i8x4" / "i8x5" --
         W K* on the int8 matrix cores with four / five 8-bit digit planes per operand (emulated-precision throughput
         options: x5 holds the plain parity tolerance on every tested model, x4 only on well-conditioned ones);
-        "auto" -- after every factorisation the engine picks the cheapest of the three whose a-priori error bound
-        (from max|W|) fits inside the parity tolerance."""
+        "auto" -- the int8 sweep with an a-posteriori repair: every candidate whose own error bound exceeds the
+        parity tolerance (and, in a fused arg-max, every candidate that could still be the float64 winner) is
+        recomputed in float64 inside the same call; four planes, then five, then float64 when too many candidates
+        needed it.  Results hold the parity tolerance candidate by candidate; the arg-max is the float64 one."""
         if precision not in _lib.PRECISIONS:
             raise ValueError(f"unknown precision {precision!r}; choose from {sorted(_lib.PRECISIONS)}")
         self._chk(self._lib.tgp_set_precision(self._h, _lib.PRECISIONS[precision]))
 
     def get_precision(self):
-        """-> (requested, in effect, max |W| the "auto" choice was made from or 0.0): tgp_get_precision."""
-        req, eff, wmax = C.c_int(), C.c_int(), C.c_double()
-        self._chk(self._lib.tgp_get_precision(self._h, C.byref(req), C.byref(eff), C.byref(wmax)))
+        """-> (requested, what the next plain sweep runs, fraction of its candidates the last "auto" sweep recomputed
+        in float64 or -1.0): tgp_get_precision."""
+        req, eff, frac = C.c_int(), C.c_int(), C.c_double()
+        self._chk(self._lib.tgp_get_precision(self._h, C.byref(req), C.byref(eff), C.byref(frac)))
         names = {v: k for k, v in _lib.PRECISIONS.items()}
-        return names[req.value], names[eff.value], wmax.value
+        return names[req.value], names[eff.value], frac.value
 
     # -- model state -----------------------------------------------------------------------------
     def clone_from(self, other: "GPEngine") -> None:
