@@ -170,6 +170,15 @@ int tgp_nlml(tgp_handle h, double* value, double* grad);
  * The handle is left WITHOUT a posterior: queries fail with TGP_ERR_STATE until the next tgp_set_data.  NOT_PD as for
  * tgp_set_data. */
 int tgp_nlml_trial(tgp_handle h, double* value);
+/* B trial evaluations at once: hypers [B][d + 3] (variance, lengthscales [d], noise_variance, mean_const per member),
+ * values [B], status [B] (TGP_OK or TGP_ERR_NOT_PD per member; a member that breaks down gets a NaN value and does not
+ * disturb the others).  From N = 3841 on up to 8 members share ONE persistent launch: B chain workgroups, one list of
+ * tile tasks interleaving the members' factor-only plans -- a single factorisation leaves half of the compute units
+ * idle behind its chain, and HIP runs at most three such launches side by side.  Each value equals tgp_nlml_trial's at
+ * the same hyper-parameters bit for bit.  The handle's own hyper-parameters and posterior are untouched (the members
+ * live in scratch matrices: 3 N^2 doubles each).  Below that size the members are evaluated one after the other.
+ * Replaces the loop of find_best_model_initialization (reference models/gpflow/models.py:294-321). */
+int tgp_nlml_trial_batch(tgp_handle h, const double* hypers, int B, double* values, int* status);
 /* Read back the cache (tests / checkpoint-free restore checks): any pointer may be NULL.
  * L [N,N] lower (upper = 0), Winv [N,N] = L^-1, alpha [N].  `where` applies to all three. */
 int tgp_get_factor(tgp_handle h, double* L, double* Winv, double* alpha, int where);
@@ -435,7 +444,14 @@ typedef struct {
   uint32_t dep[3], set, pad;
 } tgp_dag_task;
 int tgp_dag_plan(int nb, int64_t ld, tgp_dag_task* tasks, int64_t cap, int64_t* ntasks, int64_t* n_urgent,
-                 uint32_t* chain_dep, uint32_t* order, int flags /* bit 0: the factor only (tgp_nlml_trial's plan) */);
+                 uint32_t* chain_dep, uint32_t* order,
+                 int flags /* bit 0: the factor only (tgp_nlml_trial's plan); bits 8-15: B > 0 -> `order` is the dispatch
+                              list of a batched launch of B members (tgp_nlml_trial_batch): B * ntasks entries
+                              (member << 24 | task), the members' orders interleaved */);
+/* Is `update` at N training points one persistent launch on this handle (size, variant bits)?  *yes = 0 / 1.  The host
+ * layer sizes its concurrent evaluations with it (a persistent launch owns its compute units) instead of restating
+ * the rule (reference: the fit loop of models/gpflow/models.py:256-321 is what calls `update` that often). */
+int tgp_update_is_persistent(tgp_handle h, int64_t N, int* yes);
 
 #ifdef __cplusplus
 }

@@ -120,22 +120,12 @@ class FakeEngine:
         self._precision = precision
 
     def get_precision(self):
-        """The engine's rule restated (csrc/tgp_api.hip resolve_precision): twice the truncation estimate of P digit
-        planes has to fit under the cancellation floor of the parity tolerance."""
+        """tgp_get_precision: (requested, in effect, fraction the last "auto" sweep recomputed in float64 or -1).  The
+        oracle-backed stand-in computes everything in float64: "auto" reports its first rung and nothing recomputed."""
         req = getattr(self, "_precision", "f64")
         if req != "auto":
-            return req, req, 0.0
-        st = self._st()
-        N, v, noise = st.X.shape[0], float(st.variance), float(st.noise)
-        W = np.linalg.inv(st.L)
-        wmax = float(np.abs(np.tril(W)).max())
-        floor = min(64.0 * np.finfo(float).eps * v * (1.0 + N * v / noise), 1e-6 * v)
-
-        def budget(planes):
-            return 2.0 * (2.0 * np.sqrt(v) * 2.0 ** (-8 * planes) * (2.0 * v) * (2.0 * wmax) * np.sqrt(N / 6.0))
-
-        eff = "i8x4" if budget(4) <= floor else ("i8x5" if self.d <= 16 and budget(5) <= floor else "f64")
-        return req, eff, wmax
+            return req, req, -1.0
+        return req, "i8x4", 0.0
 
     def clone_from(self, other):
         if not isinstance(other, FakeEngine):
@@ -279,6 +269,26 @@ class FakeEngine:
             raise NotPositiveDefiniteError(str(e))
         self.state, self.N = None, 0
         return O.nlml_and_grad(st)[0]
+
+    def update_is_persistent(self, N):
+        return int(N) > 3840
+
+    def nlml_trial_batch(self, hypers):
+        """tgp_nlml_trial_batch: the likelihood at every row of hypers [B, d + 3] over the data of the last set_data; the
+        engine's own hyper-parameters and posterior are untouched."""
+        hy = np.ascontiguousarray(hypers, dtype=np.float64)
+        if hy.ndim != 2 or hy.shape[1] != self.d + 3:
+            raise ValueError(f"hypers must be [B, {self.d + 3}], got {hy.shape}")
+        if getattr(self, "_xy", None) is None:
+            raise RuntimeError("no data on the device: call tgp_set_data once first")
+        values, ok = np.full(hy.shape[0], np.nan), np.zeros(hy.shape[0], dtype=bool)
+        for b, row in enumerate(hy):
+            try:
+                st = O.gpr_update(self.kernel, row[0], row[1:1 + self.d], row[1 + self.d], row[2 + self.d], *self._xy)
+                values[b], ok[b] = O.nlml_and_grad(st)[0], True
+            except np.linalg.LinAlgError:
+                pass
+        return values, ok
 
     def get_factor(self):
         st = self._st()

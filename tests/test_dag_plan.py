@@ -352,3 +352,72 @@ def test_flags_order_every_conflicting_pair_and_point_backwards(nb):
             for k in range(c, i):
                 assert seen.get(("X", i, c, k)) == 1
     assert sum(seen.values()) == len(seen)
+
+
+def plan_batch(nb, B):
+    """The factor-only plan and the dispatch list of a batched launch of B members (tgp_dag_plan flags: bit 0 + B << 8)."""
+    lib = _lib.load()
+    ld = nb * T
+    flags = 1 | (B << 8)
+    n, nu = C.c_int64(), C.c_int64()
+    assert lib.tgp_dag_plan(nb, ld, None, 0, C.byref(n), C.byref(nu), None, None, flags) == _lib.TGP_ERR_SHAPE
+    tasks = (Task * max(n.value, 1))()
+    chain = (C.c_uint32 * (2 * nb))()
+    order = (C.c_uint32 * max(B * n.value, 1))()
+    assert lib.tgp_dag_plan(nb, ld, tasks, n.value, C.byref(n), C.byref(nu), chain, order, flags) == _lib.TGP_OK
+    return [tasks[i] for i in range(n.value)], list(chain), ld, nu.value, [order[i] for i in range(B * n.value)]
+
+
+@pytest.mark.parametrize("nb,B", [(2, 2), (5, 3), (9, 8)])
+def test_batched_plan_factors_every_member_from_one_list(nb, B):
+    """tgp_nlml_trial_batch: B matrices, B chains, ONE dispatch list of (member << 24 | task) entries drawn in order.
+    Executed with a single worker (the worst residency) every member's factor comes out; every member's tasks appear
+    exactly once and in an order that is topological for ITS graph (so the in-order dispatcher cannot deadlock whatever
+    the other members do); the members' plans are the factor-only plan itself (same tasks, same arithmetic: the values
+    equal tgp_nlml_trial's bit for bit)."""
+    tasks, chain, ld, nu, order = plan_batch(nb, B)
+    single, chain1, _, _ = plan(nb, flags=1)
+    assert len(tasks) == len(single) and chain == chain1
+    for a, b in zip(tasks, single):
+        assert bytes(a) == bytes(b)
+    nt = len(tasks)
+    assert len(order) == B * nt
+    seen = [[False] * nt for _ in range(B)]
+    for e in order:
+        b, i = e >> 24, e & 0xFFFFFF
+        assert b < B and i < nt and not seen[b][i]
+        for dep in tasks[i].dep:
+            assert dep == NONE or dep >= nt or seen[b][dep], "a member's entry precedes one of its producers"
+        seen[b][i] = True
+    assert all(all(s) for s in seen)
+    n = nb * T
+    mats = [spd(n, 100 + 7 * b + nb) * (1.0 + 0.25 * b) for b in range(B)]
+    ORDER[(nb, ld)] = list(range(nt))  # (the members' machines are driven by the merged list below)
+    ms = [Machine(A, nb, tasks, chain, ld, nu) for A in mats]
+    pos = 0
+    while pos < len(order) or any(m.chain_pos < 2 * nb for m in ms):
+        progressed = False
+        for m in ms:                                  # every member's chain runs whenever it can
+            while m.chain_ready():
+                m.run_chain()
+                progressed = True
+        if pos < len(order):
+            b, i = order[pos] >> 24, order[pos] & 0xFFFFFF
+            if ms[b].ready(tasks[i]):                 # the one worker waits at the head of the list
+                ms[b].run_bulk(i)
+                ms[b].taken[i] = True
+                pos += 1
+                progressed = True
+        assert progressed, f"stuck at list position {pos} of {len(order)}"
+    for A, m in zip(mats, ms):
+        L = np.tril(m.m[1])
+        np.testing.assert_allclose(L @ L.T, A, rtol=1e-11, atol=1e-11)
+    # a member alone (B = 1 machine on the single plan) gives the same bits: members do not interact
+    ORDER[(nb, ld)] = ORDER_SINGLE = [e & 0xFFFFFF for e in order if e >> 24 == 0]
+    alone = Machine(mats[0], nb, tasks, chain, ld, nu)
+    while not alone.done():
+        if alone.chain_ready():
+            alone.run_chain()
+        else:
+            alone.run_bulk(alone.acquire())
+    np.testing.assert_array_equal(alone.m[1], ms[0].m[1])

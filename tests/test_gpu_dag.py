@@ -280,3 +280,61 @@ def test_dag_update_reports_a_matrix_that_is_not_positive_definite(where):
     eng.set_data(X, Y)
     L, W, _ = eng.get_factor()
     assert np.isfinite(L).all() and np.abs(np.tril(W) @ np.tril(L) - np.eye(N)).max() < 1e-8
+
+
+def test_batched_trial_evaluations_equal_the_single_ones_bit_for_bit():
+    """tgp_nlml_trial_batch at N = 4096: 11 members (a launch of eight, a launch of three) through ONE persistent launch
+    each -- B chain workgroups, one interleaved task list.  Every value equals tgp_nlml_trial's at the same
+    hyper-parameters bit for bit; a member whose kernel matrix is not positive definite gets NaN / not-ok and does not
+    disturb the others; the engine's own hyper-parameters and posterior are untouched."""
+    N, d = 4096, 5
+    X, Y, ls, c, kind, noise = _problem(N, d=d)
+    X = X.copy()
+    X[3000:3040] = X[2999] + 1e-13 * np.random.default_rng(1).standard_normal((40, d))  # near-duplicates: PD only with noise
+    eng = _engine(X, Y, ls, c, kind, noise)
+    before = eng.predict(X[:50] + 0.01)
+    rng = np.random.default_rng(4096)
+    hy = []
+    for b in range(11):
+        ls_t = ls * np.exp(0.3 * rng.standard_normal(d))
+        hy.append(np.concatenate([[float(np.exp(0.2 * rng.standard_normal()))], ls_t, [noise * (1.0 + b), c + 0.1 * b]]))
+    hy = np.array(hy)
+    hy[4, 1 + d] = 1e-300                                   # member 4: (numerically) no noise -> not positive definite
+    values, ok = eng.nlml_trial_batch(hy)
+    assert ok.tolist() == [b != 4 for b in range(11)] and np.isnan(values[4]) and np.isfinite(np.delete(values, 4)).all()
+    again, ok2 = eng.nlml_trial_batch(hy)
+    np.testing.assert_array_equal(np.delete(again, 4), np.delete(values, 4))      # the same bits again
+    after = eng.predict(X[:50] + 0.01)
+    np.testing.assert_array_equal(before[0], after[0])                            # the posterior was not touched
+    np.testing.assert_array_equal(before[1], after[1])
+    single = _engine(X, Y, ls, c, kind, noise)
+    for b in (0, 3, 5, 7, 8, 10):                            # members of both launches against the one-by-one evaluation
+        single.set_hyper(hy[b, 0], hy[b, 1:1 + d], hy[b, 1 + d], hy[b, 2 + d])
+        assert single.nlml_trial() == values[b], (b, single.nlml_trial(), values[b])
+    st = O.gpr_update(kind, hy[0, 0], hy[0, 1:1 + d], hy[0, 1 + d], hy[0, 2 + d], X, Y)
+    assert abs(values[0] - O.nlml_and_grad(st)[0]) <= 1e-8 * abs(values[0]) + 1e-8 * N
+    # a permutation of the members permutes the values (members do not interact)
+    perm = rng.permutation(11)
+    pv, _ = eng.nlml_trial_batch(hy[perm])
+    np.testing.assert_array_equal(np.delete(pv, int(np.where(perm == 4)[0][0])), np.delete(values[perm], int(np.where(perm == 4)[0][0])))
+
+
+def test_batched_trial_evaluations_below_the_persistent_size():
+    """Below N = 3841 the members run one after the other on the handle itself: tgp_nlml_trial's values, the handle's
+    hyper-parameters and posterior restored."""
+    X, Y, ls, c, kind, noise = _problem(300, d=4)
+    eng = _engine(X, Y, ls, c, kind, noise, variant=0)
+    before = eng.predict(X[:20] + 0.01)
+    rng = np.random.default_rng(3)
+    hy = np.array([np.concatenate([[1.0 + 0.1 * b], ls * np.exp(0.2 * rng.standard_normal(4)), [noise, c]]) for b in range(5)])
+    values, ok = eng.nlml_trial_batch(hy)
+    assert ok.all()
+    single = _engine(X, Y, ls, c, kind, noise, variant=0)
+    for b in range(5):
+        single.set_hyper(hy[b, 0], hy[b, 1:5], hy[b, 5], hy[b, 6])
+        assert single.nlml_trial() == values[b]
+    after = eng.predict(X[:20] + 0.01)
+    np.testing.assert_array_equal(before[0], after[0])
+    np.testing.assert_array_equal(before[1], after[1])
+    with pytest.raises(ValueError):
+        eng.nlml_trial_batch(np.ones((2, 3)))

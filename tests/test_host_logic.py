@@ -521,22 +521,34 @@ def test_find_best_model_initialization_never_gets_worse():
 
 
 def test_find_best_model_initialization_shares_the_gpu_between_its_workers(monkeypatch):
-    """Below the size where `update` is one persistent launch the draws go to up to MAX_PARALLEL_EVALUATIONS engines with
-    whole-device launches (small dependent launches interleave by themselves); from that size on to
-    PERSISTENT_UPDATE_WORKERS engines, each told to take its share of the compute units (tgp_set_update_concurrency)."""
+    """Below the size where `update` is one persistent launch (the LIBRARY's rule: tgp_update_is_persistent) the draws go
+    to up to MAX_PARALLEL_EVALUATIONS engines with whole-device launches (small dependent launches interleave by
+    themselves); from that size on they go through ONE engine's tgp_nlml_trial_batch -- or, with BATCHED_TRIALS off, to
+    PERSISTENT_UPDATE_WORKERS engines each told to take its share of the compute units (tgp_set_update_concurrency)."""
     from tests.fakes import FakeEngine
 
-    calls = []
+    calls, batches = [], []
     monkeypatch.setattr(FakeEngine, "set_update_concurrency", lambda self, n=1: calls.append(int(n)))
+    real_batch = FakeEngine.nlml_trial_batch
+    monkeypatch.setattr(FakeEngine, "nlml_trial_batch", lambda self, hy: (batches.append(len(hy)), real_batch(self, hy))[1])
     model, data = _model(n=25, noise=1e-3)
     model.find_best_model_initialization(12, seed=1)
-    assert calls and set(calls) == {1} and len(calls) == min(model.MAX_PARALLEL_EVALUATIONS, 12)
+    assert calls and set(calls) == {1} and len(calls) == min(model.MAX_PARALLEL_EVALUATIONS, 12) and not batches
     calls.clear()
-    monkeypatch.setattr(type(model), "PERSISTENT_UPDATE_FROM", 256)   # pretend 25 points are "large"
+    monkeypatch.setattr(FakeEngine, "update_is_persistent", lambda self, N: True)   # pretend 25 points are "large"
     before = model.training_loss()
     model.find_best_model_initialization(12, seed=2)
-    assert calls == [model.PERSISTENT_UPDATE_WORKERS] * model.PERSISTENT_UPDATE_WORKERS
+    assert batches == [12] and not calls                    # one batched call for all draws, no worker engines
     assert model.training_loss() <= before + 1e-9
+    fresh, _ = _model(n=25, noise=1e-3)
+    fresh.find_best_model_initialization(12, seed=2)
+    best_batched = fresh.training_loss()
+    calls.clear()
+    monkeypatch.setattr(type(model), "BATCHED_TRIALS", False)
+    model2, _ = _model(n=25, noise=1e-3)
+    model2.find_best_model_initialization(12, seed=2)
+    assert calls == [model.PERSISTENT_UPDATE_WORKERS] * model.PERSISTENT_UPDATE_WORKERS
+    assert abs(model2.training_loss() - best_batched) <= 1e-9 * abs(best_batched)   # the same draws, the same winner
 
 
 # ---- SURVEY 8(f) rank 3/4: sibling tails, continuous Thompson sampling, fantasising ------------------

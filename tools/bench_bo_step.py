@@ -22,7 +22,19 @@ for rep in range(2):
     res = model.optimize(newd); t2 = time.perf_counter()
     print(f"N={N}: update(append 1 row) {1e3*(t1-t0):.2f} ms, optimize {1e3*(t2-t1):.0f} ms (nfev={res.nfev}), "
           f"workers={model.MAX_PARALLEL_EVALUATIONS}", flush=True)
-for w in (1, 2, 3):
+for rep in range(2):
+    t0 = time.perf_counter(); model.find_best_model_initialization(90); t1 = time.perf_counter()
+    print(f"  find_best_model_initialization(90) batched (tgp_nlml_trial_batch, 8 members per launch): {1e3*(t1-t0):.0f} ms", flush=True)
+type(model).BATCHED_TRIALS = False
+for w in (1, 3):
     model.PERSISTENT_UPDATE_WORKERS = w
     t0 = time.perf_counter(); model.find_best_model_initialization(90); t1 = time.perf_counter()
-    print(f"  find_best_model_initialization(90) workers={w}: {1e3*(t1-t0):.0f} ms", flush=True)
+    print(f"  find_best_model_initialization(90) one by one, workers={w}: {1e3*(t1-t0):.0f} ms", flush=True)
+type(model).BATCHED_TRIALS = True
+# a COLD fit: a fresh model from build_gpr defaults (first optimize: allocations, plans, worker engines)
+cold = M.GaussianProcessRegression(M.build_gpr(data, space, likelihood_variance=1e-2))
+t0 = time.perf_counter(); res = cold.optimize(data); t1 = time.perf_counter()
+print(f"  COLD optimize (fresh model, build_gpr defaults): {1e3*(t1-t0):.0f} ms (nfev={res.nfev})", flush=True)
+cold2 = M.GaussianProcessRegression(M.build_gpr(data, space, likelihood_variance=1e-2))
+t0 = time.perf_counter(); res = cold2.optimize(data); t1 = time.perf_counter()
+print(f"  second fresh model, same process (allocator warm): {1e3*(t1-t0):.0f} ms (nfev={res.nfev})", flush=True)

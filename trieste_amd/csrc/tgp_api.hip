@@ -266,7 +266,13 @@ hipError_t launch_sweep_i8_timed(tgp_handle h, SweepArgs& am) {
   const int64_t M = am.M;
   const int d = am.m.d;
   const int nb = (int)(Npad / NPAD_MULT);
-  const int g = std::min(8, nb);
+  SweepArgs b{};
+  int g = std::min(8, nb);
+  while (g > 1 && !plan_split(b, nb, g)) --g;  // (few row blocks: not every group count leaves every group a block)
+  if (g == 1) {
+    b.split_ib[0] = 0;
+    b.split_ib[1] = nb;
+  }
   const int64_t cap_blocks = (M + SW_BN - 1) / SW_BN;
   int64_t fgrid = cap_blocks * g;
   fgrid = fgrid < h->num_cu ? fgrid : h->num_cu;
@@ -306,7 +312,6 @@ hipError_t launch_sweep_i8_timed(tgp_handle h, SweepArgs& am) {
   if (ublk_val) launch_argmax_final(h->stream, ublk_val, ublk_idx, blocks, Lslot, (int64_t*)(Lslot + 1));
   launch_repair_flag(h->stream, ub, M, ublk_val ? Lslot : nullptr, list, stats);
   launch_repair_gather(h->stream, am.Xq, d, list, stats, M, Xg);
-  SweepArgs b{};
   b.m = am.m;
   b.Xq = Xg;
   b.M = M;
@@ -317,7 +322,6 @@ hipError_t launch_sweep_i8_timed(tgp_handle h, SweepArgs& am) {
   b.acq_kind = am.acq_kind;
   b.acq_param = am.acq_param;
   b.split_g = g;
-  if (!plan_split(b, nb, g)) return hipErrorInvalidValue;
   b.part = h->s_part.as<double>();
   b.kcache = h->s_kcache.as<double>();
   if ((e = launch_sweep_kind(h, b, false, fgrid)) != hipSuccess) return e;
@@ -490,37 +494,48 @@ bool dag_applies(tgp_handle h, int64_t Npad) {
   return !off && !(h->variant & VARIANT_NO_DAG) && Npad >= min_n && Npad % 128 == 0 && Npad * Npad * 8 < (int64_t)0x7fffffff;
 }
 
+// The cached plan of `slot` (0 full update, 1 factor-only, 2 batched factor-only) for this size / share of the compute
+// units / batch; built on a miss (the host vectors are copied with one synchronisation).
+int dag_plan_get(tgp_handle h, int slot, int NB, int64_t ld, int grid, int B) {
+  tgp_handle_s::DagPlan& p = h->dag_plan[slot];
+  if (p.nb == NB && p.ld == ld && p.grid == grid && p.B == B) return TGP_OK;
+  std::vector<DagTask> tasks;
+  std::vector<uint32_t> chain, topo, merged;
+  int nu = 0;
+  // the dispatch order is simulated for the workers a member can count on
+  dag_build(NB, ld, tasks, chain, nu, &topo, std::max(1, (grid - B) / B), slot == 0);
+  if (B > 1 || slot == 2) {
+    dag_merge_order(topo, B, merged);
+    topo.swap(merged);
+  }
+  HIPCHK(h, p.tasks.reserve(tasks.size() * sizeof(DagTask)));
+  HIPCHK(h, p.chain.reserve(chain.size() * sizeof(uint32_t)));
+  HIPCHK(h, p.topo.reserve((topo.size() + 1) * sizeof(uint32_t)));
+  HIPCHK(h, hipMemcpyAsync(p.tasks.p, tasks.data(), tasks.size() * sizeof(DagTask), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(p.chain.p, chain.data(), chain.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(p.topo.p, topo.data(), topo.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));  // the host vectors die here
+  p.nb = NB;
+  p.ld = ld;
+  p.grid = grid;
+  p.B = B;
+  p.ntasks = (int)tasks.size();
+  return TGP_OK;
+}
+
 // -> TGP_OK / error; the launch's own error words are read back by dag_check after the stream has drained
 int chol_inv_dag(tgp_handle h, bool factor_only = false) {
   const int64_t Npad = h->Npad;
   const int NB = (int)(Npad / 128);
   // workgroups of the launch: all compute units, or this handle's share of them (tgp_set_update_concurrency)
   const int grid = std::max(std::min(32, h->num_cu), h->num_cu / std::max(1, h->update_share));
-  if (h->dag_nb != NB || h->dag_ld != Npad || h->dag_grid != grid || h->dag_factor_only != factor_only) {
-    std::vector<DagTask> tasks;
-    std::vector<uint32_t> chain;
-    int nu = 0;
-    std::vector<uint32_t> topo;
-    dag_build(NB, Npad, tasks, chain, nu, &topo, grid - 1, !factor_only);  // (the dispatch order is simulated for this many workers)
-    // launch state: flags (tasks, then the chain's 2 NB events), control words, per-task start counts
-    const size_t nt = tasks.size();
-    const size_t state_words = nt + 2 * (size_t)NB + DAG_CTRL_WORDS + nt;
-    HIPCHK(h, h->d_dag_tasks.reserve(tasks.size() * sizeof(DagTask)));
-    HIPCHK(h, h->d_dag_chain.reserve(chain.size() * sizeof(uint32_t)));
-    HIPCHK(h, h->d_dag_flags.reserve(state_words * sizeof(uint32_t)));
-    HIPCHK(h, h->d_dag_topo.reserve((nt + 1) * sizeof(uint32_t)));
-    HIPCHK(h, hipMemcpyAsync(h->d_dag_tasks.p, tasks.data(), tasks.size() * sizeof(DagTask), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_dag_chain.p, chain.data(), chain.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_dag_topo.p, topo.data(), nt * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));  // the host vectors die here
-    h->dag_nb = NB;
-    h->dag_ld = Npad;
-    h->dag_grid = grid;
-    h->dag_factor_only = factor_only;
-    h->dag_ntasks = (int)tasks.size();
-    h->dag_state_words = state_words;
-  }
-  const size_t nflags = (size_t)h->dag_ntasks + 2 * (size_t)NB;
+  const int slot = factor_only ? 1 : 0;
+  if (int rc = dag_plan_get(h, slot, NB, Npad, grid, 1)) return rc;
+  const tgp_handle_s::DagPlan& plan = h->dag_plan[slot];
+  h->dag_last_slot = slot;
+  h->dag_state_words = (size_t)plan.ntasks + 2 * (size_t)NB + DAG_CTRL_WORDS + (size_t)plan.ntasks;
+  HIPCHK(h, h->d_dag_flags.reserve(h->dag_state_words * sizeof(uint32_t)));
+  const size_t nflags = (size_t)plan.ntasks + 2 * (size_t)NB;
   // flags, control words and start counts all start from zero, before EVERY launch
   HIPCHK(h, hipMemsetAsync(h->d_dag_flags.p, 0, h->dag_state_words * sizeof(uint32_t), h->stream));
   DagArgs a{};
@@ -529,17 +544,19 @@ int chol_inv_dag(tgp_handle h, bool factor_only = false) {
   a.Wp = h->d_W.as<double>();
   a.ld = Npad;
   a.NB = NB;
-  a.ntasks = h->dag_ntasks;
-  a.tasks = h->d_dag_tasks.as<DagTask>();
-  a.chain_dep = h->d_dag_chain.as<uint32_t>();
-  a.topo = h->d_dag_topo.as<uint32_t>();
+  a.ntasks = plan.ntasks;
+  a.tasks = plan.tasks.as<DagTask>();
+  a.chain_dep = plan.chain.as<uint32_t>();
+  a.topo = plan.topo.as<uint32_t>();
   a.flags = h->d_dag_flags.as<uint32_t>();
   a.ctrl = a.flags + nflags;
   a.info = h->d_info.as<int>();
+  a.B = 1;
+  a.flags_stride = (uint32_t)nflags;
   // development aid: TGP_DAG_TRACE=<file> -- time stamps of every chain phase and task of the LAST update, dumped as
   // uint64 [NB][32] + [ntasks][4] after the stream has drained (tools/dag_trace.py reads it)
   static const char* trace_path = getenv("TGP_DAG_TRACE");
-  const size_t trace_words = 32 * (size_t)NB + 4 * (size_t)h->dag_ntasks;
+  const size_t trace_words = 32 * (size_t)NB + 4 * (size_t)plan.ntasks;
   if (trace_path) {
     HIPCHK(h, h->d_dag_trace.reserve(trace_words * 8));
     HIPCHK(h, hipMemsetAsync(h->d_dag_trace.p, 0, trace_words * 8, h->stream));
@@ -564,7 +581,7 @@ int chol_inv_dag(tgp_handle h, bool factor_only = false) {
     HIPCHK(h, hipMemcpyAsync(host.data(), h->d_dag_trace.p, trace_words * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (FILE* f = fopen(trace_path, "wb")) {
-      const unsigned long long hdr[2] = {(unsigned long long)NB, (unsigned long long)h->dag_ntasks};
+      const unsigned long long hdr[2] = {(unsigned long long)NB, (unsigned long long)plan.ntasks};
       fwrite(hdr, 8, 2, f);
       fwrite(host.data(), 8, host.size(), f);
       fclose(f);
@@ -756,7 +773,10 @@ int tgp_destroy(tgp_handle h) {
   for (DevBuf* b : {&h->d_xn, &h->d_ls, &h->d_X, &h->d_Y, &h->d_Xs, &h->d_A, &h->d_L, &h->d_W, &h->d_alpha,
                     &h->d_err, &h->d_tmp1, &h->d_tmp2, &h->d_info, &h->d_pen, &h->d_ent, &h->d_repv, &h->d_wq, &h->d_rs, &h->s_ent, &h->s_in, &h->s_in2, &h->s_out1,
                     &h->s_out2, &h->s_out3, &h->s_blkv, &h->s_blki, &h->s_small, &h->s_kcache, &h->s_aslab, &h->s_grad, &h->s_ks, &h->s_part, &h->s_rep,
-                    &h->s_rep_stats, &h->d_dag_tasks, &h->d_dag_chain, &h->d_dag_flags, &h->d_dag_trace, &h->d_dag_topo})
+                    &h->s_rep_stats, &h->d_dag_flags, &h->d_dag_trace, &h->d_batch, &h->d_batch_vec, &h->d_batch_small,
+                    &h->dag_plan[0].tasks, &h->dag_plan[0].chain, &h->dag_plan[0].topo, &h->dag_plan[1].tasks,
+                    &h->dag_plan[1].chain, &h->dag_plan[1].topo, &h->dag_plan[2].tasks, &h->dag_plan[2].chain,
+                    &h->dag_plan[2].topo})
     b->release();
   if (h->rep_host) (void)hipHostFree(h->rep_host);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -813,16 +833,31 @@ static_assert(sizeof(tgp_dag_task) == sizeof(tgp::DagTask), "tgp_dag_task mirror
 int tgp_dag_plan(int nb, int64_t ld, tgp_dag_task* tasks, int64_t cap, int64_t* ntasks, int64_t* n_urgent,
                  uint32_t* chain_dep, uint32_t* order, int flags) {
   if (nb < 1 || nb > 126 || ld < (int64_t)nb * 128 || !ntasks || !n_urgent) return TGP_ERR_ARG;
+  const int B = (flags >> 8) & 255;  // > 0: the dispatch list of a batched launch of B members (B ntasks entries)
+  if (B > 64) return TGP_ERR_ARG;
   std::vector<tgp::DagTask> t;
-  std::vector<uint32_t> c, topo;
+  std::vector<uint32_t> c, topo, merged;
   int nu = 0;
-  tgp::dag_build(nb, ld, t, c, nu, &topo, 255, (flags & 1) == 0);
+  tgp::dag_build(nb, ld, t, c, nu, &topo, B > 0 ? std::max(1, (256 - B) / B) : 255, (flags & 1) == 0);
+  if (B > 0) {
+    tgp::dag_merge_order(topo, B, merged);
+    topo.swap(merged);
+  }
   *ntasks = (int64_t)t.size();
   *n_urgent = nu;
   if (cap < (int64_t)t.size() || !tasks || !chain_dep) return TGP_ERR_SHAPE;
   memcpy(tasks, t.data(), t.size() * sizeof(tgp::DagTask));
   memcpy(chain_dep, c.data(), c.size() * sizeof(uint32_t));
   if (order) memcpy(order, topo.data(), topo.size() * sizeof(uint32_t));
+  return TGP_OK;
+}
+
+/* Is `update` at N training points ONE persistent launch on this handle (size, variant bits, TGP_NO_DAG)?  The host layer
+ * sizes its side-by-side evaluations with it instead of restating the rule. */
+int tgp_update_is_persistent(tgp_handle h, int64_t N, int* yes) {
+  if (!h || !yes || N < 1) return TGP_ERR_ARG;
+  const int64_t Npad = ((N + NPAD_MULT - 1) / NPAD_MULT) * NPAD_MULT;
+  *yes = dag_applies(h, Npad) ? 1 : 0;
   return TGP_OK;
 }
 
@@ -979,14 +1014,15 @@ static int factorise(tgp_handle h, int64_t N, int64_t keep_rows, double* trial_v
   if (trial_out) HIPCHK(h, hipMemcpyAsync(trial_value, trial_out, sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipMemcpyAsync(&info, h->d_info.p, sizeof(int), hipMemcpyDeviceToHost, s));
   if (used_dag)
-    HIPCHK(h, hipMemcpyAsync(dag_ctrl, h->d_dag_flags.as<uint32_t>() + (size_t)h->dag_ntasks + 2 * (size_t)h->dag_nb,
+    HIPCHK(h, hipMemcpyAsync(dag_ctrl, h->d_dag_flags.as<uint32_t>() + (size_t)h->dag_plan[h->dag_last_slot].ntasks +
+                                           2 * (size_t)h->dag_plan[h->dag_last_slot].nb,
                              sizeof dag_ctrl, hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipStreamSynchronize(s));
   HIPCHK(h, hipGetLastError());
   if (dag_ctrl[2] != 0)
     return fail(h, TGP_ERR_HIP, "persistent update kernel gave up (code %u) waiting for flag %u of %d tasks + %d chain "
                 "steps: a workgroup did not become resident or a dependency is wrong", dag_ctrl[2], dag_ctrl[3],
-                h->dag_ntasks, 2 * h->dag_nb);
+                h->dag_plan[h->dag_last_slot].ntasks, 2 * h->dag_plan[h->dag_last_slot].nb);
   if (info != 0)
     return fail(h, TGP_ERR_NOT_PD, "Cholesky failed: K + noise*I is not positive definite (pivot %d)",
                 info - 1);
@@ -1002,6 +1038,145 @@ int tgp_nlml_trial(tgp_handle h, double* value) {
   if (int rc = set_device(h)) return rc;
   h->have_data = false;
   return factorise(h, h->N, 0, value);
+}
+
+// One chunk of a batched trial evaluation: members [0, B) of `hyp` ([B][d + 3]: variance, lengthscales, noise, mean)
+// through ONE persistent factor-only launch; values / status per member.
+static int nlml_trial_chunk(tgp_handle h, const double* hyp, int B, double* values, int* status) {
+  const int64_t N = h->N, Npad = h->Npad;
+  const int d = h->d, dp = h->dp, NB = (int)(Npad / 128);
+  const size_t nn = (size_t)Npad * Npad;
+  hipStream_t s = h->stream;
+  const int grid = h->num_cu;
+  if (int rc = dag_plan_get(h, 2, NB, Npad, grid, B)) return rc;
+  const tgp_handle_s::DagPlan& plan = h->dag_plan[2];
+  h->dag_last_slot = 2;
+  const size_t nflags = (size_t)plan.ntasks + 2 * (size_t)NB;
+  const size_t state_words = (size_t)B * nflags + DAG_CTRL_WORDS + (size_t)B * plan.ntasks;
+  HIPCHK(h, h->d_dag_flags.reserve(state_words * sizeof(uint32_t)));
+  HIPCHK(h, h->d_batch.reserve((size_t)B * 3 * nn * sizeof(double)));
+  // [B] scaled inputs Xs [Npad][dp]; [B] centred targets err [Npad]; [B] z [Npad]; the trsv flags [B][NB]
+  const size_t xs_per = (size_t)Npad * dp;
+  HIPCHK(h, h->d_batch_vec.reserve(((size_t)B * (xs_per + 2 * (size_t)Npad) + (size_t)B * NB) * sizeof(double)));
+  // per member: ls [dp] (32 slots), value slots [MAX_D + 8];  then B breakdown reports (ints)
+  const size_t small_per = 32 + (MAX_D + 8);
+  HIPCHK(h, h->d_batch_small.reserve(((size_t)B * small_per + B) * sizeof(double)));
+  double* const mats = h->d_batch.as<double>();
+  double* const Xs_all = h->d_batch_vec.as<double>();
+  double* const errs = Xs_all + (size_t)B * xs_per;
+  double* const zs = errs + (size_t)B * Npad;
+  uint32_t* const tflags = (uint32_t*)(zs + (size_t)B * Npad);
+  double* const small = h->d_batch_small.as<double>();
+  int* const infos = (int*)(small + (size_t)B * small_per);
+  if (h->batch_zeroed != mats || h->batch_zeroed_npad != Npad || h->batch_zeroed_B < B) {
+    // the factorisation only ever writes zeros above the diagonals: wiped once per allocation (as d_L / d_W)
+    HIPCHK(h, hipMemsetAsync(mats, 0, (size_t)B * 3 * nn * sizeof(double), s));
+    h->batch_zeroed = mats;
+    h->batch_zeroed_npad = Npad;
+    h->batch_zeroed_B = B;
+  }
+  std::vector<double> hsmall((size_t)B * small_per + B, 0.0);  // (also zeroes the breakdown reports)
+  for (int b = 0; b < B; ++b) {
+    const double* hb = hyp + (size_t)b * (d + 3);
+    for (int c = 0; c < dp; ++c) hsmall[(size_t)b * small_per + c] = c < d ? hb[1 + c] : 1.0;
+  }
+  HIPCHK(h, hipMemcpyAsync(small, hsmall.data(), hsmall.size() * sizeof(double), hipMemcpyHostToDevice, s));
+  for (int b = 0; b < B; ++b) {
+    const double* hb = hyp + (size_t)b * (d + 3);
+    double* Xs = Xs_all + (size_t)b * xs_per;
+    launch_scale_inputs(s, h->d_X.as<double>(), small + (size_t)b * small_per, Xs, N, Npad, d, dp);
+    launch_assemble_K(s, Xs, mats + (size_t)(3 * b) * nn, N, Npad, dp, h->kind, hb[0], hb[1 + d]);
+    launch_center(s, h->d_Y.as<double>(), hb[2 + d], errs + (size_t)b * Npad, N, Npad);
+  }
+  HIPCHK(h, hipMemsetAsync(h->d_dag_flags.p, 0, state_words * sizeof(uint32_t), s));
+  DagArgs a{};
+  a.Ap = mats;
+  a.Lp = mats + nn;
+  a.Wp = mats + 2 * nn;
+  a.ld = Npad;
+  a.NB = NB;
+  a.ntasks = plan.ntasks;
+  a.tasks = plan.tasks.as<DagTask>();
+  a.chain_dep = plan.chain.as<uint32_t>();
+  a.topo = plan.topo.as<uint32_t>();
+  a.flags = h->d_dag_flags.as<uint32_t>();
+  a.ctrl = a.flags + (size_t)B * nflags;
+  a.info = infos;
+  a.B = B;
+  a.mat_stride = (int64_t)(3 * nn);
+  a.flags_stride = (uint32_t)nflags;
+  HIPCHK(h, launch_dag_update(s, a, grid));
+  // z_b = L_b^-1 err_b: ONE launch for all members (a member is a 32-step chain of block products), then the values
+  HIPCHK(h, hipMemsetAsync(tflags, 0, (size_t)B * NB * sizeof(uint32_t), s));
+  launch_block_trsv(s, mats + nn, mats + 2 * nn, Npad, NB, errs, zs, tflags, B, (int64_t)(3 * nn));
+  for (int b = 0; b < B; ++b) {
+    ModelDev m{};
+    m.kind = h->kind;
+    m.d = d;
+    m.dp = dp;
+    m.N = N;
+    m.Npad = Npad;
+    m.alpha = zs + (size_t)b * Npad;
+    launch_nlml_value(s, m, mats + (size_t)(3 * b + 1) * nn, zs + (size_t)b * Npad, small + (size_t)b * small_per + 32);
+  }
+  std::vector<double> hout((size_t)B * small_per + B);
+  uint32_t dag_ctrl[4] = {0, 0, 0, 0};
+  HIPCHK(h, hipMemcpyAsync(hout.data(), small, hout.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipMemcpyAsync(dag_ctrl, a.ctrl, sizeof dag_ctrl, hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  HIPCHK(h, hipGetLastError());
+  if (dag_ctrl[2] != 0)
+    return fail(h, TGP_ERR_HIP, "batched persistent factorisation gave up (code %u) waiting for flag %u (%d members x %d "
+                "tasks)", dag_ctrl[2], dag_ctrl[3], B, plan.ntasks);
+  const int* hinfo = (const int*)(hout.data() + (size_t)B * small_per);
+  for (int b = 0; b < B; ++b) {
+    status[b] = hinfo[b] != 0 ? TGP_ERR_NOT_PD : TGP_OK;
+    values[b] = hinfo[b] != 0 ? __builtin_nan("") : hout[(size_t)b * small_per + 32];
+  }
+  return TGP_OK;
+}
+
+int tgp_nlml_trial_batch(tgp_handle h, const double* hypers, int B, double* values, int* status) {
+  if (!h || !hypers || !values || !status) return TGP_ERR_ARG;
+  if (B < 1) return fail(h, TGP_ERR_SHAPE, "B must be >= 1, got %d", B);
+  if (!h->have_xy) return fail(h, TGP_ERR_STATE, "no data on the device: call tgp_set_data once first");
+  if (int rc = set_device(h)) return rc;
+  const int d = h->d;
+  for (int b = 0; b < B; ++b) {
+    const double* hb = hypers + (size_t)b * (d + 3);
+    bool ok = hb[0] > 0.0 && hb[1 + d] > 0.0 && std::isfinite(hb[2 + d]);
+    for (int c = 0; c < d; ++c) ok = ok && hb[1 + c] > 0.0;
+    if (!ok) return fail(h, TGP_ERR_ARG, "member %d: variance, lengthscales and noise must be positive, the mean finite", b);
+  }
+  const int64_t Npad = ((h->N + NPAD_MULT - 1) / NPAD_MULT) * NPAD_MULT;
+  if (!dag_applies(h, Npad) || Npad != h->Npad) {
+    // below the persistent kernel's sizes a factorisation is a chain of small launches: evaluate the members one after
+    // the other on the handle itself (tgp_nlml_trial's arithmetic), then restore its hyper-parameters
+    const double v0 = h->variance, n0 = h->noise, c0 = h->mean_const;
+    const std::vector<double> ls0 = h->ls;
+    const bool had = h->have_data;
+    int rc_all = TGP_OK;
+    for (int b = 0; b < B && rc_all == TGP_OK; ++b) {
+      const double* hb = hypers + (size_t)b * (d + 3);
+      if (int rc = tgp_set_hyper(h, hb[0], hb + 1, hb[1 + d], hb[2 + d])) return rc;
+      const int rc = tgp_nlml_trial(h, values + b);
+      status[b] = rc == TGP_ERR_NOT_PD ? TGP_ERR_NOT_PD : TGP_OK;
+      if (rc == TGP_ERR_NOT_PD) values[b] = __builtin_nan("");
+      else if (rc != TGP_OK) rc_all = rc;
+    }
+    if (int rc = tgp_set_hyper(h, v0, ls0.data(), n0, c0)) return rc;
+    if (rc_all != TGP_OK) return rc_all;
+    if (had) return factorise(h, h->N, 0);  // the handle's own posterior, as it was
+    return TGP_OK;
+  }
+  // members per launch: up to 8, and at most 12 GiB of matrices
+  const size_t per = (size_t)3 * Npad * Npad * sizeof(double);
+  const int bmax = (int)std::max<size_t>(1, std::min<size_t>(8, ((size_t)12 << 30) / per));
+  for (int b0 = 0; b0 < B; b0 += bmax) {
+    const int nb = std::min(bmax, B - b0);
+    if (int rc = nlml_trial_chunk(h, hypers + (size_t)b0 * (d + 3), nb, values + b0, status + b0)) return rc;
+  }
+  return TGP_OK;
 }
 
 int tgp_set_data(tgp_handle h, const double* X, const double* Y, int64_t N, int where) {

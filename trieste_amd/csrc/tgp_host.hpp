@@ -114,12 +114,22 @@ struct tgp_handle_s {
   // scratch
   DevBuf s_ent, s_in, s_in2, s_out1, s_out2, s_out3, s_blkv, s_blki, s_small, s_kcache, s_aslab, s_grad, s_ks, s_part;
   // `update` as one persistent launch: the task list of the current block count (tgp_kernels_dag.hip)
-  int dag_nb = 0, dag_ntasks = 0, dag_grid = 0;
-  bool dag_factor_only = false;
+  // one cached plan per use: 0 the full update, 1 the factor-only trial (tgp_nlml_trial), 2 the batched factor-only
+  // launch (tgp_nlml_trial_batch) -- a fit alternates between them, and building a plan costs as much as the update
+  struct DagPlan {
+    int nb = 0, ntasks = 0, grid = 0, B = 0;
+    int64_t ld = 0;
+    DevBuf tasks, chain, topo;
+  } dag_plan[3];
+  int dag_last_slot = 0;  // the slot of the most recent launch (its error words are read back after the stream drains)
   int update_share = 1;  // tgp_set_update_concurrency: the persistent update kernel takes num_cu / update_share workgroups
-  int64_t dag_ld = 0;
-  DevBuf d_dag_tasks, d_dag_chain, d_dag_flags, d_dag_trace, d_dag_topo;
-  size_t dag_state_words = 0;  // d_dag_flags: [ntasks + 2 NB] flag words, control words, start counts (DagArgs), zeroed per launch
+  DevBuf d_dag_flags, d_dag_trace;
+  size_t dag_state_words = 0;  // d_dag_flags: B x [ntasks + 2 NB] flag words, control words, start counts (DagArgs), zeroed per launch
+  // batched trial evaluations: [B][3] matrices (A, L, W), [B] scaled inputs / centred targets / z, per-member scalars
+  DevBuf d_batch, d_batch_vec, d_batch_small;
+  const void* batch_zeroed = nullptr;
+  int64_t batch_zeroed_npad = 0;
+  int batch_zeroed_B = 0;
   // timing of the dominant kernel
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double last_ms = 0.0;

@@ -192,12 +192,19 @@ struct DagArgs {
                                // start counts; ALL ZERO at launch (memset before every launch)
   int* info;                   // Cholesky breakdown report (1 + index of the first bad pivot)
   unsigned long long* trace;   // development aid (TGP_DAG_TRACE): [NB][32] chain + [ntasks][4] task time stamps, or null
+  // batched launch (tgp_nlml_trial_batch): B > 1 members share the plan; member b's matrices are Ap / Lp / Wp +
+  // b mat_stride, its flags `flags + b flags_stride`, its breakdown report info[b]; topo then holds B ntasks entries
+  // (member << 24 | task) and the start counts are [B][ntasks]
+  int B;
+  int64_t mat_stride;
+  uint32_t flags_stride;
 };
+void dag_merge_order(const std::vector<uint32_t>& member_order, int B, std::vector<uint32_t>& merged);
 void dag_build(int NB, int64_t ld, std::vector<DagTask>& tasks, std::vector<uint32_t>& chain_dep, int& n_urgent,
                std::vector<uint32_t>* topo_out = nullptr, int workers = 255, bool with_inverse = true);
 // z = L^-1 r over 128-blocks from L and the diagonal inverses in W; flags: [NB] words, zero at launch
 void launch_block_trsv(hipStream_t s, const double* L, const double* W, int64_t ld, int NB, const double* r, double* z,
-                       uint32_t* flags);
+                       uint32_t* flags, int B = 1, int64_t mat_stride = 0);
 hipError_t launch_dag_update(hipStream_t s, const DagArgs& a, int grid);
 size_t dag_lds_bytes();
 

@@ -83,21 +83,35 @@ __device__ __forceinline__ void st_flag(uint32_t* p, uint32_t v) {
 }
 
 // one lane: wait until flags[id] != 0; false on timeout or when another workgroup has raised the error word
-__device__ bool wait_flag(const DagArgs& a, uint32_t id) {
+__device__ bool wait_flag_at(const uint32_t* flags, uint32_t* ctrl, uint32_t id) {
   if (id == NONE) return true;
   unsigned spins = 0;
-  while (ld_flag(a.flags + id) == 0) {
+  while (ld_flag(flags + id) == 0) {
     __builtin_amdgcn_s_sleep(8);
     if ((++spins & 255u) == 0) {
-      if (ld_flag(a.ctrl + 2) != 0) return false;
+      if (ld_flag(ctrl + 2) != 0) return false;
       if (spins > SPIN_LIMIT) {
-        st_flag(a.ctrl + 2, DAG_ERR_TIMEOUT);
-        st_flag(a.ctrl + 3, 0x80000000u | id);
+        st_flag(ctrl + 2, DAG_ERR_TIMEOUT);
+        st_flag(ctrl + 3, 0x80000000u | id);
         return false;
       }
     }
   }
   return true;
+}
+__device__ bool wait_flag(const DagArgs& a, uint32_t id) { return wait_flag_at(a.flags, a.ctrl, id); }
+
+// member b of a batched launch (DagArgs::B > 1): its own matrices, flags and breakdown report; the plan (tasks, chain
+// dependencies), the control words and the dispatch list are shared
+__device__ __forceinline__ DagArgs dag_member(const DagArgs& a, uint32_t b) {
+  DagArgs m = a;
+  m.Ap = a.Ap + (int64_t)b * a.mat_stride;
+  m.Lp = a.Lp + (int64_t)b * a.mat_stride;
+  m.Wp = a.Wp + (int64_t)b * a.mat_stride;
+  m.flags = a.flags + (size_t)b * a.flags_stride;
+  m.info = a.info + b;
+  m.trace = nullptr;
+  return m;
 }
 
 // development aid: 100 MHz wall-clock stamps of the phase boundaries (one lane; only when a trace buffer is given)
@@ -545,41 +559,57 @@ __device__ __attribute__((noinline)) void run_chain(const DagArgs& a) {
   }
 }
 
+// One launch, B >= 1 matrices (DagArgs::B; the factor-only plan of the hyper-parameter fit: tgp_nlml_trial_batch): the
+// first B workgroups to arrive are the chains of members 0 .. B - 1, everybody else draws from ONE list of
+// (member << 24 | task) entries -- the members' dispatch orders interleaved (dag_merge_order), a topological order of
+// every member's graph, so the in-order dispatcher stays deadlock-free.  A member that breaks down (not PD) poisons only
+// its own tiles.  B <= 1 is the single-matrix `update`, unchanged.
 __global__ __launch_bounds__(512) void dag_update_kernel(DagArgs a) {
   DAG_LDS_DECL;
   char* const lds = dag_lds;
   volatile uint32_t* const ctl = (volatile uint32_t*)(lds + CTL_OFF);
   const int tid = threadIdx.x;
-  if (tid == 0) ctl[0] = atomicAdd(a.ctrl + C_TICKET, 1u);  // arrival ticket: the first resident workgroup is the chain
+  if (tid == 0) ctl[0] = atomicAdd(a.ctrl + C_TICKET, 1u);  // arrival ticket: the first resident workgroups are the chains
   __syncthreads();
   const uint32_t role = ctl[0];
   __syncthreads();
-  if (role == 0) {
-    run_chain(a);
+  const uint32_t nB = a.B > 1 ? (uint32_t)a.B : 1u;
+  if (role < nB) {
+    if (nB == 1) {
+      run_chain(a);
+    } else {
+      const DagArgs m = dag_member(a, role);
+      run_chain(m);
+    }
     return;
   }
+  const uint32_t total = (uint32_t)a.ntasks * nB;
 #pragma unroll 1
   for (;;) {
     if (tid == 0) {  // the next entry of the list; wait for the flags of what was drawn
       const uint32_t pos = atomicAdd(a.ctrl + C_HEAD, 1u);
-      uint32_t got = TASK_DONE;
-      if (pos < (uint32_t)a.ntasks) {
-        got = a.topo[pos];
+      uint32_t got = TASK_DONE, mb = 0;
+      if (pos < total) {
+        const uint32_t entry = a.topo[pos];
+        mb = entry >> 24;
+        got = entry & 0xffffffu;
         if (a.trace) a.trace[CT * a.NB + 4 * (size_t)got] = wall_clock64();  // development aid: drawn (before the wait)
+        const uint32_t* const mflags = a.flags + (size_t)mb * a.flags_stride;
         bool ok = true;
-        for (int d = 0; d < 3; ++d) ok = ok && wait_flag(a, a.tasks[got].dep[d]);
+        for (int d = 0; d < 3; ++d) ok = ok && wait_flag_at(mflags, a.ctrl, a.tasks[got].dep[d]);
         if (!ok) got = TASK_ERR;
       }
       ctl[0] = got;
+      ctl[2] = mb;
     }
     __syncthreads();
-    const uint32_t idx = uni(ctl[0]);
+    const uint32_t idx = uni(ctl[0]), mb = uni(ctl[2]);
     __syncthreads();
     if (idx >= (uint32_t)a.ntasks) return;  // TASK_DONE / TASK_ERR
     unsigned long long* const tr = (a.trace && tid == 0) ? a.trace + CT * a.NB + 4 * (size_t)idx : nullptr;
     stamp(tr ? tr + 1 : nullptr);
     if (tid == 0) {  // sanity: a task starts exactly once
-      const uint32_t old = atomicAdd(dag_cnt(a) + idx, 1u);
+      const uint32_t old = atomicAdd(dag_cnt(a) + (size_t)mb * (uint32_t)a.ntasks + idx, 1u);
       if (old != 0u) {
         st_flag(a.ctrl + C_ERR, 3u);
         st_flag(a.ctrl + C_ERRINFO, idx);
@@ -594,7 +624,12 @@ __global__ __launch_bounds__(512) void dag_update_kernel(DagArgs a) {
         }
       }
     }
-    run_task(a, idx);
+    if (nB == 1) {
+      run_task(a, idx);
+    } else {
+      const DagArgs m = dag_member(a, mb);
+      run_task(m, idx);
+    }
     stamp(tr ? tr + 2 : nullptr);
     if (tr) tr[3] = blockIdx.x;
   }
@@ -898,11 +933,18 @@ namespace {
 // same hand-over as the tile tasks: write-through store, drain, barrier, flag) and then publishes z_i = W_ii (r_i - sum).
 // Workgroups are dispatched in index order and wait only for lower indices: no deadlock whatever the residency.
 // A wait that times out poisons z_i with NaN (the caller sees a NaN likelihood).
+// Batched (gridDim.y members: matrices mat_stride apart, vectors ld apart, flags gridDim.x words apart): workgroups are
+// dispatched x fastest, so member y's block i still waits only for lower linear indices.
 __global__ __launch_bounds__(256) void block_trsv_kernel(const double* __restrict__ L, const double* __restrict__ W,
                                                          int64_t ld, const double* __restrict__ r,
-                                                         double* z, uint32_t* flags) {
+                                                         double* z, uint32_t* flags, int64_t mat_stride) {
   __shared__ double zk[TILE], part[2][TILE], t[TILE];
   __shared__ uint32_t ok;
+  L += (int64_t)blockIdx.y * mat_stride;
+  W += (int64_t)blockIdx.y * mat_stride;
+  r += (int64_t)blockIdx.y * ld;
+  z += (int64_t)blockIdx.y * ld;
+  flags += (size_t)blockIdx.y * gridDim.x;
   const int i = blockIdx.x, tid = threadIdx.x, row = tid & (TILE - 1), half = tid >> 7;
   const double* const Lrow = L + ((int64_t)i * TILE + row) * ld + half * (TILE / 2);
   double s = 0.0;
@@ -943,8 +985,20 @@ __global__ __launch_bounds__(256) void block_trsv_kernel(const double* __restric
 }  // namespace
 
 void launch_block_trsv(hipStream_t s, const double* L, const double* W, int64_t ld, int NB, const double* r, double* z,
-                       uint32_t* flags) {
-  hipLaunchKernelGGL(block_trsv_kernel, dim3((unsigned)NB), dim3(256), 0, s, L, W, ld, r, z, flags);
+                       uint32_t* flags, int B, int64_t mat_stride) {
+  hipLaunchKernelGGL(block_trsv_kernel, dim3((unsigned)NB, (unsigned)std::max(1, B)), dim3(256), 0, s, L, W, ld, r, z, flags,
+                     mat_stride);
+}
+
+// Dispatch list of a batched launch: B copies of one member's order, interleaved entry by entry -- the members are the
+// same graph with the same simulated start times, so this IS the merge by start time of a simulation in which every
+// member owns 1 / B of the workers (build the member's order with dag_build(..., workers / B, ...)).  Every member's
+// entries keep their relative order: a topological order of every member's graph.
+void dag_merge_order(const std::vector<uint32_t>& member_order, int B, std::vector<uint32_t>& merged) {
+  merged.clear();
+  merged.reserve(member_order.size() * (size_t)B);
+  for (uint32_t t : member_order)
+    for (int b = 0; b < B; ++b) merged.push_back(((uint32_t)b << 24) | t);
 }
 
 hipError_t launch_dag_update(hipStream_t s, const DagArgs& a, int grid) {

@@ -696,9 +696,16 @@ __global__ __launch_bounds__(256) void w_digits_kernel(const double* __restrict_
   // S = (1 + 2^-7) max |W_ik| is enough -- half the scale of rounds 2 / 3, and the dominant error of the scheme (the
   // dropped digit pairs s + s' = NS) is proportional to S_i S'
   const double S = amax > 0.0 ? I8_TIGHT * amax : 1.0;
+  __shared__ double wrow[32];
   if (c == 0) {
     rs[i] = S;
-    rs[Npad + i] = i < N ? S * S * (double)(i + 1) : 0.0;  // weight of row i in the error model (SweepArgs::rep_ub)
+    wrow[r] = i < N ? S * S * (double)(i + 1) : 0.0;  // weight of row i in the error model (SweepArgs::rep_ub)
+  }
+  __syncthreads();
+  if (tid == 0) {  // the sweep prices a 32-row fragment at its largest row weight (one multiply-add per fragment)
+    double wmax = 0.0;
+    for (int q = 0; q < 32; ++q) wmax = fmax(wmax, wrow[q]);
+    rs[Npad + blockIdx.x] = wmax;
   }
   const double to_fixed = (NS == 4 ? 2147483648.0 : 549755813888.0) / S;  // 2^(8 NS - 1) / S
   const size_t plane = (size_t)Npad * (size_t)Npad;

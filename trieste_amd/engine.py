@@ -253,6 +253,27 @@ class GPEngine:
         self._chk(self._lib.tgp_nlml_trial(self._h, C.byref(v)))
         return v.value
 
+    def update_is_persistent(self, N: int) -> bool:
+        """Is ``set_data`` at N training points ONE persistent launch on this engine (tgp_update_is_persistent)?"""
+        yes = C.c_int()
+        self._chk(self._lib.tgp_update_is_persistent(self._h, int(N), C.byref(yes)))
+        return bool(yes.value)
+
+    def nlml_trial_batch(self, hypers):
+        """B trial evaluations on the data already on the device (tgp_nlml_trial_batch): ``hypers`` [B, d + 3] =
+        (variance, lengthscales [d], noise variance, mean) per member -> (values [B], ok [B]); a member whose kernel
+        matrix is not positive definite gets NaN / False.  From N = 3841 on up to eight members share one persistent
+        launch; the engine's own hyper-parameters and posterior are untouched."""
+        hy = np.ascontiguousarray(hypers, dtype=np.float64)
+        if hy.ndim != 2 or hy.shape[1] != self.d + 3:
+            raise ValueError(f"hypers must be [B, {self.d + 3}] (variance, lengthscales, noise, mean), got {hy.shape}")
+        B = hy.shape[0]
+        values = np.empty(B, dtype=np.float64)
+        status = np.zeros(B, dtype=np.int32)
+        if B:
+            self._chk(self._lib.tgp_nlml_trial_batch(self._h, hy.ctypes.data, B, values.ctypes.data, status.ctypes.data))
+        return values, status == 0
+
     def get_factor(self):
         """(L, W = L^-1, alpha) as numpy arrays (tests / diagnostics)."""
         n = self.N

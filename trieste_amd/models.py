@@ -477,7 +477,7 @@ class GaussianProcessRegression:
                              with_gradient=False)[0]
 
     MAX_PARALLEL_EVALUATIONS = 8
-    PERSISTENT_UPDATE_FROM = 4096      # padded size from which `update` is the persistent kernel (tgp_api.hip: dag_applies)
+    BATCHED_TRIALS = True              # prior draws through tgp_nlml_trial_batch where `update` is the persistent kernel
     PERSISTENT_UPDATE_WORKERS = 3      # (trial evaluations build the factor only: three fit side by side; HIP maps streams onto four queues)
 
     def _evaluation_engines(self, count: int):
@@ -516,7 +516,20 @@ class GaussianProcessRegression:
             return
         workers = min(self.MAX_PARALLEL_EVALUATIONS, len(draws))
         x, y = self._model.data
-        if x.shape[0] > self.PERSISTENT_UPDATE_FROM - 256:
+        persistent = self._engine.update_is_persistent(x.shape[0])  # (the library's own rule: size, variant bits, TGP_NO_DAG)
+        if persistent and self.BATCHED_TRIALS:
+            # from here on a factorisation is ONE persistent launch that leaves half of the compute units idle behind its
+            # chain: all draws go through tgp_nlml_trial_batch, up to eight members per launch sharing one task list
+            # (values equal the one-by-one trial evaluations bit for bit)
+            hy = np.array([np.concatenate([[var], ls, [noise, c]]) for ls, var in draws])
+            values, ok = self._engine.nlml_trial_batch(hy)
+            for (ls, var), v, good in zip(draws, values, ok):
+                loss = v + self._log_prior(ls, var)[0] if good else 1e100
+                if loss < best:
+                    best, best_ls, best_var = loss, ls, var
+            self.set_hyperparameters(variance=best_var, lengthscales=best_ls)
+            return
+        if persistent:
             # from here on `update` is one persistent launch that owns the compute units it runs on: side by side means
             # sharing them (tgp_set_update_concurrency), and its tile products stream enough memory that more than
             # PERSISTENT_UPDATE_WORKERS at once lose again (N = 4096, full updates: 1.97 ms alone, 1.29 per update with
