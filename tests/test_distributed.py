@@ -30,6 +30,14 @@ def test_merge_best_tie_break_nan_and_empty():
     assert (v[0], i[0]) == (0.5, 1)
     v, i = merge_best(np.array([-np.inf, 2.0]), np.array([-1, 11]))  # rank 0 had an empty shard
     assert (v[0], i[0]) == (2.0, 11)
+    # NaN values with perfectly good indices: nothing valid -> (NaN, -1), never a NaN-valued "winner"
+    v, i = merge_best(np.array([np.nan, np.nan]), np.array([3, 7]))
+    assert np.isnan(v[0]) and i[0] == -1
+    # a legitimate -inf value does not tie with a NaN entry of smaller index
+    v, i = merge_best(np.array([np.nan, -np.inf, -np.inf]), np.array([1, 9, 5]))
+    assert (v[0], i[0]) == (-np.inf, 5)
+    v, i = merge_best(np.array([np.nan, np.inf]), np.array([1, 9]), minimize=True)
+    assert (v[0], i[0]) == (np.inf, 9)
 
 
 def _free_port():

@@ -146,7 +146,7 @@ def test_auto_precision_stays_inside_the_plain_tolerance(cfg):
     """TGP_PREC_AUTO (round 4): the int8 sweep with the a-posteriori repair.  On every parity configuration -- also the
     small ill-conditioned ones the plain four-plane sweep fails -- mean, variance and EI hold the PLAIN parity tolerance
     against the oracle candidate by candidate, on EVERY rung the ladder visits, and the fused arg-max returns the float64
-    sweep's winner bit for bit (value and index)."""
+    sweep's winner (its index; its value from the float64 kernel, to the summation order of the row-group split)."""
     _, obj, d, kind, N, noise = cfg
     eng, st, Xq = _setup(obj, d, kind, N, noise)
     floor = cancellation_floor(N, 1.0, noise)
@@ -172,7 +172,9 @@ def test_auto_precision_stays_inside_the_plain_tolerance(cfg):
         assert_close(eng.acq_values("ei", eta_mid, Xq), oei_mid, atol=floor, what=f"ei (median eta) under auto ({eff})")
         for e in (eta, eta_mid):
             val, idx, _ = eng.acq_argmax("ei", e, Xq)
-            assert (val, idx) == f64[e], (eff, e, val, idx, f64[e])   # the float64 winner, bit for bit
+            # the float64 winner: its index, and its value as the float64 kernel computes it (the recomputation runs the
+            # row-group-split instantiation: the same products, the partial sums of |c|^2 added in another order: 1e-13)
+            assert idx == f64[e][1] and abs(val - f64[e][0]) <= 1e-12 * abs(f64[e][0]), (eff, e, val, idx, f64[e])
         tv, ti = eng.acq_topk("ei", eta_mid, Xq, 5)
         assert_close(tv, f64_topk[0], atol=floor, what="top-k values under auto")
         for m in (1, 63, 64, 65, 129):       # ragged tails and tiny launches
@@ -202,8 +204,8 @@ def test_auto_precision_stays_inside_the_plain_tolerance(cfg):
 
 def test_auto_precision_on_the_headline_model():
     """N = 4096, d = 8, Matern-5/2, both noise levels: AUTO stays on FOUR planes (no candidate of a 2^17 sweep needs the
-    float64 recomputation for its tolerance; the arg-max band holds a handful), the arg-max is the float64 sweep's bit for
-    bit, and variance / EI hold the plain tolerance against the oracle (test_split_precision_at_n4096... covers i8x4
+    float64 recomputation for its tolerance; the arg-max band holds a handful), the arg-max is the float64 sweep's, and
+    variance / EI hold the plain tolerance against the oracle (test_split_precision_at_n4096... covers i8x4
     without the repair)."""
     for noise in (1e-2, 1e-5):
         eng, Xq, om, ov, oei, eta, floor = _n4096(noise)
@@ -216,9 +218,11 @@ def test_auto_precision_on_the_headline_model():
         assert_close(v, ov, atol=floor, what="auto var vs oracle")
         assert_close(m, om, atol=floor * 10, what="auto mean vs oracle")
         assert_close(eng.acq_values("ei", eta, Xq).cpu().numpy(), oei, atol=floor, what="auto ei vs oracle")
-        assert eng.acq_argmax("ei", eta, Xq)[:2] == want
+        got = eng.acq_argmax("ei", eta, Xq)[:2]
+        assert got[1] == want[1] and abs(got[0] - want[0]) <= 1e-12 * abs(want[0]), (got, want)
         f_arg = eng.get_precision()[2]
-        assert eng.acq_argmax("ei", eta_mid, Xq)[:2] == want_mid
+        got = eng.acq_argmax("ei", eta_mid, Xq)[:2]
+        assert got[1] == want_mid[1] and abs(got[0] - want_mid[0]) <= 1e-12 * abs(want_mid[0]), (got, want_mid)
         req, eff, f_mid = eng.get_precision()
         print(f"[margin] auto on the headline model, noise {noise:g}: {eff}; recomputed fraction predict {f_pred:.2e}, "
               f"arg-max {f_arg:.2e}, arg-max at the median incumbent {f_mid:.2e}")

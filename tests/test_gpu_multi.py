@@ -286,6 +286,22 @@ def test_bench_prints_the_ranks_it_ran(how):
     assert len(per_rank) == want_n and all(t > 0 for t in per_rank)
 
 
+def test_scale_check_script_at_the_gpus_that_exist(tmp_path):
+    """tools/scale_check.sh (the one-command scaling run for an 8-GPU node): here over the GPU counts this box has, both
+    multi-GPU forms, a FIXED total candidate set -- it must find ONE winner across the GPU counts and the two forms, and
+    print the table with every rank's kernel time."""
+    import torch
+
+    n = torch.cuda.device_count()
+    gpus = " ".join(str(g) for g in (1, 2, 4, 8) if g <= n)
+    env = dict(os.environ, SCALE_OUT=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(["bash", "tools/scale_check.sh", "--gpus", gpus, "--workloads", "headline c5", "--steps", "1",
+                        "--m-per-gpu", "4096"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "ok headline: one winner across" in r.stdout and "ok c5: one winner across" in r.stdout, r.stdout
+    assert "kernel ms per rank" in r.stdout and "!!" not in r.stdout
+
+
 def test_model_with_devices_through_the_host_layer():
     """GaussianProcessRegression(devices=[...]) on the real engine: EGO's sweeps shard over the group, the acquired point
     equals the single-device model's, updates are replicated, the observer is called once per step."""

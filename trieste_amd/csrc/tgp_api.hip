@@ -1258,6 +1258,7 @@ int tgp_clone_from(tgp_handle dst, tgp_handle src) {
     dst->zeroed_npad = src->zeroed_npad;
     HIPCHK(dst, hipStreamSynchronize(s));
     dst->have_data = true;
+    dst->have_xy = true;  // X, Y came along: trial evaluations on the clone are legitimate
     dst->data_version = ++g_data_version;
   }
   return TGP_OK;

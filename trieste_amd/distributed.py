@@ -32,10 +32,12 @@ def merge_best(vals: np.ndarray, idxs: np.ndarray, minimize: bool = False) -> Tu
     if vals.ndim == 1:
         vals, idxs = vals[:, None], idxs[:, None]
     key = -vals if minimize else vals
-    key = np.where(np.isnan(key) | (idxs < 0), -np.inf, key)
+    valid = ~np.isnan(vals) & (idxs >= 0) & (idxs != np.iinfo(np.int64).max)
+    key = np.where(valid, key, -np.inf)
     best = np.max(key, axis=0)
-    cand = np.where(key == best[None, :], idxs, np.iinfo(np.int64).max)
-    cand = np.where(idxs < 0, np.iinfo(np.int64).max, cand)
+    # only VALID entries may tie with the best key: a NaN value with a good index (key -inf) must not tie with a
+    # legitimate -inf value, nor win a column in which nothing is valid
+    cand = np.where(valid & (key == best[None, :]), idxs, np.iinfo(np.int64).max)
     win_idx = np.min(cand, axis=0)
     win_rank = np.argmin(cand, axis=0)
     win_val = vals[win_rank, np.arange(vals.shape[1])]

@@ -173,7 +173,14 @@ class GaussianProcessRegression:
         if name in ("_engine", "_group") and "_placement" in self.__dict__ and "_model" in self.__dict__:
             version = self.__dict__.get("_data_version", 0)
             self._attach_engine()
-            self._push()
+            try:
+                self._push()
+            except BaseException:
+                # a snapshot whose factorisation fails stays engine-less: the next use retries (and fails loudly
+                # again) instead of finding an attached, unfactorised engine
+                for key in ("_engine", "_group"):
+                    self.__dict__.pop(key, None)
+                raise
             self._data_version = version  # materialising a snapshot is not a change of state
             return self.__dict__[name]
         raise AttributeError(f"{type(self).__name__!r} object has no attribute {name!r}")
@@ -204,7 +211,9 @@ class GaussianProcessRegression:
         memory -- the engine of the copy (same placement, a ``devices=[...]`` model stays sharded) is created and
         factorised on first use (``__getattr__``).  What ``BayesianOptimizer(track_state=True)`` stores per step
         (the reference deep-copies its models, bayesian_optimizer.py:745-760): a history of T steps costs T host
-        records, not T x 3 N^2 x 8 bytes of HBM held to the end of the run."""
+        records, not T x 3 N^2 x 8 bytes of HBM held to the end of the run.  The copy's factor comes from ONE full
+        factorisation of its record; when the original's came from rank-k ``append_data`` steps the two agree to the
+        parity tolerance (rtol 1e-7 in the tests), not bit for bit."""
         import copy
 
         twin = type(self).__new__(type(self))
