@@ -504,7 +504,7 @@ int dag_plan_get(tgp_handle h, int slot, int NB, int64_t ld, int grid, int B) {
   int nu = 0;
   // the dispatch order is simulated for the workers a member can count on
   dag_build(NB, ld, tasks, chain, nu, &topo, std::max(1, (grid - B) / B), slot == 0);
-  if (B > 1 || slot == 2) {
+  if (slot >= 2) {
     dag_merge_order(topo, B, merged);
     topo.swap(merged);
   }
@@ -773,11 +773,13 @@ int tgp_destroy(tgp_handle h) {
   for (DevBuf* b : {&h->d_xn, &h->d_ls, &h->d_X, &h->d_Y, &h->d_Xs, &h->d_A, &h->d_L, &h->d_W, &h->d_alpha,
                     &h->d_err, &h->d_tmp1, &h->d_tmp2, &h->d_info, &h->d_pen, &h->d_ent, &h->d_repv, &h->d_wq, &h->d_rs, &h->s_ent, &h->s_in, &h->s_in2, &h->s_out1,
                     &h->s_out2, &h->s_out3, &h->s_blkv, &h->s_blki, &h->s_small, &h->s_kcache, &h->s_aslab, &h->s_grad, &h->s_ks, &h->s_part, &h->s_rep,
-                    &h->s_rep_stats, &h->d_dag_flags, &h->d_dag_trace, &h->d_batch, &h->d_batch_vec, &h->d_batch_small,
-                    &h->dag_plan[0].tasks, &h->dag_plan[0].chain, &h->dag_plan[0].topo, &h->dag_plan[1].tasks,
-                    &h->dag_plan[1].chain, &h->dag_plan[1].topo, &h->dag_plan[2].tasks, &h->dag_plan[2].chain,
-                    &h->dag_plan[2].topo})
+                    &h->s_rep_stats, &h->d_dag_flags, &h->d_dag_trace, &h->d_batch, &h->d_batch_vec, &h->d_batch_small})
     b->release();
+  for (auto& p : h->dag_plan) {
+    p.tasks.release();
+    p.chain.release();
+    p.topo.release();
+  }
   if (h->rep_host) (void)hipHostFree(h->rep_host);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1048,9 +1050,10 @@ static int nlml_trial_chunk(tgp_handle h, const double* hyp, int B, double* valu
   const size_t nn = (size_t)Npad * Npad;
   hipStream_t s = h->stream;
   const int grid = h->num_cu;
-  if (int rc = dag_plan_get(h, 2, NB, Npad, grid, B)) return rc;
-  const tgp_handle_s::DagPlan& plan = h->dag_plan[2];
-  h->dag_last_slot = 2;
+  const int slot = 2 + (B - 1);
+  if (int rc = dag_plan_get(h, slot, NB, Npad, grid, B)) return rc;
+  const tgp_handle_s::DagPlan& plan = h->dag_plan[slot];
+  h->dag_last_slot = slot;
   const size_t nflags = (size_t)plan.ntasks + 2 * (size_t)NB;
   const size_t state_words = (size_t)B * nflags + DAG_CTRL_WORDS + (size_t)B * plan.ntasks;
   HIPCHK(h, h->d_dag_flags.reserve(state_words * sizeof(uint32_t)));
@@ -1088,6 +1091,12 @@ static int nlml_trial_chunk(tgp_handle h, const double* hyp, int B, double* valu
     launch_assemble_K(s, Xs, mats + (size_t)(3 * b) * nn, N, Npad, dp, h->kind, hb[0], hb[1 + d]);
     launch_center(s, h->d_Y.as<double>(), hb[2 + d], errs + (size_t)b * Npad, N, Npad);
   }
+  static const bool timing = getenv("TGP_TIMING") != nullptr;  // development aid: where a batched launch spends its time
+  hipEvent_t tev[4] = {nullptr, nullptr, nullptr, nullptr};
+  if (timing) {
+    for (auto& e : tev) (void)hipEventCreate(&e);
+    (void)hipEventRecord(tev[0], s);
+  }
   HIPCHK(h, hipMemsetAsync(h->d_dag_flags.p, 0, state_words * sizeof(uint32_t), s));
   DagArgs a{};
   a.Ap = mats;
@@ -1105,7 +1114,9 @@ static int nlml_trial_chunk(tgp_handle h, const double* hyp, int B, double* valu
   a.B = B;
   a.mat_stride = (int64_t)(3 * nn);
   a.flags_stride = (uint32_t)nflags;
+  if (timing) (void)hipEventRecord(tev[1], s);
   HIPCHK(h, launch_dag_update(s, a, grid));
+  if (timing) (void)hipEventRecord(tev[2], s);
   // z_b = L_b^-1 err_b: ONE launch for all members (a member is a 32-step chain of block products), then the values
   HIPCHK(h, hipMemsetAsync(tflags, 0, (size_t)B * NB * sizeof(uint32_t), s));
   launch_block_trsv(s, mats + nn, mats + 2 * nn, Npad, NB, errs, zs, tflags, B, (int64_t)(3 * nn));
@@ -1119,12 +1130,22 @@ static int nlml_trial_chunk(tgp_handle h, const double* hyp, int B, double* valu
     m.alpha = zs + (size_t)b * Npad;
     launch_nlml_value(s, m, mats + (size_t)(3 * b + 1) * nn, zs + (size_t)b * Npad, small + (size_t)b * small_per + 32);
   }
+  if (timing) (void)hipEventRecord(tev[3], s);
   std::vector<double> hout((size_t)B * small_per + B);
   uint32_t dag_ctrl[4] = {0, 0, 0, 0};
   HIPCHK(h, hipMemcpyAsync(hout.data(), small, hout.size() * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipMemcpyAsync(dag_ctrl, a.ctrl, sizeof dag_ctrl, hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipStreamSynchronize(s));
   HIPCHK(h, hipGetLastError());
+  if (timing) {
+    float t01 = 0, t12 = 0, t23 = 0;
+    (void)hipEventElapsedTime(&t01, tev[0], tev[1]);
+    (void)hipEventElapsedTime(&t12, tev[1], tev[2]);
+    (void)hipEventElapsedTime(&t23, tev[2], tev[3]);
+    fprintf(stderr, "[tgp] trial batch B=%d N=%lld: flags memset %.3f ms, persistent launch %.3f ms, trsv + values %.3f ms\n", B,
+            (long long)Npad, t01, t12, t23);
+    for (auto& e : tev) (void)hipEventDestroy(e);
+  }
   if (dag_ctrl[2] != 0)
     return fail(h, TGP_ERR_HIP, "batched persistent factorisation gave up (code %u) waiting for flag %u (%d members x %d "
                 "tasks)", dag_ctrl[2], dag_ctrl[3], B, plan.ntasks);

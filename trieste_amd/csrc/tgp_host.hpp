@@ -114,13 +114,14 @@ struct tgp_handle_s {
   // scratch
   DevBuf s_ent, s_in, s_in2, s_out1, s_out2, s_out3, s_blkv, s_blki, s_small, s_kcache, s_aslab, s_grad, s_ks, s_part;
   // `update` as one persistent launch: the task list of the current block count (tgp_kernels_dag.hip)
-  // one cached plan per use: 0 the full update, 1 the factor-only trial (tgp_nlml_trial), 2 the batched factor-only
-  // launch (tgp_nlml_trial_batch) -- a fit alternates between them, and building a plan costs as much as the update
+  // one cached plan per use: 0 the full update, 1 the factor-only trial (tgp_nlml_trial), 2 .. 9 the batched
+  // factor-only launch (tgp_nlml_trial_batch) per member count -- a fit alternates between them (90 draws are eleven
+  // launches of eight and one of two), and building a plan costs as much as the update
   struct DagPlan {
     int nb = 0, ntasks = 0, grid = 0, B = 0;
     int64_t ld = 0;
     DevBuf tasks, chain, topo;
-  } dag_plan[3];
+  } dag_plan[2 + 8];  // 0 full, 1 factor-only, 2 + (B - 1): batched factor-only with B = 1 .. 8 members
   int dag_last_slot = 0;  // the slot of the most recent launch (its error words are read back after the stream drains)
   int update_share = 1;  // tgp_set_update_concurrency: the persistent update kernel takes num_cu / update_share workgroups
   DevBuf d_dag_flags, d_dag_trace;
