@@ -1923,6 +1923,8 @@ static TrajDev traj_dev(tgp_traj t) {
   td.B = t->B;
   td.rffW = t->d_W.as<double>();
   td.rffb = t->d_b.as<double>();
+  td.rffW_ht = td.rffW + (size_t)t->F * t->h->dp;
+  td.rffb_ht = td.rffb + t->F;
   td.ws = t->d_ws.as<double>();
   td.v = t->d_v.as<double>();
   td.canonical = t->canonical;
@@ -1957,12 +1959,22 @@ int tgp_traj_create(tgp_handle h, const double* rff_W, const double* rff_b, int 
     tgp_traj_destroy(t);                                                      \
     return fail(h, e == hipErrorOutOfMemory ? TGP_ERR_ALLOC : TGP_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e)); \
   }
-  TCHK(t->d_W.reserve(Wp.size() * sizeof(double)));
-  TCHK(t->d_b.reserve((size_t)F * sizeof(double)));
+  // the basis twice: as given (radians: features matrix, gradients) and in half turns for the evaluation kernel,
+  // W / pi and b / pi + 1/2, so that cos(x . W + b) = sin(pi y) needs no range reduction by pi (tgp_kernels_traj.hip)
+  TCHK(t->d_W.reserve(2 * Wp.size() * sizeof(double)));
+  TCHK(t->d_b.reserve(2 * (size_t)F * sizeof(double)));
   TCHK(t->d_ws.reserve(ws.size() * sizeof(double)));
   TCHK(t->d_v.reserve((size_t)Npad * B * sizeof(double)));
   TCHK(hipMemcpy(t->d_W.p, Wp.data(), Wp.size() * sizeof(double), hipMemcpyHostToDevice));
   TCHK(hipMemcpy(t->d_b.p, rff_b, (size_t)F * sizeof(double), hipMemcpyHostToDevice));
+  {
+    constexpr double INV_PI = 0.31830988618379067154;
+    std::vector<double> Wh(Wp.size()), bh((size_t)F);
+    for (size_t e2 = 0; e2 < Wp.size(); ++e2) Wh[e2] = Wp[e2] * INV_PI;
+    for (int f = 0; f < F; ++f) bh[f] = rff_b[f] * INV_PI + 0.5;
+    TCHK(hipMemcpy(t->d_W.as<double>() + Wp.size(), Wh.data(), Wh.size() * sizeof(double), hipMemcpyHostToDevice));
+    TCHK(hipMemcpy(t->d_b.as<double>() + F, bh.data(), bh.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
   TCHK(hipMemcpy(t->d_ws.p, ws.data(), ws.size() * sizeof(double), hipMemcpyHostToDevice));
   TCHK(hipMemcpy(errh.data(), h->d_err.p, (size_t)N * sizeof(double), hipMemcpyDeviceToHost));
   // Phi_Z w  -> s_out1 [N][B]
@@ -2021,13 +2033,23 @@ int tgp_traj_create_rff(tgp_handle h, const double* rff_W, const double* rff_b, 
     tgp_traj_destroy(t);                                                      \
     return fail(h, e == hipErrorOutOfMemory ? TGP_ERR_ALLOC : TGP_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e)); \
   }
-  TCHK(t->d_W.reserve(Wp.size() * sizeof(double)));
-  TCHK(t->d_b.reserve((size_t)F * sizeof(double)));
+  // the basis twice: as given (radians: features matrix, gradients) and in half turns for the evaluation kernel,
+  // W / pi and b / pi + 1/2, so that cos(x . W + b) = sin(pi y) needs no range reduction by pi (tgp_kernels_traj.hip)
+  TCHK(t->d_W.reserve(2 * Wp.size() * sizeof(double)));
+  TCHK(t->d_b.reserve(2 * (size_t)F * sizeof(double)));
   TCHK(t->d_ws.reserve((size_t)F * B * sizeof(double)));
   TCHK(t->d_theta.reserve((size_t)F * B * sizeof(double)));
   TCHK(t->d_v.reserve(64));
   TCHK(hipMemcpy(t->d_W.p, Wp.data(), Wp.size() * sizeof(double), hipMemcpyHostToDevice));
   TCHK(hipMemcpy(t->d_b.p, rff_b, (size_t)F * sizeof(double), hipMemcpyHostToDevice));
+  {
+    constexpr double INV_PI = 0.31830988618379067154;
+    std::vector<double> Wh(Wp.size()), bh((size_t)F);
+    for (size_t e2 = 0; e2 < Wp.size(); ++e2) Wh[e2] = Wp[e2] * INV_PI;
+    for (int f = 0; f < F; ++f) bh[f] = rff_b[f] * INV_PI + 0.5;
+    TCHK(hipMemcpy(t->d_W.as<double>() + Wp.size(), Wh.data(), Wh.size() * sizeof(double), hipMemcpyHostToDevice));
+    TCHK(hipMemcpy(t->d_b.as<double>() + F, bh.data(), bh.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
   const bool design = (int64_t)F < N;
   const int64_t Q = design ? Fp : Npad;  // side of the first factorisation
   // workspace: Phi, Phit [Npad Fp]; R0 [Npad 64]; X1, X2 [max 64]; E, RE [Fp Bp]; squares S1..S3 [Q Q]; C1..C3 [Fp Fp]

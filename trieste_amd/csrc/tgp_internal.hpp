@@ -148,6 +148,7 @@ struct TrajDev {
   int F, B;
   const double* rffW;  // [F][dp] zero padded
   const double* rffb;  // [F]
+  const double *rffW_ht, *rffb_ht;  // the same basis in half turns: W / pi, b / pi + 1/2 (evaluation kernel)
   const double* ws;    // [F][B]  sqrt(2 variance / F) * w
   const double* v;     // [Npad][B] canonical weights, zero padded
   int canonical;       // 1: decoupled trajectory (features + k(x, X) v); 0: RFF-only trajectory (features + mean)

@@ -14,6 +14,81 @@ namespace tgp {
 
 constexpr int TRAJ_MAXB = 16;
 
+// ---- the kernel evaluation of the trajectory loops: instruction count is the bound -------
+// shape(q) = k / variance as a function of q = SCALE r^2, with SCALE folded into the distance's constants (Matern:
+// sqrt(SCALE) r is the argument of both the polynomial and the exponential, so the multiplication by sqrt(3) / sqrt(5)
+// disappears); the variance multiplies the finished sum once per candidate instead of every entry; sqrt with ONE
+// residual step (~1 ulp) and exp without the underflow clamp (v_ldexp_f64 flushes by itself; the argument is bounded by
+// the inputs).  Same accuracy class as kernel_from_r2 (1 - 2 ulp), nine instructions fewer per entry for Matern-5/2.
+template <int KIND>
+struct TrajShape {
+  static constexpr double SCALE = KIND == KIND_M32 ? 3.0 : (KIND == KIND_M52 ? 5.0 : 1.0);
+  static constexpr double FLOOR = 1e-36 * SCALE;  // gpflow: r = sqrt(max(r^2, 1e-36))
+};
+__device__ __forceinline__ double traj_sqrt(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y;
+  const double h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);  // 2^-51: one coupled step squares v_rsq_f64's 2^-26
+  const double dd = fma(-g, g, x);
+  return fma(dd, h, g);  // (the residual x - g^2 is 2^-51 x: the unrefined h = y / 2 is accurate enough for it)
+}
+// cos(x . W + b) from y = (x . W + b) / pi + 1/2 (the basis is stored in half turns): cos(theta) = sin(pi y) =
+// (-1)^n sin(pi f), n = rint(y), f = y - n exact, |f| <= 1/2.  sin(pi f) = f P(f^2) with a degree-8 minimax-fitted P
+// (truncation 3.9e-17 relative); the sign goes onto f (odd function) as one xor of its high word.  15 instructions
+// against ~30 for the Cody-Waite reduction by pi / 2 + two polynomials + quadrant selects of fast_cos.
+__device__ __forceinline__ double traj_cos_halfturns(double y) {
+  const double n = rint(y);
+  double f = y - n;
+  const unsigned flip = (unsigned)(int)n << 31;
+  f = __hiloint2double(__double2hiint(f) ^ (int)flip, __double2loint(f));
+  const double z = f * f;
+  double p = 7.697847275590284e-07;
+  p = fma(p, z, -2.1903499125519212e-05);
+  p = fma(p, z, 0.00046629981702308817);
+  p = fma(p, z, -0.007370430506093225);
+  p = fma(p, z, 0.08214588657312355);
+  p = fma(p, z, -0.599264529318946);
+  p = fma(p, z, 2.5501640398773007);
+  p = fma(p, z, -5.167712780049969);
+  p = fma(p, z, 3.141592653589793);
+  return f * p;
+}
+// exp(x) = 2^t, t = x log2(e): n = rint(t), f = t - n exact, 2^f by a degree-11 fit on |f| <= 1/2 (1.9e-17).  One
+// instruction less than the Cody-Waite form; the rounding of t costs |x| 1.1e-16 relative, i.e. an ABSOLUTE error of at
+// most 4e-17 on exp(x) <= 1 -- below the last bit of the sums the values go into.
+__device__ __forceinline__ double traj_exp2_neg(double x) {
+  const double t = x * 1.4426950408889634;
+  const double n = rint(t);
+  const double f = t - n;
+  double p = 4.456675463639861e-10;
+  p = fma(p, f, 7.074194562613105e-09);
+  p = fma(p, f, 1.0178051192117847e-07);
+  p = fma(p, f, 1.3215432534254118e-06);
+  p = fma(p, f, 1.5252733856295574e-05);
+  p = fma(p, f, 0.00015403530463727982);
+  p = fma(p, f, 0.001333355814639035);
+  p = fma(p, f, 0.009618129107587253);
+  p = fma(p, f, 0.0555041086648217);
+  p = fma(p, f, 0.24022650695910158);
+  p = fma(p, f, 0.6931471805599453);
+  p = fma(p, f, 1.0);
+  return ldexp(p, (int)n);
+}
+template <int KIND>
+__device__ __forceinline__ double traj_shape(double q) {  // q = SCALE r^2 (may be slightly negative: dot-product form)
+  if constexpr (KIND == KIND_RBF) {
+    return traj_exp2_neg(-0.5 * fmax(q, 0.0));
+  } else {
+    const double qc = fmax(q, TrajShape<KIND>::FLOOR);
+    const double s = traj_sqrt(qc);
+    if constexpr (KIND == KIND_M12) return traj_exp2_neg(-s);
+    else if constexpr (KIND == KIND_M32) return (1.0 + s) * traj_exp2_neg(-s);
+    else return fma(1.0 / 3.0, qc, 1.0 + s) * traj_exp2_neg(-s);
+  }
+}
+
 // PER_TRAJ: logical item = (candidate j, trajectory b) with its own input row (BP = 1); else item = j and the BP
 // accumulators are the trajectories.  EXACT: B == BP -- the accumulator updates carry no test of b against B.  Both are
 // template parameters because as run-time tests they sat INSIDE the two inner loops as wave-uniform branches, each
@@ -43,15 +118,15 @@ __global__ __launch_bounds__(256) void traj_eval_kernel(TrajDev t, const double*
 #pragma unroll
   for (int b = 0; b < BP; ++b) acc[b] = 0.0;
 
-  const cptr W = as_const(t.rffW);
-  const cptr bb = as_const(t.rffb);
+  const cptr W = as_const(t.rffW_ht);   // the basis in half turns (W / pi, b / pi + 1/2)
+  const cptr bb = as_const(t.rffb_ht);
   const cptr ws = as_const(t.ws);
 #pragma unroll 1  // (two features per iteration need > 100 SGPRs: the spill reloads cost more than the interleaving gains)
   for (int f = 0; f < t.F; ++f) {
     double arg = bb[f];
 #pragma unroll
     for (int c = 0; c < DP; ++c) arg = fma(xq[c], W[(int64_t)f * DP + c], arg);
-    const double ph = fast_cos(arg);
+    const double ph = traj_cos_halfturns(arg);
     if (PER_TRAJ) {
       acc[0] = fma(ph, t.ws[(int64_t)f * B + myb], acc[0]);
     } else {
@@ -64,22 +139,29 @@ __global__ __launch_bounds__(256) void traj_eval_kernel(TrajDev t, const double*
     const cptr xs = as_const(t.m.Xs);
     const cptr xn = as_const(t.m.xn);
     const cptr vv = as_const(t.v);
-    const double variance = t.m.variance;
+    constexpr double SC = TrajShape<KIND>::SCALE;
+    const double nbs = SC * nb;
+    double acck[BP];  // sum_k shape_k v[k][b]: the variance multiplies it once, below
+#pragma unroll
+    for (int b = 0; b < BP; ++b) acck[b] = 0.0;
 #pragma unroll 2
     for (int64_t k = 0; k < t.m.N; ++k) {
       double dot = 0.0;
 #pragma unroll
       for (int c = 0; c < DP; ++c) dot = fma(xq[c], xs[k * DP + c], dot);
-      const double r2 = fmax(fma(-2.0, dot, nb + xn[k]), 0.0);
-      const double kv = kernel_from_r2<KIND>(r2, variance);
+      // q = SCALE (|x|^2 + |X_k|^2 - 2 x . X_k)
+      const double q = fma(-2.0 * SC, dot, fma(SC, xn[k], nbs));
+      const double kv = traj_shape<KIND>(q);
       if (PER_TRAJ) {
-        acc[0] = fma(kv, t.v[k * B + myb], acc[0]);
+        acck[0] = fma(kv, t.v[k * B + myb], acck[0]);
       } else {
 #pragma unroll
         for (int b = 0; b < BP; ++b)
-          if (EXACT || b < B) acc[b] = fma(kv, vv[k * (EXACT ? BP : B) + b], acc[b]);
+          if (EXACT || b < B) acck[b] = fma(kv, vv[k * (EXACT ? BP : B) + b], acck[b]);
       }
     }
+#pragma unroll
+    for (int b = 0; b < BP; ++b) acc[b] = fma(t.m.variance, acck[b], acc[b]);
   }
   // 1: bare projection Phi w; 2: RFF trajectory (+ mean); 3: bare kernel sums sum_k k(x, X_k) v[k][b]
   const double c0 = (rff_only == 1 || rff_only == 3) ? 0.0 : t.m.mean_const;
