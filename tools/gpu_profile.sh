@@ -9,6 +9,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 WL=$W; EXTRA=""
 if [ "$W" = i8 ]; then WL=headline; EXTRA="--precision i8x4"; fi   # the split-precision line of the headline workload
+if [ "$W" = auto ]; then WL=headline; EXTRA="--precision auto"; fi # ... with the a-posteriori float64 repair (TGP_PREC_AUTO)
 B="python $PWD/bench.py --workload $WL $EXTRA --no-cpu-baseline --no-acquire --no-secondary $*"
 T=${ROUND}_${W}
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/prof_${T}_stats -o stats -- $B --steps 3 --warmup 1 > $OUT/prof_${T}_stats.log 2>&1 ); echo "$W stats rc=$?"

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
 workloads = sys.argv[2:] or ["headline", "c2", "c4", "c5"]
 DOMINANT = {"headline": "sweep_dma_kernel", "c2": "sweep_dma_kernel", "c3": "sweep_dma_kernel", "c4": "joint_kernel",
-            "c5": "traj_eval_kernel", "i8": "sweep_i8_kernel"}
+            "c5": "traj_eval_kernel", "i8": "sweep_i8_kernel", "auto": "sweep_i8_kernel"}
 # on the GPU box: SUMMARY_DIR=gpurun_out (the raw databases are too big to travel back); locally: profiles/
 out_dir = os.environ.get("SUMMARY_DIR") or os.path.join(ROOT, "profiles")
 os.makedirs(out_dir, exist_ok=True)
