@@ -376,10 +376,11 @@ def test_batched_plan_factors_every_member_from_one_list(nb, B):
     the other members do); the members' plans are the factor-only plan itself (same tasks, same arithmetic: the values
     equal tgp_nlml_trial's bit for bit)."""
     tasks, chain, ld, nu, order = plan_batch(nb, B)
-    single, chain1, _, _ = plan(nb, flags=1)
-    assert len(tasks) == len(single) and chain == chain1
-    for a, b in zip(tasks, single):
-        assert bytes(a) == bytes(b)
+    single, _, _, _ = plan(nb, flags=1)
+    def arithmetic(t):  # what a task computes (not where it sits in the array, nor its flag ids)
+        return (t.a_off, t.b_off, t.c_off, t.o_off, t.nk, t.flags, t.a_mat, t.b_mat, t.c_mat, t.o_mat)
+
+    assert sorted(map(arithmetic, tasks)) == sorted(map(arithmetic, single))   # the same tile products, burst for burst
     nt = len(tasks)
     assert len(order) == B * nt
     seen = [[False] * nt for _ in range(B)]
@@ -421,3 +422,25 @@ def test_batched_plan_factors_every_member_from_one_list(nb, B):
         else:
             alone.run_bulk(alone.acquire())
     np.testing.assert_array_equal(alone.m[1], ms[0].m[1])
+
+
+@pytest.mark.parametrize("nb,B", [(32, 8), (34, 2), (64, 4)])
+def test_batched_dispatch_list_is_topological_at_the_sizes_that_run(nb, B):
+    """N = 4096 (eight members per launch), 4352 and 8192: every member's tasks exactly once, every producer of an entry
+    earlier in the list or a chain step (the property the deadlock-freedom of the in-order dispatcher rests on), and the
+    members interleaved -- no member's work is queued behind another's."""
+    tasks, chain, ld, nu, order = plan_batch(nb, B)
+    nt = len(tasks)
+    assert len(order) == B * nt
+    seen = np.zeros((B, nt), dtype=bool)
+    first, last = [None] * B, [None] * B
+    for pos, e in enumerate(order):
+        b, i = e >> 24, e & 0xFFFFFF
+        assert b < B and i < nt and not seen[b, i]
+        for dep in tasks[i].dep:
+            assert dep == NONE or dep >= nt or seen[b, dep]
+        seen[b, i] = True
+        first[b] = pos if first[b] is None else first[b]
+        last[b] = pos
+    assert seen.all()
+    assert max(first) < B * nt // 4 and min(last) > B * nt // 2     # all members are in flight together

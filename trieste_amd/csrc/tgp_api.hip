@@ -503,9 +503,11 @@ int dag_plan_get(tgp_handle h, int slot, int NB, int64_t ld, int grid, int B) {
   std::vector<uint32_t> chain, topo, merged;
   int nu = 0;
   // the dispatch order is simulated for the workers a member can count on
-  dag_build(NB, ld, tasks, chain, nu, &topo, std::max(1, (grid - B) / B), slot == 0);
+  // the dispatch order is simulated for the workers there are: alone, or B members sharing grid - B of them
+  dag_build(NB, ld, tasks, chain, nu, &topo, std::max(1, slot >= 2 ? (grid - B) / B : grid - 1), slot == 0, slot >= 2 ? B : 1,
+            grid - B, &merged);
   if (slot >= 2) {
-    dag_merge_order(topo, B, merged);
+    if (B == 1) dag_merge_order(topo, 1, merged);
     topo.swap(merged);
   }
   HIPCHK(h, p.tasks.reserve(tasks.size() * sizeof(DagTask)));
@@ -840,9 +842,10 @@ int tgp_dag_plan(int nb, int64_t ld, tgp_dag_task* tasks, int64_t cap, int64_t* 
   std::vector<tgp::DagTask> t;
   std::vector<uint32_t> c, topo, merged;
   int nu = 0;
-  tgp::dag_build(nb, ld, t, c, nu, &topo, B > 0 ? std::max(1, (256 - B) / B) : 255, (flags & 1) == 0);
+  tgp::dag_build(nb, ld, t, c, nu, &topo, B > 0 ? std::max(1, (256 - B) / B) : 255, (flags & 1) == 0, std::max(1, B), 256 - B,
+                 &merged);
   if (B > 0) {
-    tgp::dag_merge_order(topo, B, merged);
+    if (B == 1) tgp::dag_merge_order(topo, 1, merged);
     topo.swap(merged);
   }
   *ntasks = (int64_t)t.size();
@@ -1042,9 +1045,13 @@ int tgp_nlml_trial(tgp_handle h, double* value) {
   return factorise(h, h->N, 0, value);
 }
 
-// One chunk of a batched trial evaluation: members [0, B) of `hyp` ([B][d + 3]: variance, lengthscales, noise, mean)
-// through ONE persistent factor-only launch; values / status per member.
-static int nlml_trial_chunk(tgp_handle h, const double* hyp, int B, double* values, int* status) {
+// One launch group of a batched trial evaluation, ENQUEUE ONLY: members [0, B) of `hyp` ([B][d + 3]: variance,
+// lengthscales, noise, mean) through ONE persistent factor-only launch.  `small` / `infos` / `ctrl_copy` are this group's
+// slices of the call's device result block (per member: ls [32], value slots; breakdown reports; the launch's error
+// words): the groups of a call follow each other on the stream without a host round trip (1.2 ms per group when each
+// was synchronised: profiles/r04_bo_step.txt) and share the matrices -- stream order keeps them apart.
+static constexpr size_t TRIAL_SMALL_PER = 32 + (MAX_D + 8);
+static int nlml_trial_enqueue(tgp_handle h, const double* hyp, int B, double* small, int* infos, uint32_t* ctrl_copy) {
   const int64_t N = h->N, Npad = h->Npad;
   const int d = h->d, dp = h->dp, NB = (int)(Npad / 128);
   const size_t nn = (size_t)Npad * Npad;
@@ -1056,34 +1063,14 @@ static int nlml_trial_chunk(tgp_handle h, const double* hyp, int B, double* valu
   h->dag_last_slot = slot;
   const size_t nflags = (size_t)plan.ntasks + 2 * (size_t)NB;
   const size_t state_words = (size_t)B * nflags + DAG_CTRL_WORDS + (size_t)B * plan.ntasks;
-  HIPCHK(h, h->d_dag_flags.reserve(state_words * sizeof(uint32_t)));
-  HIPCHK(h, h->d_batch.reserve((size_t)B * 3 * nn * sizeof(double)));
+  const size_t small_per = TRIAL_SMALL_PER;
   // [B] scaled inputs Xs [Npad][dp]; [B] centred targets err [Npad]; [B] z [Npad]; the trsv flags [B][NB]
   const size_t xs_per = (size_t)Npad * dp;
-  HIPCHK(h, h->d_batch_vec.reserve(((size_t)B * (xs_per + 2 * (size_t)Npad) + (size_t)B * NB) * sizeof(double)));
-  // per member: ls [dp] (32 slots), value slots [MAX_D + 8];  then B breakdown reports (ints)
-  const size_t small_per = 32 + (MAX_D + 8);
-  HIPCHK(h, h->d_batch_small.reserve(((size_t)B * small_per + B) * sizeof(double)));
   double* const mats = h->d_batch.as<double>();
   double* const Xs_all = h->d_batch_vec.as<double>();
   double* const errs = Xs_all + (size_t)B * xs_per;
   double* const zs = errs + (size_t)B * Npad;
   uint32_t* const tflags = (uint32_t*)(zs + (size_t)B * Npad);
-  double* const small = h->d_batch_small.as<double>();
-  int* const infos = (int*)(small + (size_t)B * small_per);
-  if (h->batch_zeroed != mats || h->batch_zeroed_npad != Npad || h->batch_zeroed_B < B) {
-    // the factorisation only ever writes zeros above the diagonals: wiped once per allocation (as d_L / d_W)
-    HIPCHK(h, hipMemsetAsync(mats, 0, (size_t)B * 3 * nn * sizeof(double), s));
-    h->batch_zeroed = mats;
-    h->batch_zeroed_npad = Npad;
-    h->batch_zeroed_B = B;
-  }
-  std::vector<double> hsmall((size_t)B * small_per + B, 0.0);  // (also zeroes the breakdown reports)
-  for (int b = 0; b < B; ++b) {
-    const double* hb = hyp + (size_t)b * (d + 3);
-    for (int c = 0; c < dp; ++c) hsmall[(size_t)b * small_per + c] = c < d ? hb[1 + c] : 1.0;
-  }
-  HIPCHK(h, hipMemcpyAsync(small, hsmall.data(), hsmall.size() * sizeof(double), hipMemcpyHostToDevice, s));
   for (int b = 0; b < B; ++b) {
     const double* hb = hyp + (size_t)b * (d + 3);
     double* Xs = Xs_all + (size_t)b * xs_per;
@@ -1117,6 +1104,7 @@ static int nlml_trial_chunk(tgp_handle h, const double* hyp, int B, double* valu
   if (timing) (void)hipEventRecord(tev[1], s);
   HIPCHK(h, launch_dag_update(s, a, grid));
   if (timing) (void)hipEventRecord(tev[2], s);
+  HIPCHK(h, hipMemcpyAsync(ctrl_copy, a.ctrl, 4 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
   // z_b = L_b^-1 err_b: ONE launch for all members (a member is a 32-step chain of block products), then the values
   HIPCHK(h, hipMemsetAsync(tflags, 0, (size_t)B * NB * sizeof(uint32_t), s));
   launch_block_trsv(s, mats + nn, mats + 2 * nn, Npad, NB, errs, zs, tflags, B, (int64_t)(3 * nn));
@@ -1130,14 +1118,9 @@ static int nlml_trial_chunk(tgp_handle h, const double* hyp, int B, double* valu
     m.alpha = zs + (size_t)b * Npad;
     launch_nlml_value(s, m, mats + (size_t)(3 * b + 1) * nn, zs + (size_t)b * Npad, small + (size_t)b * small_per + 32);
   }
-  if (timing) (void)hipEventRecord(tev[3], s);
-  std::vector<double> hout((size_t)B * small_per + B);
-  uint32_t dag_ctrl[4] = {0, 0, 0, 0};
-  HIPCHK(h, hipMemcpyAsync(hout.data(), small, hout.size() * sizeof(double), hipMemcpyDeviceToHost, s));
-  HIPCHK(h, hipMemcpyAsync(dag_ctrl, a.ctrl, sizeof dag_ctrl, hipMemcpyDeviceToHost, s));
-  HIPCHK(h, hipStreamSynchronize(s));
-  HIPCHK(h, hipGetLastError());
   if (timing) {
+    (void)hipEventRecord(tev[3], s);
+    (void)hipEventSynchronize(tev[3]);
     float t01 = 0, t12 = 0, t23 = 0;
     (void)hipEventElapsedTime(&t01, tev[0], tev[1]);
     (void)hipEventElapsedTime(&t12, tev[1], tev[2]);
@@ -1145,14 +1128,6 @@ static int nlml_trial_chunk(tgp_handle h, const double* hyp, int B, double* valu
     fprintf(stderr, "[tgp] trial batch B=%d N=%lld: flags memset %.3f ms, persistent launch %.3f ms, trsv + values %.3f ms\n", B,
             (long long)Npad, t01, t12, t23);
     for (auto& e : tev) (void)hipEventDestroy(e);
-  }
-  if (dag_ctrl[2] != 0)
-    return fail(h, TGP_ERR_HIP, "batched persistent factorisation gave up (code %u) waiting for flag %u (%d members x %d "
-                "tasks)", dag_ctrl[2], dag_ctrl[3], B, plan.ntasks);
-  const int* hinfo = (const int*)(hout.data() + (size_t)B * small_per);
-  for (int b = 0; b < B; ++b) {
-    status[b] = hinfo[b] != 0 ? TGP_ERR_NOT_PD : TGP_OK;
-    values[b] = hinfo[b] != 0 ? __builtin_nan("") : hout[(size_t)b * small_per + 32];
   }
   return TGP_OK;
 }
@@ -1191,11 +1166,62 @@ int tgp_nlml_trial_batch(tgp_handle h, const double* hypers, int B, double* valu
     return TGP_OK;
   }
   // members per launch: up to 8, and at most 12 GiB of matrices
-  const size_t per = (size_t)3 * Npad * Npad * sizeof(double);
+  const int64_t Np = h->Npad;
+  const int dp = h->dp, NB = (int)(Np / 128);
+  const size_t nn = (size_t)Np * Np, per = 3 * nn * sizeof(double);
   const int bmax = (int)std::max<size_t>(1, std::min<size_t>(8, ((size_t)12 << 30) / per));
-  for (int b0 = 0; b0 < B; b0 += bmax) {
-    const int nb = std::min(bmax, B - b0);
-    if (int rc = nlml_trial_chunk(h, hypers + (size_t)b0 * (d + 3), nb, values + b0, status + b0)) return rc;
+  const int groups = (B + bmax - 1) / bmax, bcap = std::min(bmax, B);
+  const size_t small_per = TRIAL_SMALL_PER;
+  // scratch: the matrices and vectors of ONE launch group (the groups reuse them in stream order); the per-member result
+  // block of the WHOLE call: [B] (ls, value slots), [B] breakdown reports, [groups] error words
+  size_t max_state = 0;
+  for (int bb = 1; bb <= bcap; ++bb) {  // (plans are built lazily: size the state for the largest group by its own plan)
+    if (bb != bcap && bb != (B % bmax == 0 ? bcap : B % bmax)) continue;
+    if (int rc = dag_plan_get(h, 2 + (bb - 1), NB, Np, h->num_cu, bb)) return rc;
+    const size_t nt = (size_t)h->dag_plan[2 + (bb - 1)].ntasks;
+    max_state = std::max(max_state, (size_t)bb * (nt + 2 * (size_t)NB) + DAG_CTRL_WORDS + (size_t)bb * nt);
+  }
+  HIPCHK(h, h->d_dag_flags.reserve(max_state * sizeof(uint32_t)));
+  HIPCHK(h, h->d_batch.reserve((size_t)bcap * per));
+  HIPCHK(h, h->d_batch_vec.reserve(((size_t)bcap * ((size_t)Np * dp + 2 * (size_t)Np) + (size_t)bcap * NB) * sizeof(double)));
+  const size_t small_doubles = (size_t)B * small_per + (size_t)B + (size_t)2 * groups + 8;
+  HIPCHK(h, h->d_batch_small.reserve(small_doubles * sizeof(double)));
+  double* const mats = h->d_batch.as<double>();
+  double* const small = h->d_batch_small.as<double>();
+  int* const infos = (int*)(small + (size_t)B * small_per);
+  uint32_t* const ctrls = (uint32_t*)(small + (size_t)B * small_per + B);
+  if (h->batch_zeroed != mats || h->batch_zeroed_npad != Np || h->batch_zeroed_B < bcap) {
+    // the factorisation only ever writes zeros above the diagonals: wiped once per allocation (as d_L / d_W)
+    HIPCHK(h, hipMemsetAsync(mats, 0, (size_t)bcap * per, h->stream));
+    h->batch_zeroed = mats;
+    h->batch_zeroed_npad = Np;
+    h->batch_zeroed_B = bcap;
+  }
+  std::vector<double> hsmall(small_doubles, 0.0);  // (also zeroes the breakdown reports and the error words)
+  for (int b = 0; b < B; ++b) {
+    const double* hb = hypers + (size_t)b * (d + 3);
+    for (int c = 0; c < dp; ++c) hsmall[(size_t)b * small_per + c] = c < d ? hb[1 + c] : 1.0;
+  }
+  HIPCHK(h, hipMemcpyAsync(small, hsmall.data(), hsmall.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  for (int g = 0; g < groups; ++g) {
+    const int b0 = g * bmax, nb = std::min(bmax, B - b0);
+    if (int rc = nlml_trial_enqueue(h, hypers + (size_t)b0 * (d + 3), nb, small + (size_t)b0 * small_per, infos + b0,
+                                    ctrls + 4 * g))
+      return rc;
+  }
+  std::vector<double> hout(small_doubles);
+  HIPCHK(h, hipMemcpyAsync(hout.data(), small, hout.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipGetLastError());
+  const int* hinfo = (const int*)(hout.data() + (size_t)B * small_per);
+  const uint32_t* hctrl = (const uint32_t*)(hout.data() + (size_t)B * small_per + B);
+  for (int g = 0; g < groups; ++g)
+    if (hctrl[4 * g + 2] != 0)
+      return fail(h, TGP_ERR_HIP, "batched persistent factorisation gave up (code %u) waiting for flag %u (launch group %d of %d)",
+                  hctrl[4 * g + 2], hctrl[4 * g + 3], g, groups);
+  for (int b = 0; b < B; ++b) {
+    status[b] = hinfo[b] != 0 ? TGP_ERR_NOT_PD : TGP_OK;
+    values[b] = hinfo[b] != 0 ? __builtin_nan("") : hout[(size_t)b * small_per + 32];
   }
   return TGP_OK;
 }

@@ -202,7 +202,8 @@ struct DagArgs {
 };
 void dag_merge_order(const std::vector<uint32_t>& member_order, int B, std::vector<uint32_t>& merged);
 void dag_build(int NB, int64_t ld, std::vector<DagTask>& tasks, std::vector<uint32_t>& chain_dep, int& n_urgent,
-               std::vector<uint32_t>* topo_out = nullptr, int workers = 255, bool with_inverse = true);
+               std::vector<uint32_t>* topo_out = nullptr, int workers = 255, bool with_inverse = true, int batch = 1,
+               int batch_workers = 0, std::vector<uint32_t>* batch_out = nullptr);
 // z = L^-1 r over 128-blocks from L and the diagonal inverses in W; flags: [NB] words, zero at launch
 void launch_block_trsv(hipStream_t s, const double* L, const double* W, int64_t ld, int NB, const double* r, double* z,
                        uint32_t* flags, int B = 1, int64_t mat_stride = 0);

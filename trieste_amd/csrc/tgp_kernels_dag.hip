@@ -665,7 +665,8 @@ std::vector<std::pair<int, int>> bursts(int lo, int hi, int burst) {  // long bu
 // flag ids: task n -> n;  chain: W_jj / L_jj ready -> ntasks + j;  L(j+1,j) ready -> ntasks + NB + j.
 // `with_inverse` false: the factor only (no X / E tasks: W keeps its diagonal tiles W_jj, which the T tasks need).
 void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<uint32_t>& chain_dep, int& n_urgent,
-               std::vector<uint32_t>* topo_out, int workers, bool with_inverse) {
+               std::vector<uint32_t>* topo_out, int workers, bool with_inverse, int batch, int batch_workers,
+               std::vector<uint32_t>* batch_out) {
   // k tiles per product: longer bursts amortise a task's fixed ~8 us (N = 8192 is throughput-bound: 8.0 -> 7.65 ms with
   // 8), shorter ones keep the scheduling fine where the chain is the bound (N = 4096: 1.91 ms with 4, 2.08 with 8)
   static const int burst_env = getenv("TGP_DAG_BURST") ? atoi(getenv("TGP_DAG_BURST")) : 0;  // development aid
@@ -818,7 +819,9 @@ void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<
   }
   std::vector<int> place(total, -1);  // host index -> position in the device array (urgent list, then bulk list)
   std::vector<int> topo;              // the dispatch order (bulk-side nodes only)
-  {
+  // The simulation, for `members` copies of the graph sharing `nworkers` workers (members = 1: the single update; > 1: a
+  // batched launch, every member with a chain workgroup of its own): -> (member, node) in start order.
+  auto simulate = [&](int members, int nworkers, std::vector<std::pair<int, int>>& out) {
     // A task enters the simulation when its ready time is KNOWN, i.e. when all its producers have started (chain steps
     // need no worker: they start when ready).  A free worker takes the candidate with the longest remaining path among
     // the tasks that are ready -- and among the near-critical ones (slack < SLACK_CRIT) that will be within LOOK us:
@@ -828,55 +831,62 @@ void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<
     // twice per step early in the factorisation).  Every producer of a task is still listed before it.
     constexpr double LOOK = 12.0, SLACK_CRIT = 40.0;
     typedef std::pair<double, int> Ev;
-    std::priority_queue<Ev, std::vector<Ev>, std::greater<Ev>> cand_crit, cand_norm;  // (ready time, node)
+    std::priority_queue<Ev, std::vector<Ev>, std::greater<Ev>> cand_crit, cand_norm;  // (ready time, id)
     std::priority_queue<double, std::vector<double>, std::greater<double>> busy;      // workers' free times
-    std::priority_queue<Ev> avail;                                                    // (tail, -node)
-    std::vector<int> pend = indeg;  // producers not yet started
-    std::vector<double> ready_at(total, 0.0);
-    int free_workers = std::max(1, workers);
+    std::priority_queue<Ev> avail;                                                    // (tail, -id)
+    const int Bm = members;                     // id = node * Bm + member (members = 1: id = node)
+    std::vector<int> pend((size_t)total * Bm);  // producers not yet started
+    for (int n = 0; n < total; ++n)
+      for (int m = 0; m < Bm; ++m) pend[(size_t)n * Bm + m] = indeg[n];
+    std::vector<double> ready_at((size_t)total * Bm, 0.0);
+    int free_workers = std::max(1, nworkers);
     double now = 0.0;
-    std::vector<std::pair<int, double>> work;  // (node, finish time) whose users are to be told
-    auto known = [&](int n) {
-      if (n >= nb) work.emplace_back(n, ready_at[n] + dur[n]);
-      else (span - est[n] - tail[n] < SLACK_CRIT ? cand_crit : cand_norm).push({ready_at[n], n});
+    std::vector<std::pair<int, double>> work;  // (id, finish time) whose users are to be told
+    auto known = [&](int id) {
+      const int n = id / Bm;
+      if (n >= nb) work.emplace_back(id, ready_at[id] + dur[n]);
+      else (span - est[n] - tail[n] < SLACK_CRIT ? cand_crit : cand_norm).push({ready_at[id], id});
     };
-    auto started = [&](int n0, double f0) {
-      work.emplace_back(n0, f0);
+    auto started = [&](int id0, double f0) {
+      work.emplace_back(id0, f0);
       while (!work.empty()) {
-        const auto [n, f] = work.back();
+        const auto [id, f] = work.back();
         work.pop_back();
+        const int n = id / Bm, m = id % Bm;
         for (int u : users[n]) {
-          ready_at[u] = std::max(ready_at[u], f);
-          if (--pend[u] == 0) known(u);
+          const int uid = u * Bm + m;
+          ready_at[uid] = std::max(ready_at[uid], f);
+          if (--pend[uid] == 0) known(uid);
         }
       }
     };
     for (int n = 0; n < total; ++n)
-      if (indeg[n] == 0) {
-        known(n);
-        while (!work.empty()) {  // (a chain step without producers: step 0's leaf)
-          const auto [c, f] = work.back();
-          work.pop_back();
-          started(c, f);
+      if (indeg[n] == 0)
+        for (int m = 0; m < Bm; ++m) {
+          known(n * Bm + m);
+          while (!work.empty()) {  // (a chain step without producers: step 0's leaf)
+            const auto [c, f] = work.back();
+            work.pop_back();
+            started(c, f);
+          }
         }
-      }
     for (;;) {
       while (!cand_crit.empty() && cand_crit.top().first <= now + LOOK) {
-        avail.push({tail[cand_crit.top().second], -cand_crit.top().second});
+        avail.push({tail[cand_crit.top().second / Bm], -cand_crit.top().second});
         cand_crit.pop();
       }
       while (!cand_norm.empty() && cand_norm.top().first <= now) {
-        avail.push({tail[cand_norm.top().second], -cand_norm.top().second});
+        avail.push({tail[cand_norm.top().second / Bm], -cand_norm.top().second});
         cand_norm.pop();
       }
       if (free_workers > 0 && !avail.empty()) {
-        const int n = -avail.top().second;
+        const int id = -avail.top().second;
         avail.pop();
-        const double f = std::max(now, ready_at[n]) + dur[n];
-        topo.push_back(n);
+        const double f = std::max(now, ready_at[id]) + dur[id / Bm];
+        out.emplace_back(id % Bm, id / Bm);
         busy.push(f);
         --free_workers;
-        started(n, f);
+        started(id, f);
         continue;
       }
       double next = 1e300;
@@ -892,6 +902,11 @@ void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<
         ++free_workers;
       }
     }
+  };
+  {
+    std::vector<std::pair<int, int>> one;
+    simulate(1, workers, one);
+    for (const auto& e : one) topo.push_back(e.second);
   }
   std::vector<int> order;
   for (int pass = 0; pass < 2; ++pass) {
@@ -905,6 +920,15 @@ void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<
   if (topo_out) {
     topo_out->clear();
     for (int n : topo) topo_out->push_back((uint32_t)place[n]);
+  }
+  if (batch_out && batch > 1) {
+    // the dispatch list of a batched launch: `batch` members simulated TOGETHER on the workers they share -- a free
+    // worker takes the most critical ready task of ANY member, so the members fill each other's chain-bound gaps
+    // (round 4's first form interleaved B copies of one member's order entry by entry: workers 81 % busy)
+    std::vector<std::pair<int, int>> all;
+    simulate(batch, std::max(1, batch_workers), all);
+    batch_out->clear();
+    for (const auto& e : all) batch_out->push_back(((uint32_t)e.first << 24) | (uint32_t)place[e.second]);
   }
   const uint32_t WD = (uint32_t)nb, LSUB = (uint32_t)(nb + NB);
   auto flag_of = [&](int d) -> uint32_t {
