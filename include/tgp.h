@@ -172,9 +172,10 @@ int tgp_nlml(tgp_handle h, double* value, double* grad);
 int tgp_nlml_trial(tgp_handle h, double* value);
 /* B trial evaluations at once: hypers [B][d + 3] (variance, lengthscales [d], noise_variance, mean_const per member),
  * values [B], status [B] (TGP_OK or TGP_ERR_NOT_PD per member; a member that breaks down gets a NaN value and does not
- * disturb the others).  From N = 3841 on up to 8 members share ONE persistent launch: B chain workgroups, one list of
- * tile tasks interleaving the members' factor-only plans -- a single factorisation leaves half of the compute units
- * idle behind its chain, and HIP runs at most three such launches side by side.  Each value equals tgp_nlml_trial's at
+ * disturb the others).  From N = 3841 on up to 16 members share ONE persistent launch: B chain workgroups, one list of
+ * tile tasks over all members' factor-only plans (the start order of a list-scheduling simulation of the B graphs on the
+ * workers they share) -- a single factorisation leaves half of the compute units idle behind its chain, and HIP runs at
+ * most three such launches side by side.  Each value equals tgp_nlml_trial's at
  * the same hyper-parameters bit for bit.  The handle's own hyper-parameters and posterior are untouched (the members
  * live in scratch matrices: 3 N^2 doubles each).  Below that size the members are evaluated one after the other.
  * Replaces the loop of find_best_model_initialization (reference models/gpflow/models.py:294-321). */

@@ -283,8 +283,8 @@ def test_dag_update_reports_a_matrix_that_is_not_positive_definite(where):
 
 
 def test_batched_trial_evaluations_equal_the_single_ones_bit_for_bit():
-    """tgp_nlml_trial_batch at N = 4096: 11 members (a launch of eight, a launch of three) through ONE persistent launch
-    each -- B chain workgroups, one interleaved task list.  Every value equals tgp_nlml_trial's at the same
+    """tgp_nlml_trial_batch at N = 4096: 11 members in ONE persistent launch, then 19 (a launch of ten and one of nine)
+    -- B chain workgroups, one task list over all members.  Every value equals tgp_nlml_trial's at the same
     hyper-parameters bit for bit; a member whose kernel matrix is not positive definite gets NaN / not-ok and does not
     disturb the others; the engine's own hyper-parameters and posterior are untouched."""
     N, d = 4096, 5
@@ -313,6 +313,11 @@ def test_batched_trial_evaluations_equal_the_single_ones_bit_for_bit():
         assert single.nlml_trial() == values[b], (b, single.nlml_trial(), values[b])
     st = O.gpr_update(kind, hy[0, 0], hy[0, 1:1 + d], hy[0, 1 + d], hy[0, 2 + d], X, Y)
     assert abs(values[0] - O.nlml_and_grad(st)[0]) <= 1e-8 * abs(values[0]) + 1e-8 * N
+    # more members than one launch takes (16): two launches, enqueued back to back; the first eleven are the same bits
+    hy19 = np.concatenate([hy, hy[[0, 1, 2, 3, 5, 6, 7, 8]] * (1.0 + 1e-3)])
+    v19, ok19 = eng.nlml_trial_batch(hy19)
+    np.testing.assert_array_equal(np.delete(v19[:11], 4), np.delete(values, 4))
+    assert ok19[11:].all() and np.isfinite(v19[11:]).all() and not ok19[4]
     # a permutation of the members permutes the values (members do not interact)
     perm = rng.permutation(11)
     pv, _ = eng.nlml_trial_batch(hy[perm])

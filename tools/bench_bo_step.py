@@ -24,7 +24,7 @@ for rep in range(2):
           f"workers={model.MAX_PARALLEL_EVALUATIONS}", flush=True)
 for rep in range(2):
     t0 = time.perf_counter(); model.find_best_model_initialization(90); t1 = time.perf_counter()
-    print(f"  find_best_model_initialization(90) batched (tgp_nlml_trial_batch, 8 members per launch): {1e3*(t1-t0):.0f} ms", flush=True)
+    print(f"  find_best_model_initialization(90) batched (tgp_nlml_trial_batch) after the append: N + 1 rows, padded to the next 256: {1e3*(t1-t0):.0f} ms", flush=True)
 type(model).BATCHED_TRIALS = False
 for w in (1, 3):
     model.PERSISTENT_UPDATE_WORKERS = w
@@ -35,6 +35,8 @@ type(model).BATCHED_TRIALS = True
 cold = M.GaussianProcessRegression(M.build_gpr(data, space, likelihood_variance=1e-2))
 t0 = time.perf_counter(); res = cold.optimize(data); t1 = time.perf_counter()
 print(f"  COLD optimize (fresh model, build_gpr defaults): {1e3*(t1-t0):.0f} ms (nfev={res.nfev})", flush=True)
+t0 = time.perf_counter(); cold.find_best_model_initialization(90); t1 = time.perf_counter()
+print(f"  find_best_model_initialization(90) batched at N = {N} exactly (Npad = {N}): {1e3*(t1-t0):.0f} ms", flush=True)
 cold2 = M.GaussianProcessRegression(M.build_gpr(data, space, likelihood_variance=1e-2))
 t0 = time.perf_counter(); res = cold2.optimize(data); t1 = time.perf_counter()
 print(f"  second fresh model, same process (allocator warm): {1e3*(t1-t0):.0f} ms (nfev={res.nfev})", flush=True)

@@ -670,7 +670,10 @@ void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<
   // k tiles per product: longer bursts amortise a task's fixed ~8 us (N = 8192 is throughput-bound: 8.0 -> 7.65 ms with
   // 8), shorter ones keep the scheduling fine where the chain is the bound (N = 4096: 1.91 ms with 4, 2.08 with 8)
   static const int burst_env = getenv("TGP_DAG_BURST") ? atoi(getenv("TGP_DAG_BURST")) : 0;  // development aid
-  const int BURST = burst_env > 0 ? burst_env : (NB >= 88 ? 16 : (NB >= 48 ? 8 : 4));  // (N = 12288: 24.7 -> 23.7 ms with 16)
+  // (N = 12288: 24.7 -> 23.7 ms with 16).  The factor-only plan (trial evaluations) runs batched, i.e. throughput-bound
+  // at every size: 8 from the start (a task's fixed 8 us is 17 % of a 4-tile burst; one plan for the single and the
+  // batched form, so their values stay equal bit for bit)
+  const int BURST = burst_env > 0 ? burst_env : (NB >= 88 ? 16 : ((NB >= 48 || !with_inverse) ? 8 : 4));
   constexpr int CH_WD = -1000000, CH_LSUB = -2000000;  // chain producers: CH_WD - j, CH_LSUB - j
   std::vector<HostTask> ts;
   std::vector<int> lastG((size_t)NB * NB, -1), Tid((size_t)NB * NB, -1), Eid((size_t)NB * NB, -1);

@@ -262,7 +262,7 @@ class GPEngine:
     def nlml_trial_batch(self, hypers):
         """B trial evaluations on the data already on the device (tgp_nlml_trial_batch): ``hypers`` [B, d + 3] =
         (variance, lengthscales [d], noise variance, mean) per member -> (values [B], ok [B]); a member whose kernel
-        matrix is not positive definite gets NaN / False.  From N = 3841 on up to eight members share one persistent
+        matrix is not positive definite gets NaN / False.  From N = 3841 on up to sixteen members share one persistent
         launch; the engine's own hyper-parameters and posterior are untouched."""
         hy = np.ascontiguousarray(hypers, dtype=np.float64)
         if hy.ndim != 2 or hy.shape[1] != self.d + 3:
