@@ -111,6 +111,33 @@ def test_group_winners_equal_the_single_handle(merge):
         grp.close()
 
 
+def test_group_under_auto_precision_returns_the_float64_winner(monkeypatch):
+    """TGP_PREC_AUTO on a group (also three members sharing the one GPU): every member runs the int8 sweep with the
+    float64 repair on its shard, enqueue-only; the merged winner is the float64 sweep's (index; value to the summation
+    order of the repair's row-group split), for several acquisition functions."""
+    from trieste_amd.group import GPEngineGroup
+
+    X, Y, ls, c, kind, noise = _problem()
+    eng = _single(X, Y, ls, c, kind, noise)
+    eta = eng.eta()
+    M = 20011
+    Xq = eng.sample_box(5678, 0, M, 0.0, 1.0)
+    monkeypatch.setenv("TGP_GROUP_ALLOW_DUPLICATES", "1")
+    for devices, merge in (([0], "rccl"), ([0, 0, 0], "peer")):
+        grp = GPEngineGroup(X.shape[1], kind, devices=devices, merge=merge)
+        grp.set_hyper(1.0, ls, noise, c)
+        grp.set_data(X, Y)
+        grp.set_precision("auto")
+        grp.sample_candidates(5678, M, 0.0, 1.0)
+        for acq, param in (("ei", eta), ("ei", float(np.median(Y))), ("pi", eta), ("nlcb", 1.96)):
+            want = eng.acq_argmax(acq, param, Xq)
+            for _ in range(2):          # (the second call runs after the first one's report has come back)
+                got = grp.acq_argmax(acq, param)
+                assert got[1] == want[1] and abs(got[0] - want[0]) <= 1e-12 * abs(want[0]) + 1e-300, (acq, got, want)
+        assert all(m.get_precision()[1] in ("i8x4", "i8x5", "f64") for m in grp.members)
+        grp.close()
+
+
 def test_three_members_on_one_gpu_equal_the_single_handle(monkeypatch):
     """The whole multi-member path (worker threads, contiguous shards with index_base, per-member streams, peer copies
     and events, the 3-way merge kernel, host merge of the top-k, sharded trajectories and q-batches) on a single-GPU
