@@ -48,6 +48,28 @@ def test_config_c1_ego_picks_the_oracle_argmax():
     assert O.ei_values(st, pt2, eta)[0] >= 0.9 * np.max(oei)
 
 
+def test_config_c1_ego_under_auto_precision_picks_the_same_point():
+    """The same configuration with GaussianProcessRegression(..., sweep_precision="auto"): EGO's fused sweep runs the int8
+    kernel with the float64 repair and acquires the SAME point (N = 50 is ill-conditioned for four digit planes: the ladder
+    may move to five planes or float64 on the way -- every rung returns the float64 winner)."""
+    import trieste_amd.models as M
+    from trieste_amd.acquisition import EfficientGlobalOptimization
+    from trieste_amd.space import DiscreteSearchSpace
+
+    space, data, model, st = _setup()
+    auto = M.GaussianProcessRegression(model.model, sweep_precision="auto")
+    cands = space.sample(10_000, seed=5678)
+    eta = O.eta_min_mean(st)
+    oei = O.ei_values(st, cands, eta)
+    for _ in range(3):
+        pt = EfficientGlobalOptimization().acquire_single(DiscreteSearchSpace(cands), auto, dataset=data)
+        np.testing.assert_array_equal(pt[0], cands[int(np.argmax(oei))])
+    m, v = auto.predict(cands)
+    om, ov = O.predict(st, cands)
+    assert_close(m[:, 0], om, atol=1e-9, what="mean under auto")
+    assert_close(v[:, 0], ov, atol=1e-9, what="var under auto")
+
+
 def test_ask_tell_loop_on_gpu_finds_scaled_branin_minimum():
     from trieste_amd import objectives as OBJ
     from trieste_amd.acquisition import EfficientGlobalOptimization, generate_random_search_optimizer

@@ -513,6 +513,23 @@ def test_optimize_decreases_the_loss_and_recovers_lengthscales():
     assert m2.get_observation_noise() != n0
 
 
+def test_sweep_precision_reaches_the_engine_and_survives_a_copy():
+    """GaussianProcessRegression(..., sweep_precision="auto"): the engine's plain sweeps run the int8 kernel with the
+    float64 repair (tgp_set_precision TGP_PREC_AUTO); a deep copy (BO history) re-attaches an engine with the same
+    setting; unknown names are rejected."""
+    import copy
+
+    data = Dataset(np.random.default_rng(0).uniform(size=(12, 2)), np.random.default_rng(1).standard_normal((12, 1)))
+    gpr = M.build_gpr(data, Box([0, 0], [1, 1]), likelihood_variance=1e-3)
+    model = M.GaussianProcessRegression(gpr, sweep_precision="auto")
+    assert model.engine.get_precision()[0] == "auto"
+    twin = copy.deepcopy(model)
+    assert "_engine" not in twin.__dict__ and twin.engine.get_precision()[0] == "auto"
+    assert M.GaussianProcessRegression(gpr).engine.get_precision()[0] == "f64"
+    with pytest.raises(ValueError):
+        M.GaussianProcessRegression(gpr, sweep_precision="fp8")
+
+
 def test_find_best_model_initialization_never_gets_worse():
     model, data = _model(n=25, noise=1e-3)
     before = model.training_loss()

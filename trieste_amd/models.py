@@ -137,7 +137,7 @@ class GaussianProcessRegression:
     """
 
     def __init__(self, model: GPR, optimizer=None, num_kernel_samples: int = 10, num_rff_features: int = 1000,
-                 use_decoupled_sampler: bool = True, device: int = 0, devices=None):
+                 use_decoupled_sampler: bool = True, device: int = 0, devices=None, sweep_precision: str = "f64"):
         if num_kernel_samples < 0:
             raise ValueError(f"num_kernel_samples must be greater or equal to zero but got {num_kernel_samples}.")
         if num_rff_features <= 0:
@@ -151,6 +151,14 @@ class GaussianProcessRegression:
         # tgp_group_*): updates are replicated, the fused candidate sweeps of the acquisition functions shard over
         # the devices, everything else (predictions, gradients, fits) runs on member 0.  The BO loop is unchanged.
         self._placement = (int(device), None if devices is None else [int(v) for v in devices])
+        # arithmetic of the fused candidate sweeps behind the acquisition functions (engine.set_precision): "f64" (the
+        # parity path, default) or "auto" -- W K* on the int8 matrix cores with every candidate outside the parity
+        # tolerance by its own error bound, and every candidate that could be the float64 arg-max, recomputed in float64
+        # inside the call (2.6x the float64 sweep at N = 4096; same winner; `predict` values inside the parity tolerance
+        # candidate by candidate).  predict_joint, sample, gradients, `update` and `optimize` are float64 either way.
+        if sweep_precision not in ("f64", "auto", "i8x4", "i8x5"):
+            raise ValueError(f"sweep_precision must be 'f64', 'auto', 'i8x4' or 'i8x5', got {sweep_precision!r}")
+        self._sweep_precision = sweep_precision
         self._attach_engine()
         self._push()
 
@@ -166,6 +174,9 @@ class GaussianProcessRegression:
             self._engine = self._group.primary
         else:
             self._engine = GPEngine(d, kind, device=device)
+        precision = self.__dict__.get("_sweep_precision", "f64")
+        if precision != "f64":
+            (self._group if self._group is not None else self._engine).set_precision(precision)
 
     def __getattr__(self, name):
         # A deep copy (one per step in the BO history) holds the GPR record only; its engine -- same placement,
