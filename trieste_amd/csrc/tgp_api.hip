@@ -279,7 +279,8 @@ hipError_t launch_sweep_i8_timed(tgp_handle h, SweepArgs& am) {
   const size_t kc_i8 = (size_t)wgrid * (size_t)Npad * 64 * planes, kc_f64 = (size_t)fgrid * (size_t)Npad * SW_BN * sizeof(double);
   if ((e = h->s_kcache.reserve(std::max(kc_i8, kc_f64))) != hipSuccess) return e;
   if ((e = h->s_part.reserve((size_t)cap_blocks * g * 256 * sizeof(double))) != hipSuccess) return e;
-  if ((e = h->s_rep.reserve((size_t)M * (5 + d) * sizeof(double) + 64)) != hipSuccess) return e;
+  // ub [M], vals [M], recomputed (mean, var, acq) [3][M], list [M] (int64), gathered candidates [M][d]
+  if ((e = h->s_rep.reserve((size_t)M * (6 + d) * sizeof(double) + 64)) != hipSuccess) return e;
   if ((e = h->s_rep_stats.reserve(64)) != hipSuccess) return e;
   if (!h->rep_host && (e = hipHostMalloc((void**)&h->rep_host, 64, hipHostMallocDefault)) != hipSuccess) return e;
   double* ub = h->s_rep.as<double>();

@@ -37,6 +37,10 @@
 #include "tgp_dev.hpp"
 #include "tgp_internal.hpp"
 
+#ifndef TGP_DAG_STAGGER
+#define TGP_DAG_STAGGER 1
+#endif
+
 namespace tgp {
 namespace {
 
@@ -224,7 +228,11 @@ __device__ __attribute__((noinline)) void run_task(const DagArgs& a, uint32_t id
   for (int c = 0; c < nchunks; ++c) {
     drain_vm();        // this wave's share of chunk c has landed ...
     __syncthreads();   // ... everyone's has, and everyone is done with the other stage (chunk c - 1)
-    if (c + 1 < nchunks) issue(c + 1);
+    // Waves w and w + 4 share a SIMD: the first four request chunk c + 1 now, their partners after half of this chunk's
+    // MFMAs -- eight LDS-DMA instructions cost a wave several hundred issue cycles, during which its partner feeds the
+    // matrix pipe (TGP_DAG_STAGGER = 0: everybody up front, round 3)
+    const bool issue_early = !TGP_DAG_STAGGER || w < 4;
+    if (issue_early && c + 1 < nchunks) issue(c + 1);
     const char* const sa = lds + (c & 1) * STAGE;
     const char* const sb = sa + STAGE_A;
     // operands of k step k4 + 1 are fetched BEFORE the MFMAs of step k4 are issued (the scheduling barriers keep hipcc
@@ -252,6 +260,7 @@ __device__ __attribute__((noinline)) void run_task(const DagArgs& a, uint32_t id
 #pragma unroll
         for (int bj = 0; bj < 2; ++bj) acc[bi][bj] = mfma_f64(av[k4 & 1][bi], bv[k4 & 1][bj], acc[bi][bj]);
       __builtin_amdgcn_sched_barrier(0);
+      if (k4 == KC / 8 - 1 && !issue_early && c + 1 < nchunks) issue(c + 1);
     }
   }
   __syncthreads();  // the stages are dead: the tile goes through LDS once, so that global traffic is 16 B per lane
