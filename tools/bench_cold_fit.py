@@ -34,4 +34,8 @@ for rep in range(4):
     print(f"fresh model {rep}: construct {1e3*(t1-t0):.1f} ms, 10 prior draws {1e3*(t2-t1):.1f} ms, L-BFGS-B {1e3*(t3-t2):.1f} ms "
           f"(nfev={res.nfev}; loss calls {len(calls)}: first {1e3*calls[0]:.1f} ms, median {1e3*np.median(calls):.2f} ms, max {1e3*max(calls):.1f} ms)",
           flush=True)
-    del model
+    import gc
+    t4 = time.perf_counter()
+    del model, timed, orig
+    gc.collect()
+    print(f"   releasing the model (engine buffers + {10} x 3 N^2 doubles of batch scratch): {1e3*(time.perf_counter()-t4):.1f} ms", flush=True)
