@@ -40,6 +40,12 @@
 #ifndef TGP_DAG_STAGGER
 #define TGP_DAG_STAGGER 1
 #endif
+#ifndef TGP_DAG_LATE_K4
+#define TGP_DAG_LATE_K4 3   // the k4 step (of 8 per chunk) after which the late waves request the next chunk
+#endif
+#ifndef TGP_DAG_SETPRIO
+#define TGP_DAG_SETPRIO 1   // s_setprio around a chunk's MFMAs: N = 8192 update 7.52 -> 7.42 ms (profiles/r04_dag_stagger_ab.txt)
+#endif
 
 namespace tgp {
 namespace {
@@ -251,6 +257,7 @@ __device__ __attribute__((noinline)) void run_task(const DagArgs& a, uint32_t id
       }
     };
     fetch(0, av[0], bv[0]);
+    if (TGP_DAG_SETPRIO) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
     for (int k4 = 0; k4 < KC / 4; ++k4) {
       if (k4 + 1 < KC / 4) fetch(k4 + 1, av[(k4 + 1) & 1], bv[(k4 + 1) & 1]);
@@ -260,8 +267,9 @@ __device__ __attribute__((noinline)) void run_task(const DagArgs& a, uint32_t id
 #pragma unroll
         for (int bj = 0; bj < 2; ++bj) acc[bi][bj] = mfma_f64(av[k4 & 1][bi], bv[k4 & 1][bj], acc[bi][bj]);
       __builtin_amdgcn_sched_barrier(0);
-      if (k4 == KC / 8 - 1 && !issue_early && c + 1 < nchunks) issue(c + 1);
+      if (k4 == TGP_DAG_LATE_K4 && !issue_early && c + 1 < nchunks) issue(c + 1);
     }
+    if (TGP_DAG_SETPRIO) __builtin_amdgcn_s_setprio(0);
   }
   __syncthreads();  // the stages are dead: the tile goes through LDS once, so that global traffic is 16 B per lane
   double* const T = (double*)lds;
