@@ -1051,7 +1051,7 @@ int tgp_nlml_trial(tgp_handle h, double* value) {
 // slices of the call's device result block (per member: ls [32], value slots; breakdown reports; the launch's error
 // words): the groups of a call follow each other on the stream without a host round trip (1.2 ms per group when each
 // was synchronised: profiles/r04_bo_step.txt) and share the matrices -- stream order keeps them apart.
-static constexpr size_t TRIAL_SMALL_PER = 32 + (MAX_D + 8);
+static constexpr size_t TRIAL_SMALL_PER = 40 + (MAX_D + 8);  // ls [32], variance, noise, mean (32 .. 34), value slots from 40
 static int nlml_trial_enqueue(tgp_handle h, const double* hyp, int B, double* small, int* infos, uint32_t* ctrl_copy) {
   const int64_t N = h->N, Npad = h->Npad;
   const int d = h->d, dp = h->dp, NB = (int)(Npad / 128);
@@ -1072,13 +1072,11 @@ static int nlml_trial_enqueue(tgp_handle h, const double* hyp, int B, double* sm
   double* const errs = Xs_all + (size_t)B * xs_per;
   double* const zs = errs + (size_t)B * Npad;
   uint32_t* const tflags = (uint32_t*)(zs + (size_t)B * Npad);
-  for (int b = 0; b < B; ++b) {
-    const double* hb = hyp + (size_t)b * (d + 3);
-    double* Xs = Xs_all + (size_t)b * xs_per;
-    launch_scale_inputs(s, h->d_X.as<double>(), small + (size_t)b * small_per, Xs, N, Npad, d, dp);
-    launch_assemble_K(s, Xs, mats + (size_t)(3 * b) * nn, N, Npad, dp, h->kind, hb[0], hb[1 + d]);
-    launch_center(s, h->d_Y.as<double>(), hb[2 + d], errs + (size_t)b * Npad, N, Npad);
-  }
+  // every member's scaled inputs / centred targets, then every member's K + noise I: two launches for the group (the
+  // per-member scalars -- variance, noise, mean: slots 32 .. 34 of the member's block -- were uploaded with the call)
+  (void)hyp;
+  launch_batch_prep(s, h->d_X.as<double>(), h->d_Y.as<double>(), small, (int64_t)small_per, B, Xs_all, errs, N, Npad, d, dp);
+  launch_assemble_K_batch(s, Xs_all, mats, N, Npad, dp, h->kind, small, (int64_t)small_per, (int64_t)(3 * nn), B);
   static const bool timing = getenv("TGP_TIMING") != nullptr;  // development aid: where a batched launch spends its time
   hipEvent_t tev[4] = {nullptr, nullptr, nullptr, nullptr};
   if (timing) {
@@ -1109,15 +1107,14 @@ static int nlml_trial_enqueue(tgp_handle h, const double* hyp, int B, double* sm
   // z_b = L_b^-1 err_b: ONE launch for all members (a member is a 32-step chain of block products), then the values
   HIPCHK(h, hipMemsetAsync(tflags, 0, (size_t)B * NB * sizeof(uint32_t), s));
   launch_block_trsv(s, mats + nn, mats + 2 * nn, Npad, NB, errs, zs, tflags, B, (int64_t)(3 * nn));
-  for (int b = 0; b < B; ++b) {
+  {
     ModelDev m{};
     m.kind = h->kind;
     m.d = d;
     m.dp = dp;
     m.N = N;
     m.Npad = Npad;
-    m.alpha = zs + (size_t)b * Npad;
-    launch_nlml_value(s, m, mats + (size_t)(3 * b + 1) * nn, zs + (size_t)b * Npad, small + (size_t)b * small_per + 32);
+    launch_nlml_value_batch(s, m, mats + nn, zs, small + 40, B, (int64_t)(3 * nn), Npad, (int64_t)small_per);
   }
   if (timing) {
     (void)hipEventRecord(tev[3], s);
@@ -1204,6 +1201,9 @@ int tgp_nlml_trial_batch(tgp_handle h, const double* hypers, int B, double* valu
   for (int b = 0; b < B; ++b) {
     const double* hb = hypers + (size_t)b * (d + 3);
     for (int c = 0; c < dp; ++c) hsmall[(size_t)b * small_per + c] = c < d ? hb[1 + c] : 1.0;
+    hsmall[(size_t)b * small_per + 32] = hb[0];      // variance
+    hsmall[(size_t)b * small_per + 33] = hb[1 + d];  // noise variance
+    hsmall[(size_t)b * small_per + 34] = hb[2 + d];  // constant mean
   }
   HIPCHK(h, hipMemcpyAsync(small, hsmall.data(), hsmall.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
   for (int g = 0; g < groups; ++g) {
@@ -1224,7 +1224,7 @@ int tgp_nlml_trial_batch(tgp_handle h, const double* hypers, int B, double* valu
                   hctrl[4 * g + 2], hctrl[4 * g + 3], g, groups);
   for (int b = 0; b < B; ++b) {
     status[b] = hinfo[b] != 0 ? TGP_ERR_NOT_PD : TGP_OK;
-    values[b] = hinfo[b] != 0 ? __builtin_nan("") : hout[(size_t)b * small_per + 32];
+    values[b] = hinfo[b] != 0 ? __builtin_nan("") : hout[(size_t)b * small_per + 40];
   }
   return TGP_OK;
 }

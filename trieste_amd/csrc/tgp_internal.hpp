@@ -77,6 +77,10 @@ void launch_scale_inputs(hipStream_t s, const double* X, const double* ls, doubl
                          int64_t Npad, int d, int dp);
 void launch_assemble_K(hipStream_t s, const double* Xs, double* A, int64_t N, int64_t Npad, int dp,
                        int kind, double variance, double noise, int64_t row0 = 0);
+void launch_assemble_K_batch(hipStream_t s, const double* Xs, double* A, int64_t N, int64_t Npad, int dp, int kind,
+                             const double* hyp, int64_t hyp_stride, int64_t a_stride, int B);
+void launch_batch_prep(hipStream_t s, const double* X, const double* Y, const double* hyp, int64_t hyp_stride, int B,
+                       double* Xs, double* err, int64_t N, int64_t Npad, int d, int dp);
 void launch_leaf(hipStream_t s, const double* A, double* L, double* W, int64_t ld, int64_t off,
                  int* info);
 void launch_leaf128(hipStream_t s, const double* A, double* L, double* W, int64_t ld, int64_t off, int* info);
@@ -142,6 +146,8 @@ int64_t nlml_blocks(int64_t Npad);
 void launch_nlml(hipStream_t s, const ModelDev& m, const double* Kinv, const double* L, const double* err,
                  double* partial, double* out);
 void launch_nlml_value(hipStream_t s, const ModelDev& m, const double* L, const double* err, double* out);
+void launch_nlml_value_batch(hipStream_t s, const ModelDev& m, const double* L, const double* z, double* out, int B,
+                             int64_t l_stride, int64_t v_stride, int64_t o_stride);
 // trajectories
 struct TrajDev {
   ModelDev m;

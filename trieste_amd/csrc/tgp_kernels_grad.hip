@@ -338,10 +338,17 @@ __global__ __launch_bounds__(256) void nlml_grad_kernel(ModelDev m, const double
 
 // out[0] = nlml, out[1..d] = d/d lengthscale, out[d+1] = d/d variance, out[d+2] = d/d noise,
 // out[d+3] = d/d mean.  One workgroup; fixed summation order.
+// Batched value-only form (tgp_nlml_trial_batch): member blockIdx.x has its factor at L + x l_stride, its z (passed as
+// both err and m.alpha) at + x v_stride, its result at out + x o_stride -- the same arithmetic in the same order.
 __global__ __launch_bounds__(1024) void nlml_final_kernel(ModelDev m, const double* __restrict__ L,
                                                           const double* __restrict__ err,
                                                           const double* __restrict__ partial, int64_t nblocks,
-                                                          double* __restrict__ out) {
+                                                          double* __restrict__ out, int64_t l_stride = 0,
+                                                          int64_t v_stride = 0, int64_t o_stride = 0) {
+  L += (int64_t)blockIdx.x * l_stride;
+  err += (int64_t)blockIdx.x * v_stride;
+  m.alpha += (int64_t)blockIdx.x * v_stride;
+  out += (int64_t)blockIdx.x * o_stride;
   // up to 1024 threads: the N diagonal entries of L are N separate cache lines and the block partials are d + 2 rows of
   // `nblocks` values -- with 256 threads and a block-major layout this kernel walked them 16 deep per thread
   // (100 us at N = 4096, as long as the N^2 pair reduction before it)
@@ -377,6 +384,15 @@ __global__ __launch_bounds__(1024) void nlml_final_kernel(ModelDev m, const doub
 // value only (find_best_model_initialization compares losses, no gradient): no K^-1, no pair reduction
 void launch_nlml_value(hipStream_t s, const ModelDev& m, const double* L, const double* err, double* out) {
   hipLaunchKernelGGL(nlml_final_kernel, dim3(1), dim3(m.N > 1024 ? 1024 : 256), 0, s, m, L, err, (const double*)nullptr, (int64_t)0, out);
+}
+
+// B members' values in one launch (value only: err = alpha = z)
+void launch_nlml_value_batch(hipStream_t s, const ModelDev& m, const double* L, const double* z, double* out, int B,
+                             int64_t l_stride, int64_t v_stride, int64_t o_stride) {
+  ModelDev mm = m;
+  mm.alpha = z;
+  hipLaunchKernelGGL(nlml_final_kernel, dim3((unsigned)B), dim3(m.N > 1024 ? 1024 : 256), 0, s, mm, L, z, (const double*)nullptr,
+                     (int64_t)0, out, l_stride, v_stride, o_stride);
 }
 
 int64_t nlml_blocks(int64_t Npad) { return (Npad / 64) * (Npad / 64); }

@@ -28,18 +28,50 @@ void launch_scale_inputs(hipStream_t s, const double* X, const double* ls, doubl
                      Xs, N, Npad, d, dp);
 }
 
+// Batched trial evaluations (tgp_nlml_trial_batch): member b = blockIdx.y has its own lengthscales / mean (hyp + b
+// hyp_stride: ls [dp] at 0, variance at 32, noise at 33, mean at 34) -- its scaled inputs and centred targets in ONE
+// launch for all members (the same arithmetic as scale_inputs_kernel / center_kernel).
+__global__ void batch_prep_kernel(const double* __restrict__ X, const double* __restrict__ Y, const double* __restrict__ hyp,
+                                  int64_t hyp_stride, double* __restrict__ Xs, double* __restrict__ err, int64_t N,
+                                  int64_t Npad, int d, int dp) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const double* h = hyp + (int64_t)blockIdx.y * hyp_stride;
+  if (t < Npad * dp) {
+    const int64_t i = t / dp;
+    const int c = (int)(t % dp);
+    Xs[(int64_t)blockIdx.y * Npad * dp + t] = (i < N && c < d) ? X[i * d + c] / h[c] : 0.0;
+  }
+  if (t < Npad) err[(int64_t)blockIdx.y * Npad + t] = (t < N) ? Y[t] - h[34] : 0.0;
+}
+void launch_batch_prep(hipStream_t s, const double* X, const double* Y, const double* hyp, int64_t hyp_stride, int B,
+                       double* Xs, double* err, int64_t N, int64_t Npad, int d, int dp) {
+  const int64_t n = Npad * dp;
+  hipLaunchKernelGGL(batch_prep_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)B), dim3(256), 0, s, X, Y, hyp, hyp_stride,
+                     Xs, err, N, Npad, d, dp);
+}
+
 // K[i][j] = k(x_i, x_j) + noise * (i == j) on the N x N part; identity on the padding so that the
 // padded matrix stays SPD and factorises to blockdiag(L, I).  Only the 64 x 64 tiles on and below the
 // diagonal are written: nothing downstream reads the upper triangle (the leaf mirrors its diagonal tiles
 // inside LDS, the node products read A21 / the lower tiles of A22).  One workgroup per tile: lane -> column
 // (coalesced stores, x_j in registers), wave -> 16 rows (wave-uniform: x_i through scalar loads); the same
 // branch-free kernel_from_r2<KIND> as the sweep, so K and K* are the same function bit for bit.
+// Batched form (hyp != nullptr; tgp_nlml_trial_batch): member blockIdx.z reads its variance / noise from hyp (+ z
+// hyp_stride: slots 32, 33), its scaled inputs at Xs + z Npad DP, and writes A + z a_stride.
 template <int KIND, int DP>
 __global__ __launch_bounds__(256) void assemble_K_kernel(const double* __restrict__ Xs, double* __restrict__ A,
                                                          int64_t N, int64_t Npad, double variance, double noise,
-                                                         int64_t row0) {
+                                                         int64_t row0, const double* __restrict__ hyp = nullptr,
+                                                         int64_t hyp_stride = 0, int64_t a_stride = 0) {
   const int64_t tj = blockIdx.x, ti = row0 / 64 + blockIdx.y;
   if (tj > ti) return;
+  if (hyp) {
+    const int64_t z = blockIdx.z;
+    variance = hyp[z * hyp_stride + 32];
+    noise = hyp[z * hyp_stride + 33];
+    Xs += z * Npad * DP;
+    A += z * a_stride;
+  }
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t j = tj * 64 + lane;
   double xj[DP];
@@ -68,27 +100,43 @@ __global__ __launch_bounds__(256) void assemble_K_kernel(const double* __restric
 
 template <int KIND>
 static void launch_assemble_K_dp(hipStream_t s, const double* Xs, double* A, int64_t N, int64_t Npad, int dp,
-                                 double variance, double noise, int64_t row0) {
+                                 double variance, double noise, int64_t row0, const double* hyp, int64_t hyp_stride,
+                                 int64_t a_stride, int B) {
   // A is addressed with GLOBAL row indices: for row0 > 0 the caller passes (scratch - row0 * Npad)
-  dim3 g((unsigned)(Npad / 64), (unsigned)((Npad - row0) / 64)), b(256);
+  dim3 g((unsigned)(Npad / 64), (unsigned)((Npad - row0) / 64), (unsigned)B), b(256);
+#define TGP_ASM_K(DPV) \
+  hipLaunchKernelGGL((assemble_K_kernel<KIND, DPV>), g, b, 0, s, Xs, A, N, Npad, variance, noise, row0, hyp, hyp_stride, a_stride)
   switch (dp) {
-    case 2: hipLaunchKernelGGL((assemble_K_kernel<KIND, 2>), g, b, 0, s, Xs, A, N, Npad, variance, noise, row0); break;
-    case 4: hipLaunchKernelGGL((assemble_K_kernel<KIND, 4>), g, b, 0, s, Xs, A, N, Npad, variance, noise, row0); break;
-    case 6: hipLaunchKernelGGL((assemble_K_kernel<KIND, 6>), g, b, 0, s, Xs, A, N, Npad, variance, noise, row0); break;
-    case 8: hipLaunchKernelGGL((assemble_K_kernel<KIND, 8>), g, b, 0, s, Xs, A, N, Npad, variance, noise, row0); break;
-    case 16: hipLaunchKernelGGL((assemble_K_kernel<KIND, 16>), g, b, 0, s, Xs, A, N, Npad, variance, noise, row0); break;
-    default: hipLaunchKernelGGL((assemble_K_kernel<KIND, 32>), g, b, 0, s, Xs, A, N, Npad, variance, noise, row0); break;
+    case 2: TGP_ASM_K(2); break;
+    case 4: TGP_ASM_K(4); break;
+    case 6: TGP_ASM_K(6); break;
+    case 8: TGP_ASM_K(8); break;
+    case 16: TGP_ASM_K(16); break;
+    default: TGP_ASM_K(32); break;
+  }
+#undef TGP_ASM_K
+}
+
+static void launch_assemble_K_any(hipStream_t s, const double* Xs, double* A, int64_t N, int64_t Npad, int dp, int kind,
+                                  double variance, double noise, int64_t row0, const double* hyp, int64_t hyp_stride,
+                                  int64_t a_stride, int B) {
+  switch (kind) {
+    case KIND_RBF: launch_assemble_K_dp<KIND_RBF>(s, Xs, A, N, Npad, dp, variance, noise, row0, hyp, hyp_stride, a_stride, B); break;
+    case KIND_M12: launch_assemble_K_dp<KIND_M12>(s, Xs, A, N, Npad, dp, variance, noise, row0, hyp, hyp_stride, a_stride, B); break;
+    case KIND_M32: launch_assemble_K_dp<KIND_M32>(s, Xs, A, N, Npad, dp, variance, noise, row0, hyp, hyp_stride, a_stride, B); break;
+    default: launch_assemble_K_dp<KIND_M52>(s, Xs, A, N, Npad, dp, variance, noise, row0, hyp, hyp_stride, a_stride, B); break;
   }
 }
 
 void launch_assemble_K(hipStream_t s, const double* Xs, double* A, int64_t N, int64_t Npad, int dp,
                        int kind, double variance, double noise, int64_t row0) {
-  switch (kind) {
-    case KIND_RBF: launch_assemble_K_dp<KIND_RBF>(s, Xs, A, N, Npad, dp, variance, noise, row0); break;
-    case KIND_M12: launch_assemble_K_dp<KIND_M12>(s, Xs, A, N, Npad, dp, variance, noise, row0); break;
-    case KIND_M32: launch_assemble_K_dp<KIND_M32>(s, Xs, A, N, Npad, dp, variance, noise, row0); break;
-    default: launch_assemble_K_dp<KIND_M52>(s, Xs, A, N, Npad, dp, variance, noise, row0); break;
-  }
+  launch_assemble_K_any(s, Xs, A, N, Npad, dp, kind, variance, noise, row0, nullptr, 0, 0, 1);
+}
+// B members in one launch: member b's inputs at Xs + b Npad dp, its matrix at A + b a_stride, its (variance, noise) at
+// hyp [b hyp_stride + 32 / 33]
+void launch_assemble_K_batch(hipStream_t s, const double* Xs, double* A, int64_t N, int64_t Npad, int dp, int kind,
+                             const double* hyp, int64_t hyp_stride, int64_t a_stride, int B) {
+  launch_assemble_K_any(s, Xs, A, N, Npad, dp, kind, 0.0, 0.0, 0, hyp, hyp_stride, a_stride, B);
 }
 
 // ---------------------------------------------------------------------------------------------
