@@ -1046,13 +1046,12 @@ int tgp_nlml_trial(tgp_handle h, double* value) {
   return factorise(h, h->N, 0, value);
 }
 
-// One launch group of a batched trial evaluation, ENQUEUE ONLY: members [0, B) of `hyp` ([B][d + 3]: variance,
-// lengthscales, noise, mean) through ONE persistent factor-only launch.  `small` / `infos` / `ctrl_copy` are this group's
-// slices of the call's device result block (per member: ls [32], value slots; breakdown reports; the launch's error
-// words): the groups of a call follow each other on the stream without a host round trip (1.2 ms per group when each
+// One launch group of a batched trial evaluation, ENQUEUE ONLY: B members through ONE persistent factor-only launch.
+// `small` / `infos` / `ctrl_copy` are this group's slices of the call's device block (per member: ls [32], variance,
+// noise, mean, value slots -- uploaded by the caller; breakdown reports; the launch's error words): the groups of a call follow each other on the stream without a host round trip (1.2 ms per group when each
 // was synchronised: profiles/r04_bo_step.txt) and share the matrices -- stream order keeps them apart.
 static constexpr size_t TRIAL_SMALL_PER = 40 + (MAX_D + 8);  // ls [32], variance, noise, mean (32 .. 34), value slots from 40
-static int nlml_trial_enqueue(tgp_handle h, const double* hyp, int B, double* small, int* infos, uint32_t* ctrl_copy) {
+static int nlml_trial_enqueue(tgp_handle h, int B, double* small, int* infos, uint32_t* ctrl_copy) {
   const int64_t N = h->N, Npad = h->Npad;
   const int d = h->d, dp = h->dp, NB = (int)(Npad / 128);
   const size_t nn = (size_t)Npad * Npad;
@@ -1074,7 +1073,6 @@ static int nlml_trial_enqueue(tgp_handle h, const double* hyp, int B, double* sm
   uint32_t* const tflags = (uint32_t*)(zs + (size_t)B * Npad);
   // every member's scaled inputs / centred targets, then every member's K + noise I: two launches for the group (the
   // per-member scalars -- variance, noise, mean: slots 32 .. 34 of the member's block -- were uploaded with the call)
-  (void)hyp;
   launch_batch_prep(s, h->d_X.as<double>(), h->d_Y.as<double>(), small, (int64_t)small_per, B, Xs_all, errs, N, Npad, d, dp);
   launch_assemble_K_batch(s, Xs_all, mats, N, Npad, dp, h->kind, small, (int64_t)small_per, (int64_t)(3 * nn), B);
   static const bool timing = getenv("TGP_TIMING") != nullptr;  // development aid: where a batched launch spends its time
@@ -1208,9 +1206,7 @@ int tgp_nlml_trial_batch(tgp_handle h, const double* hypers, int B, double* valu
   HIPCHK(h, hipMemcpyAsync(small, hsmall.data(), hsmall.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
   for (int g = 0; g < groups; ++g) {
     const int b0 = g * bmax, nb = std::min(bmax, B - b0);
-    if (int rc = nlml_trial_enqueue(h, hypers + (size_t)b0 * (d + 3), nb, small + (size_t)b0 * small_per, infos + b0,
-                                    ctrls + 4 * g))
-      return rc;
+    if (int rc = nlml_trial_enqueue(h, nb, small + (size_t)b0 * small_per, infos + b0, ctrls + 4 * g)) return rc;
   }
   std::vector<double> hout(small_doubles);
   HIPCHK(h, hipMemcpyAsync(hout.data(), small, hout.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
