@@ -267,8 +267,14 @@ hipError_t launch_sweep_i8_timed(tgp_handle h, SweepArgs& am) {
   const int d = am.m.d;
   const int nb = (int)(Npad / NPAD_MULT);
   SweepArgs b{};
-  int g = std::min(8, nb);
-  while (g > 1 && !plan_split(b, nb, g)) --g;  // (few row blocks: not every group count leaves every group a block)
+  // one row block per group where there are at most 16: a handful of recomputed candidates is ONE candidate block, and
+  // its latency is the heaviest group's walk (N = 4096: the last row block alone is 12 % of the triangle, 0.9 ms)
+  int g = std::min(16, nb);
+  if (g == nb) {
+    for (int k = 0; k <= nb; ++k) b.split_ib[k] = k;
+  } else {
+    while (g > 1 && !plan_split(b, nb, g)) --g;  // (not every group count leaves every group a row block)
+  }
   if (g == 1) {
     b.split_ib[0] = 0;
     b.split_ib[1] = nb;

@@ -56,7 +56,7 @@ struct SweepArgs {
   // row-group split of small sweeps (SPLIT instantiation): group g of a candidate block owns the row
   // blocks [split_ib[g], split_ib[g+1]) of W and leaves partial (mean, sum c^2) in `part`
   int split_g;            // 0/1: off
-  int split_ib[9];
+  int split_ib[17];       // up to 16 groups (8 for the ordinary small sweeps; 16 for the repair pass of TGP_PREC_AUTO)
   double* part;           // [blocks][split_g][2][128]
   // a-posteriori repair of the split-precision sweep (TGP_PREC_AUTO, tgp_api.hip sweep_i8_repaired): the int8
   // kernel prices every candidate's own truncation error on the variance,
