@@ -278,6 +278,79 @@ def make_case(name, kind, d, N, variance, ls, noise, mean_const, seed, M=6, q=3,
     }
 
 
+def make_wide_qei_case(name, kind, d, N, variance, ls, noise, mean_const, seed, q, S=8, G=2, keep_cov=True):
+    """Batch Monte-Carlo EI at the group sizes the engine's one-wave tail is instantiated for (QP = 16 / 32 / 64 and
+    BASELINE config 4's q = 50): joint mean / covariance, the reparametrised samples mean + chol(cov + 1e-6 I) eps and
+    qEI = mean_S max(eta - min_q sample, 0) in 50-digit arithmetic (function.py:1181-1186, sampler.py:276-287).  eta = the
+    median of the groups' posterior means, so that every value is O(0.1 .. 1) -- at the reference's eta = min training
+    mean random groups have qEI = 0 exactly and a comparison says nothing."""
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(size=(N, d))
+    Y = rng.normal(size=N)
+    ls = [float(v) for v in np.broadcast_to(np.asarray(ls, dtype=float), (d,))]
+    K = mp.zeros(N, N)
+    for i in range(N):
+        for j in range(N):
+            K[i, j] = kern(kind, variance, ls, X[i], X[j])
+        K[i, i] += mpf(noise)
+    L = chol(K)
+    err = [mpf(Y[i]) - mpf(mean_const) for i in range(N)]
+    alpha = bsub(L, fsub(L, err))
+    Xg = rng.uniform(size=(G, q, d))
+    Xg[0, 0] = X[0]          # a point AT a training input inside a group
+    eps = rng.normal(size=(q, S))
+    jitter = mp.mpf("1e-6")
+    means, covs = [], []
+    for g in range(G):
+        A, m = [], []
+        for a in range(q):
+            ks = [kern(kind, variance, ls, X[i], Xg[g, a]) for i in range(N)]
+            A.append(fsub(L, ks))
+            m.append(sum(ks[i] * alpha[i] for i in range(N)) + mpf(mean_const))
+        c = mp.zeros(q, q)
+        for a in range(q):
+            for b_ in range(a + 1):
+                c[a, b_] = c[b_, a] = kern(kind, variance, ls, Xg[g, a], Xg[g, b_]) - sum(A[a][i] * A[b_][i] for i in range(N))
+            c[a, a] = max(c[a, a], mp.mpf("1e-12"))
+        means.append(m)
+        covs.append(c)
+    flat = sorted(v for m in means for v in m)
+    eta = (flat[len(flat) // 2 - 1] + flat[len(flat) // 2]) / 2 if len(flat) % 2 == 0 else flat[len(flat) // 2]
+    samples, qei = [], []
+    for g in range(G):
+        cj = covs[g].copy()
+        for a in range(q):
+            cj[a, a] += jitter
+        Lq = chol(cj)
+        acc, smp_g = mp.mpf(0), []
+        for sidx in range(S):
+            smp = [means[g][a] + sum(Lq[a, k] * mpf(eps[k, sidx]) for k in range(a + 1)) for a in range(q)]
+            smp_g.append([f64(v) for v in smp])
+            acc += max(eta - min(smp), mp.mpf(0))
+        samples.append(smp_g)
+        qei.append(f64(acc / S))
+    out = {"name": name, "kind": kind, "d": d, "N": N, "q": q, "S": S, "variance": variance, "lengthscales": ls,
+           "noise": noise, "mean_const": mean_const, "X": X.tolist(), "Y": Y.tolist(), "Xg": Xg.tolist(),
+           "eps": eps.tolist(), "eta": f64(eta), "jitter": 1e-6,
+           "joint_mean": [[f64(v) for v in m] for m in means], "samples": samples, "qei": qei}
+    if keep_cov:  # (q^2 numbers per group: kept where it is small, and for one q = 50 case)
+        out["joint_cov"] = [[[f64(c[a, b_]) for b_ in range(q)] for a in range(q)] for c in covs]
+    return out
+
+
+def main_wide(out_path):
+    cases, sid = [], 900
+    for kind, d, N in (("matern52", 2, 8), ("rbf", 6, 8)):
+        for q in (9, 17, 33, 50):
+            sid += 1
+            ls = [0.2 * np.sqrt(d) * (1.0 + 0.3 * k) for k in range(d)]
+            cases.append(make_wide_qei_case(f"{kind}_d{d}_q{q}", kind, d, N, 1.3, ls, 1e-2, 0.1, sid, q,
+                                            keep_cov=q <= 17 or (q == 50 and kind == "matern52")))
+    with open(out_path, "w") as f:
+        json.dump({"generator": "oracle/make_goldens.py --wide-qei", "mp_dps": mp.mp.dps, "cases": cases}, f)
+    print(f"wrote {len(cases)} wide-qEI cases to {out_path} ({os.path.getsize(out_path)} bytes)")
+
+
 def main(out_path):
     cases = []
     sid = 100
@@ -299,6 +372,10 @@ def main(out_path):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--wide-qei":
+        main_wide(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+                               "qei_wide_goldens.json"))
+        sys.exit(0)
     main(sys.argv[1] if len(sys.argv) > 1 else os.path.join(
         os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
         "gp_goldens.json"))

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from oracle import gp_oracle as O
-from tests.util import assert_close, cancellation_floor, load_goldens
+from tests.util import assert_close, cancellation_floor, load_goldens, load_wide_qei_goldens, reparam_sample_atol
 
 pytestmark = pytest.mark.gpu
 
@@ -242,13 +242,30 @@ def test_edge_cases_and_errors():
     assert_close(v, ov, atol=1e-10)
 
 
-def _sample_atol(cov, floor, eps, jitter=1e-6):
-    """Absolute tolerance of a reparametrised sample mean + (chol(cov + jitter I) eps): an error `floor` in the
-    covariance entries moves the Cholesky factor by about floor / (2 sqrt(lambda_min)) per entry (first-order
-    perturbation of the factorisation), times |eps| summed over a row."""
-    lam = min(float(np.linalg.eigvalsh(c + jitter * np.eye(c.shape[-1])).min()) for c in cov)
-    q = cov.shape[-1]
-    return floor + floor * q * float(np.abs(eps).max()) / (2.0 * np.sqrt(max(lam, jitter)))
+_sample_atol = reparam_sample_atol
+
+WIDE = load_wide_qei_goldens()
+
+
+@pytest.mark.parametrize("variant", [0, 4], ids=["packed-128x256", "slots-256x128"])
+@pytest.mark.parametrize("c", WIDE, ids=[c["name"] for c in WIDE])
+def test_engine_wide_qei_matches_mpmath_goldens(c, variant):
+    """The engine against 50-digit arithmetic at q = 9, 17, 33, 50 -- every instantiation of the one-wave qEI tail
+    (QP = 16, 32, 64) and BASELINE config 4's group size -- joint mean / covariance, the reparametrised samples
+    (tgp_reparam_samples) and qEI (tgp_qei) at an incumbent where every value is O(1).  Independent of the numpy oracle."""
+    eng = _engine(c["kind"], c["d"], c["variance"], c["lengthscales"], c["noise"], c["mean_const"], np.array(c["X"]),
+                  np.array(c["Y"]), variant)
+    floor = cancellation_floor(c["N"], c["variance"], c["noise"])
+    Xg, eps = np.array(c["Xg"]), np.array(c["eps"])
+    jm, jc = eng.predict_joint(Xg)
+    assert_close(jm, c["joint_mean"], atol=floor * 10, what="wide joint mean")
+    if "joint_cov" in c:
+        assert_close(jc, c["joint_cov"], atol=floor, what="wide joint cov")
+    atol = reparam_sample_atol(jc, floor, eps)
+    assert_close(eng.reparam_samples(Xg, eps, c["jitter"]), c["samples"], atol=atol, what=f"golden samples q={c['q']}")
+    want = np.array(c["qei"])
+    assert np.all(want > 0.1)
+    assert_close(eng.qei(Xg, eps, c["eta"], c["jitter"]), want, atol=atol, what=f"golden qEI q={c['q']}")
 
 
 @pytest.mark.parametrize("variant", [0, 4], ids=["packed-128x256", "slots-256x128"])

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 from oracle import gp_oracle as O
-from tests.util import assert_close, cancellation_floor, load_goldens
+from tests.util import assert_close, cancellation_floor, load_goldens, load_wide_qei_goldens, reparam_sample_atol
 
 CASES = load_goldens()
 
@@ -115,3 +115,26 @@ def test_oracle_entropy_tails_match_mpmath(c):
         _, vt = O.predict(O.fantasized_state(st, pend, np.zeros(len(pend))), Xq)
         twin_form = 0.5 * (np.log(vt + c["noise"]) - np.log(v0 + c["noise"])) / len(pend) ** 2
         assert_close(twin_form, c["gibbon_repulsion"], atol=rel, what="repulsion through the conditioned model")
+
+
+WIDE = load_wide_qei_goldens()
+
+
+@pytest.mark.parametrize("c", WIDE, ids=[c["name"] for c in WIDE])
+def test_oracle_wide_qei_matches_mpmath(c):
+    """Batch Monte-Carlo EI at q = 9, 17, 33, 50 (the group sizes the engine's tail is instantiated for and BASELINE
+    config 4's q): joint mean / covariance, the reparametrised samples and qEI against 50-digit arithmetic, at an
+    incumbent where every value is O(1) (reference function.py:1181-1186, models/gpflow/sampler.py:276-287)."""
+    st = O.gpr_update(c["kind"], c["variance"], np.array(c["lengthscales"]), c["noise"], c["mean_const"],
+                      np.array(c["X"]), np.array(c["Y"]))
+    floor = cancellation_floor(c["N"], c["variance"], c["noise"])
+    Xg, eps = np.array(c["Xg"]), np.array(c["eps"])
+    jm, jc = O.predict_joint(st, Xg)
+    assert_close(jm, c["joint_mean"], atol=floor * 10, what="wide joint mean")
+    if "joint_cov" in c:
+        assert_close(jc, c["joint_cov"], atol=floor, what="wide joint cov")
+    atol = reparam_sample_atol(jc, floor, eps)
+    assert_close(O.batch_reparam_samples(st, Xg, eps, c["jitter"]), c["samples"], atol=atol, what=f"samples q={c['q']}")
+    want = np.array(c["qei"])
+    assert np.all(want > 0.1)
+    assert_close(O.batch_mc_ei(st, Xg, eps, c["eta"], c["jitter"]), want, atol=atol, what=f"qEI q={c['q']}")

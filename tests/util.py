@@ -17,6 +17,22 @@ def load_goldens():
         return json.load(f)["cases"]
 
 
+def load_wide_qei_goldens():
+    """mpmath goldens of batch Monte-Carlo EI at q = 9, 17, 33, 50 (oracle/make_goldens.py --wide-qei)."""
+    with open(os.path.join(os.path.dirname(GOLDEN), "qei_wide_goldens.json")) as f:
+        return json.load(f)["cases"]
+
+
+def reparam_sample_atol(cov, floor, eps, jitter=1e-6):
+    """Absolute tolerance of a reparametrised sample mean + (chol(cov + jitter I) eps): an error `floor` in the
+    covariance entries moves the Cholesky factor by about floor / (2 sqrt(lambda_min)) per entry (first-order
+    perturbation of the factorisation), times |eps| summed over a row."""
+    cov = np.asarray(cov, dtype=np.float64)
+    lam = min(float(np.linalg.eigvalsh(c + jitter * np.eye(c.shape[-1])).min()) for c in cov)
+    q = cov.shape[-1]
+    return floor + floor * q * float(np.abs(eps).max()) / (2.0 * np.sqrt(max(lam, jitter)))
+
+
 def cancellation_floor(N: int, variance: float, noise: float) -> float:
     """Absolute floor for variance-derived quantities.
 
