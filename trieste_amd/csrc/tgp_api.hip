@@ -1003,8 +1003,8 @@ static int factorise(tgp_handle h, int64_t N, int64_t keep_rows, double* trial_v
   double* trial_out = nullptr;
   if (factor_only) {
     // z (into the alpha buffer) = L^-1 err; the value kernel's err . alpha is then |z|^2
-    uint32_t* const tflags = h->d_tmp1.as<uint32_t>();  // [Npad / 128][stride] words of the Npad doubles (2 Npad words)
-    HIPCHK(h, hipMemsetAsync(tflags, 0, (size_t)(Npad / 128) * trsv_flag_stride() * sizeof(uint32_t), s));
+    uint32_t* const tflags = h->d_tmp1.as<uint32_t>();  // [Npad / 128] words of the Npad doubles
+    HIPCHK(h, hipMemsetAsync(tflags, 0, (size_t)(Npad / 128) * sizeof(uint32_t), s));
     launch_block_trsv(s, L, W, Npad, (int)(Npad / 128), h->d_err.as<double>(), h->d_alpha.as<double>(), tflags);
     HIPCHK(h, h->s_small.reserve(64 + (MAX_D + 8) * sizeof(double)));
     trial_out = h->s_small.as<double>() + 8;
@@ -1109,7 +1109,7 @@ static int nlml_trial_enqueue(tgp_handle h, int B, double* small, int* infos, ui
   if (timing) (void)hipEventRecord(tev[2], s);
   HIPCHK(h, hipMemcpyAsync(ctrl_copy, a.ctrl, 4 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
   // z_b = L_b^-1 err_b: ONE launch for all members (a member is a 32-step chain of block products), then the values
-  HIPCHK(h, hipMemsetAsync(tflags, 0, (size_t)B * NB * trsv_flag_stride() * sizeof(uint32_t), s));
+  HIPCHK(h, hipMemsetAsync(tflags, 0, (size_t)B * NB * sizeof(uint32_t), s));
   launch_block_trsv(s, mats + nn, mats + 2 * nn, Npad, NB, errs, zs, tflags, B, (int64_t)(3 * nn));
   {
     ModelDev m{};
@@ -1187,8 +1187,7 @@ int tgp_nlml_trial_batch(tgp_handle h, const double* hypers, int B, double* valu
   }
   HIPCHK(h, h->d_dag_flags.reserve(max_state * sizeof(uint32_t)));
   HIPCHK(h, h->d_batch.reserve((size_t)bcap * per));
-  HIPCHK(h, h->d_batch_vec.reserve(((size_t)bcap * ((size_t)Np * dp + 2 * (size_t)Np) +
-                                    (size_t)bcap * NB * trsv_flag_stride() / 2 + 8) * sizeof(double)));
+  HIPCHK(h, h->d_batch_vec.reserve(((size_t)bcap * ((size_t)Np * dp + 2 * (size_t)Np) + (size_t)bcap * NB) * sizeof(double)));
   const size_t small_doubles = (size_t)B * small_per + (size_t)B + (size_t)2 * groups + 8;
   HIPCHK(h, h->d_batch_small.reserve(small_doubles * sizeof(double)));
   double* const mats = h->d_batch.as<double>();

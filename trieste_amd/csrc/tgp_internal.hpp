@@ -215,7 +215,6 @@ void launch_block_trsv(hipStream_t s, const double* L, const double* W, int64_t 
                        uint32_t* flags, int B = 1, int64_t mat_stride = 0);
 hipError_t launch_dag_update(hipStream_t s, const DagArgs& a, int grid);
 size_t dag_lds_bytes();
-int trsv_flag_stride();  // words between two flags of launch_block_trsv (flags: [B][NB][stride] words, zero at launch)
 
 // rs: [2][Npad] -- row scales S_i, then the row weights S_i^2 (i + 1) of the a-posteriori error model
 void launch_w_digits(hipStream_t s, const double* W, int64_t N, int64_t Npad, double* rs, void* Wq, int planes);

@@ -970,7 +970,6 @@ void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<
 }
 
 size_t dag_lds_bytes() { return DAG_LDS; }
-int trsv_flag_stride() { return 32; }
 
 namespace {
 // z = L^-1 r by block forward substitution over the 128-blocks, given the diagonal inverses W_jj (what a factor-only
@@ -980,7 +979,6 @@ namespace {
 // A wait that times out poisons z_i with NaN (the caller sees a NaN likelihood).
 // Batched (gridDim.y members: matrices mat_stride apart, vectors ld apart, flags gridDim.x words apart): workgroups are
 // dispatched x fastest, so member y's block i still waits only for lower linear indices.
-constexpr int TRSV_FLAG_STRIDE = 32;  // one flag per 128-byte line: up to NB - 1 workgroups poll the newest one
 __global__ __launch_bounds__(256) void block_trsv_kernel(const double* __restrict__ L, const double* __restrict__ W,
                                                          int64_t ld, const double* __restrict__ r,
                                                          double* z, uint32_t* flags, int64_t mat_stride) {
@@ -990,7 +988,7 @@ __global__ __launch_bounds__(256) void block_trsv_kernel(const double* __restric
   W += (int64_t)blockIdx.y * mat_stride;
   r += (int64_t)blockIdx.y * ld;
   z += (int64_t)blockIdx.y * ld;
-  flags += (size_t)blockIdx.y * gridDim.x * TRSV_FLAG_STRIDE;
+  flags += (size_t)blockIdx.y * gridDim.x;
   const int i = blockIdx.x, tid = threadIdx.x, row = tid & (TILE - 1), half = tid >> 7;
   const double* const Lrow = L + ((int64_t)i * TILE + row) * ld + half * (TILE / 2);
   double s = 0.0;
@@ -998,7 +996,7 @@ __global__ __launch_bounds__(256) void block_trsv_kernel(const double* __restric
   for (int k = 0; k < i; ++k) {
     if (tid == 0) {
       unsigned spins = 0;
-      while (ld_flag(flags + (size_t)k * TRSV_FLAG_STRIDE) == 0 && ++spins < SPIN_LIMIT) __builtin_amdgcn_s_sleep(2);
+      while (ld_flag(flags + k) == 0 && ++spins < SPIN_LIMIT) __builtin_amdgcn_s_sleep(4);
       ok = spins < SPIN_LIMIT ? 1u : 0u;
     }
     __syncthreads();
@@ -1026,7 +1024,7 @@ __global__ __launch_bounds__(256) void block_trsv_kernel(const double* __restric
   }
   drain_vm();
   __syncthreads();
-  if (tid == 0) st_flag(flags + (size_t)i * TRSV_FLAG_STRIDE, 1u);
+  if (tid == 0) st_flag(flags + i, 1u);
 }
 }  // namespace
 
