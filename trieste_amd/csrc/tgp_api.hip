@@ -156,7 +156,8 @@ constexpr int VARIANT_NO_SPLIT = 1, VARIANT_FORCE_SPLIT = 2, VARIANT_JOINT_V1 = 
 // than AUTO_DEMOTE of a sweep's candidates were recomputed on the current rung the next sweep moves one rung down
 // (the recomputation costs more than the wider arithmetic saves: 0.095 + 0.255 f us per candidate against 0.125 at
 // the headline size).  tgp_set_hyper / tgp_set_precision restart the ladder at four planes.  Whatever the rung, every
-// result is inside the parity tolerance by construction, and the fused arg-max returns the float64 winner.
+// result is inside the parity tolerance as far as the 8-sigma bound of the error model goes (a statistical model of the
+// dropped digit pairs, not a worst-case bound), and the fused arg-max returns the float64 winner.
 constexpr double AUTO_DEMOTE = 0.05;
 constexpr int64_t I8_MAX_N = 16384;  // int32 accumulators: 5 pairs x 2^14 x N < 2^31
 int auto_rung_precision(tgp_handle h) {
