@@ -85,6 +85,36 @@ def test_ask_tell_loop_on_gpu_finds_scaled_branin_minimum():
     assert np.min(opt.dataset.observations) < -1.0  # minimum -1.047393 (reference rtol 0.005 in <= 20 steps)
 
 
+def test_ask_tell_loop_under_auto_precision_matches_the_float64_loop():
+    """The same Ask-Tell loop with sweep_precision="auto": every step's fused sweep runs the int8 kernel with the float64
+    repair on a model that is re-factorised every step (N = 6 ... 17: as ill-conditioned for digit planes as it gets) --
+    the acquired points are the float64 loop's, step by step (the device-sampled candidates are the same Philox table)."""
+    import trieste_amd.models as M
+    from trieste_amd import objectives as OBJ
+    from trieste_amd.acquisition import EfficientGlobalOptimization, generate_random_search_optimizer
+    from trieste_amd.ask_tell_optimization import AskTellOptimizer
+    from trieste_amd.data import Dataset
+
+    class UpdateOnly(AskTellOptimizer):     # (the fit draws its prior samples unseeded: keep the two loops comparable)
+        def update_model(self, mdl, dataset):
+            mdl.update(dataset)
+
+    space, data, model, _ = _setup(n=6, noise=1e-5, seed=0)
+    auto = M.GaussianProcessRegression(model.model, sweep_precision="auto")
+    loops = []
+    for mdl in (model, auto):
+        rule = EfficientGlobalOptimization(optimizer=generate_random_search_optimizer(20_000, seed=1))
+        opt = UpdateOnly(space, data, mdl, rule, fit_model=False)
+        pts = []
+        for _ in range(12):
+            q = opt.ask()
+            pts.append(q[0].copy())
+            opt.tell(Dataset(q, OBJ.scaled_branin(q)))
+        loops.append(np.array(pts))
+    np.testing.assert_array_equal(loops[1], loops[0])
+    assert auto.engine.get_precision()[0] == "auto"
+
+
 def test_batch_rule_and_reparam_samples_match_oracle():
     from trieste_amd.acquisition import (BatchMonteCarloExpectedImprovement, EfficientGlobalOptimization,
                                          generate_random_search_optimizer)
