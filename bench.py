@@ -571,6 +571,11 @@ def main():
                     sec[key] = secondary_line(name, prec, args.secondary_steps, local_rank)
                 except Exception as e:  # a secondary line never breaks the graded one
                     sec[key] = {"error": f"{type(e).__name__}: {e}"}
+            if isinstance(sec.get("headline_auto"), dict) and "best" in sec["headline_auto"]:
+                # the repaired int8 sweep ran over the same Philox candidates as the float64 headline steps above
+                sec["headline_auto"]["same_winner_as_f64_headline"] = bool(
+                    sec["headline_auto"]["best"][1] == out["config"]["best_index"]
+                    and abs(sec["headline_auto"]["best"][0] - out["config"]["best_value"]) <= 1e-12 * abs(out["config"]["best_value"]))
             out["secondary"] = sec
         if not args.no_cpu_baseline and nshards == 1:
             out["cpu_baseline"] = cpu_baseline(w)
