@@ -177,7 +177,8 @@ int tgp_nlml_trial(tgp_handle h, double* value);
  * workers they share) -- a single factorisation leaves half of the compute units idle behind its chain, and HIP runs at
  * most three such launches side by side.  Each value equals tgp_nlml_trial's at
  * the same hyper-parameters bit for bit.  The handle's own hyper-parameters and posterior are untouched (the members
- * live in scratch matrices: 3 N^2 doubles each).  Below that size the members are evaluated one after the other.
+ * live in scratch matrices, 3 N^2 doubles each: a process-wide scratch per device, allocated on first use and kept;
+ * concurrent calls on one device are serialised).  Below that size the members are evaluated one after the other.
  * Replaces the loop of find_best_model_initialization (reference models/gpflow/models.py:294-321). */
 int tgp_nlml_trial_batch(tgp_handle h, const double* hypers, int B, double* values, int* status);
 /* Read back the cache (tests / checkpoint-free restore checks): any pointer may be NULL.

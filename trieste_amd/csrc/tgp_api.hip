@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <algorithm>
@@ -783,7 +785,7 @@ int tgp_destroy(tgp_handle h) {
   for (DevBuf* b : {&h->d_xn, &h->d_ls, &h->d_X, &h->d_Y, &h->d_Xs, &h->d_A, &h->d_L, &h->d_W, &h->d_alpha,
                     &h->d_err, &h->d_tmp1, &h->d_tmp2, &h->d_info, &h->d_pen, &h->d_ent, &h->d_repv, &h->d_wq, &h->d_rs, &h->s_ent, &h->s_in, &h->s_in2, &h->s_out1,
                     &h->s_out2, &h->s_out3, &h->s_blkv, &h->s_blki, &h->s_small, &h->s_kcache, &h->s_aslab, &h->s_grad, &h->s_ks, &h->s_part, &h->s_rep,
-                    &h->s_rep_stats, &h->d_dag_flags, &h->d_dag_trace, &h->d_batch, &h->d_batch_vec, &h->d_batch_small})
+                    &h->s_rep_stats, &h->d_dag_flags, &h->d_dag_trace})
     b->release();
   for (auto& p : h->dag_plan) {
     p.tasks.release();
@@ -1057,8 +1059,28 @@ int tgp_nlml_trial(tgp_handle h, double* value) {
 // `small` / `infos` / `ctrl_copy` are this group's slices of the call's device block (per member: ls [32], variance,
 // noise, mean, value slots -- uploaded by the caller; breakdown reports; the launch's error words): the groups of a call follow each other on the stream without a host round trip (1.2 ms per group when each
 // was synchronised: profiles/r04_bo_step.txt) and share the matrices -- stream order keeps them apart.
+// The scratch of the batched trial evaluations -- the members' K / L / W (3 N^2 doubles each: 5.8 GiB for fifteen members
+// at N = 4096), their vectors and result slots -- is PROCESS-WIDE, one per device, allocated on first use and kept: a BO
+// loop fits a fresh or re-attached model every step, and allocating / releasing gigabytes per model cost 10 - 40 ms each
+// way (sporadically hundreds).  A call holds the device's mutex from its first launch to its synchronisation.
+struct BatchScratch {
+  std::mutex mu;
+  DevBuf mats, vec, small;
+  const void* zeroed = nullptr;
+  int64_t zeroed_npad = 0;
+  int zeroed_B = 0;
+};
+static BatchScratch& batch_scratch(int device) {
+  static std::mutex table_mu;
+  static std::map<int, BatchScratch*> table;  // (never freed: process lifetime)
+  std::lock_guard<std::mutex> lk(table_mu);
+  BatchScratch*& p = table[device];
+  if (!p) p = new BatchScratch();
+  return *p;
+}
+
 static constexpr size_t TRIAL_SMALL_PER = 40 + (MAX_D + 8);  // ls [32], variance, noise, mean (32 .. 34), value slots from 40
-static int nlml_trial_enqueue(tgp_handle h, int B, double* small, int* infos, uint32_t* ctrl_copy) {
+static int nlml_trial_enqueue(tgp_handle h, BatchScratch& bs, int B, double* small, int* infos, uint32_t* ctrl_copy) {
   const int64_t N = h->N, Npad = h->Npad;
   const int d = h->d, dp = h->dp, NB = (int)(Npad / 128);
   const size_t nn = (size_t)Npad * Npad;
@@ -1073,8 +1095,8 @@ static int nlml_trial_enqueue(tgp_handle h, int B, double* small, int* infos, ui
   const size_t small_per = TRIAL_SMALL_PER;
   // [B] scaled inputs Xs [Npad][dp]; [B] centred targets err [Npad]; [B] z [Npad]; the trsv flags [B][NB]
   const size_t xs_per = (size_t)Npad * dp;
-  double* const mats = h->d_batch.as<double>();
-  double* const Xs_all = h->d_batch_vec.as<double>();
+  double* const mats = bs.mats.as<double>();
+  double* const Xs_all = bs.vec.as<double>();
   double* const errs = Xs_all + (size_t)B * xs_per;
   double* const zs = errs + (size_t)B * Npad;
   uint32_t* const tflags = (uint32_t*)(zs + (size_t)B * Npad);
@@ -1187,20 +1209,22 @@ int tgp_nlml_trial_batch(tgp_handle h, const double* hypers, int B, double* valu
     max_state = std::max(max_state, (size_t)bb * (nt + 2 * (size_t)NB) + DAG_CTRL_WORDS + (size_t)bb * nt);
   }
   HIPCHK(h, h->d_dag_flags.reserve(max_state * sizeof(uint32_t)));
-  HIPCHK(h, h->d_batch.reserve((size_t)bcap * per));
-  HIPCHK(h, h->d_batch_vec.reserve(((size_t)bcap * ((size_t)Np * dp + 2 * (size_t)Np) + (size_t)bcap * NB) * sizeof(double)));
+  BatchScratch& bs = batch_scratch(h->device);
+  std::lock_guard<std::mutex> scratch_lock(bs.mu);
+  HIPCHK(h, bs.mats.reserve((size_t)bcap * per));
+  HIPCHK(h, bs.vec.reserve(((size_t)bcap * ((size_t)Np * dp + 2 * (size_t)Np) + (size_t)bcap * NB) * sizeof(double)));
   const size_t small_doubles = (size_t)B * small_per + (size_t)B + (size_t)2 * groups + 8;
-  HIPCHK(h, h->d_batch_small.reserve(small_doubles * sizeof(double)));
-  double* const mats = h->d_batch.as<double>();
-  double* const small = h->d_batch_small.as<double>();
+  HIPCHK(h, bs.small.reserve(small_doubles * sizeof(double)));
+  double* const mats = bs.mats.as<double>();
+  double* const small = bs.small.as<double>();
   int* const infos = (int*)(small + (size_t)B * small_per);
   uint32_t* const ctrls = (uint32_t*)(small + (size_t)B * small_per + B);
-  if (h->batch_zeroed != mats || h->batch_zeroed_npad != Np || h->batch_zeroed_B < bcap) {
-    // the factorisation only ever writes zeros above the diagonals: wiped once per allocation (as d_L / d_W)
+  if (bs.zeroed != mats || bs.zeroed_npad != Np || bs.zeroed_B < bcap) {
+    // the factorisation only ever writes zeros above the diagonals: wiped once per allocation and size (as d_L / d_W)
     HIPCHK(h, hipMemsetAsync(mats, 0, (size_t)bcap * per, h->stream));
-    h->batch_zeroed = mats;
-    h->batch_zeroed_npad = Np;
-    h->batch_zeroed_B = bcap;
+    bs.zeroed = mats;
+    bs.zeroed_npad = Np;
+    bs.zeroed_B = bcap;
   }
   std::vector<double> hsmall(small_doubles, 0.0);  // (also zeroes the breakdown reports and the error words)
   for (int b = 0; b < B; ++b) {
@@ -1213,7 +1237,7 @@ int tgp_nlml_trial_batch(tgp_handle h, const double* hypers, int B, double* valu
   HIPCHK(h, hipMemcpyAsync(small, hsmall.data(), hsmall.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
   for (int g = 0; g < groups; ++g) {
     const int b0 = g * bmax, nb = std::min(bmax, B - b0);
-    if (int rc = nlml_trial_enqueue(h, nb, small + (size_t)b0 * small_per, infos + b0, ctrls + 4 * g)) return rc;
+    if (int rc = nlml_trial_enqueue(h, bs, nb, small + (size_t)b0 * small_per, infos + b0, ctrls + 4 * g)) return rc;
   }
   std::vector<double> hout(small_doubles);
   HIPCHK(h, hipMemcpyAsync(hout.data(), small, hout.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));

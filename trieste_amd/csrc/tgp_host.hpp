@@ -127,10 +127,7 @@ struct tgp_handle_s {
   DevBuf d_dag_flags, d_dag_trace;
   size_t dag_state_words = 0;  // d_dag_flags: B x [ntasks + 2 NB] flag words, control words, start counts (DagArgs), zeroed per launch
   // batched trial evaluations: [B][3] matrices (A, L, W), [B] scaled inputs / centred targets / z, per-member scalars
-  DevBuf d_batch, d_batch_vec, d_batch_small;
-  const void* batch_zeroed = nullptr;
-  int64_t batch_zeroed_npad = 0;
-  int batch_zeroed_B = 0;
+  // (they live in a PROCESS-WIDE scratch per device, tgp_api.hip BatchScratch: every fit of every model reuses it)
   // timing of the dominant kernel
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double last_ms = 0.0;
