@@ -11,6 +11,7 @@
 #include <limits>
 #include <map>
 #include <mutex>
+#include <tuple>
 #include <new>
 #include <string>
 #include <algorithm>
@@ -504,34 +505,60 @@ bool dag_applies(tgp_handle h, int64_t Npad) {
   return !off && !(h->variant & VARIANT_NO_DAG) && Npad >= min_n && Npad % 128 == 0 && Npad * Npad * 8 < (int64_t)0x7fffffff;
 }
 
-// The cached plan of `slot` (0 full update, 1 factor-only, 2 batched factor-only) for this size / share of the compute
-// units / batch; built on a miss (the host vectors are copied with one synchronisation).
+// The plan of `slot` (0 full update, 1 factor-only, >= 2 batched factor-only) for this size / share of the compute units /
+// batch.  Plans are immutable and depend on nothing but (kind, NB, ld, workgroups, B): they live in a PROCESS-WIDE cache
+// per device, built on the first miss (host simulation 2 - 10 ms, three copies, one synchronisation) -- a BO loop fits
+// a fresh or re-attached model every step, and each used to rebuild its three plans (~15 ms of a 115 ms fit).
+struct SharedPlan {
+  DevBuf tasks, chain, topo;
+  int ntasks = 0;
+};
 int dag_plan_get(tgp_handle h, int slot, int NB, int64_t ld, int grid, int B) {
   tgp_handle_s::DagPlan& p = h->dag_plan[slot];
   if (p.nb == NB && p.ld == ld && p.grid == grid && p.B == B) return TGP_OK;
-  std::vector<DagTask> tasks;
-  std::vector<uint32_t> chain, topo, merged;
-  int nu = 0;
-  // the dispatch order is simulated for the workers a member can count on
-  // the dispatch order is simulated for the workers there are: alone, or B members sharing grid - B of them
-  dag_build(NB, ld, tasks, chain, nu, &topo, std::max(1, slot >= 2 ? (grid - B) / B : grid - 1), slot == 0, slot >= 2 ? B : 1,
-            grid - B, &merged);
-  if (slot >= 2) {
-    if (B == 1) dag_merge_order(topo, 1, merged);
-    topo.swap(merged);
+  static std::mutex mu;
+  static std::map<std::tuple<int, int, int, int64_t, int, int>, SharedPlan*> cache;  // (never freed: process lifetime)
+  std::lock_guard<std::mutex> lk(mu);
+  const int kind = slot == 0 ? 0 : (slot == 1 ? 1 : 2);
+  SharedPlan*& sp = cache[std::make_tuple(h->device, kind, NB, ld, grid, B)];
+  if (!sp) {
+    std::vector<DagTask> tasks;
+    std::vector<uint32_t> chain, topo, merged;
+    int nu = 0;
+    // the dispatch order is simulated for the workers there are: alone, or B members sharing grid - B of them
+    dag_build(NB, ld, tasks, chain, nu, &topo, std::max(1, slot >= 2 ? (grid - B) / B : grid - 1), slot == 0, slot >= 2 ? B : 1,
+              grid - B, &merged);
+    if (slot >= 2) {
+      if (B == 1) dag_merge_order(topo, 1, merged);
+      topo.swap(merged);
+    }
+    SharedPlan* fresh = new SharedPlan();
+    hipError_t e = fresh->tasks.reserve(tasks.size() * sizeof(DagTask));
+    if (e == hipSuccess) e = fresh->chain.reserve(chain.size() * sizeof(uint32_t));
+    if (e == hipSuccess) e = fresh->topo.reserve((topo.size() + 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemcpyAsync(fresh->tasks.p, tasks.data(), tasks.size() * sizeof(DagTask), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(fresh->chain.p, chain.data(), chain.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(fresh->topo.p, topo.data(), topo.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);  // the host vectors die here; the plan is complete for every stream
+    if (e != hipSuccess) {
+      fresh->tasks.release();
+      fresh->chain.release();
+      fresh->topo.release();
+      delete fresh;
+      cache.erase(std::make_tuple(h->device, kind, NB, ld, grid, B));
+      HIPCHK(h, e);
+    }
+    fresh->ntasks = (int)tasks.size();
+    sp = fresh;
   }
-  HIPCHK(h, p.tasks.reserve(tasks.size() * sizeof(DagTask)));
-  HIPCHK(h, p.chain.reserve(chain.size() * sizeof(uint32_t)));
-  HIPCHK(h, p.topo.reserve((topo.size() + 1) * sizeof(uint32_t)));
-  HIPCHK(h, hipMemcpyAsync(p.tasks.p, tasks.data(), tasks.size() * sizeof(DagTask), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipMemcpyAsync(p.chain.p, chain.data(), chain.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipMemcpyAsync(p.topo.p, topo.data(), topo.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));  // the host vectors die here
   p.nb = NB;
   p.ld = ld;
   p.grid = grid;
   p.B = B;
-  p.ntasks = (int)tasks.size();
+  p.ntasks = sp->ntasks;
+  p.tasks = sp->tasks.p;
+  p.chain = sp->chain.p;
+  p.topo = sp->topo.p;
   return TGP_OK;
 }
 
@@ -557,9 +584,9 @@ int chol_inv_dag(tgp_handle h, bool factor_only = false) {
   a.ld = Npad;
   a.NB = NB;
   a.ntasks = plan.ntasks;
-  a.tasks = plan.tasks.as<DagTask>();
-  a.chain_dep = plan.chain.as<uint32_t>();
-  a.topo = plan.topo.as<uint32_t>();
+  a.tasks = (const DagTask*)plan.tasks;
+  a.chain_dep = (const uint32_t*)plan.chain;
+  a.topo = (const uint32_t*)plan.topo;
   a.flags = h->d_dag_flags.as<uint32_t>();
   a.ctrl = a.flags + nflags;
   a.info = h->d_info.as<int>();
@@ -787,11 +814,7 @@ int tgp_destroy(tgp_handle h) {
                     &h->s_out2, &h->s_out3, &h->s_blkv, &h->s_blki, &h->s_small, &h->s_kcache, &h->s_aslab, &h->s_grad, &h->s_ks, &h->s_part, &h->s_rep,
                     &h->s_rep_stats, &h->d_dag_flags, &h->d_dag_trace})
     b->release();
-  for (auto& p : h->dag_plan) {
-    p.tasks.release();
-    p.chain.release();
-    p.topo.release();
-  }
+
   if (h->rep_host) (void)hipHostFree(h->rep_host);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1118,9 +1141,9 @@ static int nlml_trial_enqueue(tgp_handle h, BatchScratch& bs, int B, double* sma
   a.ld = Npad;
   a.NB = NB;
   a.ntasks = plan.ntasks;
-  a.tasks = plan.tasks.as<DagTask>();
-  a.chain_dep = plan.chain.as<uint32_t>();
-  a.topo = plan.topo.as<uint32_t>();
+  a.tasks = (const DagTask*)plan.tasks;
+  a.chain_dep = (const uint32_t*)plan.chain;
+  a.topo = (const uint32_t*)plan.topo;
   a.flags = h->d_dag_flags.as<uint32_t>();
   a.ctrl = a.flags + (size_t)B * nflags;
   a.info = infos;

@@ -117,10 +117,10 @@ struct tgp_handle_s {
   // one cached plan per use: 0 the full update, 1 the factor-only trial (tgp_nlml_trial), 2 .. 9 the batched
   // factor-only launch (tgp_nlml_trial_batch) per member count -- a fit alternates between them (90 draws are eleven
   // launches of eight and one of two), and building a plan costs as much as the update
-  struct DagPlan {
-    int nb = 0, ntasks = 0, grid = 0, B = 0;
+  struct DagPlan {         // (a view: the device arrays belong to the process-wide plan cache of tgp_api.hip -- plans are
+    int nb = 0, ntasks = 0, grid = 0, B = 0;   //  immutable once built, every handle of a device shares them)
     int64_t ld = 0;
-    DevBuf tasks, chain, topo;
+    const void *tasks = nullptr, *chain = nullptr, *topo = nullptr;
   } dag_plan[2 + 16];  // 0 full, 1 factor-only, 2 + (B - 1): batched factor-only with B = 1 .. 16 members
   int dag_last_slot = 0;  // the slot of the most recent launch (its error words are read back after the stream drains)
   int update_share = 1;  // tgp_set_update_concurrency: the persistent update kernel takes num_cu / update_share workgroups
