@@ -15,7 +15,10 @@ def c4(G=20000, q=50, S=512, N=2048, d=6):
     eng.use_torch_stream()
     for _ in range(2):
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        out = eng.qei(Xq, eps, eta, 1e-6)
+        try:
+            out = eng.qei(Xq, eps, eta, 1e-6)
+        except Exception as e:   # knock-out builds (tools/build_exp.sh) produce garbage the qEI tail rejects: timing only
+            out = torch.zeros(1); print("  (", str(e)[:60], ")")
         torch.cuda.synchronize(); t1 = time.perf_counter()
     ms_joint, nl = eng.last_kernel_ms()
     flops = G * (q * float(N) * N + q * q * N)
