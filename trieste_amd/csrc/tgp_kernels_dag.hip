@@ -159,11 +159,56 @@ static_assert(DAG_CTRL_WORDS >= 64, "control block");
 
 __device__ __forceinline__ uint32_t* dag_cnt(const DagArgs& a) { return a.ctrl + DAG_CTRL_WORDS; }  // [ntasks] start counts
 
+#ifndef TGP_DAG_KERNARG
+#define TGP_DAG_KERNARG 0
+// 1 = run_task (the workers' tile task) reads the launch arguments from the KERNARG segment with scalar loads.  As shipped
+// (0) the noinline functions take `const DagArgs&`: the argument block then lives in scratch (42 scratch accesses per
+// dispatched task in dag_update_kernel, a second 120-byte copy per task of a batched launch, six flat loads at the head of
+// every task; tools/isa_spills.py).  run_chain keeps the reference: with the block in SGPRs the chain, which already
+// fills 256 VGPRs, spills them (224 scratch accesses in its body against 6).  Written at the end of round 4 with no GPU budget left: NOT MEASURED, NOT VALIDATED -- build
+// it (tools/build_exp.sh-style, this TU), run tests/test_gpu_dag.py and tools/bench_update.py before turning it on.  With
+// 0 the preprocessor leaves the shipped source text untouched.
+#endif
+#if TGP_DAG_KERNARG
+static_assert(sizeof(DagArgs) == 120, "dag_args reads the block by offset");
+// the launch arguments from the kernarg segment (explicit arguments start at offset 0): scalar loads only
+__device__ __forceinline__ DagArgs dag_args(const void* kernarg) {
+  const uint64_t p = (uint64_t)(uintptr_t)kernarg;
+  const uint64_t pu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(p >> 32)) << 32) |
+                      (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)p);   // (the builtin returns a signed int)
+  const __attribute__((address_space(4))) uint64_t* q = (const __attribute__((address_space(4))) uint64_t*)pu;
+  DagArgs a;
+  a.Ap = (double*)q[0];
+  a.Lp = (double*)q[1];
+  a.Wp = (double*)q[2];
+  a.ld = (int64_t)q[3];
+  a.NB = (int)(uint32_t)q[4];
+  a.ntasks = (int)(uint32_t)(q[4] >> 32);
+  a.tasks = (const DagTask*)q[5];
+  a.chain_dep = (const uint32_t*)q[6];
+  a.topo = (const uint32_t*)q[7];
+  a.flags = (uint32_t*)q[8];
+  a.ctrl = (uint32_t*)q[9];
+  a.info = (int*)q[10];
+  a.trace = (unsigned long long*)q[11];
+  a.B = (int)(uint32_t)q[12];
+  a.mat_stride = (int64_t)q[13];
+  a.flags_stride = (uint32_t)q[14];
+  return a;
+}
+#endif
+
 // ---- generic tile task ----------------------------------------------------------------------------------------------
 struct TaskU {  // a task descriptor with every field in scalar registers
   uint32_t a_off, b_off, c_off, o_off, nk, flags, a_mat, b_mat, c_mat, o_mat, set;
 };
+#if TGP_DAG_KERNARG
+__device__ __attribute__((noinline)) void run_task(const void* kernarg, uint32_t mb, uint32_t idx) {
+  const DagArgs a0 = dag_args(kernarg);
+  const DagArgs a = a0.B > 1 ? dag_member(a0, (uint32_t)__builtin_amdgcn_readfirstlane(mb)) : a0;
+#else
 __device__ __attribute__((noinline)) void run_task(const DagArgs& a, uint32_t idx) {
+#endif
   DAG_LDS_DECL;
   char* const lds = dag_lds;
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
@@ -600,20 +645,26 @@ __global__ __launch_bounds__(512) void dag_update_kernel(DagArgs a) {
     }
     return;
   }
-  const uint32_t total = (uint32_t)a.ntasks * nB;
+#if TGP_DAG_KERNARG
+  const void* const kernarg = (const void*)__builtin_amdgcn_kernarg_segment_ptr();
+  const DagArgs wa = dag_args(kernarg);   // the dispatcher's own copy, in scalar registers
+#else
+  const DagArgs& wa = a;
+#endif
+  const uint32_t total = (uint32_t)wa.ntasks * nB;
 #pragma unroll 1
   for (;;) {
     if (tid == 0) {  // the next entry of the list; wait for the flags of what was drawn
-      const uint32_t pos = atomicAdd(a.ctrl + C_HEAD, 1u);
+      const uint32_t pos = atomicAdd(wa.ctrl + C_HEAD, 1u);
       uint32_t got = TASK_DONE, mb = 0;
       if (pos < total) {
-        const uint32_t entry = a.topo[pos];
+        const uint32_t entry = wa.topo[pos];
         mb = entry >> 24;
         got = entry & 0xffffffu;
-        if (a.trace) a.trace[CT * a.NB + 4 * (size_t)got] = wall_clock64();  // development aid: drawn (before the wait)
-        const uint32_t* const mflags = a.flags + (size_t)mb * a.flags_stride;
+        if (wa.trace) wa.trace[CT * wa.NB + 4 * (size_t)got] = wall_clock64();  // development aid: drawn (before the wait)
+        const uint32_t* const mflags = wa.flags + (size_t)mb * wa.flags_stride;
         bool ok = true;
-        for (int d = 0; d < 3; ++d) ok = ok && wait_flag_at(mflags, a.ctrl, a.tasks[got].dep[d]);
+        for (int d = 0; d < 3; ++d) ok = ok && wait_flag_at(mflags, wa.ctrl, wa.tasks[got].dep[d]);
         if (!ok) got = TASK_ERR;
       }
       ctl[0] = got;
@@ -622,31 +673,35 @@ __global__ __launch_bounds__(512) void dag_update_kernel(DagArgs a) {
     __syncthreads();
     const uint32_t idx = uni(ctl[0]), mb = uni(ctl[2]);
     __syncthreads();
-    if (idx >= (uint32_t)a.ntasks) return;  // TASK_DONE / TASK_ERR
-    unsigned long long* const tr = (a.trace && tid == 0) ? a.trace + CT * a.NB + 4 * (size_t)idx : nullptr;
+    if (idx >= (uint32_t)wa.ntasks) return;  // TASK_DONE / TASK_ERR
+    unsigned long long* const tr = (wa.trace && tid == 0) ? wa.trace + CT * wa.NB + 4 * (size_t)idx : nullptr;
     stamp(tr ? tr + 1 : nullptr);
     if (tid == 0) {  // sanity: a task starts exactly once
-      const uint32_t old = atomicAdd(dag_cnt(a) + (size_t)mb * (uint32_t)a.ntasks + idx, 1u);
+      const uint32_t old = atomicAdd(dag_cnt(wa) + (size_t)mb * (uint32_t)wa.ntasks + idx, 1u);
       if (old != 0u) {
-        st_flag(a.ctrl + C_ERR, 3u);
-        st_flag(a.ctrl + C_ERRINFO, idx);
+        st_flag(wa.ctrl + C_ERR, 3u);
+        st_flag(wa.ctrl + C_ERRINFO, idx);
       }
     }
-    if (a.trace && tid == 0) {  // development aid: a task must never start before its producers' flags are up
+    if (wa.trace && tid == 0) {  // development aid: a task must never start before its producers' flags are up
       for (int d = 0; d < 3; ++d) {
-        const uint32_t dep = a.tasks[idx].dep[d];
-        if (dep != NONE && ld_flag(a.flags + dep) == 0) {
-          st_flag(a.ctrl + C_ERR, 2u);
-          st_flag(a.ctrl + C_ERRINFO, idx);
+        const uint32_t dep = wa.tasks[idx].dep[d];
+        if (dep != NONE && ld_flag(wa.flags + dep) == 0) {
+          st_flag(wa.ctrl + C_ERR, 2u);
+          st_flag(wa.ctrl + C_ERRINFO, idx);
         }
       }
     }
+#if TGP_DAG_KERNARG
+    run_task(kernarg, mb, idx);
+#else
     if (nB == 1) {
-      run_task(a, idx);
+      run_task(wa, idx);
     } else {
-      const DagArgs m = dag_member(a, mb);
+      const DagArgs m = dag_member(wa, mb);
       run_task(m, idx);
     }
+#endif
     stamp(tr ? tr + 2 : nullptr);
     if (tr) tr[3] = blockIdx.x;
   }
