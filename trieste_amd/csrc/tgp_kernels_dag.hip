@@ -198,6 +198,45 @@ __device__ __forceinline__ DagArgs dag_args(const void* kernarg) {
 }
 #endif
 
+#ifndef TGP_DAG_CHAIN_LOCAL
+#define TGP_DAG_CHAIN_LOCAL 0
+// 1 = run_chain works on a LOCAL copy of the argument block with every field made wave-uniform at entry.  As shipped (0)
+// the chain reads `a.x` through the reference each time: the block lives in scratch and may alias every global store, so
+// the compiler re-loads fields inside the step loop -- 63 flat loads at loop depth 1, most of them dependent pairs on the
+// chain's critical path (a.chain_dep -> chain_dep[j], a.flags -> flags[id], a.trace for every stamp), each behind an
+// s_waitcnt vmcnt(0) lgkmcnt(0) that also drains whatever else is in flight.  Written at the end of round 4 with no GPU
+// budget left: NOT MEASURED, NOT VALIDATED (tools/gpu_r5_first.sh).  With 0 the shipped source text is untouched.
+#endif
+#if TGP_DAG_CHAIN_LOCAL
+#define TGP_DAG_CHAIN_INLINE __forceinline__
+__device__ __forceinline__ int64_t uni64(int64_t v) {
+  const uint64_t u = (uint64_t)v;
+  return (int64_t)(((uint64_t)uni((uint32_t)(u >> 32)) << 32) | uni((uint32_t)u));
+}
+__device__ __forceinline__ DagArgs dag_uniform_copy(const DagArgs& m) {
+  DagArgs a;
+  a.Ap = uniptr(m.Ap);
+  a.Lp = uniptr(m.Lp);
+  a.Wp = uniptr(m.Wp);
+  a.ld = uni64(m.ld);
+  a.NB = (int)uni((uint32_t)m.NB);
+  a.ntasks = (int)uni((uint32_t)m.ntasks);
+  a.tasks = uniptr(m.tasks);
+  a.chain_dep = uniptr(m.chain_dep);
+  a.topo = uniptr(m.topo);
+  a.flags = uniptr(m.flags);
+  a.ctrl = uniptr(m.ctrl);
+  a.info = uniptr(m.info);
+  a.trace = uniptr(m.trace);
+  a.B = (int)uni((uint32_t)m.B);
+  a.mat_stride = uni64(m.mat_stride);
+  a.flags_stride = uni(m.flags_stride);
+  return a;
+}
+#else
+#define TGP_DAG_CHAIN_INLINE
+#endif
+
 // ---- generic tile task ----------------------------------------------------------------------------------------------
 struct TaskU {  // a task descriptor with every field in scalar registers
   uint32_t a_off, b_off, c_off, o_off, nk, flags, a_mat, b_mat, c_mat, o_mat, set;
@@ -359,7 +398,7 @@ __device__ __attribute__((noinline)) void run_task(const DagArgs& a, uint32_t id
 }
 
 // ---- the chain workgroup ------------------------------------------------------------------------------------------
-__device__ bool chain_wait(const DagArgs& a, uint32_t id, volatile uint32_t* ctl) {
+__device__ TGP_DAG_CHAIN_INLINE bool chain_wait(const DagArgs& a, uint32_t id, volatile uint32_t* ctl) {
   if (threadIdx.x == 0) ctl[1] = wait_flag(a, id) ? 1u : 0u;
   __syncthreads();
   const bool ok = ctl[1] != 0;
@@ -567,7 +606,12 @@ __device__ __forceinline__ bool chain_sub(const DagArgs& a, int j, uint32_t peek
   return ctl[1] != 0;
 }
 
+#if TGP_DAG_CHAIN_LOCAL
+__device__ __attribute__((noinline)) void run_chain(const DagArgs& a_mem) {
+  const DagArgs a = dag_uniform_copy(a_mem);
+#else
 __device__ __attribute__((noinline)) void run_chain(const DagArgs& a) {
+#endif
   DAG_LDS_DECL;
   char* const lds = dag_lds;
   double* const S = (double*)lds;
