@@ -159,17 +159,12 @@ static_assert(DAG_CTRL_WORDS >= 64, "control block");
 
 __device__ __forceinline__ uint32_t* dag_cnt(const DagArgs& a) { return a.ctrl + DAG_CTRL_WORDS; }  // [ntasks] start counts
 
-#ifndef TGP_DAG_KERNARG
-#define TGP_DAG_KERNARG 0
-// 1 = run_task (the workers' tile task) reads the launch arguments from the KERNARG segment with scalar loads.  As shipped
-// (0) the noinline functions take `const DagArgs&`: the argument block then lives in scratch (42 scratch accesses per
-// dispatched task in dag_update_kernel, a second 120-byte copy per task of a batched launch, six flat loads at the head of
-// every task; tools/isa_spills.py).  run_chain keeps the reference: with the block in SGPRs the chain, which already
-// fills 256 VGPRs, spills them (224 scratch accesses in its body against 6).  Written at the end of round 4 with no GPU budget left: NOT MEASURED, NOT VALIDATED -- build
-// it (tools/build_exp.sh-style, this TU), run tests/test_gpu_dag.py and tools/bench_update.py before turning it on.  With
-// 0 the preprocessor leaves the shipped source text untouched.
-#endif
-#if TGP_DAG_KERNARG
+// The workers' tile task (run_task) reads the launch arguments from the KERNARG segment with scalar loads.  (Rounds 3 / 4
+// passed `const DagArgs&` to the noinline functions: the argument block then lived in scratch -- 42 scratch accesses per
+// dispatched task, a second 120-byte copy per task of a batched launch, six flat loads at the head of every task.
+// Measured in round 5, profiles/r05_dagk_ab.txt: N = 8192 update 7.42 -> 7.29 ms, a batched launch of fifteen 9.0 -> 8.2 ms,
+// find_best_model_initialization(90) 62 -> 57 ms.)  run_chain keeps the reference: with the block in SGPRs the chain,
+// which already fills 256 VGPRs, spills them.
 static_assert(sizeof(DagArgs) == 120, "dag_args reads the block by offset");
 // the launch arguments from the kernarg segment (explicit arguments start at offset 0): scalar loads only
 __device__ __forceinline__ DagArgs dag_args(const void* kernarg) {
@@ -196,18 +191,11 @@ __device__ __forceinline__ DagArgs dag_args(const void* kernarg) {
   a.flags_stride = (uint32_t)q[14];
   return a;
 }
-#endif
 
-#ifndef TGP_DAG_CHAIN_LOCAL
-#define TGP_DAG_CHAIN_LOCAL 0
-// 1 = run_chain works on a LOCAL copy of the argument block with every field made wave-uniform at entry.  As shipped (0)
-// the chain reads `a.x` through the reference each time: the block lives in scratch and may alias every global store, so
-// the compiler re-loads fields inside the step loop -- 63 flat loads at loop depth 1, most of them dependent pairs on the
-// chain's critical path (a.chain_dep -> chain_dep[j], a.flags -> flags[id], a.trace for every stamp), each behind an
-// s_waitcnt vmcnt(0) lgkmcnt(0) that also drains whatever else is in flight.  Written at the end of round 4 with no GPU
-// budget left: NOT MEASURED, NOT VALIDATED (tools/gpu_r5_first.sh).  With 0 the shipped source text is untouched.
-#endif
-#if TGP_DAG_CHAIN_LOCAL
+// run_chain works on a LOCAL copy of the argument block with every field made wave-uniform at entry.  (Through the
+// reference the block lives in scratch and may alias every global store, so the compiler re-loaded fields inside the
+// step loop -- 63 flat loads at loop depth 1, most of them dependent pairs on the chain's critical path, each behind an
+// s_waitcnt vmcnt(0) lgkmcnt(0).  Measured in round 5, profiles/r05_dagk_ab.txt: N = 4096 update 1.88 -> 1.83 ms.)
 #define TGP_DAG_CHAIN_INLINE __forceinline__
 __device__ __forceinline__ int64_t uni64(int64_t v) {
   const uint64_t u = (uint64_t)v;
@@ -233,21 +221,14 @@ __device__ __forceinline__ DagArgs dag_uniform_copy(const DagArgs& m) {
   a.flags_stride = uni(m.flags_stride);
   return a;
 }
-#else
-#define TGP_DAG_CHAIN_INLINE
-#endif
 
 // ---- generic tile task ----------------------------------------------------------------------------------------------
 struct TaskU {  // a task descriptor with every field in scalar registers
   uint32_t a_off, b_off, c_off, o_off, nk, flags, a_mat, b_mat, c_mat, o_mat, set;
 };
-#if TGP_DAG_KERNARG
 __device__ __attribute__((noinline)) void run_task(const void* kernarg, uint32_t mb, uint32_t idx) {
   const DagArgs a0 = dag_args(kernarg);
   const DagArgs a = a0.B > 1 ? dag_member(a0, (uint32_t)__builtin_amdgcn_readfirstlane(mb)) : a0;
-#else
-__device__ __attribute__((noinline)) void run_task(const DagArgs& a, uint32_t idx) {
-#endif
   DAG_LDS_DECL;
   char* const lds = dag_lds;
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
@@ -606,12 +587,8 @@ __device__ __forceinline__ bool chain_sub(const DagArgs& a, int j, uint32_t peek
   return ctl[1] != 0;
 }
 
-#if TGP_DAG_CHAIN_LOCAL
 __device__ __attribute__((noinline)) void run_chain(const DagArgs& a_mem) {
   const DagArgs a = dag_uniform_copy(a_mem);
-#else
-__device__ __attribute__((noinline)) void run_chain(const DagArgs& a) {
-#endif
   DAG_LDS_DECL;
   char* const lds = dag_lds;
   double* const S = (double*)lds;
@@ -689,12 +666,8 @@ __global__ __launch_bounds__(512) void dag_update_kernel(DagArgs a) {
     }
     return;
   }
-#if TGP_DAG_KERNARG
   const void* const kernarg = (const void*)__builtin_amdgcn_kernarg_segment_ptr();
   const DagArgs wa = dag_args(kernarg);   // the dispatcher's own copy, in scalar registers
-#else
-  const DagArgs& wa = a;
-#endif
   const uint32_t total = (uint32_t)wa.ntasks * nB;
 #pragma unroll 1
   for (;;) {
@@ -736,16 +709,7 @@ __global__ __launch_bounds__(512) void dag_update_kernel(DagArgs a) {
         }
       }
     }
-#if TGP_DAG_KERNARG
     run_task(kernarg, mb, idx);
-#else
-    if (nB == 1) {
-      run_task(wa, idx);
-    } else {
-      const DagArgs m = dag_member(wa, mb);
-      run_task(m, idx);
-    }
-#endif
     stamp(tr ? tr + 2 : nullptr);
     if (tr) tr[3] = blockIdx.x;
   }
