@@ -396,20 +396,40 @@ int tgp_last_kernel_ms(tgp_handle h, double* ms, int* launches);
  *                 never the default and never what the float64 parity claims are made on.
  *   TGP_PREC_I8X5 the same with five digit planes (15 int8 products, digit pairs below 2^-40 dropped); d <= 16.
  *   TGP_PREC_AUTO the split-precision sweep WITH an a-posteriori repair: the int8 kernel prices every candidate's own
- *                 truncation error on the variance (8 standard deviations of  2 2^-32.8 S' sqrt(sum_i c_i^2 S_i^2 (i+1)),
- *                 c = W k*), every candidate whose bound exceeds the parity tolerance 1e-5 var + min(64 eps s_f^2
- *                 (1 + N s_f^2 / s^2), 1e-6 s_f^2) -- and, in a fused arg-max, every candidate whose value interval
- *                 reaches the best lower bound -- is recomputed by the float64 kernel in the same call.  Results are
- *                 inside the parity tolerance candidate by candidate and the arg-max (value and index) is the
- *                 float64 sweep's.  The engine starts on four planes and moves to five (d <= 16), then to float64,
- *                 when a sweep had to recompute more than 5 % of its candidates; tgp_set_hyper / tgp_set_precision
- *                 restart the ladder.  N <= 16384 (int32 accumulators), float64 above. */
+ *                 truncation error on the variance (K_SIGMA = 8 standard deviations of  2 2^-32.8 S' sqrt(sum_i c_i^2
+ *                 S_i^2 (i+1)), c = W k*), every candidate whose bound exceeds the parity tolerance 1e-5 var + min(64
+ *                 eps s_f^2 (1 + N s_f^2 / s^2), 1e-6 s_f^2) -- and, in a fused arg-max, every candidate whose value
+ *                 interval reaches the best lower bound -- is recomputed by the float64 kernel in the same call.  The
+ *                 bound is a STATISTICAL model of the dropped digit pairs (independent errors; measured against 80-bit
+ *                 sums), not a worst case; what it promises -- results inside the parity tolerance candidate by
+ *                 candidate, the float64 arg-max -- holds as far as that model does, and float64 stays the only
+ *                 arithmetic the parity claims are made on.  Every sweep therefore carries a CANARY: one candidate in
+ *                 4096 (pseudo-randomly offset per sweep) is recomputed in float64 whatever its interval says and
+ *                 |var_f64 - var_int8| is compared with that candidate's own bound on the device; a violation moves
+ *                 the engine one rung down -- before the next sweep, and for the synchronising entry points before they
+ *                 return: they repeat their sweeps on the next rung (tgp_get_auto_report).  The ladder: four planes,
+ *                 five (d <= 16), float64; a rung is also left when a sweep had to recompute more than 5 % of its
+ *                 candidates.  tgp_set_precision restarts the ladder, tgp_set_hyper does unless a rung was left under
+ *                 hyper-parameters within a factor two of the new ones.  N <= 16384 (int32 accumulators), float64
+ *                 above. */
 enum tgp_precision { TGP_PREC_F64 = 0, TGP_PREC_I8X4 = 1, TGP_PREC_I8X5 = 2, TGP_PREC_AUTO = 3 };
 int tgp_set_precision(tgp_handle h, int precision);
 /* What was asked for, what the next plain sweep will run (never TGP_PREC_AUTO) and, under AUTO, the fraction of its
  * candidates the last completed sweep recomputed in float64 (-1: none yet / not AUTO).  Under AUTO it needs data
  * (TGP_ERR_STATE before tgp_set_data) and synchronises the handle's stream. */
 int tgp_get_precision(tgp_handle h, int* requested, int* effective, double* repaired_fraction);
+/* K_SIGMA of TGP_PREC_AUTO's per-candidate bound (default 8; restarts the ladder).  Smaller values recompute fewer
+ * candidates and make the canary stricter: with a bound tighter than the arithmetic's real error the canary fires and
+ * the ladder ends on float64 (tests/test_gpu_i8.py drives it that way). */
+int tgp_set_auto_sigma(tgp_handle h, double k_sigma);
+/* The canary of TGP_PREC_AUTO since the ladder last restarted: sampled candidates compared, samples outside their
+ * bound, the worst |var_f64 - var_int8| / bound seen, rungs left BECAUSE of a violation, the current rung (0 four
+ * planes, 1 five, 2 float64; -1 when the precision is not AUTO).  Synchronises the handle's stream.  The reference has
+ * no counterpart: its arithmetic is float64 throughout (trieste/models/gpflow/interface.py:119-124); this is the
+ * run-time check that keeps the emulated arithmetic inside the tolerance the reference's own tests state
+ * (tests/unit/models/gpflow/test_models.py:363-365). */
+int tgp_get_auto_report(tgp_handle h, int64_t* checked, int64_t* violations, double* worst_ratio, int* demotions,
+                        int* level);
 /* Sweep launch policy knob for experiments and tests (0 = default): bit 0 = never use the row-group split of
  * small launches, bit 1 = always use it, bit 2 = joint mode on the first-generation kernel (64-column group slots;
  * dp = 32 always uses it), bit 3 = fused plain launches on the register-staged kernel instead of the LDS-DMA one, bit 4 =

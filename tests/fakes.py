@@ -127,6 +127,16 @@ class FakeEngine:
             return req, req, -1.0
         return req, "i8x4", 0.0
 
+    def set_auto_sigma(self, k_sigma=8.0):
+        if not (k_sigma > 0.0) or not np.isfinite(k_sigma):
+            raise ValueError("k_sigma must be positive and finite")
+        self._auto_sigma = float(k_sigma)
+
+    def get_auto_report(self):
+        """tgp_get_auto_report: the float64 stand-in has nothing to sample."""
+        return dict(checked=0, violations=0, worst_ratio=0.0, demotions=0,
+                    level=0 if getattr(self, "_precision", "f64") == "auto" else -1)
+
     def clone_from(self, other):
         if not isinstance(other, FakeEngine):
             raise TypeError(f"can only clone from an engine, got {other!r}")

@@ -226,4 +226,57 @@ def test_auto_precision_on_the_headline_model():
         print(f"[margin] auto on the headline model, noise {noise:g}: {eff}; recomputed fraction predict {f_pred:.2e}, "
               f"arg-max {f_arg:.2e}, arg-max at the median incumbent {f_mid:.2e}")
         assert eff == "i8x4" and max(f_pred, f_arg, f_mid) < 0.01
+        # the canary: every sweep recomputed its sample (one candidate in 4096) in float64 and compared it with the bound the
+        # int8 kernel priced it at -- nothing outside, the worst sample well inside, the ladder still on its first rung
+        rep = eng.get_auto_report()
+        print(f"[margin] auto canary on the headline model, noise {noise:g}: {rep}")
+        assert rep["checked"] >= 4 * (Xq.shape[0] // 4096) and rep["violations"] == 0 and rep["demotions"] == 0, rep
+        assert rep["level"] == 0 and 0.0 <= rep["worst_ratio"] < 1.0, rep
         eng.set_precision("f64")
+        assert eng.get_auto_report()["level"] == -1
+
+
+@pytest.mark.parametrize("cfg", [CONFIGS[2], CONFIGS[3], CONFIGS[0]], ids=[CONFIGS[2][0], CONFIGS[3][0], CONFIGS[0][0]])
+def test_auto_canary_fires_when_its_error_model_is_wrong_for_the_input(cfg):
+    """The per-candidate bound of TGP_PREC_AUTO is K_SIGMA = 8 standard deviations of a STATISTICAL model of the dropped
+    digit pairs.  K* is generated inside the kernel, so digits aligned on purpose cannot be fed through the boundary; what
+    the run-time check must catch is `the float64 value lies outside the bound`, and that is driven here from the other
+    side: with K_SIGMA = 0.02 the bound is 400 times tighter than the arithmetic's real error, i.e. the model is wrong for
+    every candidate.  The canary (one candidate in 4096, recomputed in float64 inside the sweep and compared on the device)
+    must fire on the first sweep, the ladder must leave its rungs -- five planes fail the same way -- and the values the
+    SAME call returns must hold the plain parity tolerance: the synchronising entry points repeat their sweeps on the next
+    rung before they return."""
+    _, obj, d, kind, N, noise = cfg
+    eng, st, Xq = _setup(obj, d, kind, N, noise, M=3 * 4096 + 77)
+    floor = cancellation_floor(N, 1.0, noise)
+    om, ov = O.predict(st, Xq)
+    eta_mid = float(np.median(om))
+    want = eng.acq_argmax("ei", eta_mid, Xq)[:2]
+    eng.set_precision("auto")
+    eng.set_auto_sigma(0.02)
+    assert eng.get_precision()[:2] == ("auto", "i8x4") and eng.get_auto_report()["checked"] == 0
+    mean, var = eng.predict(Xq)              # first sweep: samples break their bounds -> five planes -> float64 -> returned
+    rep = eng.get_auto_report()
+    print(f"[margin] auto canary, bound 400 x too tight, {cfg[0]}: {rep}; in effect {eng.get_precision()[1]}")
+    assert rep["violations"] >= 1 and rep["demotions"] >= 1 and rep["worst_ratio"] > 1.0, rep
+    assert rep["level"] >= 1 and eng.get_precision()[1] in ("i8x5", "f64"), rep
+    assert_close(var, ov, atol=floor, what="var returned by the call whose canary fired")
+    assert_close(mean, om, atol=floor * 10, what="mean returned by the call whose canary fired")
+    got = eng.acq_argmax("ei", eta_mid, Xq)[:2]
+    assert got[1] == want[1] and abs(got[0] - want[0]) <= 1e-12 * abs(want[0]), (got, want)
+    # the fused arg-max repeats its sweep as well: a fresh ladder, first call
+    eng.set_auto_sigma(0.02)
+    assert eng.get_precision()[1] == "i8x4"
+    got = eng.acq_argmax("ei", eta_mid, Xq)[:2]
+    assert got[1] == want[1] and abs(got[0] - want[0]) <= 1e-12 * abs(want[0]), (got, want)
+    assert eng.get_auto_report()["demotions"] >= 1
+    # the default bound restarts the ladder and holds on the same input
+    eng.set_auto_sigma(8.0)
+    assert eng.get_precision()[1] == "i8x4"
+    mean, var = eng.predict(Xq)
+    assert_close(var, ov, atol=floor, what="var under auto, default K_SIGMA")
+    rep = eng.get_auto_report()
+    assert rep["violations"] == 0 and rep["demotions"] == 0 and rep["checked"] >= 3, rep
+    with pytest.raises(ValueError):
+        eng.set_auto_sigma(0.0)
+    eng.set_precision("f64")

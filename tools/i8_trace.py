@@ -21,7 +21,7 @@ for _ in range(2):
     eng.acq_argmax("ei", eta, Xq)
 print("kernel ms", eng.last_kernel_ms()[0], "for", M, "candidates")
 lib = ctypes.CDLL(_lib.LIB_PATH)
-NT, S = 128, 8
+NT, S = 128, 12
 buf = np.zeros((2, NT, 8, S), dtype=np.uint64)
 rc = lib.tgp_dev_i8_trace(buf.ctypes.data_as(ctypes.c_void_p))
 assert rc == 0, rc
@@ -32,6 +32,7 @@ for wg in range(2):
     gen = (info >> 32) & 1
     diag = (info >> 16) & 1
     st = t[:, :, :7]
+    st_all = t
     step = st[:, :, 6] - st[:, :, 0]
     nxt = st[1:, :, 0] - st[:-1, :, 6]
     print(f"== workgroup {wg}: step (stamp 0 -> 6) mean {step.mean():.0f} cycles, median {np.median(step):.0f}; "
@@ -53,6 +54,13 @@ for wg in range(2):
             else:
                 dd = b - a
             print(f"     {nm:12s} mean {dd.mean():7.0f}   per wave " + " ".join(f"{x:6.0f}" for x in dd.mean(axis=0)))
+    gsel = st_all[gen[:, 0] == 1]
+    if gsel.size:
+        g0, g1, g2 = gsel[:, :, 8], gsel[:, :, 9], gsel[:, :, 10]
+        ok = g0 > 0
+        print("  inside generate_B, per wave: start after step start", " ".join(f"{x:6.0f}" for x in np.where(ok, g0 - gsel[:, :, 0], 0).mean(axis=0)))
+        print("     distances (scalar loads, LDS reads, 16 x d FMAs)  ", " ".join(f"{x:6.0f}" for x in np.where(ok, g1 - g0, 0).mean(axis=0)))
+        print("     4 x kernel + digits + LDS writes                 ", " ".join(f"{x:6.0f}" for x in np.where(ok, g2 - g1, 0).mean(axis=0)))
     # skew: when does each wave arrive at the barrier relative to the last
     arr = st[:, :, 5] - st[:, :, 5].max(axis=1, keepdims=True)
     print("  arrival at the barrier relative to the last wave, per wave:", " ".join(f"{x:6.0f}" for x in arr.mean(axis=0)))

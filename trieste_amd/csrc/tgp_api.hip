@@ -133,6 +133,7 @@ int set_device(tgp_handle h) {
   // this thread (another library's, or a failed cleanup call of a garbage-collected handle) would be
   // reported by the next launch check of this call.  Every entry point starts from a clean slate.
   (void)hipGetLastError();
+  h->auto_pinned = false;  // (a call that failed between sweep_blocks and its launch must not freeze the next call's choice)
   return TGP_OK;
 }
 
@@ -169,6 +170,15 @@ int auto_rung_precision(tgp_handle h) {
   if (h->auto_level == 1 && h->dp <= 16) return TGP_PREC_I8X5;
   return TGP_PREC_F64;
 }
+static void auto_restart(tgp_handle h) {   // the ladder starts over at four planes
+  h->auto_level = 0;
+  ++h->auto_epoch;
+  h->rep_last_M = h->rep_last_count = 0;
+  h->can_checked = h->can_viol = h->can_checked_total = h->can_viol_total = 0;
+  h->can_worst = 0.0;
+  h->can_demotions = 0;
+  h->auto_hyp.clear();
+}
 hipError_t resolve_precision(tgp_handle h) {
   if (h->precision_req != TGP_PREC_AUTO) {
     h->precision = h->precision_req;
@@ -177,22 +187,46 @@ hipError_t resolve_precision(tgp_handle h) {
   }
   if (h->auto_pinned) return hipSuccess;  // already resolved for the call in progress (sweep_blocks)
   if (h->rep_host) {
-    // {count, M, epoch, -}: the last COMPLETED repaired sweep's report (stream-ordered copy into pinned memory; a torn or
-    // stale read only delays the decision by one sweep)
+    // the last COMPLETED repaired sweep's report (stream-ordered copy into pinned memory; a torn or stale read only
+    // delays the decision by one sweep)
     const volatile int64_t* r = h->rep_host;
-    const int64_t cnt = r[0], M = r[1], ep = r[2];
+    const int64_t cnt = r[0], M = r[1], ep = r[2], viol = r[3], chk = r[4], wbits = r[5];
     if (ep == (int64_t)h->auto_epoch && M > 0) {
       h->rep_last_count = cnt;
       h->rep_last_M = M;
-      if (M >= 1024 && (double)cnt > AUTO_DEMOTE * (double)M && h->auto_level < 2) {
+      h->can_viol = viol;
+      h->can_checked = chk;
+      double worst;
+      memcpy(&worst, &wbits, sizeof(double));
+      if (worst == worst && worst > h->can_worst) h->can_worst = worst;
+      // a rung is left when the repair costs more than the wider arithmetic saves, or when a sampled candidate's float64
+      // value lay outside the bound the int8 kernel priced it at: the error model is wrong for this input
+      const bool costly = M >= 1024 && (double)cnt > AUTO_DEMOTE * (double)M;
+      if ((costly || viol > 0) && h->auto_level < 2) {
         h->auto_level += (h->auto_level == 0 && h->dp > 16) ? 2 : 1;
         ++h->auto_epoch;
+        h->can_checked_total += chk;
+        h->can_viol_total += viol;
+        h->can_checked = h->can_viol = 0;
+        if (viol > 0) ++h->can_demotions;
+        h->auto_hyp.assign(1, h->variance / h->noise);
+        h->auto_hyp.insert(h->auto_hyp.end(), h->ls.begin(), h->ls.end());
       }
     }
   }
   h->precision = auto_rung_precision(h);
   h->repair = h->precision != TGP_PREC_F64;
   return hipSuccess;
+}
+// after a synchronising call under TGP_PREC_AUTO: did a canary of the sweeps just completed fire?  Then the rung is left
+// NOW and the caller repeats its sweeps, so that what it returns was computed on a rung whose samples all held
+static bool auto_canary_tripped(tgp_handle h) {
+  if (h->precision_req != TGP_PREC_AUTO || !h->repair || !h->rep_host || h->auto_level >= 2) return false;
+  const volatile int64_t* r = h->rep_host;
+  if (r[2] != (int64_t)h->auto_epoch || r[3] <= 0) return false;
+  h->auto_pinned = false;
+  (void)resolve_precision(h);
+  return true;
 }
 
 // number of per-block winner slots a fused arg-max over `a` fills (one per candidate block of the kernel in use)
@@ -249,6 +283,7 @@ hipError_t launch_sweep_i8_timed(tgp_handle h, SweepArgs& am) {
     if ((e = h->s_kcache.reserve((size_t)wgrid * (size_t)Npad * 64 * planes)) != hipSuccess) return e;
     am.kcache = h->s_kcache.as<double>();
     am.rep_ub = nullptr;
+    am.canary_rec = nullptr;
     (void)hipEventRecord(h->ev0, h->stream);
     switch (h->kind) {
       case TGP_RBF: e = launch_sweep_i8_kind0(h->stream, am, wgrid, planes); break;
@@ -289,30 +324,39 @@ hipError_t launch_sweep_i8_timed(tgp_handle h, SweepArgs& am) {
   const size_t kc_i8 = (size_t)wgrid * (size_t)Npad * 64 * planes, kc_f64 = (size_t)fgrid * (size_t)Npad * SW_BN * sizeof(double);
   if ((e = h->s_kcache.reserve(std::max(kc_i8, kc_f64))) != hipSuccess) return e;
   if ((e = h->s_part.reserve((size_t)cap_blocks * g * 256 * sizeof(double))) != hipSuccess) return e;
-  // ub [M], vals [M], recomputed (mean, var, acq) [3][M], list [M] (int64), gathered candidates [M][d]
-  if ((e = h->s_rep.reserve((size_t)M * (6 + d) * sizeof(double) + 64)) != hipSuccess) return e;
-  if ((e = h->s_rep_stats.reserve(64)) != hipSuccess) return e;
+  // ub [M], vals [M], recomputed (mean, var, acq) [3][M], list [M] (int64), gathered candidates [M][d], canary records
+  const int64_t n_can = (M + I8_CANARY_PERIOD - 1) / I8_CANARY_PERIOD + 2;
+  if ((e = h->s_rep.reserve((size_t)(M * (6 + d) + 2 * n_can) * sizeof(double) + 64)) != hipSuccess) return e;
+  if ((e = h->s_rep_stats.reserve(128)) != hipSuccess) return e;
   if (!h->rep_host && (e = hipHostMalloc((void**)&h->rep_host, 64, hipHostMallocDefault)) != hipSuccess) return e;
   double* ub = h->s_rep.as<double>();
   double* vals = ub + M;          // acquisition values when the caller wants none written
   double* rout = vals + M;        // [3][M] mean, var, acq of the recomputed candidates
   int64_t* list = (int64_t*)(rout + 3 * M);
   double* Xg = (double*)(list + M);
-  int64_t* stats = h->s_rep_stats.as<int64_t>();   // {count, M, epoch, -}
-  double* Lslot = (double*)(stats + 4);             // {L, its index}
+  double* crec = Xg + M * d;                        // [n_can][2]: the sampled candidates' int8 variance and bound
+  int64_t* stats = h->s_rep_stats.as<int64_t>();   // {count, M, epoch, canary violations, checked, worst ratio, -, -}
+  double* Lslot = (double*)(stats + 8);             // {L, its index}
+  // the sample of this sweep: candidates j with (j + off) % 4096 == 0, off from a counter through splitmix64
+  uint64_t z = (h->canary_seq++ + 0x9E3779B97F4A7C15ull) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  const int64_t can_off = (int64_t)((z ^ (z >> 31)) & (uint64_t)(I8_CANARY_PERIOD - 1));
+  am.canary_rec = crec;
+  am.canary_off = can_off;
   const double v = h->variance, eps = 2.220446049250313e-16;
   am.rep_ub = ub;
   am.rep_floor = std::min(64.0 * eps * v * (1.0 + (double)h->N * v / h->noise), 1e-6 * v);
   // K_SIGMA = 8 standard deviations of the error model (tools/ozaki_tight.py: observed / model rms = 0.95 ... 0.97,
   // max over 2048 candidates 3.5); dropped digit pairs: 3 at weight 2^-32 (four planes), 4 at 2^-40 (five)
-  am.rep_scale = 8.0 * 2.0 * (planes == 4 ? std::exp2(-32.8) : std::exp2(-40.6)) * (I8_TIGHT * v);
+  am.rep_scale = h->auto_sigma * 2.0 * (planes == 4 ? std::exp2(-32.8) : std::exp2(-40.6)) * (I8_TIGHT * v);
   double* user_acq = am.acq_out;
   double* ublk_val = am.blk_val;
   int64_t* ublk_idx = am.blk_idx;
   if (am.acq_kind >= 0 && !am.acq_out) am.acq_out = vals;
   am.kcache = h->s_kcache.as<double>();
   (void)hipEventRecord(h->ev0, h->stream);
-  launch_repair_begin(h->stream, stats, M, (int64_t)h->auto_epoch);
+  launch_repair_begin(h->stream, stats, M, (int64_t)h->auto_epoch, h->canary_epoch != h->auto_epoch);
+  h->canary_epoch = h->auto_epoch;
   switch (h->kind) {
     case TGP_RBF: e = launch_sweep_i8_kind0(h->stream, am, wgrid, planes); break;
     case TGP_MATERN12: e = launch_sweep_i8_kind1(h->stream, am, wgrid, planes); break;
@@ -321,14 +365,14 @@ hipError_t launch_sweep_i8_timed(tgp_handle h, SweepArgs& am) {
   }
   if (e != hipSuccess) return e;
   if (ublk_val) launch_argmax_final(h->stream, ublk_val, ublk_idx, blocks, Lslot, (int64_t*)(Lslot + 1));
-  launch_repair_flag(h->stream, ub, M, ublk_val ? Lslot : nullptr, list, stats);
+  launch_repair_flag(h->stream, ub, M, ublk_val ? Lslot : nullptr, list, stats, can_off);
   launch_repair_gather(h->stream, am.Xq, d, list, stats, M, Xg);
   b.m = am.m;
   b.Xq = Xg;
   b.M = M;
   b.M_dev = stats;
   b.mean_out = am.mean_out ? rout : nullptr;
-  b.var_out = am.var_out ? rout + M : nullptr;
+  b.var_out = rout + M;   // (always: the canary compares the recomputed variances)
   b.acq_out = am.acq_kind >= 0 ? rout + 2 * M : nullptr;
   b.acq_kind = am.acq_kind;
   b.acq_param = am.acq_param;
@@ -337,10 +381,13 @@ hipError_t launch_sweep_i8_timed(tgp_handle h, SweepArgs& am) {
   b.kcache = h->s_kcache.as<double>();
   if ((e = launch_sweep_kind(h, b, false, fgrid)) != hipSuccess) return e;
   launch_sweep_combine(h->stream, b, std::min<int64_t>(cap_blocks, 2048));
-  launch_repair_scatter(h->stream, list, stats, M, b.mean_out, b.var_out, b.acq_out, am.mean_out, am.var_out, am.acq_out);
+  // float64 against int8 on the sampled candidates; slack: the float64 kernels' own rounding (two summation orders)
+  launch_repair_canary(h->stream, list, stats, M, b.var_out, crec, can_off, 1e-12 * v);
+  launch_repair_scatter(h->stream, list, stats, M, b.mean_out, am.var_out ? b.var_out : nullptr, b.acq_out, am.mean_out,
+                        am.var_out, am.acq_out);
   if (ublk_val) launch_values_argmax(h->stream, am.acq_out, M, am.index_base, ublk_val, ublk_idx, blocks);
   (void)hipEventRecord(h->ev1, h->stream);
-  e = hipMemcpyAsync(h->rep_host, stats, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream);
+  e = hipMemcpyAsync(h->rep_host, stats, 8 * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream);
   am.acq_out = user_acq;
   h->last_launches = 1;
   h->last_ms = -1.0;
@@ -846,10 +893,32 @@ int tgp_set_precision(tgp_handle h, int precision) {
   h->precision_req = precision;
   h->precision = precision == TGP_PREC_AUTO ? TGP_PREC_F64 : precision;  // AUTO: resolved at the next plain sweep
   h->repair = false;
-  h->auto_level = 0;  // AUTO restarts its ladder at four planes
-  ++h->auto_epoch;
+  auto_restart(h);  // AUTO restarts its ladder at four planes
   h->auto_pinned = false;
-  h->rep_last_M = h->rep_last_count = 0;
+  return TGP_OK;
+}
+
+int tgp_set_auto_sigma(tgp_handle h, double k_sigma) {
+  if (!h) return TGP_ERR_ARG;
+  if (!(k_sigma > 0.0) || !std::isfinite(k_sigma)) return fail(h, TGP_ERR_ARG, "k_sigma must be positive and finite");
+  h->auto_sigma = k_sigma;
+  auto_restart(h);
+  h->auto_pinned = false;
+  return TGP_OK;
+}
+
+int tgp_get_auto_report(tgp_handle h, int64_t* checked, int64_t* violations, double* worst_ratio, int* demotions, int* level) {
+  if (!h) return TGP_ERR_ARG;
+  if (int rc = set_device(h)) return rc;
+  if (h->precision_req == TGP_PREC_AUTO && h->have_data) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // the last sweep's report has landed
+    HIPCHK(h, resolve_precision(h));
+  }
+  if (checked) *checked = h->can_checked_total + h->can_checked;
+  if (violations) *violations = h->can_viol_total + h->can_viol;
+  if (worst_ratio) *worst_ratio = h->can_worst;
+  if (demotions) *demotions = h->can_demotions;
+  if (level) *level = h->precision_req == TGP_PREC_AUTO ? h->auto_level : -1;
   return TGP_OK;
 }
 
@@ -934,8 +1003,19 @@ int tgp_set_hyper(tgp_handle h, double variance, const double* lengthscales, dou
   HIPCHK(h, h->d_ls.reserve(h->dp * sizeof(double)));
   HIPCHK(h, hipMemcpy(h->d_ls.p, lsp.data(), h->dp * sizeof(double), hipMemcpyHostToDevice));
   h->have_hyper = true;
-  h->auto_level = 0;  // TGP_PREC_AUTO restarts its ladder: new hyper-parameters, new conditioning
-  ++h->auto_epoch;
+  {
+    // TGP_PREC_AUTO restarts its ladder with new hyper-parameters (new conditioning) -- unless a rung was left under
+    // hyper-parameters within a factor two of these (variance / noise, every lengthscale): a BO loop whose refit moves
+    // them a little would otherwise re-pay the failed rung's sweep plus its repair at every step
+    bool keep = h->auto_level > 0 && h->auto_hyp.size() == (size_t)h->d + 1;
+    if (keep) {
+      auto far = [](double a, double b) { return !(a < 2.0 * b && b < 2.0 * a); };
+      keep = !far(variance / noise_variance, h->auto_hyp[0]);
+      for (int c = 0; keep && c < h->d; ++c) keep = !far(lengthscales[c], h->auto_hyp[1 + c]);
+    }
+    if (keep) ++h->auto_epoch;   // same rung, fresh counters on the device
+    else auto_restart(h);
+  }
   h->have_data = false;  // factorisation is stale
   return TGP_OK;
 }
@@ -1513,13 +1593,17 @@ static int sweep_common(tgp_handle h, const double* Xq, int64_t M, double* mean,
   if (int rc = stage_out_prepare(h, h->s_out3, acq, M, where, &a.acq_out)) return rc;
   a.acq_kind = acq_kind;
   a.acq_param = param;
-  HIPCHK(h, launch_sweep_timed(h, a, false));
-  if (acq_kind >= 0) apply_penalization(h, a.acq_out, dXq, M);
-  if (int rc = stage_out_finish(h, a.mean_out, mean, M, where)) return rc;
-  if (int rc = stage_out_finish(h, a.var_out, var, M, where)) return rc;
-  if (int rc = stage_out_finish(h, a.acq_out, acq, M, where)) return rc;
-  if (int rc = sync(h)) return rc;
-  HIPCHK(h, hipGetLastError());
+  for (int attempt = 0;; ++attempt) {
+    HIPCHK(h, launch_sweep_timed(h, a, false));
+    if (acq_kind >= 0) apply_penalization(h, a.acq_out, dXq, M);
+    if (int rc = stage_out_finish(h, a.mean_out, mean, M, where)) return rc;
+    if (int rc = stage_out_finish(h, a.var_out, var, M, where)) return rc;
+    if (int rc = stage_out_finish(h, a.acq_out, acq, M, where)) return rc;
+    if (int rc = sync(h)) return rc;
+    HIPCHK(h, hipGetLastError());
+    if (attempt < 2 && auto_canary_tripped(h)) continue;  // TGP_PREC_AUTO: a sample broke its bound -> next rung, again
+    break;
+  }
   return TGP_OK;
 }
 
@@ -1572,10 +1656,14 @@ int tgp_acq_values(tgp_handle h, int acq_kind, double param, const double* Xq, i
     double* dout;
     if (int rc = stage_in(h, h->s_in, Xq, (size_t)M * h->d, where, &dXq)) return rc;
     if (int rc = stage_out_prepare(h, h->s_out3, out, M, where, &dout)) return rc;
-    if (int rc = acq_values_device(h, acq_kind, param, dXq, M, dout)) return rc;
-    if (int rc = stage_out_finish(h, dout, out, M, where)) return rc;
-    if (int rc = sync(h)) return rc;
-    HIPCHK(h, hipGetLastError());
+    for (int attempt = 0;; ++attempt) {
+      if (int rc = acq_values_device(h, acq_kind, param, dXq, M, dout)) return rc;
+      if (int rc = stage_out_finish(h, dout, out, M, where)) return rc;
+      if (int rc = sync(h)) return rc;
+      HIPCHK(h, hipGetLastError());
+      if (attempt < 2 && auto_canary_tripped(h)) continue;
+      break;
+    }
     return TGP_OK;
   }
   return sweep_common(h, Xq, M, nullptr, nullptr, out, acq_kind, param, where);
@@ -1792,13 +1880,17 @@ int tgp_acq_argmax(tgp_handle h, int acq_kind, double param, const double* Xq, i
   HIPCHK(h, h->s_small.reserve(64));
   double* fv = h->s_small.as<double>();
   int64_t* fi = (int64_t*)(fv + 1);
-  if (int rc = enqueue_argmax(h, acq_kind, param, dXq, M, index_base, fv, fi)) return rc;
   double hv;
   int64_t hi;
-  HIPCHK(h, hipMemcpyAsync(&hv, fv, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipMemcpyAsync(&hi, fi, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-  if (int rc = sync(h)) return rc;
-  HIPCHK(h, hipGetLastError());
+  for (int attempt = 0;; ++attempt) {
+    if (int rc = enqueue_argmax(h, acq_kind, param, dXq, M, index_base, fv, fi)) return rc;
+    HIPCHK(h, hipMemcpyAsync(&hv, fv, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(&hi, fi, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    if (int rc = sync(h)) return rc;
+    HIPCHK(h, hipGetLastError());
+    if (attempt < 2 && auto_canary_tripped(h)) continue;  // TGP_PREC_AUTO: a sample broke its bound -> next rung, again
+    break;
+  }
   if (best_val) *best_val = hv;
   if (best_idx) *best_idx = hi;
   if (best_x) {
@@ -1844,19 +1936,21 @@ int tgp_acq_topk(tgp_handle h, int acq_kind, double param, const double* Xq, int
   // acquisition values stay on the device (8 B / candidate), then k extraction passes
   HIPCHK(h, h->s_out3.reserve((size_t)M * sizeof(double)));
   double* dvals = h->s_out3.as<double>();
-  {
-    const double* dXq;
-    if (int rc = stage_in(h, h->s_in, Xq, (size_t)M * h->d, where, &dXq)) return rc;
-    if (int rc = acq_values_device(h, acq_kind, param, dXq, M, dvals)) return rc;
-  }
+  const double* dXq;
+  if (int rc = stage_in(h, h->s_in, Xq, (size_t)M * h->d, where, &dXq)) return rc;
   HIPCHK(h, h->s_small.reserve((size_t)k * 16 + 64));
   double* fv = h->s_small.as<double>();       // [k] winners' values
   int64_t* fi = (int64_t*)(fv + k);           // [k] winners' indices
-  if (int rc = enqueue_topk_of_values(h, dvals, M, index_base, k, fv, fi)) return rc;
-  HIPCHK(h, hipMemcpyAsync(vals, fv, (size_t)k * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipMemcpyAsync(idx, fi, (size_t)k * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-  if (int rc = sync(h)) return rc;
-  HIPCHK(h, hipGetLastError());
+  for (int attempt = 0;; ++attempt) {
+    if (int rc = acq_values_device(h, acq_kind, param, dXq, M, dvals)) return rc;
+    if (int rc = enqueue_topk_of_values(h, dvals, M, index_base, k, fv, fi)) return rc;
+    HIPCHK(h, hipMemcpyAsync(vals, fv, (size_t)k * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(idx, fi, (size_t)k * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    if (int rc = sync(h)) return rc;
+    HIPCHK(h, hipGetLastError());
+    if (attempt < 2 && auto_canary_tripped(h)) continue;
+    break;
+  }
   return TGP_OK;
 }
 

@@ -88,8 +88,19 @@ struct tgp_handle_s {
   int auto_level = 0;
   uint64_t auto_epoch = 1;    // bumps whenever the rung changes or the ladder restarts: stale reports are ignored
   bool auto_pinned = false;   // resolved by sweep_blocks for the call in progress
-  int64_t* rep_host = nullptr;  // pinned: {count, M, epoch, -} of the last completed repaired sweep
+  int64_t* rep_host = nullptr;  // pinned: {count, M, epoch, canary violations, checked, worst ratio bits, -, -} of the last completed repaired sweep
   int64_t rep_last_M = 0, rep_last_count = 0;
+  // the canary (tgp_api.hip launch_sweep_i8_timed): one candidate in 4096 of every AUTO sweep is recomputed in float64 and
+  // compared with the bound the int8 kernel priced it at; a violation demotes the ladder
+  double auto_sigma = 8.0;       // K_SIGMA of the per-candidate bound (tgp_set_auto_sigma)
+  uint64_t canary_seq = 0;       // the next sweep's sample offset comes from this counter
+  uint64_t canary_epoch = 0;     // the rung (auto_epoch) whose canary words are live on the device
+  int64_t can_checked = 0, can_viol = 0;              // the current rung, as of the last report read
+  int64_t can_checked_total = 0, can_viol_total = 0;  // rungs left since the ladder restarted
+  double can_worst = 0.0;        // worst |d var| / bound seen since the ladder restarted
+  int can_demotions = 0;         // rungs left BECAUSE of a violation since the ladder restarted
+  std::vector<double> auto_hyp;  // (variance / noise, lengthscales) when a rung was last left: tgp_set_hyper keeps the rung
+                                 // while the new hyper-parameters stay within a factor two of these
   DevBuf s_rep, s_rep_stats;
   DevBuf d_wq, d_rs;
   uint64_t wq_version = 0;

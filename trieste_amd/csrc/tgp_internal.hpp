@@ -65,11 +65,17 @@ struct SweepArgs {
   // else the upper end of its acquisition value's interval; the block winners then carry the LOWER ends.
   double* rep_ub;         // [M] or null (null: the plain emulated-precision sweep, no bounds)
   double rep_scale, rep_floor;
+  // the canary of TGP_PREC_AUTO: candidate j is a sample when (j + canary_off) % 4096 == 0; the int8 kernel leaves its
+  // (variance, bound) in canary_rec[2 ((j + canary_off) / 4096)], it is recomputed in float64 with the repair list and
+  // repair_canary_kernel compares the two (null: no samples)
+  double* canary_rec;
+  int64_t canary_off;
   const int64_t* M_dev;   // SPLIT instantiation + combine kernel: the candidate count lives on the device (the
                           // repair pass over the flagged candidates is enqueued without a host round trip)
 };
 constexpr double I8_TIGHT = 1.0078125;  // digit-plane scales S_i = I8_TIGHT max_k |W_ik|, S' = I8_TIGHT variance: the
                                         // balanced digits reach |q| <= 0x7f7f7f7f = 0.99609 2^31 > 2^31 / I8_TIGHT
+constexpr int64_t I8_CANARY_PERIOD = 4096;  // one sampled candidate in 4096 (a power of two)
 void launch_sweep_combine(hipStream_t s, const SweepArgs& a, int64_t nblk);
 
 // ---- linalg (tgp_kernels_linalg.hip) ----
@@ -219,10 +225,16 @@ size_t dag_lds_bytes();
 // rs: [2][Npad] -- row scales S_i, then the row weights S_i^2 (i + 1) of the a-posteriori error model
 void launch_w_digits(hipStream_t s, const double* W, int64_t N, int64_t Npad, double* rs, void* Wq, int planes);
 // ---- a-posteriori repair of the split-precision sweep (tgp_kernels_misc.hip) ----
-// stats [4]: {count (zeroed here), M, tag, 0}
-void launch_repair_begin(hipStream_t s, int64_t* stats, int64_t M, int64_t tag);
-// list [<= M]: indices j with ub[j] == +inf or ub[j] >= *L (L null: only +inf); count = stats[0]
-void launch_repair_flag(hipStream_t s, const double* ub, int64_t M, const double* L, int64_t* list, int64_t* stats);
+// stats [8]: {count (zeroed here), M, tag, canary violations, canaries checked, worst |d var| / bound as the bits of a
+// double, -, -}; the canary words accumulate until `reset_canary`
+void launch_repair_begin(hipStream_t s, int64_t* stats, int64_t M, int64_t tag, bool reset_canary);
+// list [<= M]: indices j with ub[j] == +inf or ub[j] >= *L (L null: only +inf) or (j + canary_off) % 4096 == 0
+// (canary_off < 0: no samples); count = stats[0]
+void launch_repair_flag(hipStream_t s, const double* ub, int64_t M, const double* L, int64_t* list, int64_t* stats,
+                        int64_t canary_off);
+// the sampled candidates among list[0 .. stats[0]): |rvar[r] - rec var| against rec bound + slack -> stats[3..5]
+void launch_repair_canary(hipStream_t s, const int64_t* list, int64_t* stats, int64_t cap, const double* rvar,
+                          const double* rec, int64_t canary_off, double slack);
 void launch_repair_gather(hipStream_t s, const double* Xq, int d, const int64_t* list, const int64_t* count, int64_t cap,
                           double* Xg);
 void launch_repair_scatter(hipStream_t s, const int64_t* list, const int64_t* count, int64_t cap, const double* rmean,

@@ -789,17 +789,19 @@ __global__ void merge_winners_kernel(const double* __restrict__ gathered, int P,
 // end of the interval its acquisition value lies in; *L = the largest LOWER end over the sweep.  Whatever could still
 // be the float64 arg-max (ub >= L) and whatever violates the tolerance goes on a list, is recomputed by the float64
 // sweep (SPLIT instantiation, count on the device) and scattered back.
-__global__ void repair_begin_kernel(int64_t* stats, int64_t M, int64_t tag) {
+// stats: {count, M, epoch tag, canary violations, canaries checked, worst |d var| / bound (bits of a double), -, -}; the
+// canary words accumulate over the sweeps of one rung of the ladder (reset_canary: the rung is new)
+__global__ void repair_begin_kernel(int64_t* stats, int64_t M, int64_t tag, int reset_canary) {
   stats[0] = 0;
   stats[1] = M;
   stats[2] = tag;
-  stats[3] = 0;
+  if (reset_canary) stats[3] = stats[4] = stats[5] = 0;
 }
-void launch_repair_begin(hipStream_t s, int64_t* stats, int64_t M, int64_t tag) {
-  hipLaunchKernelGGL(repair_begin_kernel, dim3(1), dim3(1), 0, s, stats, M, tag);
+void launch_repair_begin(hipStream_t s, int64_t* stats, int64_t M, int64_t tag, bool reset_canary) {
+  hipLaunchKernelGGL(repair_begin_kernel, dim3(1), dim3(1), 0, s, stats, M, tag, reset_canary ? 1 : 0);
 }
 __global__ __launch_bounds__(256) void repair_flag_kernel(const double* __restrict__ ub, int64_t M, const double* L,
-                                                          int64_t* __restrict__ list, int64_t* stats) {
+                                                          int64_t* __restrict__ list, int64_t* stats, int64_t canary_off) {
   const double Lv = L ? *L : INFINITY;
   const int lane = threadIdx.x & 63;
   const int64_t stride = (int64_t)gridDim.x * 256;
@@ -808,7 +810,8 @@ __global__ __launch_bounds__(256) void repair_flag_kernel(const double* __restri
     bool flag = false;
     if (i < M) {
       const double u = ub[i];
-      flag = u == INFINITY || (Lv > -INFINITY && Lv < INFINITY && u >= Lv);
+      flag = u == INFINITY || (Lv > -INFINITY && Lv < INFINITY && u >= Lv) ||
+             (canary_off >= 0 && ((i + canary_off) & (I8_CANARY_PERIOD - 1)) == 0);
     }
     // wave-aggregated append: one atomic per wave
     const unsigned long long mask = __ballot(flag);
@@ -821,9 +824,33 @@ __global__ __launch_bounds__(256) void repair_flag_kernel(const double* __restri
     }
   }
 }
-void launch_repair_flag(hipStream_t s, const double* ub, int64_t M, const double* L, int64_t* list, int64_t* stats) {
+void launch_repair_flag(hipStream_t s, const double* ub, int64_t M, const double* L, int64_t* list, int64_t* stats,
+                        int64_t canary_off) {
   const int64_t blocks = std::min<int64_t>((M + 255) / 256, 1024);
-  hipLaunchKernelGGL(repair_flag_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ub, M, L, list, stats);
+  hipLaunchKernelGGL(repair_flag_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ub, M, L, list, stats, canary_off);
+}
+// The canary of TGP_PREC_AUTO: the sampled candidates were recomputed in float64 with the repair list; |var_f64 - var_int8|
+// against the bound the int8 kernel priced that candidate at.  `slack` covers the float64 kernels' own rounding (their
+// summation orders differ).  Violations, samples and the worst ratio accumulate in stats[3..5].
+__global__ __launch_bounds__(256) void repair_canary_kernel(const int64_t* __restrict__ list, int64_t* stats,
+                                                            const double* __restrict__ rvar, const double* __restrict__ rec,
+                                                            int64_t canary_off, double slack) {
+  const int64_t n = stats[0];
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256) {
+    const int64_t j = list[r];
+    if (((j + canary_off) & (I8_CANARY_PERIOD - 1)) != 0) continue;
+    const double* c = rec + 2 * ((j + canary_off) / I8_CANARY_PERIOD);
+    const double dv = fabs(rvar[r] - c[0]), bound = c[1];
+    atomicAdd((unsigned long long*)(stats + 4), 1ull);
+    if (!(dv <= bound + slack)) atomicAdd((unsigned long long*)(stats + 3), 1ull);
+    const double ratio = dv / fmax(bound + slack, 1e-300);   // >= 0: the bit patterns order like the values
+    atomicMax((unsigned long long*)(stats + 5), (unsigned long long)__double_as_longlong(ratio));
+  }
+}
+void launch_repair_canary(hipStream_t s, const int64_t* list, int64_t* stats, int64_t cap, const double* rvar,
+                          const double* rec, int64_t canary_off, double slack) {
+  const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((cap + 255) / 256, 256));
+  hipLaunchKernelGGL(repair_canary_kernel, dim3((unsigned)blocks), dim3(256), 0, s, list, stats, rvar, rec, canary_off, slack);
 }
 __global__ __launch_bounds__(256) void repair_gather_kernel(const double* __restrict__ Xq, int d,
                                                             const int64_t* __restrict__ list, const int64_t* count,

@@ -115,7 +115,10 @@ class GPEngine:
         "auto" -- the int8 sweep with an a-posteriori repair: every candidate whose own error bound exceeds the
         parity tolerance (and, in a fused arg-max, every candidate that could still be the float64 winner) is
         recomputed in float64 inside the same call; four planes, then five, then float64 when too many candidates
-        needed it.  Results hold the parity tolerance candidate by candidate; the arg-max is the float64 one."""
+        needed it.  Results hold the parity tolerance candidate by candidate and the arg-max is the float64 one -- to
+        the 8-sigma error model the bounds come from (a statistical model, not a worst case); every sweep re-checks a
+        pseudo-random sample of its candidates in float64 against their bounds and leaves the rung when one fails
+        (:meth:`get_auto_report`).  Float64 remains the only arithmetic the parity claims are made on."""
         if precision not in _lib.PRECISIONS:
             raise ValueError(f"unknown precision {precision!r}; choose from {sorted(_lib.PRECISIONS)}")
         self._chk(self._lib.tgp_set_precision(self._h, _lib.PRECISIONS[precision]))
@@ -127,6 +130,20 @@ class GPEngine:
         self._chk(self._lib.tgp_get_precision(self._h, C.byref(req), C.byref(eff), C.byref(frac)))
         names = {v: k for k, v in _lib.PRECISIONS.items()}
         return names[req.value], names[eff.value], frac.value
+
+    def set_auto_sigma(self, k_sigma: float = 8.0):
+        """K_SIGMA of the "auto" precision's per-candidate error bound (tgp_set_auto_sigma; restarts the ladder)."""
+        self._chk(self._lib.tgp_set_auto_sigma(self._h, float(k_sigma)))
+
+    def get_auto_report(self):
+        """The canary of the "auto" precision since its ladder last restarted (tgp_get_auto_report) ->
+        dict(checked, violations, worst_ratio, demotions, level): sampled candidates compared in float64, samples outside
+        their bound, worst |var_f64 - var_int8| / bound, rungs left because of a violation, current rung (0 four planes,
+        1 five, 2 float64, -1 not "auto")."""
+        chk, viol, worst, dem, lev = C.c_int64(), C.c_int64(), C.c_double(), C.c_int(), C.c_int()
+        self._chk(self._lib.tgp_get_auto_report(self._h, C.byref(chk), C.byref(viol), C.byref(worst), C.byref(dem),
+                                                C.byref(lev)))
+        return dict(checked=chk.value, violations=viol.value, worst_ratio=worst.value, demotions=dem.value, level=lev.value)
 
     # -- model state -----------------------------------------------------------------------------
     def clone_from(self, other: "GPEngine") -> None:
