@@ -177,10 +177,19 @@ int tgp_nlml_trial(tgp_handle h, double* value);
  * workers they share) -- a single factorisation leaves half of the compute units idle behind its chain, and HIP runs at
  * most three such launches side by side.  Each value equals tgp_nlml_trial's at
  * the same hyper-parameters bit for bit.  The handle's own hyper-parameters and posterior are untouched (the members
- * live in scratch matrices, 3 N^2 doubles each: a process-wide scratch per device, allocated on first use and kept;
- * concurrent calls on one device are serialised).  Below that size the members are evaluated one after the other.
+ * live in scratch matrices, 3 N^2 doubles each: a process-wide scratch per device, allocated on first use and kept --
+ * tgp_release_scratch frees it; concurrent calls on one device are serialised).  A launch takes at most 16 members, at
+ * most a quarter of the compute units as chains, at most 12 GiB and at most four fifths of the device's free memory; a
+ * failed allocation halves the group.  Below that size -- and when not even one member's matrices fit, or the device has
+ * too few compute units for chains and workers -- the members are evaluated one after the other on the handle
+ * (tgp_nlml_trial's arithmetic, the same values).
  * Replaces the loop of find_best_model_initialization (reference models/gpflow/models.py:294-321). */
 int tgp_nlml_trial_batch(tgp_handle h, const double* hypers, int B, double* values, int* status);
+/* Free the process-wide scratch tgp_nlml_trial_batch keeps on `device_id` (waits for a call in progress; the next batched
+ * fit allocates it again).  It is kept between fits on purpose -- a BO loop fits a fresh model every step, and allocating /
+ * releasing gigabytes per model cost 10 - 40 ms each way -- so nothing frees it implicitly.  The reference has no
+ * counterpart (TensorFlow's allocator owns its arena: models/gpflow/models.py:294-321 never sees memory). */
+int tgp_release_scratch(int device_id);
 /* Read back the cache (tests / checkpoint-free restore checks): any pointer may be NULL.
  * L [N,N] lower (upper = 0), Winv [N,N] = L^-1, alpha [N].  `where` applies to all three. */
 int tgp_get_factor(tgp_handle h, double* L, double* Winv, double* alpha, int where);

@@ -127,6 +127,9 @@ class FakeEngine:
             return req, req, -1.0
         return req, "i8x4", 0.0
 
+    def release_scratch(self):
+        """tgp_release_scratch: the stand-in keeps no device scratch."""
+
     def set_auto_sigma(self, k_sigma=8.0):
         if not (k_sigma > 0.0) or not np.isfinite(k_sigma):
             raise ValueError("k_sigma must be positive and finite")

@@ -322,6 +322,13 @@ def test_batched_trial_evaluations_equal_the_single_ones_bit_for_bit():
     perm = rng.permutation(11)
     pv, _ = eng.nlml_trial_batch(hy[perm])
     np.testing.assert_array_equal(np.delete(pv, int(np.where(perm == 4)[0][0])), np.delete(values[perm], int(np.where(perm == 4)[0][0])))
+    # the process-wide scratch (3 N^2 doubles per member) can be handed back; the next call allocates it again: same bits
+    import torch
+    free0 = torch.cuda.mem_get_info()[0]
+    eng.release_scratch()
+    assert torch.cuda.mem_get_info()[0] >= free0 + 10 * 3 * 4096 * 4096 * 8   # (the launch of ten members' matrices, at least)
+    again, _ = eng.nlml_trial_batch(hy)
+    np.testing.assert_array_equal(np.delete(again, 4), np.delete(values, 4))
 
 
 def test_batched_trial_evaluations_below_the_persistent_size():

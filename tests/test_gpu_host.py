@@ -82,7 +82,9 @@ def test_ask_tell_loop_on_gpu_finds_scaled_branin_minimum():
     for _ in range(16):
         q = opt.ask()
         opt.tell(Dataset(q, OBJ.scaled_branin(q)))
-    assert np.min(opt.dataset.observations) < -1.0  # minimum -1.047393 (reference rtol 0.005 in <= 20 steps)
+    # the reference's own bar: the minimum -1.047393 to rtol 0.005 (tests/integration/test_ask_tell_optimization.py:149-286,
+    # <= 20 steps for EGO on the scaled Branin function)
+    np.testing.assert_allclose(np.min(opt.dataset.observations), -1.047393, rtol=0.005)
 
 
 def test_ask_tell_loop_under_auto_precision_matches_the_float64_loop():

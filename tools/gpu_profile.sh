@@ -9,6 +9,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 WL=$W; EXTRA=""
 if [ "$W" = i8 ]; then WL=headline; EXTRA="--precision i8x4"; fi   # the split-precision line of the headline workload
+if [ "$W" = i8x5 ]; then WL=headline; EXTRA="--precision i8x5"; fi
 if [ "$W" = auto ]; then WL=headline; EXTRA="--precision auto"; fi # ... with the a-posteriori float64 repair (TGP_PREC_AUTO)
 B="python $PWD/bench.py --workload $WL $EXTRA --no-cpu-baseline --no-acquire --no-secondary $*"
 T=${ROUND}_${W}

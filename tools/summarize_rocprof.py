@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
 workloads = sys.argv[2:] or ["headline", "c2", "c4", "c5"]
 DOMINANT = {"headline": "sweep_dma_kernel", "c2": "sweep_dma_kernel", "c3": "sweep_dma_kernel", "c4": "joint_kernel",
-            "c5": "traj_eval_kernel", "i8": "sweep_i8_kernel", "auto": "sweep_i8_kernel"}
+            "c5": "traj_eval_kernel", "i8": "sweep_i8_kernel", "auto": "sweep_i8_kernel", "i8x5": "sweep_i8_kernel"}
 # on the GPU box: SUMMARY_DIR=gpurun_out (the raw databases are too big to travel back); locally: profiles/
 out_dir = os.environ.get("SUMMARY_DIR") or os.path.join(ROOT, "profiles")
 os.makedirs(out_dir, exist_ok=True)
@@ -62,6 +62,7 @@ for w in workloads:
             traffic_all["_raw"] = {"headline_r01": traffic_all["_raw"]}
         traffic_all["_raw"][f"{w}_{rnd}"] = traffic
         traffic_all["_round"] = rnd
+        traffic_all.setdefault("_rounds", {})[w] = rnd   # the round EVERY entry was measured in (bench.py prints it)
         traffic_all["_note"] = ("HBM bytes per step of the workload's dominant kernel = 2*FETCH_SIZE + WRITE_SIZE (KiB->bytes; the x2 "
                                 "on FETCH_SIZE is the gfx950 correction of MI355X_MICROARCH.md, WRITE_SIZE uncalibrated); "
                                 "the profiled run = the bench's untimed first call + 1 timed step, so the sums over dispatches are halved")

@@ -42,6 +42,7 @@ SIGNATURES = {
     "tgp_nlml": (C.c_int, [_vp, _dp, _vp]),
     "tgp_nlml_trial": (C.c_int, [_vp, _dp]),
     "tgp_nlml_trial_batch": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
+    "tgp_release_scratch": (C.c_int, [C.c_int]),
     "tgp_update_is_persistent": (C.c_int, [_vp, C.c_int64, C.POINTER(C.c_int)]),
     "tgp_get_factor": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int]),
     "tgp_predict": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, C.c_int]),

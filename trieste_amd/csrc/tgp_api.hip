@@ -1273,9 +1273,10 @@ int tgp_nlml_trial_batch(tgp_handle h, const double* hypers, int B, double* valu
     if (!ok) return fail(h, TGP_ERR_ARG, "member %d: variance, lengthscales and noise must be positive, the mean finite", b);
   }
   const int64_t Npad = ((h->N + NPAD_MULT - 1) / NPAD_MULT) * NPAD_MULT;
-  if (!dag_applies(h, Npad) || Npad != h->Npad) {
-    // below the persistent kernel's sizes a factorisation is a chain of small launches: evaluate the members one after
-    // the other on the handle itself (tgp_nlml_trial's arithmetic), then restore its hyper-parameters
+  // the members one after the other on the handle itself (tgp_nlml_trial's arithmetic), then its hyper-parameters restored:
+  // below the persistent kernel's sizes, where a factorisation is a chain of small launches -- and the way out when the
+  // batched launch cannot be had (no memory for even one member's matrices, too few compute units for chains AND workers)
+  auto one_by_one = [&]() -> int {
     const double v0 = h->variance, n0 = h->noise, c0 = h->mean_const;
     const std::vector<double> ls0 = h->ls;
     const bool had = h->have_data;
@@ -1292,18 +1293,54 @@ int tgp_nlml_trial_batch(tgp_handle h, const double* hypers, int B, double* valu
     if (rc_all != TGP_OK) return rc_all;
     if (had) return factorise(h, h->N, 0);  // the handle's own posterior, as it was
     return TGP_OK;
-  }
-  // members per launch: up to 16 and at most 12 GiB of matrices, the members spread evenly over the launches (90 draws =
-  // six launches of fifteen: a launch has fixed costs -- the ramp-up and the chain-bound tail of the persistent kernel,
-  // the block forward substitution -- of ~1.2 ms at N = 4096 whatever its size)
+  };
+  if (!dag_applies(h, Npad) || Npad != h->Npad) return one_by_one();
+  // members per launch: up to 16, at most a quarter of the compute units (every member's chain is a workgroup of its own
+  // and the launch needs workers beside them: tgp_kernels_dag.hip), at most 12 GiB of matrices and at most what the device
+  // has free; the members spread evenly over the launches (90 draws = six launches of fifteen: a launch has fixed costs
+  // -- the ramp-up and the chain-bound tail of the persistent kernel, the block forward substitution -- of ~1.2 ms at
+  // N = 4096 whatever its size)
   const int64_t Np = h->Npad;
   const int dp = h->dp, NB = (int)(Np / 128);
   const size_t nn = (size_t)Np * Np, per = 3 * nn * sizeof(double);
-  const int blimit = (int)std::max<size_t>(1, std::min<size_t>(16, ((size_t)12 << 30) / per));
-  const int groups = (B + blimit - 1) / blimit, bmax = (B + groups - 1) / groups, bcap = std::min(bmax, B);
   const size_t small_per = TRIAL_SMALL_PER;
-  // scratch: the matrices and vectors of ONE launch group (the groups reuse them in stream order); the per-member result
-  // block of the WHOLE call: [B] (ls, value slots), [B] breakdown reports, [groups] error words
+  BatchScratch& bs = batch_scratch(h->device);
+  std::unique_lock<std::mutex> scratch_lock(bs.mu);
+  // whatever leaves this function early from here on first waits for what it has enqueued: the scratch is shared
+  struct DrainOnExit {
+    hipStream_t s;
+    bool armed = false;
+    ~DrainOnExit() { if (armed) (void)hipStreamSynchronize(s); }
+  } drain{h->stream};
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+  (void)hipGetLastError();
+  const size_t budget = std::min<size_t>((size_t)12 << 30, bs.mats.cap + free_b - free_b / 5);  // (a fifth of what is free stays free)
+  int blimit = (int)std::min<size_t>(16, budget / per);
+  blimit = std::min(blimit, std::max(1, h->num_cu / 4));
+  if (blimit < 1 || h->num_cu < 2 * blimit + 2) {
+    scratch_lock.unlock();
+    return one_by_one();
+  }
+  int groups = 0, bmax = 0, bcap = 0;
+  for (;;) {  // the scratch of ONE launch group; a failed allocation halves the group
+    groups = (B + blimit - 1) / blimit;
+    bmax = (B + groups - 1) / groups;
+    bcap = std::min(bmax, B);
+    hipError_t ea = bs.mats.reserve((size_t)bcap * per);
+    if (ea == hipSuccess)
+      ea = bs.vec.reserve(((size_t)bcap * ((size_t)Np * dp + 2 * (size_t)Np) + (size_t)bcap * NB) * sizeof(double));
+    if (ea == hipSuccess) break;
+    (void)hipGetLastError();
+    bs.zeroed = nullptr;  // (reserve released the old buffer before it failed)
+    if (ea != hipErrorOutOfMemory) return fail(h, TGP_ERR_HIP, "batch scratch: %s", hipGetErrorString(ea));
+    if (blimit == 1) {
+      scratch_lock.unlock();
+      return one_by_one();
+    }
+    blimit = (blimit + 1) / 2;
+  }
+  // the per-member result block of the WHOLE call: [B] (ls, value slots), [B] breakdown reports, [groups] error words
   size_t max_state = 0;
   for (int bb = 1; bb <= bcap; ++bb) {  // (plans are built lazily: size the state for the largest group by its own plan)
     if (bb != bcap && bb != (B % bmax == 0 ? bcap : B % bmax)) continue;
@@ -1312,16 +1349,13 @@ int tgp_nlml_trial_batch(tgp_handle h, const double* hypers, int B, double* valu
     max_state = std::max(max_state, (size_t)bb * (nt + 2 * (size_t)NB) + DAG_CTRL_WORDS + (size_t)bb * nt);
   }
   HIPCHK(h, h->d_dag_flags.reserve(max_state * sizeof(uint32_t)));
-  BatchScratch& bs = batch_scratch(h->device);
-  std::lock_guard<std::mutex> scratch_lock(bs.mu);
-  HIPCHK(h, bs.mats.reserve((size_t)bcap * per));
-  HIPCHK(h, bs.vec.reserve(((size_t)bcap * ((size_t)Np * dp + 2 * (size_t)Np) + (size_t)bcap * NB) * sizeof(double)));
   const size_t small_doubles = (size_t)B * small_per + (size_t)B + (size_t)2 * groups + 8;
   HIPCHK(h, bs.small.reserve(small_doubles * sizeof(double)));
   double* const mats = bs.mats.as<double>();
   double* const small = bs.small.as<double>();
   int* const infos = (int*)(small + (size_t)B * small_per);
   uint32_t* const ctrls = (uint32_t*)(small + (size_t)B * small_per + B);
+  drain.armed = true;
   if (bs.zeroed != mats || bs.zeroed_npad != Np || bs.zeroed_B < bcap) {
     // the factorisation only ever writes zeros above the diagonals: wiped once per allocation and size (as d_L / d_W)
     HIPCHK(h, hipMemsetAsync(mats, 0, (size_t)bcap * per, h->stream));
@@ -1345,6 +1379,7 @@ int tgp_nlml_trial_batch(tgp_handle h, const double* hypers, int B, double* valu
   std::vector<double> hout(small_doubles);
   HIPCHK(h, hipMemcpyAsync(hout.data(), small, hout.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  drain.armed = false;
   HIPCHK(h, hipGetLastError());
   const int* hinfo = (const int*)(hout.data() + (size_t)B * small_per);
   const uint32_t* hctrl = (const uint32_t*)(hout.data() + (size_t)B * small_per + B);
@@ -1356,6 +1391,30 @@ int tgp_nlml_trial_batch(tgp_handle h, const double* hypers, int B, double* valu
     status[b] = hinfo[b] != 0 ? TGP_ERR_NOT_PD : TGP_OK;
     values[b] = hinfo[b] != 0 ? __builtin_nan("") : hout[(size_t)b * small_per + 40];
   }
+  return TGP_OK;
+}
+
+int tgp_release_scratch(int device_id) {
+  // the process-wide scratch of the batched trial evaluations on this device (gigabytes, kept between fits on purpose):
+  // waits for a call in progress, frees it; the next batched fit allocates again
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) {
+    (void)hipGetLastError();
+    return TGP_ERR_ARG;
+  }
+  BatchScratch& bs = batch_scratch(device_id);
+  std::lock_guard<std::mutex> lk(bs.mu);
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  (void)hipSetDevice(device_id);
+  bs.mats.release();
+  bs.vec.release();
+  bs.small.release();
+  bs.zeroed = nullptr;
+  bs.zeroed_npad = 0;
+  bs.zeroed_B = 0;
+  (void)hipSetDevice(prev);
+  (void)hipGetLastError();
   return TGP_OK;
 }
 

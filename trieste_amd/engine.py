@@ -291,6 +291,13 @@ class GPEngine:
             self._chk(self._lib.tgp_nlml_trial_batch(self._h, hy.ctypes.data, B, values.ctypes.data, status.ctypes.data))
         return values, status == 0
 
+    def release_scratch(self):
+        """Free the process-wide scratch the batched trial evaluations keep on this engine's device
+        (tgp_release_scratch): gigabytes at N = 4096, kept between fits on purpose; the next batched fit allocates again."""
+        rc = self._lib.tgp_release_scratch(int(self.device))
+        if rc != 0:
+            raise RuntimeError(f"tgp_release_scratch failed with status {rc}")
+
     def get_factor(self):
         """(L, W = L^-1, alpha) as numpy arrays (tests / diagnostics)."""
         n = self.N

@@ -542,13 +542,18 @@ class GaussianProcessRegression:
             # chain: all draws go through tgp_nlml_trial_batch, up to sixteen members per launch sharing one task list
             # (values equal the one-by-one trial evaluations bit for bit)
             hy = np.array([np.concatenate([[var], ls, [noise, c]]) for ls, var in draws])
-            values, ok = self._engine.nlml_trial_batch(hy)
-            for (ls, var), v, good in zip(draws, values, ok):
-                loss = v + self._log_prior(ls, var)[0] if good else 1e100
-                if loss < best:
-                    best, best_ls, best_var = loss, ls, var
-            self.set_hyperparameters(variance=best_var, lengthscales=best_ls)
-            return
+            try:
+                values, ok = self._engine.nlml_trial_batch(hy)
+            except MemoryError:
+                values = None   # (the library already falls back to one-by-one evaluation when its scratch cannot be had;
+                                #  should an allocation fail all the same, the worker path below needs no scratch)
+            if values is not None:
+                for (ls, var), v, good in zip(draws, values, ok):
+                    loss = v + self._log_prior(ls, var)[0] if good else 1e100
+                    if loss < best:
+                        best, best_ls, best_var = loss, ls, var
+                self.set_hyperparameters(variance=best_var, lengthscales=best_ls)
+                return
         if persistent:
             # from here on `update` is one persistent launch that owns the compute units it runs on: side by side means
             # sharing them (tgp_set_update_concurrency), and its tile products stream enough memory that more than
