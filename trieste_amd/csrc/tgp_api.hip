@@ -272,11 +272,17 @@ hipError_t launch_sweep_i8_timed(tgp_handle h, SweepArgs& am) {
     if ((e = h->d_wq.reserve((size_t)planes * Npad * Npad)) != hipSuccess) return e;
     if ((e = h->d_rs.reserve((size_t)2 * Npad * sizeof(double))) != hipSuccess) return e;
     launch_w_digits(h->stream, h->d_W.as<double>(), h->N, Npad, h->d_rs.as<double>(), h->d_wq.p, planes);
+    if (h->dp <= 16) {   // the generating steps' training rows as DMA-able tiles
+      const int xt = i8_xs_tile_doubles(h->dp);
+      if ((e = h->d_xsa.reserve((size_t)(Npad / 32) * xt * sizeof(double))) != hipSuccess) return e;
+      launch_xs_tiles(h->stream, h->d_Xs.as<double>(), h->d_alpha.as<double>(), Npad, h->dp, xt, h->d_xsa.as<double>());
+    }
     h->wq_version = h->data_version;
     h->wq_planes = planes;
   }
   am.i8_wq = h->d_wq.p;
   am.i8_rs = h->d_rs.as<double>();
+  am.i8_xsa = (planes == 4 && h->dp <= 16) ? h->d_xsa.as<double>() : nullptr;   // (five planes leave no LDS for the tiles)
   const int64_t blocks = (am.M + 63) / 64;
   const int64_t wgrid = blocks < h->num_cu ? blocks : h->num_cu;
   if (!h->repair) {
@@ -857,7 +863,7 @@ int tgp_destroy(tgp_handle h) {
     (void)hipStreamSynchronize(nullptr);
   }
   for (DevBuf* b : {&h->d_xn, &h->d_ls, &h->d_X, &h->d_Y, &h->d_Xs, &h->d_A, &h->d_L, &h->d_W, &h->d_alpha,
-                    &h->d_err, &h->d_tmp1, &h->d_tmp2, &h->d_info, &h->d_pen, &h->d_ent, &h->d_repv, &h->d_wq, &h->d_rs, &h->s_ent, &h->s_in, &h->s_in2, &h->s_out1,
+                    &h->d_err, &h->d_tmp1, &h->d_tmp2, &h->d_info, &h->d_pen, &h->d_ent, &h->d_repv, &h->d_wq, &h->d_rs, &h->d_xsa, &h->s_ent, &h->s_in, &h->s_in2, &h->s_out1,
                     &h->s_out2, &h->s_out3, &h->s_blkv, &h->s_blki, &h->s_small, &h->s_kcache, &h->s_aslab, &h->s_grad, &h->s_ks, &h->s_part, &h->s_rep,
                     &h->s_rep_stats, &h->d_dag_flags, &h->d_dag_trace})
     b->release();

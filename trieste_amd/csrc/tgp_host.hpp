@@ -102,7 +102,7 @@ struct tgp_handle_s {
   std::vector<double> auto_hyp;  // (variance / noise, lengthscales) when a rung was last left: tgp_set_hyper keeps the rung
                                  // while the new hyper-parameters stay within a factor two of these
   DevBuf s_rep, s_rep_stats;
-  DevBuf d_wq, d_rs;
+  DevBuf d_wq, d_rs, d_xsa;
   uint64_t wq_version = 0;
   int wq_planes = 0;
   // model state on device

@@ -52,6 +52,7 @@ struct SweepArgs {
   double* kcache;     // [grid][Npad][128] per-workgroup K* slabs (device scratch; int8 sweep: [grid][Npad][64][4] bytes)
   const void* i8_wq;  // int8 sweep: digit planes of W, Wq[s][k/32][i][32] (4 or 5 planes of Npad^2 bytes)
   const double* i8_rs; // int8 sweep: [Npad] row scales S_i = 2 max_k |W_ik|
+  const double* i8_xsa; // int8 sweep: [Npad / 32] tiles (32 rows of Xs + alpha) for LDS staging, or null (scalar loads)
   double* aslab;      // [grid][Npad][128] C = W K* slabs of joint mode (device scratch)
   // row-group split of small sweeps (SPLIT instantiation): group g of a candidate block owns the row
   // blocks [split_ib[g], split_ib[g+1]) of W and leaves partial (mean, sum c^2) in `part`
@@ -224,6 +225,9 @@ size_t dag_lds_bytes();
 
 // rs: [2][Npad] -- row scales S_i, then the row weights S_i^2 (i + 1) of the a-posteriori error model
 void launch_w_digits(hipStream_t s, const double* W, int64_t N, int64_t Npad, double* rs, void* Wq, int planes);
+// [Npad / 32] tiles of xt doubles: 32 rows of Xs, their alpha, zero padding (the int8 sweep stages them in LDS by DMA)
+void launch_xs_tiles(hipStream_t s, const double* Xs, const double* alpha, int64_t Npad, int dp, int xt, double* out);
+inline int i8_xs_tile_doubles(int dp) { return ((32 * dp + 32 + 127) / 128) * 128; }
 // ---- a-posteriori repair of the split-precision sweep (tgp_kernels_misc.hip) ----
 // stats [8]: {count (zeroed here), M, tag, canary violations, canaries checked, worst |d var| / bound as the bits of a
 // double, -, -}; the canary words accumulate until `reset_canary`

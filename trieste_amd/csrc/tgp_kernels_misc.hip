@@ -757,6 +757,22 @@ void launch_w_digits(hipStream_t s, const double* W, int64_t N, int64_t Npad, do
     hipLaunchKernelGGL(w_digits_kernel<4>, dim3((unsigned)(Npad / 32)), dim3(256), 0, s, W, N, Npad, rs, (unsigned char*)Wq);
 }
 
+// The training rows of the int8 sweep's generating steps as DMA-able tiles (tgp_kernels_sweep_i8.inc): tile t =
+// [32 rows of Xs][dp] then alpha[32], zero padded to xt doubles (whole KiB).
+__global__ __launch_bounds__(256) void xs_tiles_kernel(const double* __restrict__ Xs, const double* __restrict__ alpha, int dp, int xt,
+                                                       double* __restrict__ out) {
+  const int64_t tile = blockIdx.x;
+  for (int e = threadIdx.x; e < xt; e += 256) {
+    double v = 0.0;
+    if (e < 32 * dp) v = Xs[tile * 32 * dp + e];
+    else if (e < 32 * dp + 32) v = alpha[tile * 32 + (e - 32 * dp)];
+    out[tile * xt + e] = v;
+  }
+}
+void launch_xs_tiles(hipStream_t s, const double* Xs, const double* alpha, int64_t Npad, int dp, int xt, double* out) {
+  hipLaunchKernelGGL(xs_tiles_kernel, dim3((unsigned)(Npad / 32)), dim3(256), 0, s, Xs, alpha, dp, xt, out);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Cross-device merge of per-shard winners (host mirror: trieste_amd/distributed.py merge_best):
 // gathered [P][2][V] -- rank p's V values followed by its V global indices (int64 bit patterns in the 8-byte
