@@ -3,6 +3,7 @@ L-BFGS-B).  usage: python tools/bench_bo_step.py [N]      (TGP_NO_DAG=1 forces t
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+import scipy.optimize  # noqa: F401  (a ~190 ms import the first optimize() of a process would otherwise pay)
 from trieste_amd import objectives as O
 import trieste_amd.models as M
 from trieste_amd.data import Dataset
@@ -21,7 +22,8 @@ for rep in range(2):
     t0 = time.perf_counter(); model.update(newd); t1 = time.perf_counter()
     res = model.optimize(newd); t2 = time.perf_counter()
     print(f"N={N}: update(append 1 row) {1e3*(t1-t0):.2f} ms, optimize {1e3*(t2-t1):.0f} ms (nfev={res.nfev}), "
-          f"workers={model.MAX_PARALLEL_EVALUATIONS}", flush=True)
+          f"workers={model.MAX_PARALLEL_EVALUATIONS}" + ("  [first call of the process: allocations, task plans, scratch]" if rep == 0 else ""),
+          flush=True)
 for rep in range(2):
     t0 = time.perf_counter(); model.find_best_model_initialization(90); t1 = time.perf_counter()
     print(f"  find_best_model_initialization(90) batched (tgp_nlml_trial_batch) after the append: N + 1 rows, padded to the next 256: {1e3*(t1-t0):.0f} ms", flush=True)
