@@ -42,6 +42,10 @@ def c5(M=1 << 20, F=2048, N=8192, d=16, B=4):
     print(f"C5 TS: M={M} F={F} N={N} d={d} B={B}: update {1e3*(t1-t0):.0f} ms, weights {1e3*(t3-t2):.0f} ms, "
           f"argmin wall {1e3*(t5-t4):.1f} ms (kernel {ms:.1f}) -> {M*B/(t5-t4):.3e} candidate-trajectory evals/s; idx {idx}", flush=True)
 
-if __name__ == "__main__":
-    c4()
-    c5()
+if __name__ == "__main__":   # usage: bench_c4c5.py [c4 [G] | c5 [M]]
+    which = sys.argv[1] if len(sys.argv) > 1 else "both"
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    if which in ("c4", "both"):
+        c4(G=n) if n else c4()
+    if which in ("c5", "both"):
+        c5(M=n) if n else c5()
