@@ -22,17 +22,20 @@ constexpr int TRAJ_MAXB = 16;
 // the inputs).  Same accuracy class as kernel_from_r2 (1 - 2 ulp), nine instructions fewer per entry for Matern-5/2.
 template <int KIND>
 struct TrajShape {
-  static constexpr double SCALE = KIND == KIND_M32 ? 3.0 : (KIND == KIND_M52 ? 5.0 : 1.0);
+  // q = SCALE r^2 with log2(e) folded in as well (round 5): u = sqrt(q) IS the base-2 exponent of the exponential,
+  // exp(-sqrt(c) r) = 2^-u with SCALE = c log2(e)^2 (RBF: exp(-r^2 / 2) = 2^-q with SCALE = log2(e) / 2) -- the
+  // multiplication by log2(e) inside the exponential is gone; the polynomial factor takes u / log2(e) through its constants
+  static constexpr double L2E = 1.4426950408889634;
+  static constexpr double C = KIND == KIND_M32 ? 3.0 : (KIND == KIND_M52 ? 5.0 : 1.0);
+  static constexpr double SCALE = KIND == KIND_RBF ? 0.5 * L2E : C * L2E * L2E;
   static constexpr double FLOOR = 1e-36 * SCALE;  // gpflow: r = sqrt(max(r^2, 1e-36))
 };
+// sqrt(x), x > 0: v_rsq_f64 (2^-26) + ONE coupled Goldschmidt step = 2^-51 relative.  (Rounds 3 / 4 added a residual step
+// for the last ulp: two instructions of ~50 per kernel evaluation that a sum of 8192 terms compared at 1e-5 cannot see.)
 __device__ __forceinline__ double traj_sqrt(double x) {
   const double y = __builtin_amdgcn_rsq(x);
-  double g = x * y;
-  const double h = 0.5 * y;
-  const double r = fma(-h, g, 0.5);
-  g = fma(g, r, g);  // 2^-51: one coupled step squares v_rsq_f64's 2^-26
-  const double dd = fma(-g, g, x);
-  return fma(dd, h, g);  // (the residual x - g^2 is 2^-51 x: the unrefined h = y / 2 is accurate enough for it)
+  const double g = x * y, h = 0.5 * y;
+  return fma(g, fma(-h, g, 0.5), g);
 }
 // cos(x . W + b) from y = (x . W + b) / pi + 1/2 (the basis is stored in half turns): cos(theta) = sin(pi y) =
 // (-1)^n sin(pi f), n = rint(y), f = y - n exact, |f| <= 1/2.  sin(pi f) = f P(f^2) with a degree-8 minimax-fitted P
@@ -55,11 +58,8 @@ __device__ __forceinline__ double traj_cos_halfturns(double y) {
   p = fma(p, z, 3.141592653589793);
   return f * p;
 }
-// exp(x) = 2^t, t = x log2(e): n = rint(t), f = t - n exact, 2^f by a degree-11 fit on |f| <= 1/2 (1.9e-17).  One
-// instruction less than the Cody-Waite form; the rounding of t costs |x| 1.1e-16 relative, i.e. an ABSOLUTE error of at
-// most 4e-17 on exp(x) <= 1 -- below the last bit of the sums the values go into.
-__device__ __forceinline__ double traj_exp2_neg(double x) {
-  const double t = x * 1.4426950408889634;
+// 2^t for t <= 0: n = rint(t), f = t - n exact, 2^f by a degree-11 fit on |f| <= 1/2 (1.9e-17).
+__device__ __forceinline__ double traj_exp2(double t) {
   const double n = rint(t);
   const double f = t - n;
   double p = 4.456675463639861e-10;
@@ -79,13 +79,14 @@ __device__ __forceinline__ double traj_exp2_neg(double x) {
 template <int KIND>
 __device__ __forceinline__ double traj_shape(double q) {  // q = SCALE r^2 (may be slightly negative: dot-product form)
   if constexpr (KIND == KIND_RBF) {
-    return traj_exp2_neg(-0.5 * fmax(q, 0.0));
+    return traj_exp2(-fmax(q, 0.0));
   } else {
+    constexpr double IL = 1.0 / TrajShape<KIND>::L2E;   // s = sqrt(c) r = u / log2(e)
     const double qc = fmax(q, TrajShape<KIND>::FLOOR);
-    const double s = traj_sqrt(qc);
-    if constexpr (KIND == KIND_M12) return traj_exp2_neg(-s);
-    else if constexpr (KIND == KIND_M32) return (1.0 + s) * traj_exp2_neg(-s);
-    else return fma(1.0 / 3.0, qc, 1.0 + s) * traj_exp2_neg(-s);
+    const double u = traj_sqrt(qc);
+    if constexpr (KIND == KIND_M12) return traj_exp2(-u);
+    else if constexpr (KIND == KIND_M32) return fma(IL, u, 1.0) * traj_exp2(-u);
+    else return fma(IL * IL / 3.0, qc, fma(IL, u, 1.0)) * traj_exp2(-u);   // 1 + s + s^2 / 3
   }
 }
 
@@ -146,11 +147,23 @@ __global__ __launch_bounds__(256) void traj_eval_kernel(TrajDev t, const double*
     for (int b = 0; b < BP; ++b) acck[b] = 0.0;
 #pragma unroll 2
     for (int64_t k = 0; k < t.m.N; ++k) {
-      double dot = 0.0;
+      double q;
+      if constexpr (KIND == KIND_M12) {
+        // exp(-r) has a kink at r = 0: the dot-product form's cancellation error (~1e-15 on r^2, i.e. 3e-8 on r) would
+        // show at candidates that coincide with training inputs -- the difference form is exact there (2 D instructions)
+        double r2 = 0.0;
 #pragma unroll
-      for (int c = 0; c < DP; ++c) dot = fma(xq[c], xs[k * DP + c], dot);
-      // q = SCALE (|x|^2 + |X_k|^2 - 2 x . X_k)
-      const double q = fma(-2.0 * SC, dot, fma(SC, xn[k], nbs));
+        for (int c = 0; c < DP; ++c) {
+          const double t0 = xq[c] - xs[k * DP + c];
+          r2 = fma(t0, t0, r2);
+        }
+        q = SC * r2;
+      } else {
+        double dot = 0.0;
+#pragma unroll
+        for (int c = 0; c < DP; ++c) dot = fma(xq[c], xs[k * DP + c], dot);
+        q = fma(-2.0 * SC, dot, fma(SC, xn[k], nbs));   // SCALE (|x|^2 + |X_k|^2 - 2 x . X_k)
+      }
       const double kv = traj_shape<KIND>(q);
       if (PER_TRAJ) {
         acck[0] = fma(kv, t.v[k * B + myb], acck[0]);
