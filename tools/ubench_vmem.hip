@@ -122,6 +122,32 @@ __global__ __launch_bounds__(512, 2) void k(const unsigned char* __restrict__ bu
       for (int s = 0; s < 4; ++s) { dfa[s] = av[s]; dfb[s] = bv[s]; }
       return;
     }
+    if (MODE == 16 || MODE == 17) {
+      // wave grid 8 x 1: one A fragment per plane in REGISTERS (a_reg, landed), two B fragments from LDS; the iteration's
+      // vector memory traffic (1 LDS-DMA of the B tile + 4 plain loads of the A operand two tiles ahead) goes out between the
+      // two B fragments' MFMAs (16) or before them (17)
+      const unsigned char* sB = lds + (it % 3) * 40960 + 32768;
+      v4i bv[2][4];
+#pragma unroll
+      for (int bf = 0; bf < 2; ++bf)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) bv[bf][s] = *(const v4i*)(sB + s * 2048 + (bf * 32 + (lane & 31)) * 32 + (lane >> 5) * 16);
+      auto traffic = [&]() {
+        glds16(next_ptr(), __builtin_amdgcn_readfirstlane(lds0 + ((it + 2) % 3) * 40960 + 32768 + w * 1024));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) PLAIN(ra[(it + 2) % 3][j], next_ptr());
+      };
+      if (MODE == 17) traffic();
+#pragma unroll
+      for (int bf = 0; bf < 2; ++bf) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int s = 0; s <= g; ++s) acc[bf][g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_reg[s], bv[bf][g - s], acc[bf][g], 0, 0, 0);
+        if (MODE == 16 && bf == 0) traffic();
+      }
+      return;
+    }
     const unsigned char* sA = lds + (MODE == 9 ? (it & 3) * 30720 : (it % 3) * 40960);
     const unsigned char* sB = sA + 32768;
     v4i bv[4];
@@ -182,10 +208,14 @@ __global__ __launch_bounds__(512, 2) void k(const unsigned char* __restrict__ bu
         wait_vm<20>();
       }
       if (do_compute) {
-        compute(it, ra[(u + 1) % 3], MODE == 5, MODE == 8 || MODE == 9 || MODE == 12);
+        compute(it, ra[(MODE == 16 || MODE == 17) ? u : (u + 1) % 3], MODE == 5, MODE == 8 || MODE == 9 || MODE == 12);
         if (MODE == 6 || MODE == 8 || MODE == 10 || MODE == 12 || MODE == 13 || MODE == 14 || MODE == 15) wait_vm<5>();
+        if (MODE == 16 || MODE == 17) {   // everything older than this iteration's five operations has landed: the next A set is usable
+          wait_vm<5>();
+          asm volatile("" : "+v"(ra[(u + 1) % 3][0]), "+v"(ra[(u + 1) % 3][1]), "+v"(ra[(u + 1) % 3][2]), "+v"(ra[(u + 1) % 3][3]));
+        }
         if (MODE == 9 && (it & 1)) wait_vm<5>();
-        if (MODE == 2 || MODE == 5 || MODE == 6 || MODE == 8 || MODE == 10 || MODE == 13 || MODE == 14 || MODE == 15 || (MODE == 9 && (it & 1))) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+        if (MODE == 2 || MODE == 5 || MODE == 6 || MODE == 8 || MODE == 10 || MODE == 13 || MODE == 14 || MODE == 15 || MODE == 16 || MODE == 17 || (MODE == 9 && (it & 1))) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
       }
     }
   }
@@ -415,6 +445,8 @@ int main(int argc, char** argv) {
   RUN(11, "20 MFMA only (floor 1280)");
   RUN(12, "as 8 without the barrier");
   RUN(13, "as 10, both fragments' A operands requested up front");
+  RUN(16, "A operand in REGISTERS (plain loads, two iterations ahead), B via LDS; traffic between the B fragments + barrier");
+  RUN(17, "as 16, the traffic before the MFMAs");
   RUN(14, "as 8, the last 4 MFMAs of an iteration deferred behind the barrier");
   RUN(15, "as 8, the last 7 MFMAs of an iteration deferred behind the barrier");
   return 0;
