@@ -443,8 +443,10 @@ int tgp_get_auto_report(tgp_handle h, int64_t* checked, int64_t* violations, dou
  * small launches, bit 1 = always use it, bit 2 = joint mode on the first-generation kernel (64-column group slots;
  * dp = 32 always uses it), bit 3 = fused plain launches on the register-staged kernel instead of the LDS-DMA one, bit 4 =
  * `update` through the recursion of dependent launches instead of the persistent task-DAG kernel, bit 5 = the persistent
- * kernel from Npad = 256 on (default: from 4096 on, where it is the faster one).  Bits 0-3: every setting computes the same
- * arithmetic on every candidate; bits 4, 5: the same factor up to the rounding of another summation order. */
+ * kernel from Npad = 256 on (default: from 4096 on, where it is the faster one), bit 6 = TGP_PREC_AUTO recomputes every
+ * flagged candidate through the row-group-split sweep instead of the product path it takes for lists of up to 512.  Bits 0-3:
+ * every setting computes the same arithmetic on every candidate; bits 4 - 6: the same values up to the rounding of another
+ * summation order. */
 int tgp_set_variant(tgp_handle h, int variant);
 /* `update` on SEVERAL handles at once (the prior draws of a hyper-parameter fit: reference models.py:294-321 evaluates
  * them one after the other): the persistent update kernel of a handle takes 1 / n of the compute units (n = 1 ... 16, default

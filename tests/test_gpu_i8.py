@@ -236,6 +236,37 @@ def test_auto_precision_on_the_headline_model():
         assert eng.get_auto_report()["level"] == -1
 
 
+@pytest.mark.parametrize("cfg", [CONFIGS[2], CONFIGS[0], CONFIGS[6]], ids=[CONFIGS[2][0], CONFIGS[0][0], CONFIGS[6][0]])
+def test_auto_repair_paths_agree(cfg):
+    """TGP_PREC_AUTO recomputes a SHORT list of candidates (up to 512: the canary's sample and a handful of flagged ones) as a
+    product -- K*^T, W K*^T, column sums, tail -- and a longer one through the row-group-split sweep (variant bit 6 forces the
+    sweep for every list).  Both are the float64 posterior of the same candidates: the values agree to the rounding of the
+    two summation orders, the lists are the same, the winner is the same.  (The well-conditioned configurations recompute a
+    candidate or two; the ill-conditioned one about half of its candidates in its first sweep -- ~300 of 600 through the
+    product, ~800 of 1500 and ~3000 of 6000 through the sweep: both sides of the routing are met with lists of some length.)"""
+    _, obj, d, kind, N, noise = cfg
+    seen = []
+    for M in (600, 1500, 6000):
+        out = {}
+        for variant in (0, 64):
+            eng, st, Xq = _setup(obj, d, kind, N, noise, M=M)
+            eta = eng.eta()
+            eng.set_variant(variant)
+            eng.set_precision("auto")
+            mean, var = eng.predict(Xq)          # the FIRST sweep on four planes, whatever the ladder does afterwards
+            eff, frac = eng.get_precision()[1:]
+            val, idx, _ = eng.acq_argmax("ei", eta, Xq)
+            out[variant] = (np.asarray(mean), np.asarray(var), frac, val, idx, eng.get_precision()[1])
+            eng.set_precision("f64")
+        a, b = out[0], out[64]
+        assert a[2] == b[2] and a[5] == b[5], (a[2], b[2], a[5], b[5])   # the same list, the same rung afterwards
+        np.testing.assert_allclose(a[0], b[0], rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(a[1], b[1], rtol=1e-11, atol=1e-13)   # var = sigma^2 - |c|^2: the cancellation's rounding
+        assert a[4] == b[4] and abs(a[3] - b[3]) <= 1e-11 * abs(b[3]) + 1e-300, (a[3:5], b[3:5])
+        seen.append(round(a[2] * M))
+    print(f"[margin] auto repair paths, {cfg[0]}: recomputed candidates of the first sweeps {seen} (product path up to 512)")
+
+
 @pytest.mark.parametrize("cfg", [CONFIGS[2], CONFIGS[3], CONFIGS[0]], ids=[CONFIGS[2][0], CONFIGS[3][0], CONFIGS[0][0]])
 def test_auto_canary_fires_when_its_error_model_is_wrong_for_the_input(cfg):
     """The per-candidate bound of TGP_PREC_AUTO is K_SIGMA = 8 standard deviations of a STATISTICAL model of the dropped

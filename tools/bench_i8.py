@@ -11,6 +11,7 @@ N, d, M = 4096, 8, 1 << 20
 X, Y = O.synthetic_problem(O.ackley, d, N)
 eng = GPEngine(d, "matern52")
 eng.use_torch_stream()
+eng.set_variant(int(os.environ.get("TGP_VARIANT", "0")))   # e.g. 64: AUTO repairs through the SPLIT sweep only
 eng.set_hyper(1.0, O.default_lengthscales(d), 1e-2, float(Y.mean()))
 eng.set_data(X, Y)
 eta = eng.eta()

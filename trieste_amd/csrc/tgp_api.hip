@@ -151,8 +151,13 @@ void apply_penalization(tgp_handle h, double* dvals, const double* dXq, int64_t 
 //   VARIANT_REG_STAGING (8): fused plain launches on the register-staged kernel instead of the LDS-DMA one
 //   VARIANT_NO_DAG (16): `update` through the recursion of dependent launches instead of the persistent task-DAG kernel
 //   VARIANT_DAG_SMALL (32): the persistent kernel from Npad = 256 on (default: from 4096 on, where it wins)
+//   VARIANT_NO_REPAIR_PRODUCT (64): TGP_PREC_AUTO recomputes every flagged candidate through the SPLIT sweep (rounds 4 / 5)
+//                                   instead of the product path for short lists
 constexpr int VARIANT_NO_SPLIT = 1, VARIANT_FORCE_SPLIT = 2, VARIANT_JOINT_V1 = 4, VARIANT_REG_STAGING = 8, VARIANT_NO_DAG = 16,
-              VARIANT_DAG_SMALL = 32;
+              VARIANT_DAG_SMALL = 32, VARIANT_NO_REPAIR_PRODUCT = 64;
+constexpr int64_t REPAIR_PCAP = 512;   // TGP_PREC_AUTO: lists up to this many candidates are recomputed as a product
+int gemm_tall(tgp_handle h, bool tb, int m, int n, int k, double alpha, const double* A, int64_t lda, const double* B,
+              int64_t ldb, double beta, double* C, int64_t ldc, int tri);
 
 // TGP_PREC_AUTO (round 4): the split-precision sweep WITH an a-posteriori repair (sweep_i8_repaired below) on a
 // ladder four planes -> five planes (d <= 16) -> float64.  Every repaired sweep reports how many candidates it had to
@@ -343,6 +348,20 @@ hipError_t launch_sweep_i8_timed(tgp_handle h, SweepArgs& am) {
   double* crec = Xg + M * d;                        // [n_can][2]: the sampled candidates' int8 variance and bound
   int64_t* stats = h->s_rep_stats.as<int64_t>();   // {count, M, epoch, canary violations, checked, worst ratio, -, -}
   double* Lslot = (double*)(stats + 8);             // {L, its index}
+  int64_t* route = (int64_t*)(Lslot + 2);           // {count if the SPLIT sweep recomputes, count if the product path does}
+  // Up to pcap recomputed candidates (the canary's M / 4096 and a handful of flagged ones: the usual case) take the
+  // product path of tgp_kernels_misc.hip -- K*^T, W K*^T as a tall product, column sums, tail -- which spreads over the chip;
+  // more than that go through the SPLIT sweep.  Both are enqueued, repair_route_kernel gives the count to one of them.
+  const int64_t pcap = std::min<int64_t>(REPAIR_PCAP, ((M + 63) / 64) * 64);
+  const bool product = !(h->variant & VARIANT_NO_REPAIR_PRODUCT);
+  double *pB = nullptr, *pC = nullptr, *ppart = nullptr;
+  if (product) {
+    if ((e = h->s_grad.reserve(((size_t)2 * Npad * pcap + (size_t)repair_product_part_doubles(pcap)) * sizeof(double))) != hipSuccess)
+      return e;
+    pB = h->s_grad.as<double>();
+    pC = pB + (size_t)Npad * pcap;
+    ppart = pC + (size_t)Npad * pcap;
+  }
   // the sample of this sweep: candidates j with (j + off) % 4096 == 0, off from a counter through splitmix64
   uint64_t z = (h->canary_seq++ + 0x9E3779B97F4A7C15ull) * 0xBF58476D1CE4E5B9ull;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
@@ -377,6 +396,10 @@ hipError_t launch_sweep_i8_timed(tgp_handle h, SweepArgs& am) {
   b.Xq = Xg;
   b.M = M;
   b.M_dev = stats;
+  if (product) {
+    launch_repair_route(h->stream, stats, pcap, route);
+    b.M_dev = route;   // zero unless the list is longer than pcap
+  }
   b.mean_out = am.mean_out ? rout : nullptr;
   b.var_out = rout + M;   // (always: the canary compares the recomputed variances)
   b.acq_out = am.acq_kind >= 0 ? rout + 2 * M : nullptr;
@@ -387,6 +410,13 @@ hipError_t launch_sweep_i8_timed(tgp_handle h, SweepArgs& am) {
   b.kcache = h->s_kcache.as<double>();
   if ((e = launch_sweep_kind(h, b, false, fgrid)) != hipSuccess) return e;
   launch_sweep_combine(h->stream, b, std::min<int64_t>(cap_blocks, 2048));
+  if (product) {
+    launch_kstar_t_dev(h->stream, am.m, Xg, route + 1, pcap, pB);
+    if (gemm_tall(h, false, (int)Npad, (int)pcap, (int)Npad, 1.0, h->d_W.as<double>(), Npad, pB, pcap, 0.0, pC, pcap, 3) != TGP_OK)
+      return hipErrorOutOfMemory;
+    launch_repair_product_tail(h->stream, am.m, pB, pC, pcap, route + 1, b.acq_kind, b.acq_param, ppart, b.mean_out, b.var_out,
+                               b.acq_out);
+  }
   // float64 against int8 on the sampled candidates; slack: the float64 kernels' own rounding (two summation orders)
   launch_repair_canary(h->stream, list, stats, M, b.var_out, crec, can_off, 1e-12 * v);
   launch_repair_scatter(h->stream, list, stats, M, b.mean_out, am.var_out ? b.var_out : nullptr, b.acq_out, am.mean_out,

@@ -239,6 +239,14 @@ void launch_repair_flag(hipStream_t s, const double* ub, int64_t M, const double
 // the sampled candidates among list[0 .. stats[0]): |rvar[r] - rec var| against rec bound + slack -> stats[3..5]
 void launch_repair_canary(hipStream_t s, const int64_t* list, int64_t* stats, int64_t cap, const double* rvar,
                           const double* rec, int64_t canary_off, double slack);
+// the repair of a few candidates as a product (tgp_kernels_misc.hip): count routing, K*^T with the count on the device,
+// column sums + the sweep's tail
+void launch_repair_route(hipStream_t s, const int64_t* stats, int64_t pcap, int64_t* route);
+void launch_kstar_t_dev(hipStream_t s, const ModelDev& m, const double* Xq, const int64_t* P_dev, int64_t Ppad, double* B);
+void launch_repair_product_tail(hipStream_t s, const ModelDev& m, const double* B, const double* C, int64_t Ppad,
+                                const int64_t* P_dev, int acq_kind, double acq_param, double* part, double* mean_out,
+                                double* var_out, double* acq_out);
+int64_t repair_product_part_doubles(int64_t Ppad);
 void launch_repair_gather(hipStream_t s, const double* Xq, int d, const int64_t* list, const int64_t* count, int64_t cap,
                           double* Xg);
 void launch_repair_scatter(hipStream_t s, const int64_t* list, const int64_t* count, int64_t cap, const double* rmean,

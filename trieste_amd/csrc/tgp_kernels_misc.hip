@@ -945,4 +945,97 @@ void launch_merge_winners(hipStream_t s, const double* gathered, int P, int V, i
                      minimize, out);
 }
 
+// ---------------------------------------------------------------------------------------------
+// TGP_PREC_AUTO, the repair of a FEW candidates as a product (round 5).  The SPLIT sweep recomputes a handful of candidates
+// in the latency of its heaviest row group's walk (N = 4096: the last row block alone is 12 % of the triangle on ONE CU,
+// 0.9 - 1.2 ms).  Up to `pcap` candidates go through building blocks that spread over the chip instead: B = K*^T
+// [Npad][Ppad] (kstar_t with the count on the device), C = W B (gemm_tall of tgp_api.hip), then column sums
+// (k*.alpha, sum c^2) in two deterministic steps and the common tail.  Reference: the same posterior as the sweep,
+// models/gpflow/interface.py:119-124.  Nothing here reads the count on the host: repair_route_kernel hands it to exactly
+// one of the two paths (the other one sees zero candidates).
+__global__ void repair_route_kernel(const int64_t* __restrict__ stats, int64_t pcap, int64_t* __restrict__ route) {
+  const int64_t c = stats[0];
+  route[0] = c > pcap ? c : 0;    // the SPLIT sweep's count
+  route[1] = c <= pcap ? c : 0;   // the product path's count
+}
+void launch_repair_route(hipStream_t s, const int64_t* stats, int64_t pcap, int64_t* route) {
+  hipLaunchKernelGGL(repair_route_kernel, dim3(1), dim3(1), 0, s, stats, pcap, route);
+}
+
+// B[k][p] = k(X_k, x_p), k-major [Npad][Ppad]; columns from *P_dev on are zero (kstar_t_kernel of tgp_kernels_grad.hip
+// with the count on the device)
+__global__ void kstar_t_dev_kernel(ModelDev m, const double* __restrict__ Xq, const int64_t* __restrict__ P_dev,
+                                   int64_t Ppad, double* __restrict__ B) {
+  const int64_t p = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int64_t k = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (p >= Ppad || k >= m.Npad) return;
+  const int64_t P = *P_dev;
+  double v = 0.0;
+  if (p < P && k < m.N) {
+    double r2 = 0.0;
+    for (int c = 0; c < m.d; ++c) {
+      const double t = Xq[p * m.d + c] / m.ls[c] - m.Xs[k * m.dp + c];
+      r2 = fma(t, t, r2);
+    }
+    v = kernel_rt(m.kind, r2, m.variance);
+  }
+  B[k * Ppad + p] = v;
+}
+void launch_kstar_t_dev(hipStream_t s, const ModelDev& m, const double* Xq, const int64_t* P_dev, int64_t Ppad, double* B) {
+  dim3 grid((unsigned)(Ppad / 64), (unsigned)(m.Npad / 4));
+  hipLaunchKernelGGL(kstar_t_dev_kernel, grid, dim3(256), 0, s, m, Xq, P_dev, Ppad, B);
+}
+
+// part[chunk][0][p] = sum_{k in chunk} B[k][p] alpha[k],  part[chunk][1][p] = sum_{k in chunk} C[k][p]^2:
+// block (column group of 64, row chunk), thread (column, row lane of 4); the four lanes' sums are added in lane order
+constexpr int REPAIR_CHUNKS = 32;
+__global__ __launch_bounds__(256) void repair_colsums_kernel(const double* __restrict__ B, const double* __restrict__ C,
+                                                             const double* __restrict__ alpha, int64_t Npad, int64_t Ppad,
+                                                             double* __restrict__ part) {
+  __shared__ double sm[4][64], sq[4][64];
+  const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int64_t p = (int64_t)blockIdx.x * 64 + col;
+  const int64_t rows = Npad / REPAIR_CHUNKS, r0 = (int64_t)blockIdx.y * rows;
+  double m = 0.0, q = 0.0;
+  for (int64_t r = r0 + rl; r < r0 + rows; r += 4) {
+    const double c = C[r * Ppad + p];
+    m = fma(B[r * Ppad + p], alpha[r], m);
+    q = fma(c, c, q);
+  }
+  sm[rl][col] = m;
+  sq[rl][col] = q;
+  __syncthreads();
+  if (rl == 0) {
+    part[((size_t)blockIdx.y * 2 + 0) * Ppad + p] = ((sm[0][col] + sm[1][col]) + sm[2][col]) + sm[3][col];
+    part[((size_t)blockIdx.y * 2 + 1) * Ppad + p] = ((sq[0][col] + sq[1][col]) + sq[2][col]) + sq[3][col];
+  }
+}
+// the chunks in order, then the sweep's own tail (sweep_combine_kernel above): clip, acquisition value, outputs
+__global__ __launch_bounds__(256) void repair_tail_kernel(ModelDev md, const double* __restrict__ part, int64_t Ppad,
+                                                          const int64_t* __restrict__ P_dev, int acq_kind, double acq_param,
+                                                          double* __restrict__ mean_out, double* __restrict__ var_out,
+                                                          double* __restrict__ acq_out) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= *P_dev || p >= Ppad) return;
+  double m = 0.0, q = 0.0;
+  for (int c = 0; c < REPAIR_CHUNKS; ++c) {
+    m += part[((size_t)c * 2 + 0) * Ppad + p];
+    q += part[((size_t)c * 2 + 1) * Ppad + p];
+  }
+  const double mean = m + md.mean_const;
+  const double var = fmax(md.variance - q, VAR_FLOOR);
+  if (mean_out) mean_out[p] = mean;
+  if (var_out) var_out[p] = var;
+  if (acq_kind >= 0 && acq_out) acq_out[p] = acq_tail(acq_kind, acq_param, mean, var, md.noise);
+}
+void launch_repair_product_tail(hipStream_t s, const ModelDev& m, const double* B, const double* C, int64_t Ppad,
+                                const int64_t* P_dev, int acq_kind, double acq_param, double* part, double* mean_out,
+                                double* var_out, double* acq_out) {
+  hipLaunchKernelGGL(repair_colsums_kernel, dim3((unsigned)(Ppad / 64), REPAIR_CHUNKS), dim3(256), 0, s, B, C, m.alpha,
+                     m.Npad, Ppad, part);
+  hipLaunchKernelGGL(repair_tail_kernel, dim3((unsigned)((Ppad + 255) / 256)), dim3(256), 0, s, m, part, Ppad, P_dev,
+                     acq_kind, acq_param, mean_out, var_out, acq_out);
+}
+int64_t repair_product_part_doubles(int64_t Ppad) { return (int64_t)REPAIR_CHUNKS * 2 * Ppad; }
+
 }  // namespace tgp
