@@ -444,7 +444,8 @@ int tgp_get_auto_report(tgp_handle h, int64_t* checked, int64_t* violations, dou
  * dp = 32 always uses it), bit 3 = fused plain launches on the register-staged kernel instead of the LDS-DMA one, bit 4 =
  * `update` through the recursion of dependent launches instead of the persistent task-DAG kernel, bit 5 = the persistent
  * kernel from Npad = 256 on (default: from 4096 on, where it is the faster one), bit 6 = TGP_PREC_AUTO recomputes every
- * flagged candidate through the row-group-split sweep instead of the product path it takes for lists of up to 512.  Bits 0-3:
+ * flagged candidate through the row-group-split sweep instead of the product path it takes for lists of up to 512, bit 7 =
+ * the int8 sweep's workgroups take candidate blocks i, i + #WG, ... instead of drawing them from a counter.  Bits 0-3, 7:
  * every setting computes the same arithmetic on every candidate; bits 4 - 6: the same values up to the rounding of another
  * summation order. */
 int tgp_set_variant(tgp_handle h, int variant);

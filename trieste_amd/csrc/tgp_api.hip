@@ -153,8 +153,9 @@ void apply_penalization(tgp_handle h, double* dvals, const double* dXq, int64_t 
 //   VARIANT_DAG_SMALL (32): the persistent kernel from Npad = 256 on (default: from 4096 on, where it wins)
 //   VARIANT_NO_REPAIR_PRODUCT (64): TGP_PREC_AUTO recomputes every flagged candidate through the SPLIT sweep (rounds 4 / 5)
 //                                   instead of the product path for short lists
+//   VARIANT_STATIC_BLOCKS (128): the int8 sweep's workgroups take candidate blocks i, i + #WG, ... instead of drawing them from a counter
 constexpr int VARIANT_NO_SPLIT = 1, VARIANT_FORCE_SPLIT = 2, VARIANT_JOINT_V1 = 4, VARIANT_REG_STAGING = 8, VARIANT_NO_DAG = 16,
-              VARIANT_DAG_SMALL = 32, VARIANT_NO_REPAIR_PRODUCT = 64;
+              VARIANT_DAG_SMALL = 32, VARIANT_NO_REPAIR_PRODUCT = 64, VARIANT_STATIC_BLOCKS = 128;
 constexpr int64_t REPAIR_PCAP = 512;   // TGP_PREC_AUTO: lists up to this many candidates are recomputed as a product
 int gemm_tall(tgp_handle h, bool tb, int m, int n, int k, double alpha, const double* A, int64_t lda, const double* B,
               int64_t ldb, double beta, double* C, int64_t ldc, int tri);
@@ -290,6 +291,13 @@ hipError_t launch_sweep_i8_timed(tgp_handle h, SweepArgs& am) {
   am.i8_xsa = (planes == 4 && h->dp <= 16) ? h->d_xsa.as<double>() : nullptr;   // (five planes leave no LDS for the tiles)
   const int64_t blocks = (am.M + 63) / 64;
   const int64_t wgrid = blocks < h->num_cu ? blocks : h->num_cu;
+  // candidate blocks beyond one per workgroup are drawn from a counter (the workgroups of a launch differ in speed)
+  am.blk_ctr = nullptr;
+  if (blocks > wgrid && !(h->variant & VARIANT_STATIC_BLOCKS)) {
+    if ((e = h->s_blkctr.reserve(64)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(h->s_blkctr.p, 0, sizeof(unsigned), h->stream)) != hipSuccess) return e;
+    am.blk_ctr = h->s_blkctr.as<unsigned>();
+  }
   if (!h->repair) {
     if ((e = h->s_kcache.reserve((size_t)wgrid * (size_t)Npad * 64 * planes)) != hipSuccess) return e;
     am.kcache = h->s_kcache.as<double>();

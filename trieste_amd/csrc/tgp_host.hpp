@@ -101,7 +101,7 @@ struct tgp_handle_s {
   int can_demotions = 0;         // rungs left BECAUSE of a violation since the ladder restarted
   std::vector<double> auto_hyp;  // (variance / noise, lengthscales) when a rung was last left: tgp_set_hyper keeps the rung
                                  // while the new hyper-parameters stay within a factor two of these
-  DevBuf s_rep, s_rep_stats;
+  DevBuf s_rep, s_rep_stats, s_blkctr;   // (s_blkctr: the int8 sweep's candidate-block counter, one word)
   DevBuf d_wq, d_rs, d_xsa;
   uint64_t wq_version = 0;
   int wq_planes = 0;

@@ -53,6 +53,8 @@ struct SweepArgs {
   const void* i8_wq;  // int8 sweep: digit planes of W, Wq[s][k/32][i][32] (4 or 5 planes of Npad^2 bytes)
   const double* i8_rs; // int8 sweep: [Npad] row scales S_i = 2 max_k |W_ik|
   const double* i8_xsa; // int8 sweep: [Npad / 32] tiles (32 rows of Xs + alpha) for LDS staging, or null (scalar loads)
+  unsigned* blk_ctr;    // sweep_i8_kernel: a workgroup's candidate blocks after its first are drawn from this counter (zero at
+                        // launch); null: blocks i, i + #WG, ...  (sweep_dma_kernel, 8 ms per block: measured neutral, not wired)
   double* aslab;      // [grid][Npad][128] C = W K* slabs of joint mode (device scratch)
   // row-group split of small sweeps (SPLIT instantiation): group g of a candidate block owns the row
   // blocks [split_ib[g], split_ib[g+1]) of W and leaves partial (mean, sum c^2) in `part`
