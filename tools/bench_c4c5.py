@@ -7,7 +7,7 @@ from trieste_amd.engine import GPEngine
 
 def c4(G=20000, q=50, S=512, N=2048, d=6):
     X, Y = O.synthetic_problem(O.hartmann_6, d, N)
-    eng = GPEngine(d, "matern52"); eng.set_hyper(1.0, O.default_lengthscales(d), 1e-2, float(Y.mean())); eng.set_data(X, Y)
+    eng = GPEngine(d, "matern52"); eng.set_variant(int(os.environ.get("TGP_VARIANT", "0"))); eng.set_hyper(1.0, O.default_lengthscales(d), 1e-2, float(Y.mean())); eng.set_data(X, Y)
     eta = eng.eta()
     rng = np.random.default_rng(91011)
     eps = torch.from_numpy(rng.standard_normal((q, S))).cuda()
@@ -27,7 +27,7 @@ def c4(G=20000, q=50, S=512, N=2048, d=6):
 
 def c5(M=1 << 20, F=2048, N=8192, d=16, B=4):
     X, Y = O.synthetic_problem(O.ackley, d, N)
-    eng = GPEngine(d, "matern52"); eng.set_hyper(1.0, O.default_lengthscales(d), 1e-2, float(Y.mean()))
+    eng = GPEngine(d, "matern52"); eng.set_variant(int(os.environ.get("TGP_VARIANT", "0"))); eng.set_hyper(1.0, O.default_lengthscales(d), 1e-2, float(Y.mean()))
     t0 = time.perf_counter(); eng.set_data(X, Y); t1 = time.perf_counter()
     rng = np.random.default_rng(7)
     W = rng.standard_t(5, size=(F, d)); b = rng.uniform(0, 2 * np.pi, F)
