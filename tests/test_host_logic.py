@@ -921,22 +921,6 @@ def test_fit_model_false_leaves_the_models_alone():
     assert model2.engine.N == 8 and len(nt.dataset) == 9
 
 
-def test_multiple_optimism_lcb_accepts_flat_points_and_single_query_point():
-    from trieste_amd.acquisition import MultipleOptimismNegativeLowerConfidenceBound
-
-    model, data = _model(n=10)
-    box = Box([0.0, 0.0], [1.0, 1.0])
-    fn = MultipleOptimismNegativeLowerConfidenceBound(box).prepare_acquisition_function(model, dataset=data)
-    pts = np.random.default_rng(0).uniform(size=(5, 2))
-    v2, g2 = fn.value_and_gradient(pts)                 # [P, D]: what batch-size-one optimizers pass
-    v3, g3 = fn.value_and_gradient(pts[:, None, :])
-    assert v2.shape == (5,) and g2.shape == (5, 2)
-    np.testing.assert_array_equal(v2, v3[:, 0])
-    np.testing.assert_array_equal(g2, g3[:, 0, :])
-    rule = EfficientGlobalOptimization(MultipleOptimismNegativeLowerConfidenceBound(box), num_query_points=1)
-    assert rule.acquire_single(box, model, dataset=data).shape == (1, 2)
-
-
 def test_split_wrapper_keeps_the_fused_api_and_rejects_zero_vectorization():
     model, data = _model(n=10)
     fn = ExpectedImprovement().prepare_acquisition_function(model, dataset=data)
