@@ -412,15 +412,27 @@ int tgp_last_kernel_ms(tgp_handle h, double* ms, int* launches);
  *                 bound is a STATISTICAL model of the dropped digit pairs (independent errors; measured against 80-bit
  *                 sums), not a worst case; what it promises -- results inside the parity tolerance candidate by
  *                 candidate, the float64 arg-max -- holds as far as that model does, and float64 stays the only
- *                 arithmetic the parity claims are made on.  Every sweep therefore carries a CANARY: one candidate in
- *                 4096 (pseudo-randomly offset per sweep) is recomputed in float64 whatever its interval says and
- *                 |var_f64 - var_int8| is compared with that candidate's own bound on the device; a violation moves
- *                 the engine one rung down -- before the next sweep, and for the synchronising entry points before they
- *                 return: they repeat their sweeps on the next rung (tgp_get_auto_report).  The ladder: four planes,
- *                 five (d <= 16), float64; a rung is also left when a sweep had to recompute more than 5 % of its
- *                 candidates.  tgp_set_precision restarts the ladder, tgp_set_hyper does unless a rung was left under
- *                 hyper-parameters within a factor two of the new ones.  N <= 16384 (int32 accumulators), float64
- *                 above. */
+ *                 arithmetic the parity claims are made on.  Every sweep therefore carries a CANARY in two strata: a
+ *                 UNIFORM sample -- one candidate in 4096, at an offset that is a function of (N, hyper-parameters, M, rung)
+ *                 -- and an ADVERSARIAL one -- of every 1 / 64 of the sweep the unflagged candidate whose bound sits
+ *                 closest to its tolerance, where a failure of the error model would show first.  Both are recomputed
+ *                 in float64 whatever their intervals say and |var_f64 - var_int8| is compared with the candidate's
+ *                 own bound on the device (+ the float64 kernels' rounding floor); a violation in either moves the
+ *                 engine one rung down -- before the next sweep, and for the SYNCHRONISING entry points (tgp_predict,
+ *                 tgp_acq_values, tgp_acq_argmax, tgp_acq_topk) before they return: they repeat their sweeps on the
+ *                 next rung.  The enqueue-only entry points (tgp_acq_argmax_async, the group / multi-device sweeps,
+ *                 tgp_merge_winners_async) return what the rung in effect computed; a violation they meet takes effect
+ *                 at the next call (tgp_get_auto_report after the stream is synchronised tells).
+ *                 REPRODUCIBILITY: the samples are compared, never written over the int8 results; only what a sweep
+ *                 FLAGGED (bound above the tolerance; in a fused arg-max: interval reaching the best lower end) is
+ *                 replaced by its float64 value.  tgp_predict / tgp_acq_values under AUTO are therefore a pure function
+ *                 of (model state, rung, candidate) -- two identical calls return identical bits, and a candidate's
+ *                 value does not depend on which other candidates share its call; the fused arg-max returns the
+ *                 float64 winner.  The ladder: four planes, five (d <= 16), float64; a rung is also left when a sweep
+ *                 had to recompute more than 5 % of its candidates.  tgp_set_precision restarts the ladder; after
+ *                 tgp_set_hyper / tgp_clone_from the next SWEEP does unless a rung was left under hyper-parameters
+ *                 within a factor two of the ones then in effect (a fit's trial evaluations do not count).
+ *                 N <= 16384 (int32 accumulators), float64 above. */
 enum tgp_precision { TGP_PREC_F64 = 0, TGP_PREC_I8X4 = 1, TGP_PREC_I8X5 = 2, TGP_PREC_AUTO = 3 };
 int tgp_set_precision(tgp_handle h, int precision);
 /* What was asked for, what the next plain sweep will run (never TGP_PREC_AUTO) and, under AUTO, the fraction of its
@@ -431,7 +443,7 @@ int tgp_get_precision(tgp_handle h, int* requested, int* effective, double* repa
  * candidates and make the canary stricter: with a bound tighter than the arithmetic's real error the canary fires and
  * the ladder ends on float64 (tests/test_gpu_i8.py drives it that way). */
 int tgp_set_auto_sigma(tgp_handle h, double k_sigma);
-/* The canary of TGP_PREC_AUTO since the ladder last restarted: sampled candidates compared, samples outside their
+/* The canary of TGP_PREC_AUTO since tgp_set_precision / tgp_set_auto_sigma: sampled candidates compared, samples outside their
  * bound, the worst |var_f64 - var_int8| / bound seen, rungs left BECAUSE of a violation, the current rung (0 four
  * planes, 1 five, 2 float64; -1 when the precision is not AUTO).  Synchronises the handle's stream.  The reference has
  * no counterpart: its arithmetic is float64 throughout (trieste/models/gpflow/interface.py:119-124); this is the
@@ -439,6 +451,12 @@ int tgp_set_auto_sigma(tgp_handle h, double k_sigma);
  * (tests/unit/models/gpflow/test_models.py:363-365). */
 int tgp_get_auto_report(tgp_handle h, int64_t* checked, int64_t* violations, double* worst_ratio, int* demotions,
                         int* level);
+/* The same report per stratum of the canary (round 6): checked2 / violations2 / worst_ratio2 are arrays of TWO -- [0] the
+ * uniform sample, [1] the adversarial one (tgp_get_auto_report returns their sums / maximum); slack_saved: samples that
+ * were inside bound + rounding floor but outside the bound alone (float64 rounding of the reference values, not the int8
+ * arithmetic).  Accumulated since tgp_set_precision / tgp_set_auto_sigma.  Synchronises the handle's stream.  No reference
+ * counterpart (see tgp_get_auto_report). */
+int tgp_get_auto_strata(tgp_handle h, int64_t* checked2, int64_t* violations2, double* worst_ratio2, int64_t* slack_saved);
 /* Sweep launch policy knob for experiments and tests (0 = default): bit 0 = never use the row-group split of
  * small launches, bit 1 = always use it, bit 2 = joint mode on the first-generation kernel (64-column group slots;
  * dp = 32 always uses it), bit 3 = fused plain launches on the register-staged kernel instead of the LDS-DMA one, bit 4 =

@@ -140,6 +140,11 @@ class FakeEngine:
         return dict(checked=0, violations=0, worst_ratio=0.0, demotions=0,
                     level=0 if getattr(self, "_precision", "f64") == "auto" else -1)
 
+    def get_auto_strata(self):
+        """tgp_get_auto_strata: the float64 stand-in has nothing to sample."""
+        none = dict(checked=0, violations=0, worst_ratio=0.0)
+        return dict(uniform=dict(none), adversarial=dict(none), slack_saved=0)
+
     def clone_from(self, other):
         if not isinstance(other, FakeEngine):
             raise TypeError(f"can only clone from an engine, got {other!r}")

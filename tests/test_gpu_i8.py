@@ -311,3 +311,125 @@ def test_auto_canary_fires_when_its_error_model_is_wrong_for_the_input(cfg):
     with pytest.raises(ValueError):
         eng.set_auto_sigma(0.0)
     eng.set_precision("f64")
+
+
+def test_auto_outputs_are_a_pure_function_of_model_and_inputs():
+    """Round 6: the canary's samples are compared on the device and NOT written over the int8 results, and
+    the uniform sample's offset is a function of (N, hyper-parameters, M, rung) instead of a call counter.  Hence two identical
+    calls return identical bits, the ladder takes the same decisions, and a candidate's value does not depend on which other
+    candidates share its call (only what a sweep FLAGS is replaced by its float64 value, and a flag is the candidate's own)."""
+    _, obj, d, kind, N, noise = CONFIGS[2]
+    eng, st, Xq = _setup(obj, d, kind, N, noise, M=3 * 4096 + 77)
+    eta = float(np.median(O.predict(st, Xq)[0]))
+    eng.set_precision("auto")
+    runs = []
+    for _ in range(3):
+        m, v = (np.asarray(t).copy() for t in eng.predict(Xq))
+        ei = np.asarray(eng.acq_values("ei", eta, Xq)).copy()
+        runs.append((m, v, ei, eng.acq_argmax("ei", eta, Xq)[:2], eng.get_precision()[1]))
+    for m, v, ei, win, eff in runs[1:]:
+        assert eff == runs[0][4] == "i8x4"
+        assert np.array_equal(m, runs[0][0]) and np.array_equal(v, runs[0][1]) and np.array_equal(ei, runs[0][2])
+        assert win == runs[0][3], (win, runs[0][3])
+    # a sub-batch (another M: other uniform samples, other adversarial picks): the shared candidates' values are the same bits
+    for m_sub in (4096 + 100, 700, 64):
+        ms, vs = (np.asarray(t) for t in eng.predict(Xq[:m_sub]))
+        es = np.asarray(eng.acq_values("ei", eta, Xq[:m_sub]))
+        assert np.array_equal(ms, runs[0][0][:m_sub]) and np.array_equal(vs, runs[0][1][:m_sub])
+        assert np.array_equal(es, runs[0][2][:m_sub])
+    # ... and a second engine on the same data returns them too (the offset does not depend on a handle's history)
+    eng2, _, _ = _setup(obj, d, kind, N, noise, M=16)
+    eng2.set_precision("auto")
+    m2, v2 = (np.asarray(t) for t in eng2.predict(Xq))
+    assert np.array_equal(m2, runs[0][0]) and np.array_equal(v2, runs[0][1])
+    eng.set_precision("f64")
+    eng2.set_precision("f64")
+
+
+def test_auto_canary_strata_are_reported_apart():
+    """Round 6: besides the uniform 1-in-4096 sample every AUTO sweep recomputes an ADVERSARIAL stratum -- of every 1 / 64 of
+    the sweep the unflagged candidate whose bound sits closest to its tolerance (where a failure of the independence model
+    would show first; the uniform sample meets those at the same 1 / 4096 as the far field) -- and compares it with its own
+    bound on the device.  tgp_get_auto_strata reports the two apart; tgp_get_auto_report their sum."""
+    _, obj, d, kind, N, noise = CONFIGS[2]
+    M = 3 * 4096 + 77
+    eng, st, Xq = _setup(obj, d, kind, N, noise, M=M)
+    om, ov = O.predict(st, Xq)
+    floor = cancellation_floor(N, 1.0, noise)
+    eng.set_precision("auto")
+    assert eng.get_auto_strata() == dict(uniform=dict(checked=0, violations=0, worst_ratio=0.0),
+                                         adversarial=dict(checked=0, violations=0, worst_ratio=0.0), slack_saved=0)
+    n_sweeps = 3
+    for _ in range(n_sweeps):
+        mean, var = eng.predict(Xq)
+    s = eng.get_auto_strata()
+    rep = eng.get_auto_report()
+    print(f"[margin] auto canary strata, {CONFIGS[2][0]}: {s}")
+    assert s["uniform"]["checked"] in (n_sweeps * (M // 4096), n_sweeps * (M // 4096 + 1)), s
+    assert s["adversarial"]["checked"] == n_sweeps * 64, s       # 193 blocks of 64 candidates: every group has a pick
+    assert s["uniform"]["violations"] == s["adversarial"]["violations"] == 0 and rep["level"] == 0, (s, rep)
+    assert rep["checked"] == s["uniform"]["checked"] + s["adversarial"]["checked"]
+    assert 0.0 < s["adversarial"]["worst_ratio"] < 1.0 and 0.0 <= s["uniform"]["worst_ratio"] < 1.0, s
+    assert_close(var, ov, atol=floor, what="var under auto with both strata")
+    # a tiny sweep: one block -> one adversarial pick, no uniform sample unless the offset hits
+    eng.predict(Xq[:40])
+    s2 = eng.get_auto_strata()
+    assert s2["adversarial"]["checked"] == s["adversarial"]["checked"] + 1, (s, s2)
+    # the bound made 400 x too tight: the adversarial stratum fires as well (it samples where the bound / tolerance is LARGEST,
+    # the violation ratio is |d var| / bound -- any candidate breaks a bound that tight)
+    eng.set_auto_sigma(0.02)
+    assert eng.get_auto_strata()["adversarial"]["checked"] == 0      # tgp_set_auto_sigma clears the report
+    mean, var = eng.predict(Xq)
+    s3 = eng.get_auto_strata()
+    print(f"[margin] auto canary strata, bound 400 x too tight: {s3}; in effect {eng.get_precision()[1]}")
+    assert s3["adversarial"]["violations"] >= 1 and s3["uniform"]["violations"] >= 1, s3
+    assert eng.get_auto_report()["demotions"] >= 1
+    assert_close(var, ov, atol=floor, what="var returned by the call whose canaries fired")
+    eng.set_precision("f64")
+
+
+def test_auto_ladder_survives_the_trial_evaluations_of_a_refit():
+    """tgp_set_hyper used to decide keep-or-restart on the spot, so a fit's trial evaluations (prior draws, L-BFGS-B
+    steps: far-away hyper-parameters, then back) restarted a ladder whose rung the refit itself would have kept -- and the
+    failed rung plus its repeat sweep were paid again at every BO step.  The decision is now taken at the next SWEEP from the
+    hyper-parameters in effect then; what the closed epoch's canary counted joins the report's totals."""
+    _, obj, d, kind, N, noise = CONFIGS[0]        # ill-conditioned: four planes recompute ~half of the candidates -> five planes
+    eng, st, Xq = _setup(obj, d, kind, N, noise, M=1500)
+    X, Y = O.synthetic_problem(obj, d, N)
+    ls = O.default_lengthscales(d)
+    c = float(np.mean(Y))
+    eng.set_precision("auto")
+    for _ in range(3):
+        eng.predict(Xq)
+    level = eng.get_auto_report()["level"]
+    checked = eng.get_auto_report()["checked"]
+    assert level >= 1 and checked > 0, eng.get_auto_report()
+    # a "fit": far-away trial hyper-parameters, then values within a factor two of where the rung was left
+    for trial in (dict(v=30.0, l=0.05, n=1e-6), dict(v=0.01, l=7.0, n=0.5)):
+        eng.set_hyper(trial["v"], ls * trial["l"], trial["n"], c)
+        eng.nlml_trial()
+    eng.set_hyper(1.0, ls * 1.2, noise * 1.3, c)
+    eng.set_data(X, Y)
+    assert eng.get_auto_report()["level"] == level, eng.get_auto_report()      # kept: no sweep ran under the trial values
+    assert eng.get_auto_report()["checked"] >= checked                          # the closed epochs' samples are in the totals
+    st2 = O.gpr_update(kind, 1.0, ls * 1.2, noise * 1.3, c, X, Y)
+    mean, var = eng.predict(Xq)
+    assert_close(var, O.predict(st2, Xq)[1], atol=cancellation_floor(N, 1.0, noise * 1.3), what="var after the kept refit")
+    assert eng.get_auto_report()["checked"] > checked
+    # hyper-parameters far from where the rung was left restart the ladder at four planes -- at the next sweep
+    eng.set_hyper(1.0, ls, 0.5, c)
+    eng.set_data(X, Y)
+    assert eng.get_precision()[1] == "i8x4"
+    # a clone takes the source's rung along
+    eng.set_hyper(1.0, ls, noise, c)
+    eng.set_data(X, Y)
+    for _ in range(3):
+        eng.predict(Xq)
+    level = eng.get_auto_report()["level"]
+    assert level >= 1
+    from trieste_amd.engine import GPEngine
+    twin = GPEngine(d, kind)
+    twin.set_precision("auto")
+    twin.clone_from(eng)
+    assert twin.get_auto_report()["level"] == level
+    eng.set_precision("f64")

@@ -98,6 +98,7 @@ SIGNATURES = {
     "tgp_set_auto_sigma": (C.c_int, [_vp, C.c_double]),
     "tgp_get_auto_report": (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _dp, C.POINTER(C.c_int),
                                       C.POINTER(C.c_int)]),
+    "tgp_get_auto_strata": (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _dp, C.POINTER(C.c_int64)]),
     "tgp_dag_plan": (C.c_int, [C.c_int, C.c_int64, _vp, C.c_int64, _ip, _ip, _vp, _vp, C.c_int]),
 }
 

@@ -176,14 +176,65 @@ int auto_rung_precision(tgp_handle h) {
   if (h->auto_level == 1 && h->dp <= 16) return TGP_PREC_I8X5;
   return TGP_PREC_F64;
 }
-static void auto_restart(tgp_handle h) {   // the ladder starts over at four planes
+// the current epoch's canary counters (as last read) join the totals: the device's words restart with the epoch
+static void auto_fold_counters(tgp_handle h) {
+  for (int k = 0; k < 2; ++k) {
+    h->can_checked_total[k] += h->can_checked[k];
+    h->can_viol_total[k] += h->can_viol[k];
+    h->can_checked[k] = h->can_viol[k] = 0;
+  }
+  h->can_slack_total += h->can_slack;
+  h->can_slack = 0;
+}
+// the ladder starts over at four planes; `zero_report`: tgp_set_precision / tgp_set_auto_sigma also clear what
+// tgp_get_auto_report accumulates (a restart because the hyper-parameters moved keeps it)
+static void auto_restart(tgp_handle h, bool zero_report) {
+  auto_fold_counters(h);
   h->auto_level = 0;
   ++h->auto_epoch;
   h->rep_last_M = h->rep_last_count = 0;
-  h->can_checked = h->can_viol = h->can_checked_total = h->can_viol_total = 0;
-  h->can_worst = 0.0;
-  h->can_demotions = 0;
+  if (zero_report) {
+    for (int k = 0; k < 2; ++k) {
+      h->can_checked_total[k] = h->can_viol_total[k] = 0;
+      h->can_worst[k] = 0.0;
+    }
+    h->can_slack_total = 0;
+    h->can_demotions = 0;
+  }
   h->auto_hyp.clear();
+  h->auto_hyper_dirty = false;
+}
+// the last COMPLETED repaired sweep's report (stream-ordered copy into pinned memory; a torn or stale read only delays the
+// decision by one sweep): counters, and the decision to leave the rung
+static void auto_read_report(tgp_handle h) {
+  if (!h->rep_host) return;
+  const volatile int64_t* r = h->rep_host;
+  const int64_t cnt = r[RS_COUNT], M = r[RS_M], ep = r[RS_TAG];
+  const int64_t viol[2] = {r[RS_VIOL], r[RS_ADV_VIOL]}, chk[2] = {r[RS_CHECKED], r[RS_ADV_CHECKED]};
+  const int64_t wbits[2] = {r[RS_WORST], r[RS_ADV_WORST]};
+  if (ep != (int64_t)h->auto_epoch || M <= 0) return;
+  h->rep_last_count = cnt;
+  h->rep_last_M = M;
+  for (int k = 0; k < 2; ++k) {
+    h->can_viol[k] = viol[k];
+    h->can_checked[k] = chk[k];
+    double worst;
+    memcpy(&worst, &wbits[k], sizeof(double));
+    if (worst == worst && worst > h->can_worst[k]) h->can_worst[k] = worst;
+  }
+  h->can_slack = r[RS_SLACK_SAVED];
+  // a rung is left when the repair costs more than the wider arithmetic saves, or when a sampled candidate's float64
+  // value lay outside the bound the int8 kernel priced it at: the error model is wrong for this input
+  const bool costly = M >= 1024 && (double)cnt > AUTO_DEMOTE * (double)M;
+  const bool violated = viol[0] + viol[1] > 0;
+  if ((costly || violated) && h->auto_level < 2) {
+    h->auto_level += (h->auto_level == 0 && h->dp > 16) ? 2 : 1;
+    auto_fold_counters(h);
+    ++h->auto_epoch;
+    if (violated) ++h->can_demotions;
+    h->auto_hyp.assign(1, h->variance / h->noise);
+    h->auto_hyp.insert(h->auto_hyp.end(), h->ls.begin(), h->ls.end());
+  }
 }
 hipError_t resolve_precision(tgp_handle h) {
   if (h->precision_req != TGP_PREC_AUTO) {
@@ -192,33 +243,22 @@ hipError_t resolve_precision(tgp_handle h) {
     return hipSuccess;
   }
   if (h->auto_pinned) return hipSuccess;  // already resolved for the call in progress (sweep_blocks)
-  if (h->rep_host) {
-    // the last COMPLETED repaired sweep's report (stream-ordered copy into pinned memory; a torn or stale read only
-    // delays the decision by one sweep)
-    const volatile int64_t* r = h->rep_host;
-    const int64_t cnt = r[0], M = r[1], ep = r[2], viol = r[3], chk = r[4], wbits = r[5];
-    if (ep == (int64_t)h->auto_epoch && M > 0) {
-      h->rep_last_count = cnt;
-      h->rep_last_M = M;
-      h->can_viol = viol;
-      h->can_checked = chk;
-      double worst;
-      memcpy(&worst, &wbits, sizeof(double));
-      if (worst == worst && worst > h->can_worst) h->can_worst = worst;
-      // a rung is left when the repair costs more than the wider arithmetic saves, or when a sampled candidate's float64
-      // value lay outside the bound the int8 kernel priced it at: the error model is wrong for this input
-      const bool costly = M >= 1024 && (double)cnt > AUTO_DEMOTE * (double)M;
-      if ((costly || viol > 0) && h->auto_level < 2) {
-        h->auto_level += (h->auto_level == 0 && h->dp > 16) ? 2 : 1;
-        ++h->auto_epoch;
-        h->can_checked_total += chk;
-        h->can_viol_total += viol;
-        h->can_checked = h->can_viol = 0;
-        if (viol > 0) ++h->can_demotions;
-        h->auto_hyp.assign(1, h->variance / h->noise);
-        h->auto_hyp.insert(h->auto_hyp.end(), h->ls.begin(), h->ls.end());
-      }
+  auto_read_report(h);
+  if (h->auto_hyper_dirty) {
+    // tgp_set_hyper ran since the last sweep (it closed the epoch: reports of sweeps under the old hyper-parameters are
+    // stale).  New hyper-parameters (new conditioning) restart the ladder -- unless a rung was left under hyper-parameters
+    // within a factor two of the ones in effect NOW (variance / noise, every lengthscale): a BO loop whose refit moves them a
+    // little would otherwise re-pay the failed rung's sweep plus its repair at every step.  Decided here, at the next sweep,
+    // not inside tgp_set_hyper: the trial evaluations of a fit (prior draws, L-BFGS-B steps) pass through far-away values
+    // and come back.
+    h->auto_hyper_dirty = false;
+    bool keep = h->auto_level > 0 && h->auto_hyp.size() == (size_t)h->d + 1;
+    if (keep) {
+      auto far = [](double a, double b) { return !(a < 2.0 * b && b < 2.0 * a); };
+      keep = !far(h->variance / h->noise, h->auto_hyp[0]);
+      for (int c = 0; keep && c < h->d; ++c) keep = !far(h->ls[c], h->auto_hyp[1 + c]);
     }
+    if (!keep) auto_restart(h, false);
   }
   h->precision = auto_rung_precision(h);
   h->repair = h->precision != TGP_PREC_F64;
@@ -229,7 +269,7 @@ hipError_t resolve_precision(tgp_handle h) {
 static bool auto_canary_tripped(tgp_handle h) {
   if (h->precision_req != TGP_PREC_AUTO || !h->repair || !h->rep_host || h->auto_level >= 2) return false;
   const volatile int64_t* r = h->rep_host;
-  if (r[2] != (int64_t)h->auto_epoch || r[3] <= 0) return false;
+  if (r[RS_TAG] != (int64_t)h->auto_epoch || r[RS_VIOL] + r[RS_ADV_VIOL] <= 0) return false;
   h->auto_pinned = false;
   (void)resolve_precision(h);
   return true;
@@ -303,6 +343,7 @@ hipError_t launch_sweep_i8_timed(tgp_handle h, SweepArgs& am) {
     am.kcache = h->s_kcache.as<double>();
     am.rep_ub = nullptr;
     am.canary_rec = nullptr;
+    am.adv_rec = nullptr;
     (void)hipEventRecord(h->ev0, h->stream);
     switch (h->kind) {
       case TGP_RBF: e = launch_sweep_i8_kind0(h->stream, am, wgrid, planes); break;
@@ -337,30 +378,40 @@ hipError_t launch_sweep_i8_timed(tgp_handle h, SweepArgs& am) {
     b.split_ib[0] = 0;
     b.split_ib[1] = nb;
   }
-  const int64_t cap_blocks = (M + SW_BN - 1) / SW_BN;
+  const int64_t cap = M + I8_ADV_GROUPS;   // the repair list: at most every candidate + the adversarial picks
+  const int64_t cap_blocks = (cap + SW_BN - 1) / SW_BN;
   int64_t fgrid = cap_blocks * g;
   fgrid = fgrid < h->num_cu ? fgrid : h->num_cu;
   const size_t kc_i8 = (size_t)wgrid * (size_t)Npad * 64 * planes, kc_f64 = (size_t)fgrid * (size_t)Npad * SW_BN * sizeof(double);
   if ((e = h->s_kcache.reserve(std::max(kc_i8, kc_f64))) != hipSuccess) return e;
   if ((e = h->s_part.reserve((size_t)cap_blocks * g * 256 * sizeof(double))) != hipSuccess) return e;
-  // ub [M], vals [M], recomputed (mean, var, acq) [3][M], list [M] (int64), gathered candidates [M][d], canary records
+  // ub [M], vals [M]; with room for the adversarial picks behind a list of everything (cap = M + 64): recomputed (mean, var,
+  // acq) [3][cap], list [cap] (int64), gathered candidates [cap][d]; then the uniform canary's records [n_can][2], the
+  // int8 sweep's per-block adversarial records [blocks][4] and the picks [64][3]
   const int64_t n_can = (M + I8_CANARY_PERIOD - 1) / I8_CANARY_PERIOD + 2;
-  if ((e = h->s_rep.reserve((size_t)(M * (6 + d) + 2 * n_can) * sizeof(double) + 64)) != hipSuccess) return e;
-  if ((e = h->s_rep_stats.reserve(128)) != hipSuccess) return e;
-  if (!h->rep_host && (e = hipHostMalloc((void**)&h->rep_host, 64, hipHostMallocDefault)) != hipSuccess) return e;
+  if ((e = h->s_rep.reserve((size_t)(2 * M + cap * (4 + d) + 2 * n_can + 4 * blocks + 3 * I8_ADV_GROUPS) * sizeof(double) + 64)) !=
+      hipSuccess)
+    return e;
+  if ((e = h->s_rep_stats.reserve(RS_WORDS * sizeof(int64_t))) != hipSuccess) return e;
+  if (!h->rep_host && (e = hipHostMalloc((void**)&h->rep_host, RS_WORDS * sizeof(int64_t), hipHostMallocDefault)) != hipSuccess)
+    return e;
   double* ub = h->s_rep.as<double>();
   double* vals = ub + M;          // acquisition values when the caller wants none written
-  double* rout = vals + M;        // [3][M] mean, var, acq of the recomputed candidates
-  int64_t* list = (int64_t*)(rout + 3 * M);
-  double* Xg = (double*)(list + M);
-  double* crec = Xg + M * d;                        // [n_can][2]: the sampled candidates' int8 variance and bound
-  int64_t* stats = h->s_rep_stats.as<int64_t>();   // {count, M, epoch, canary violations, checked, worst ratio, -, -}
-  double* Lslot = (double*)(stats + 8);             // {L, its index}
-  int64_t* route = (int64_t*)(Lslot + 2);           // {count if the SPLIT sweep recomputes, count if the product path does}
+  double* rout = vals + M;        // [3][cap] mean, var, acq of the recomputed candidates
+  int64_t* list = (int64_t*)(rout + 3 * cap);
+  double* Xg = (double*)(list + cap);
+  double* crec = Xg + cap * d;                      // [n_can][2]: the sampled candidates' int8 variance and bound
+  double* adv_rec = crec + 2 * n_can;               // [blocks][4]
+  double* adv_sel = adv_rec + 4 * blocks;           // [64][3]
+  int64_t* stats = h->s_rep_stats.as<int64_t>();   // tgp_internal.hpp RS_*
+  double* Lslot = (double*)(stats + RS_L);          // {L, its index}
+  int64_t* route = stats + RS_ROUTE;                // {count if the SPLIT sweep recomputes, count if the product path does}
   // Up to pcap recomputed candidates (the canary's M / 4096 and a handful of flagged ones: the usual case) take the
   // product path of tgp_kernels_misc.hip -- K*^T, W K*^T as a tall product, column sums, tail -- which spreads over the chip;
   // more than that go through the SPLIT sweep.  Both are enqueued, repair_route_kernel gives the count to one of them.
-  const int64_t pcap = std::min<int64_t>(REPAIR_PCAP, ((M + 63) / 64) * 64);
+  // pcap follows the list the sweep is expected to leave -- the two strata of the canary plus a margin for the arg-max band
+  // (the product's K*^T / gemm / column sums run whatever the count is, so small sweeps get a small product)
+  const int64_t pcap = std::min<int64_t>(REPAIR_PCAP, ((n_can + std::min<int64_t>(I8_ADV_GROUPS, blocks) + 128 + 63) / 64) * 64);
   const bool product = !(h->variant & VARIANT_NO_REPAIR_PRODUCT);
   double *pB = nullptr, *pC = nullptr, *ppart = nullptr;
   if (product) {
@@ -370,12 +421,29 @@ hipError_t launch_sweep_i8_timed(tgp_handle h, SweepArgs& am) {
     pC = pB + (size_t)Npad * pcap;
     ppart = pC + (size_t)Npad * pcap;
   }
-  // the sample of this sweep: candidates j with (j + off) % 4096 == 0, off from a counter through splitmix64
-  uint64_t z = (h->canary_seq++ + 0x9E3779B97F4A7C15ull) * 0xBF58476D1CE4E5B9ull;
+  // the uniform sample of this sweep: candidates j with (j + off) % 4096 == 0, off = a hash of (N, hyper-parameters, M, rung)
+  // -- a function of the model and the call's shape, not of a call counter (round 5) nor of the handle (two handles on the
+  // same model sample alike): two identical calls sample, decide and return the same
+  auto mix = [](uint64_t zz, uint64_t x) {
+    zz = (zz ^ x) * 0xBF58476D1CE4E5B9ull;
+    return zz ^ (zz >> 29);
+  };
+  auto bits = [](double x) {
+    uint64_t u;
+    memcpy(&u, &x, sizeof u);
+    return u;
+  };
+  uint64_t z = mix(0x9E3779B97F4A7C15ull, (uint64_t)h->N);
+  z = mix(z, (uint64_t)M);
+  z = mix(z, (uint64_t)h->auto_level);
+  z = mix(z, bits(h->variance));
+  z = mix(z, bits(h->noise));
+  for (int c = 0; c < h->d; ++c) z = mix(z, bits(h->ls[c]));
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   const int64_t can_off = (int64_t)((z ^ (z >> 31)) & (uint64_t)(I8_CANARY_PERIOD - 1));
   am.canary_rec = crec;
   am.canary_off = can_off;
+  am.adv_rec = adv_rec;
   const double v = h->variance, eps = 2.220446049250313e-16;
   am.rep_ub = ub;
   am.rep_floor = std::min(64.0 * eps * v * (1.0 + (double)h->N * v / h->noise), 1e-6 * v);
@@ -399,18 +467,19 @@ hipError_t launch_sweep_i8_timed(tgp_handle h, SweepArgs& am) {
   if (e != hipSuccess) return e;
   if (ublk_val) launch_argmax_final(h->stream, ublk_val, ublk_idx, blocks, Lslot, (int64_t*)(Lslot + 1));
   launch_repair_flag(h->stream, ub, M, ublk_val ? Lslot : nullptr, list, stats, can_off);
-  launch_repair_gather(h->stream, am.Xq, d, list, stats, M, Xg);
+  launch_repair_adv(h->stream, adv_rec, blocks, list, stats, adv_sel);
+  launch_repair_gather(h->stream, am.Xq, d, list, stats, cap, Xg);
   b.m = am.m;
   b.Xq = Xg;
-  b.M = M;
+  b.M = cap;
   b.M_dev = stats;
   if (product) {
     launch_repair_route(h->stream, stats, pcap, route);
     b.M_dev = route;   // zero unless the list is longer than pcap
   }
   b.mean_out = am.mean_out ? rout : nullptr;
-  b.var_out = rout + M;   // (always: the canary compares the recomputed variances)
-  b.acq_out = am.acq_kind >= 0 ? rout + 2 * M : nullptr;
+  b.var_out = rout + cap;   // (always: the canary compares the recomputed variances)
+  b.acq_out = am.acq_kind >= 0 ? rout + 2 * cap : nullptr;
   b.acq_kind = am.acq_kind;
   b.acq_param = am.acq_param;
   b.split_g = g;
@@ -425,13 +494,18 @@ hipError_t launch_sweep_i8_timed(tgp_handle h, SweepArgs& am) {
     launch_repair_product_tail(h->stream, am.m, pB, pC, pcap, route + 1, b.acq_kind, b.acq_param, ppart, b.mean_out, b.var_out,
                                b.acq_out);
   }
-  // float64 against int8 on the sampled candidates; slack: the float64 kernels' own rounding (two summation orders)
-  launch_repair_canary(h->stream, list, stats, M, b.var_out, crec, can_off, 1e-12 * v);
-  launch_repair_scatter(h->stream, list, stats, M, b.mean_out, am.var_out ? b.var_out : nullptr, b.acq_out, am.mean_out,
-                        am.var_out, am.acq_out);
+  // float64 against int8 on the sampled candidates.  Slack: the float64 reference's own rounding -- the two recomputation
+  // paths sum in different orders, and var = s_f^2 - |W k*|^2 is a difference whose rounding grows with N and, through
+  // |W| ~ 1 / s, with 1 / sqrt(noise): 4 eps N s_f^2 sqrt(s_f^2 / s^2), never below 1e-12 s_f^2 (round 5's fixed value) and
+  // never above the parity tolerance's absolute floor (that floor itself, 1e-6 s_f^2 at low noise, would hide
+  // real int8 errors: measured worst |d var| 2.6e-8 on the N = 1000, s^2 = 1e-5 model with the bound made 400 x too tight)
+  const double can_slack = std::min(am.rep_floor, std::max(1e-12 * v, 4.0 * eps * (double)h->N * v * std::sqrt(v / h->noise)));
+  launch_repair_canary(h->stream, list, stats, cap, b.var_out, crec, can_off, can_slack, adv_sel);
+  launch_repair_scatter(h->stream, list, stats, cap, b.mean_out, am.var_out ? b.var_out : nullptr, b.acq_out, am.mean_out,
+                        am.var_out, am.acq_out, ub, ublk_val ? Lslot : nullptr);
   if (ublk_val) launch_values_argmax(h->stream, am.acq_out, M, am.index_base, ublk_val, ublk_idx, blocks);
   (void)hipEventRecord(h->ev1, h->stream);
-  e = hipMemcpyAsync(h->rep_host, stats, 8 * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream);
+  e = hipMemcpyAsync(h->rep_host, stats, RS_WORDS * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream);
   am.acq_out = user_acq;
   h->last_launches = 1;
   h->last_ms = -1.0;
@@ -448,7 +522,10 @@ hipError_t launch_sweep_timed(tgp_handle h, const SweepArgs& a, bool joint) {
     e = resolve_precision(h);
     h->auto_pinned = false;
     if (e != hipSuccess) return e;
-    if (h->precision != TGP_PREC_F64) return launch_sweep_i8_timed(h, am);
+    // the digit planes, row scales and training-row tiles are built from THIS handle's factorisation (and cached per its
+    // data_version): a sweep over another handle's model -- the repulsion twin of the entropy tails -- runs in float64
+    const bool own_model = a.m.alpha == h->d_alpha.as<double>() && a.m.Npad == h->Npad;
+    if (h->precision != TGP_PREC_F64 && own_model) return launch_sweep_i8_timed(h, am);
   }
   if (joint && a.m.dp <= 16 && !(h->variant & VARIANT_JOINT_V1)) {
     // contiguously packed 128 x 256 tiles, Gram phase out of LDS (tgp_kernels_joint.inc)
@@ -937,7 +1014,7 @@ int tgp_set_precision(tgp_handle h, int precision) {
   h->precision_req = precision;
   h->precision = precision == TGP_PREC_AUTO ? TGP_PREC_F64 : precision;  // AUTO: resolved at the next plain sweep
   h->repair = false;
-  auto_restart(h);  // AUTO restarts its ladder at four planes
+  auto_restart(h, true);  // AUTO restarts its ladder at four planes
   h->auto_pinned = false;
   return TGP_OK;
 }
@@ -946,7 +1023,7 @@ int tgp_set_auto_sigma(tgp_handle h, double k_sigma) {
   if (!h) return TGP_ERR_ARG;
   if (!(k_sigma > 0.0) || !std::isfinite(k_sigma)) return fail(h, TGP_ERR_ARG, "k_sigma must be positive and finite");
   h->auto_sigma = k_sigma;
-  auto_restart(h);
+  auto_restart(h, true);
   h->auto_pinned = false;
   return TGP_OK;
 }
@@ -958,11 +1035,27 @@ int tgp_get_auto_report(tgp_handle h, int64_t* checked, int64_t* violations, dou
     HIPCHK(h, hipStreamSynchronize(h->stream));  // the last sweep's report has landed
     HIPCHK(h, resolve_precision(h));
   }
-  if (checked) *checked = h->can_checked_total + h->can_checked;
-  if (violations) *violations = h->can_viol_total + h->can_viol;
-  if (worst_ratio) *worst_ratio = h->can_worst;
+  if (checked) *checked = h->can_checked_total[0] + h->can_checked[0] + h->can_checked_total[1] + h->can_checked[1];
+  if (violations) *violations = h->can_viol_total[0] + h->can_viol[0] + h->can_viol_total[1] + h->can_viol[1];
+  if (worst_ratio) *worst_ratio = std::max(h->can_worst[0], h->can_worst[1]);
   if (demotions) *demotions = h->can_demotions;
   if (level) *level = h->precision_req == TGP_PREC_AUTO ? h->auto_level : -1;
+  return TGP_OK;
+}
+
+int tgp_get_auto_strata(tgp_handle h, int64_t* checked2, int64_t* violations2, double* worst_ratio2, int64_t* slack_saved) {
+  if (!h) return TGP_ERR_ARG;
+  if (int rc = set_device(h)) return rc;
+  if (h->precision_req == TGP_PREC_AUTO && h->have_data) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // the last sweep's report has landed
+    HIPCHK(h, resolve_precision(h));
+  }
+  for (int k = 0; k < 2; ++k) {
+    if (checked2) checked2[k] = h->can_checked_total[k] + h->can_checked[k];
+    if (violations2) violations2[k] = h->can_viol_total[k] + h->can_viol[k];
+    if (worst_ratio2) worst_ratio2[k] = h->can_worst[k];
+  }
+  if (slack_saved) *slack_saved = h->can_slack_total + h->can_slack;
   return TGP_OK;
 }
 
@@ -1047,18 +1140,15 @@ int tgp_set_hyper(tgp_handle h, double variance, const double* lengthscales, dou
   HIPCHK(h, h->d_ls.reserve(h->dp * sizeof(double)));
   HIPCHK(h, hipMemcpy(h->d_ls.p, lsp.data(), h->dp * sizeof(double), hipMemcpyHostToDevice));
   h->have_hyper = true;
-  {
-    // TGP_PREC_AUTO restarts its ladder with new hyper-parameters (new conditioning) -- unless a rung was left under
-    // hyper-parameters within a factor two of these (variance / noise, every lengthscale): a BO loop whose refit moves
-    // them a little would otherwise re-pay the failed rung's sweep plus its repair at every step
-    bool keep = h->auto_level > 0 && h->auto_hyp.size() == (size_t)h->d + 1;
-    if (keep) {
-      auto far = [](double a, double b) { return !(a < 2.0 * b && b < 2.0 * a); };
-      keep = !far(variance / noise_variance, h->auto_hyp[0]);
-      for (int c = 0; keep && c < h->d; ++c) keep = !far(lengthscales[c], h->auto_hyp[1 + c]);
-    }
-    if (keep) ++h->auto_epoch;   // same rung, fresh counters on the device
-    else auto_restart(h);
+  if (h->precision_req == TGP_PREC_AUTO) {
+    // TGP_PREC_AUTO: the epoch ends here (what its canary counted joins the totals, in-flight reports become stale); whether
+    // the ladder keeps its rung or restarts is decided at the next sweep from the hyper-parameters in effect THEN
+    // (resolve_precision), so that a fit's trial evaluations do not undo a rung the refit would have kept
+    h->auto_pinned = false;
+    auto_read_report(h);
+    auto_fold_counters(h);
+    ++h->auto_epoch;
+    h->auto_hyper_dirty = true;
   }
   h->have_data = false;  // factorisation is stale
   return TGP_OK;
@@ -1514,6 +1604,20 @@ int tgp_clone_from(tgp_handle dst, tgp_handle src) {
   dst->mean_const = src->mean_const;
   dst->ls = src->ls;
   dst->have_hyper = true;
+  if (dst->precision_req == TGP_PREC_AUTO) {
+    // the hyper-parameters changed under the ladder: the epoch ends as in tgp_set_hyper; a source on the same
+    // arithmetic hands its rung over (a fantasised copy of a model that left four planes starts where the model is),
+    // otherwise the next sweep decides from the copied hyper-parameters
+    dst->auto_pinned = false;
+    auto_read_report(dst);
+    auto_fold_counters(dst);
+    ++dst->auto_epoch;
+    if (src->precision_req == TGP_PREC_AUTO) {
+      dst->auto_level = src->auto_level;
+      dst->auto_hyp = src->auto_hyp;
+    }
+    dst->auto_hyper_dirty = true;
+  }
   hipStream_t s = dst->stream;
   auto copy = [&](DevBuf& to, const DevBuf& from, size_t bytes) -> hipError_t {
     if (bytes == 0) return hipSuccess;

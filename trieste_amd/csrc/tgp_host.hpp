@@ -88,19 +88,25 @@ struct tgp_handle_s {
   int auto_level = 0;
   uint64_t auto_epoch = 1;    // bumps whenever the rung changes or the ladder restarts: stale reports are ignored
   bool auto_pinned = false;   // resolved by sweep_blocks for the call in progress
-  int64_t* rep_host = nullptr;  // pinned: {count, M, epoch, canary violations, checked, worst ratio bits, -, -} of the last completed repaired sweep
+  int64_t* rep_host = nullptr;  // pinned, RS_WORDS words: the stats block (tgp_internal.hpp RS_*) of the last completed repaired sweep
   int64_t rep_last_M = 0, rep_last_count = 0;
-  // the canary (tgp_api.hip launch_sweep_i8_timed): one candidate in 4096 of every AUTO sweep is recomputed in float64 and
-  // compared with the bound the int8 kernel priced it at; a violation demotes the ladder
+  // the canary (tgp_api.hip launch_sweep_i8_timed): of every AUTO sweep a UNIFORM sample (one candidate in 4096) and an
+  // ADVERSARIAL one (per 1 / 64 of the sweep the unflagged candidate whose bound sits closest to its tolerance) are recomputed
+  // in float64 and compared with the bounds the int8 kernel priced them at; a violation in either demotes the ladder.  The
+  // samples are compared, never scattered, and the uniform offset is a function of (N, hyper-parameters, M, rung): a sweep's outputs
+  // and the ladder's decisions are a pure function of (model state, inputs).
   double auto_sigma = 8.0;       // K_SIGMA of the per-candidate bound (tgp_set_auto_sigma)
-  uint64_t canary_seq = 0;       // the next sweep's sample offset comes from this counter
   uint64_t canary_epoch = 0;     // the rung (auto_epoch) whose canary words are live on the device
-  int64_t can_checked = 0, can_viol = 0;              // the current rung, as of the last report read
-  int64_t can_checked_total = 0, can_viol_total = 0;  // rungs left since the ladder restarted
-  double can_worst = 0.0;        // worst |d var| / bound seen since the ladder restarted
-  int can_demotions = 0;         // rungs left BECAUSE of a violation since the ladder restarted
-  std::vector<double> auto_hyp;  // (variance / noise, lengthscales) when a rung was last left: tgp_set_hyper keeps the rung
-                                 // while the new hyper-parameters stay within a factor two of these
+  // [0] the uniform stratum, [1] the adversarial one
+  int64_t can_checked[2] = {0, 0}, can_viol[2] = {0, 0};              // the current rung, as of the last report read
+  int64_t can_checked_total[2] = {0, 0}, can_viol_total[2] = {0, 0};  // earlier rungs / epochs since tgp_set_precision / tgp_set_auto_sigma
+  double can_worst[2] = {0.0, 0.0};   // worst |d var| / (bound + slack) seen
+  int64_t can_slack = 0, can_slack_total = 0;   // samples inside bound + slack but outside the bound alone (float64 rounding)
+  int can_demotions = 0;         // rungs left BECAUSE of a violation
+  std::vector<double> auto_hyp;  // (variance / noise, lengthscales) when a rung was last left: the rung is kept while the
+                                 // hyper-parameters in effect at the next SWEEP stay within a factor two of these
+  bool auto_hyper_dirty = false; // tgp_set_hyper ran since the last sweep: the keep-or-restart decision is taken at the next
+                                 // sweep (a fit's trial evaluations move the hyper-parameters far and back again)
   DevBuf s_rep, s_rep_stats, s_blkctr;   // (s_blkctr: the int8 sweep's candidate-block counter, one word)
   DevBuf d_wq, d_rs, d_xsa;
   uint64_t wq_version = 0;

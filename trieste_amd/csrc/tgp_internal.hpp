@@ -73,6 +73,9 @@ struct SweepArgs {
   // repair_canary_kernel compares the two (null: no samples)
   double* canary_rec;
   int64_t canary_off;
+  // the canary's adversarial stratum (round 6): per 64-candidate block of the int8 sweep (ratio = bound / tolerance, index as
+  // the bits of an int64, int8 variance, bound) of its worst UNFLAGGED candidate (ratio < 0: none); null: no stratum
+  double* adv_rec;
   const int64_t* M_dev;   // SPLIT instantiation + combine kernel: the candidate count lives on the device (the
                           // repair pass over the flagged candidates is enqueued without a host round trip)
 };
@@ -227,20 +230,30 @@ size_t dag_lds_bytes();
 
 // rs: [2][Npad] -- row scales S_i, then the row weights S_i^2 (i + 1) of the a-posteriori error model
 void launch_w_digits(hipStream_t s, const double* W, int64_t N, int64_t Npad, double* rs, void* Wq, int planes);
-// [Npad / 32] tiles of xt doubles: 32 rows of Xs, their alpha, zero padding (the int8 sweep stages them in LDS by DMA)
+// [Npad / 32] tiles of xt doubles: 32 rows of Xs, their alpha, their squared norms, zero padding (the int8 sweep stages them
+// in LDS by DMA)
 void launch_xs_tiles(hipStream_t s, const double* Xs, const double* alpha, int64_t Npad, int dp, int xt, double* out);
-inline int i8_xs_tile_doubles(int dp) { return ((32 * dp + 32 + 127) / 128) * 128; }
+inline int i8_xs_tile_doubles(int dp) { return ((32 * dp + 64 + 127) / 128) * 128; }
 // ---- a-posteriori repair of the split-precision sweep (tgp_kernels_misc.hip) ----
 // stats [8]: {count (zeroed here), M, tag, canary violations, canaries checked, worst |d var| / bound as the bits of a
 // double, -, -}; the canary words accumulate until `reset_canary`
 void launch_repair_begin(hipStream_t s, int64_t* stats, int64_t M, int64_t tag, bool reset_canary);
+// stats words (int64 unless said otherwise): the layout of the 16-word block launch_repair_begin owns
+constexpr int RS_COUNT = 0, RS_M = 1, RS_TAG = 2, RS_VIOL = 3, RS_CHECKED = 4, RS_WORST = 5 /* bits of a double */,
+              RS_ADV_VIOL = 6, RS_ADV_CHECKED = 7, RS_L = 8 /* double L, int64 index */, RS_ROUTE = 10 /* two counts */,
+              RS_ADV_WORST = 12 /* bits of a double */, RS_SLACK_SAVED = 13, RS_WORDS = 16;
+constexpr int I8_ADV_GROUPS = 64;   // the adversarial stratum: the worst bound / tolerance of every 1 / 64 of the sweep
+// adversarial stratum: group g of <= 64 scans its share of the nblk block records (adv_rec of the int8 sweep), appends its
+// worst candidate to the repair list (stats[0]) and leaves adv_sel[g] = {list position or -1 (as the bits of an int64), its
+// int8 variance, its bound}
+void launch_repair_adv(hipStream_t s, const double* adv_rec, int64_t nblk, int64_t* list, int64_t* stats, double* adv_sel);
 // list [<= M]: indices j with ub[j] == +inf or ub[j] >= *L (L null: only +inf) or (j + canary_off) % 4096 == 0
 // (canary_off < 0: no samples); count = stats[0]
 void launch_repair_flag(hipStream_t s, const double* ub, int64_t M, const double* L, int64_t* list, int64_t* stats,
                         int64_t canary_off);
 // the sampled candidates among list[0 .. stats[0]): |rvar[r] - rec var| against rec bound + slack -> stats[3..5]
 void launch_repair_canary(hipStream_t s, const int64_t* list, int64_t* stats, int64_t cap, const double* rvar,
-                          const double* rec, int64_t canary_off, double slack);
+                          const double* rec, int64_t canary_off, double slack, const double* adv_sel);
 // the repair of a few candidates as a product (tgp_kernels_misc.hip): count routing, K*^T with the count on the device,
 // column sums + the sweep's tail
 void launch_repair_route(hipStream_t s, const int64_t* stats, int64_t pcap, int64_t* route);
@@ -251,8 +264,11 @@ void launch_repair_product_tail(hipStream_t s, const ModelDev& m, const double* 
 int64_t repair_product_part_doubles(int64_t Ppad);
 void launch_repair_gather(hipStream_t s, const double* Xq, int d, const int64_t* list, const int64_t* count, int64_t cap,
                           double* Xg);
+// only what the sweep FLAGGED is written over the int8 results (ub[j] == +inf, or ub[j] >= *L in a fused arg-max): the
+// canary's samples are compared, not scattered, so that a sweep's outputs do not depend on which candidates it sampled
 void launch_repair_scatter(hipStream_t s, const int64_t* list, const int64_t* count, int64_t cap, const double* rmean,
-                           const double* rvar, const double* racq, double* mean, double* var, double* acq);
+                           const double* rvar, const double* racq, double* mean, double* var, double* acq, const double* ub,
+                           const double* L);
 // per-slot (max value, min index) partials of vals [M] (NaN never wins) into blk_val / blk_idx [nslots]
 void launch_values_argmax(hipStream_t s, const double* vals, int64_t M, int64_t index_base, double* blk_val,
                           int64_t* blk_idx, int64_t nslots);

@@ -758,7 +758,7 @@ void launch_w_digits(hipStream_t s, const double* W, int64_t N, int64_t Npad, do
 }
 
 // The training rows of the int8 sweep's generating steps as DMA-able tiles (tgp_kernels_sweep_i8.inc): tile t =
-// [32 rows of Xs][dp] then alpha[32], zero padded to xt doubles (whole KiB).
+// [32 rows of Xs][dp], alpha[32], |row|^2 [32], zero padded to xt doubles (whole KiB).
 __global__ __launch_bounds__(256) void xs_tiles_kernel(const double* __restrict__ Xs, const double* __restrict__ alpha, int dp, int xt,
                                                        double* __restrict__ out) {
   const int64_t tile = blockIdx.x;
@@ -766,6 +766,10 @@ __global__ __launch_bounds__(256) void xs_tiles_kernel(const double* __restrict_
     double v = 0.0;
     if (e < 32 * dp) v = Xs[tile * 32 * dp + e];
     else if (e < 32 * dp + 32) v = alpha[tile * 32 + (e - 32 * dp)];
+    else if (e < 32 * dp + 64) {   // |row|^2: the dot-product form of the distances (generation on the matrix core)
+      const double* row = Xs + (tile * 32 + (e - 32 * dp - 32)) * dp;
+      for (int c = 0; c < dp; ++c) v = fma(row[c], row[c], v);
+    }
     out[tile * xt + e] = v;
   }
 }
@@ -805,13 +809,16 @@ __global__ void merge_winners_kernel(const double* __restrict__ gathered, int P,
 // end of the interval its acquisition value lies in; *L = the largest LOWER end over the sweep.  Whatever could still
 // be the float64 arg-max (ub >= L) and whatever violates the tolerance goes on a list, is recomputed by the float64
 // sweep (SPLIT instantiation, count on the device) and scattered back.
-// stats: {count, M, epoch tag, canary violations, canaries checked, worst |d var| / bound (bits of a double), -, -}; the
+// stats (tgp_internal.hpp RS_*): {count, M, epoch tag, uniform-canary violations, checked, worst |d var| / bound (bits of a
+// double), adversarial violations, checked, [L slot], [route], adversarial worst ratio, samples only the slack saved}; the
 // canary words accumulate over the sweeps of one rung of the ladder (reset_canary: the rung is new)
 __global__ void repair_begin_kernel(int64_t* stats, int64_t M, int64_t tag, int reset_canary) {
-  stats[0] = 0;
-  stats[1] = M;
-  stats[2] = tag;
-  if (reset_canary) stats[3] = stats[4] = stats[5] = 0;
+  stats[RS_COUNT] = 0;
+  stats[RS_M] = M;
+  stats[RS_TAG] = tag;
+  if (reset_canary)
+    stats[RS_VIOL] = stats[RS_CHECKED] = stats[RS_WORST] = stats[RS_ADV_VIOL] = stats[RS_ADV_CHECKED] = stats[RS_ADV_WORST] =
+        stats[RS_SLACK_SAVED] = 0;
 }
 void launch_repair_begin(hipStream_t s, int64_t* stats, int64_t M, int64_t tag, bool reset_canary) {
   hipLaunchKernelGGL(repair_begin_kernel, dim3(1), dim3(1), 0, s, stats, M, tag, reset_canary ? 1 : 0);
@@ -847,26 +854,82 @@ void launch_repair_flag(hipStream_t s, const double* ub, int64_t M, const double
 }
 // The canary of TGP_PREC_AUTO: the sampled candidates were recomputed in float64 with the repair list; |var_f64 - var_int8|
 // against the bound the int8 kernel priced that candidate at.  `slack` covers the float64 kernels' own rounding (their
-// summation orders differ).  Violations, samples and the worst ratio accumulate in stats[3..5].
+// summation orders differ; ADVICE r05: it scales with the sweep's rounding floor, and what only the slack saved is counted).
+// Two strata, reported apart: the UNIFORM sample (one candidate in 4096, list entries recognised by their index) and the
+// ADVERSARIAL one (adv_sel: per 1 / 64 of the sweep the unflagged candidate whose bound sits closest to its tolerance).
+__device__ __forceinline__ void canary_compare(int64_t* stats, double v64, double v8, double bound, double slack, int w_viol,
+                                               int w_checked, int w_worst) {
+  const double dv = fabs(v64 - v8);
+  atomicAdd((unsigned long long*)(stats + w_checked), 1ull);
+  if (!(dv <= bound + slack)) atomicAdd((unsigned long long*)(stats + w_viol), 1ull);
+  else if (!(dv <= bound)) atomicAdd((unsigned long long*)(stats + RS_SLACK_SAVED), 1ull);
+  const double ratio = dv / fmax(bound + slack, 1e-300);   // >= 0: the bit patterns order like the values
+  atomicMax((unsigned long long*)(stats + w_worst), (unsigned long long)__double_as_longlong(ratio));
+}
 __global__ __launch_bounds__(256) void repair_canary_kernel(const int64_t* __restrict__ list, int64_t* stats,
                                                             const double* __restrict__ rvar, const double* __restrict__ rec,
-                                                            int64_t canary_off, double slack) {
-  const int64_t n = stats[0];
+                                                            int64_t canary_off, double slack,
+                                                            const double* __restrict__ adv_sel) {
+  const int64_t n = stats[RS_COUNT];
   for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256) {
     const int64_t j = list[r];
     if (((j + canary_off) & (I8_CANARY_PERIOD - 1)) != 0) continue;
     const double* c = rec + 2 * ((j + canary_off) / I8_CANARY_PERIOD);
-    const double dv = fabs(rvar[r] - c[0]), bound = c[1];
-    atomicAdd((unsigned long long*)(stats + 4), 1ull);
-    if (!(dv <= bound + slack)) atomicAdd((unsigned long long*)(stats + 3), 1ull);
-    const double ratio = dv / fmax(bound + slack, 1e-300);   // >= 0: the bit patterns order like the values
-    atomicMax((unsigned long long*)(stats + 5), (unsigned long long)__double_as_longlong(ratio));
+    canary_compare(stats, rvar[r], c[0], c[1], slack, RS_VIOL, RS_CHECKED, RS_WORST);
+  }
+  if (adv_sel && blockIdx.x == 0 && threadIdx.x < I8_ADV_GROUPS) {
+    const double* c = adv_sel + 3 * threadIdx.x;
+    const int64_t pos = (int64_t)__double_as_longlong(c[0]);
+    if (pos >= 0 && pos < n) canary_compare(stats, rvar[pos], c[1], c[2], slack, RS_ADV_VIOL, RS_ADV_CHECKED, RS_ADV_WORST);
   }
 }
 void launch_repair_canary(hipStream_t s, const int64_t* list, int64_t* stats, int64_t cap, const double* rvar,
-                          const double* rec, int64_t canary_off, double slack) {
+                          const double* rec, int64_t canary_off, double slack, const double* adv_sel) {
   const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((cap + 255) / 256, 256));
-  hipLaunchKernelGGL(repair_canary_kernel, dim3((unsigned)blocks), dim3(256), 0, s, list, stats, rvar, rec, canary_off, slack);
+  hipLaunchKernelGGL(repair_canary_kernel, dim3((unsigned)blocks), dim3(256), 0, s, list, stats, rvar, rec, canary_off, slack,
+                     adv_sel);
+}
+// the adversarial stratum: one wave per group of consecutive block records; the group's worst (largest bound / tolerance,
+// lowest index on ties) unflagged candidate goes on the repair list
+__global__ __launch_bounds__(64) void repair_adv_kernel(const double* __restrict__ adv_rec, int64_t nblk, int groups,
+                                                        int64_t* __restrict__ list, int64_t* stats, double* __restrict__ adv_sel) {
+  const int g = blockIdx.x, lane = threadIdx.x;
+  if (g >= groups) {   // fewer blocks than groups: the slots beyond carry "nothing"
+    if (lane == 0) {
+      adv_sel[3 * g] = __longlong_as_double(-1ll);
+      adv_sel[3 * g + 1] = adv_sel[3 * g + 2] = 0.0;
+    }
+    return;
+  }
+  const int64_t b0 = nblk * g / groups, b1 = nblk * (g + 1) / groups;
+  double r = -1.0;
+  int64_t at = INT64_MAX;   // the record (block) the best ratio came from
+  for (int64_t b = b0 + lane; b < b1; b += 64) {
+    const double x = adv_rec[4 * b];
+    if (x >= 0.0 && better(x, b, r, at)) {
+      r = x;
+      at = b;
+    }
+  }
+  wave_argmax(r, at);
+  if (lane == 0) {
+    double* sel = adv_sel + 3 * g;
+    if (r >= 0.0 && at != INT64_MAX) {
+      const double* rec = adv_rec + 4 * at;
+      const unsigned long long pos = atomicAdd((unsigned long long*)(stats + RS_COUNT), 1ull);
+      list[pos] = (int64_t)__double_as_longlong(rec[1]);
+      sel[0] = __longlong_as_double((long long)pos);
+      sel[1] = rec[2];
+      sel[2] = rec[3];
+    } else {
+      sel[0] = __longlong_as_double(-1ll);
+      sel[1] = sel[2] = 0.0;
+    }
+  }
+}
+void launch_repair_adv(hipStream_t s, const double* adv_rec, int64_t nblk, int64_t* list, int64_t* stats, double* adv_sel) {
+  const int groups = (int)std::min<int64_t>(I8_ADV_GROUPS, nblk);
+  hipLaunchKernelGGL(repair_adv_kernel, dim3(I8_ADV_GROUPS), dim3(64), 0, s, adv_rec, nblk, groups, list, stats, adv_sel);
 }
 __global__ __launch_bounds__(256) void repair_gather_kernel(const double* __restrict__ Xq, int d,
                                                             const int64_t* __restrict__ list, const int64_t* count,
@@ -884,20 +947,26 @@ void launch_repair_gather(hipStream_t s, const double* Xq, int d, const int64_t*
 }
 __global__ __launch_bounds__(256) void repair_scatter_kernel(const int64_t* __restrict__ list, const int64_t* count,
                                                              const double* rmean, const double* rvar, const double* racq,
-                                                             double* mean, double* var, double* acq) {
+                                                             double* mean, double* var, double* acq,
+                                                             const double* __restrict__ ub, const double* L) {
   const int64_t n = *count;
+  const double Lv = L ? *L : INFINITY;
+  const bool band = Lv > -INFINITY && Lv < INFINITY;
   for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256) {
     const int64_t j = list[r];
+    const double u = ub[j];
+    if (!(u == INFINITY || (band && u >= Lv))) continue;   // a sample of the canary: compared, not scattered
     if (mean) mean[j] = rmean[r];
     if (var) var[j] = rvar[r];
     if (acq) acq[j] = racq[r];
   }
 }
 void launch_repair_scatter(hipStream_t s, const int64_t* list, const int64_t* count, int64_t cap, const double* rmean,
-                           const double* rvar, const double* racq, double* mean, double* var, double* acq) {
+                           const double* rvar, const double* racq, double* mean, double* var, double* acq, const double* ub,
+                           const double* L) {
   const int64_t blocks = std::min<int64_t>((cap + 255) / 256, 1024);
   hipLaunchKernelGGL(repair_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, s, list, count, rmean, rvar, racq, mean,
-                     var, acq);
+                     var, acq, ub, L);
 }
 __global__ __launch_bounds__(256) void values_argmax_kernel(const double* __restrict__ vals, int64_t M, int64_t index_base,
                                                             double* blk_val, int64_t* blk_idx, int64_t nslots) {

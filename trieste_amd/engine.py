@@ -117,8 +117,11 @@ class GPEngine:
         recomputed in float64 inside the same call; four planes, then five, then float64 when too many candidates
         needed it.  Results hold the parity tolerance candidate by candidate and the arg-max is the float64 one -- to
         the 8-sigma error model the bounds come from (a statistical model, not a worst case); every sweep re-checks a
-        pseudo-random sample of its candidates in float64 against their bounds and leaves the rung when one fails
-        (:meth:`get_auto_report`).  Float64 remains the only arithmetic the parity claims are made on."""
+        uniform sample of its candidates AND the unflagged candidates whose bounds sit closest to their tolerance in float64
+        against their bounds and leaves the rung when one fails (:meth:`get_auto_report`, :meth:`get_auto_strata`; the
+        synchronising calls repeat their sweep on the next rung before returning, the ``*_async`` / group calls take the
+        demotion at their next call).  The samples are compared, not written back: values are a pure function of
+        (model, rung, candidate).  Float64 remains the only arithmetic the parity claims are made on."""
         if precision not in _lib.PRECISIONS:
             raise ValueError(f"unknown precision {precision!r}; choose from {sorted(_lib.PRECISIONS)}")
         self._chk(self._lib.tgp_set_precision(self._h, _lib.PRECISIONS[precision]))
@@ -144,6 +147,15 @@ class GPEngine:
         self._chk(self._lib.tgp_get_auto_report(self._h, C.byref(chk), C.byref(viol), C.byref(worst), C.byref(dem),
                                                 C.byref(lev)))
         return dict(checked=chk.value, violations=viol.value, worst_ratio=worst.value, demotions=dem.value, level=lev.value)
+
+    def get_auto_strata(self):
+        """The canary's report per stratum (tgp_get_auto_strata) -> dict(uniform=dict(checked, violations, worst_ratio),
+        adversarial=dict(...), slack_saved): the uniform 1-in-4096 sample and the adversarial one (per 1 / 64 of a sweep the
+        unflagged candidate whose bound sits closest to its tolerance)."""
+        chk, viol, worst, slack = (C.c_int64 * 2)(), (C.c_int64 * 2)(), (C.c_double * 2)(), C.c_int64()
+        self._chk(self._lib.tgp_get_auto_strata(self._h, chk, viol, worst, C.byref(slack)))
+        return dict(uniform=dict(checked=chk[0], violations=viol[0], worst_ratio=worst[0]),
+                    adversarial=dict(checked=chk[1], violations=viol[1], worst_ratio=worst[1]), slack_saved=slack.value)
 
     # -- model state -----------------------------------------------------------------------------
     def clone_from(self, other: "GPEngine") -> None:
