@@ -328,7 +328,7 @@ hipError_t launch_sweep_i8_timed(tgp_handle h, SweepArgs& am) {
   }
   am.i8_wq = h->d_wq.p;
   am.i8_rs = h->d_rs.as<double>();
-  am.i8_xsa = (planes == 4 && h->dp <= 16) ? h->d_xsa.as<double>() : nullptr;   // (five planes leave no LDS for the tiles)
+  am.i8_xsa = i8_tiles_fit(planes, h->dp) ? h->d_xsa.as<double>() : nullptr;   // (five planes: two tile buffers, d <= 8)
   const int64_t blocks = (am.M + 63) / 64;
   const int64_t wgrid = blocks < h->num_cu ? blocks : h->num_cu;
   // candidate blocks beyond one per workgroup are drawn from a counter (the workgroups of a launch differ in speed)

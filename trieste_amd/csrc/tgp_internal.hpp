@@ -233,7 +233,19 @@ void launch_w_digits(hipStream_t s, const double* W, int64_t N, int64_t Npad, do
 // [Npad / 32] tiles of xt doubles: 32 rows of Xs, their alpha, their squared norms, zero padding (the int8 sweep stages them
 // in LDS by DMA)
 void launch_xs_tiles(hipStream_t s, const double* Xs, const double* alpha, int64_t Npad, int dp, int xt, double* out);
-inline int i8_xs_tile_doubles(int dp) { return ((32 * dp + 64 + 127) / 128) * 128; }
+constexpr int i8_xs_tile_doubles(int dp) { return ((32 * dp + 64 + 127) / 128) * 128; }
+// LDS budget of sweep_i8_kernel (tgp_kernels_sweep_i8.inc), shared with the launch code of tgp_api.hip: three stages of NS
+// digit planes of a [256 rows + 64 candidates] x 32 B tile, the scaled candidate coordinates [dp][64], and -- when they fit --
+// the staged training-row tiles of the generating steps: three buffers beside four planes, TWO beside five (round 6), plus the
+// candidates' squared norms [64], which live in the first tile buffer's padding when that has 64 spare doubles
+constexpr int i8_stage_bytes(int ns) { return ns * (256 + 64) * 32; }
+constexpr int i8_tile_buffers(int ns) { return ns == 4 ? 3 : 2; }
+constexpr bool i8_qn_in_pad(int dp) { return i8_xs_tile_doubles(dp) - (32 * dp + 64) >= 64; }
+constexpr int i8_lds_bytes(int ns, int dp, bool tiles) {
+  return 3 * i8_stage_bytes(ns) + 64 * dp * 8 +
+         (tiles ? i8_tile_buffers(ns) * i8_xs_tile_doubles(dp) * 8 + (i8_qn_in_pad(dp) ? 0 : 512) : 0);
+}
+constexpr bool i8_tiles_fit(int ns, int dp) { return dp <= 16 && i8_lds_bytes(ns, dp, true) <= 160 * 1024; }
 // ---- a-posteriori repair of the split-precision sweep (tgp_kernels_misc.hip) ----
 // stats [8]: {count (zeroed here), M, tag, canary violations, canaries checked, worst |d var| / bound as the bits of a
 // double, -, -}; the canary words accumulate until `reset_canary`

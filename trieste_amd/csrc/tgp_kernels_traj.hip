@@ -14,29 +14,8 @@ namespace tgp {
 
 constexpr int TRAJ_MAXB = 16;
 
-// ---- the kernel evaluation of the trajectory loops: instruction count is the bound -------
-// shape(q) = k / variance as a function of q = SCALE r^2, with SCALE folded into the distance's constants (Matern:
-// sqrt(SCALE) r is the argument of both the polynomial and the exponential, so the multiplication by sqrt(3) / sqrt(5)
-// disappears); the variance multiplies the finished sum once per candidate instead of every entry; sqrt with ONE
-// residual step (~1 ulp) and exp without the underflow clamp (v_ldexp_f64 flushes by itself; the argument is bounded by
-// the inputs).  Same accuracy class as kernel_from_r2 (1 - 2 ulp), nine instructions fewer per entry for Matern-5/2.
-template <int KIND>
-struct TrajShape {
-  // q = SCALE r^2 with log2(e) folded in as well (round 5): u = sqrt(q) IS the base-2 exponent of the exponential,
-  // exp(-sqrt(c) r) = 2^-u with SCALE = c log2(e)^2 (RBF: exp(-r^2 / 2) = 2^-q with SCALE = log2(e) / 2) -- the
-  // multiplication by log2(e) inside the exponential is gone; the polynomial factor takes u / log2(e) through its constants
-  static constexpr double L2E = 1.4426950408889634;
-  static constexpr double C = KIND == KIND_M32 ? 3.0 : (KIND == KIND_M52 ? 5.0 : 1.0);
-  static constexpr double SCALE = KIND == KIND_RBF ? 0.5 * L2E : C * L2E * L2E;
-  static constexpr double FLOOR = 1e-36 * SCALE;  // gpflow: r = sqrt(max(r^2, 1e-36))
-};
-// sqrt(x), x > 0: v_rsq_f64 (2^-26) + ONE coupled Goldschmidt step = 2^-51 relative.  (Rounds 3 / 4 added a residual step
-// for the last ulp: two instructions of ~50 per kernel evaluation that a sum of 8192 terms compared at 1e-5 cannot see.)
-__device__ __forceinline__ double traj_sqrt(double x) {
-  const double y = __builtin_amdgcn_rsq(x);
-  const double g = x * y, h = 0.5 * y;
-  return fma(g, fma(-h, g, 0.5), g);
-}
+// (the kernel evaluation of the trajectory loops -- TrajShape, traj_sqrt, traj_exp2, traj_shape -- lives in tgp_dev.hpp since
+// round 6: the int8 sweep's generating steps use the same forms)
 // cos(x . W + b) from y = (x . W + b) / pi + 1/2 (the basis is stored in half turns): cos(theta) = sin(pi y) =
 // (-1)^n sin(pi f), n = rint(y), f = y - n exact, |f| <= 1/2.  sin(pi f) = f P(f^2) with a degree-8 minimax-fitted P
 // (truncation 3.9e-17 relative); the sign goes onto f (odd function) as one xor of its high word.  15 instructions
@@ -58,38 +37,6 @@ __device__ __forceinline__ double traj_cos_halfturns(double y) {
   p = fma(p, z, 3.141592653589793);
   return f * p;
 }
-// 2^t for t <= 0: n = rint(t), f = t - n exact, 2^f by a degree-11 fit on |f| <= 1/2 (1.9e-17).
-__device__ __forceinline__ double traj_exp2(double t) {
-  const double n = rint(t);
-  const double f = t - n;
-  double p = 4.456675463639861e-10;
-  p = fma(p, f, 7.074194562613105e-09);
-  p = fma(p, f, 1.0178051192117847e-07);
-  p = fma(p, f, 1.3215432534254118e-06);
-  p = fma(p, f, 1.5252733856295574e-05);
-  p = fma(p, f, 0.00015403530463727982);
-  p = fma(p, f, 0.001333355814639035);
-  p = fma(p, f, 0.009618129107587253);
-  p = fma(p, f, 0.0555041086648217);
-  p = fma(p, f, 0.24022650695910158);
-  p = fma(p, f, 0.6931471805599453);
-  p = fma(p, f, 1.0);
-  return ldexp(p, (int)n);
-}
-template <int KIND>
-__device__ __forceinline__ double traj_shape(double q) {  // q = SCALE r^2 (may be slightly negative: dot-product form)
-  if constexpr (KIND == KIND_RBF) {
-    return traj_exp2(-fmax(q, 0.0));
-  } else {
-    constexpr double IL = 1.0 / TrajShape<KIND>::L2E;   // s = sqrt(c) r = u / log2(e)
-    const double qc = fmax(q, TrajShape<KIND>::FLOOR);
-    const double u = traj_sqrt(qc);
-    if constexpr (KIND == KIND_M12) return traj_exp2(-u);
-    else if constexpr (KIND == KIND_M32) return fma(IL, u, 1.0) * traj_exp2(-u);
-    else return fma(IL * IL / 3.0, qc, fma(IL, u, 1.0)) * traj_exp2(-u);   // 1 + s + s^2 / 3
-  }
-}
-
 // PER_TRAJ: logical item = (candidate j, trajectory b) with its own input row (BP = 1); else item = j and the BP
 // accumulators are the trajectories.  EXACT: B == BP -- the accumulator updates carry no test of b against B.  Both are
 // template parameters because as run-time tests they sat INSIDE the two inner loops as wave-uniform branches, each
