@@ -429,7 +429,7 @@ int tgp_last_kernel_ms(tgp_handle h, double* ms, int* launches);
  *                 of (model state, rung, candidate) -- two identical calls return identical bits, and a candidate's
  *                 value does not depend on which other candidates share its call; the fused arg-max returns the
  *                 float64 winner.  The ladder: four planes, five (d <= 16), float64; a rung is also left when a sweep
- *                 had to recompute more than 5 % of its candidates.  tgp_set_precision restarts the ladder; after
+ *                 had to recompute more than 10 % of its candidates.  tgp_set_precision restarts the ladder; after
  *                 tgp_set_hyper / tgp_clone_from the next SWEEP does unless a rung was left under hyper-parameters
  *                 within a factor two of the ones then in effect (a fit's trial evaluations do not count).
  *                 N <= 16384 (int32 accumulators), float64 above. */

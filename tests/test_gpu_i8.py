@@ -181,7 +181,7 @@ def test_auto_precision_stays_inside_the_plain_tolerance(cfg):
             mm, vv = eng.predict(Xq[:m])
             assert_close(vv, ov[:m], atol=floor, what=f"var under auto, M={m}")
     print(f"[margin] auto {cfg[0]}: rungs (arithmetic, recomputed fraction) {rungs}; last var error / tolerance {worst:.4f}")
-    # the ladder only ever moves down (a move follows a sweep that recomputed more than 5 % of its candidates -- any of the
+    # the ladder only ever moves down (a move follows a sweep that recomputed more than 10 % of its candidates -- any of the
     # sweeps of an iteration, the arg-max ones recompute their band as well, so the recorded predict fraction is a hint)
     order = {"i8x4": 0, "i8x5": 1, "f64": 2}
     for (a, fa), (b, _) in zip(rungs, rungs[1:]):

@@ -1,8 +1,6 @@
 #!/bin/bash
-# GPU batch (round 6, scratch script: the commands of the current A/B session)
+# GPU batch (round 6): C4 with the joint kernel back at its round-5 source, against the round-5 tree, one box
 set -u; OUT=$PWD/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_i8.py -x -q 2>&1 | grep -v "^$" | tail -25 > $OUT/r06_i8_tests.txt; cat $OUT/r06_i8_tests.txt
-bash tools/gpu_ab.sh r06_i8_genmfma "python tools/bench_i8.py i8x4 i8x5 auto" tools/exp/libtgp_i8nomfma.so default tools/exp/libtgp_i8nomfma.so default
-for v in i8trmfma; do
-  echo "== $v i8x4"; TGP_LIB=$PWD/tools/exp/libtgp_$v.so timeout 300 python tools/i8_trace.py i8x4 2>&1 | grep -v amdgpu.ids | head -40
-done | tee $OUT/r06_i8_trace_mfma.txt
+run() { timeout 300 python bench.py --workload c4 --no-cpu-baseline --no-acquire --no-secondary --steps 3 --warmup 1 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['kernel_ms'])"; }
+{ for rep in 1 2; do echo "== r06 tree (joint kernel = round-5 source)"; run; echo "== r05 tree"; ( cd tools/exp/r05tree && run ); done; } | tee $OUT/r06_joint_reverted_c4.txt
+timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -x -q 2>&1 | tail -3

@@ -45,6 +45,33 @@ __global__ void k(double x0) {
     } else if (MODE == 9) {  // dependent dpp fmac chain through the DPP operand: fmac -> (nop) -> fmac reading it via dpp
 #pragma unroll
       for (int i = 0; i < 16; ++i) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, -%0, %1 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "+v"(a[0]) : "v"(z));
+    } else if (MODE == 10) {  // round 6: the other instructions of the int8 sweep's K* generation, 16 independent each
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_rsq_f64_e32 %0, %1" : "=v"(a[i]) : "v"(y));
+    } else if (MODE == 11) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_rndne_f64_e32 %0, %1" : "=v"(a[i]) : "v"(y));
+    } else if (MODE == 12) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { int r; asm volatile("v_cvt_i32_f64_e32 %0, %1" : "=v"(r) : "v"(a[i])); a[i] = __hiloint2double(r, r); }
+    } else if (MODE == 13) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_ldexp_f64 %0, %1, %2" : "=v"(a[i]) : "v"(y), "v"(3));
+    } else if (MODE == 14) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_max_f64 %0, %1, %2" : "=v"(a[i]) : "v"(y), "v"(z));
+    } else if (MODE == 15) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_add_f64 %0, %1, %2" : "=v"(a[i]) : "v"(y), "v"(z));
+    } else if (MODE == 16) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_cvt_f64_i32_e32 %0, %1" : "=v"(a[i]) : "v"(it));
+    } else if (MODE == 17) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { int r; asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(r) : "v"(it), "v"(i), "v"(0x05010400)); a[i] = __hiloint2double(r, r); }
+    } else if (MODE == 18) {  // 64-bit integer shift-add (the digits of the fold)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { long long r; asm volatile("v_lshl_add_u64 %0, %1, 8, %2" : "=v"(r) : "v"((long long)it), "v"((long long)i)); a[i] = __longlong_as_double(r); }
     }
   }
   asm volatile("s_nop 0" ::: "memory");
@@ -57,12 +84,16 @@ __global__ void k(double x0) {
 int main() {
   k<0><<<1, 64>>>(1.5); k<1><<<1, 64>>>(1.5); k<2><<<1, 64>>>(1.5); k<3><<<1, 64>>>(1.5); k<4><<<1, 64>>>(1.5);
   k<5><<<1, 64>>>(1.5); k<6><<<1, 64>>>(1.5); k<7><<<1, 64>>>(1.5); k<8><<<1, 64>>>(1.5); k<9><<<1, 64>>>(1.5);
+  k<10><<<1, 64>>>(1.5); k<11><<<1, 64>>>(1.5); k<12><<<1, 64>>>(1.5); k<13><<<1, 64>>>(1.5); k<14><<<1, 64>>>(1.5);
+  k<15><<<1, 64>>>(1.5); k<16><<<1, 64>>>(1.5); k<17><<<1, 64>>>(1.5); k<18><<<1, 64>>>(1.5);
   hipDeviceSynchronize();
   unsigned long long t[32];
   hipMemcpyFromSymbol(t, HIP_SYMBOL(g_t), sizeof(t));
   const char* names[] = {"independent v_fmac_f64", "independent v_fmac_f64_dpp", "dependent v_fmac_f64", "dependent nop+v_mov_b64_dpp",
                          "dependent v_rsq_f64", "dependent v_mul_f64", "independent v_mov_b64_dpp", "independent readlane pair",
-                         "independent v_fmac_f32", "dependent nop+v_fmac_f64_dpp (via dpp src)"};
-  for (int m = 0; m < 10; ++m) printf("%-44s %.1f ticks per instruction (256 instructions, s_memtime)\n", names[m], t[m] / 256.0);
+                         "independent v_fmac_f32", "dependent nop+v_fmac_f64_dpp (via dpp src)", "independent v_rsq_f64", "independent v_rndne_f64",
+                         "independent v_cvt_i32_f64", "independent v_ldexp_f64", "independent v_max_f64", "independent v_add_f64",
+                         "independent v_cvt_f64_i32", "independent v_perm_b32", "independent v_lshl_add_u64"};
+  for (int m = 0; m < 19; ++m) printf("%-44s %.1f ticks per instruction (256 instructions, s_memtime)\n", names[m], t[m] / 256.0);
   return 0;
 }

@@ -163,12 +163,14 @@ int gemm_tall(tgp_handle h, bool tb, int m, int n, int k, double alpha, const do
 // TGP_PREC_AUTO (round 4): the split-precision sweep WITH an a-posteriori repair (sweep_i8_repaired below) on a
 // ladder four planes -> five planes (d <= 16) -> float64.  Every repaired sweep reports how many candidates it had to
 // recompute in float64 (an 8-byte copy into pinned host memory, read back lazily -- no synchronisation); when more
-// than AUTO_DEMOTE of a sweep's candidates were recomputed on the current rung the next sweep moves one rung down
-// (the recomputation costs more than the wider arithmetic saves: 0.095 + 0.255 f us per candidate against 0.125 at
-// the headline size).  tgp_set_hyper / tgp_set_precision restart the ladder at four planes.  Whatever the rung, every
-// result is inside the parity tolerance as far as the 8-sigma bound of the error model goes (a statistical model of the
-// dropped digit pairs, not a worst-case bound), and the fused arg-max returns the float64 winner.
-constexpr double AUTO_DEMOTE = 0.05;
+// than AUTO_DEMOTE of a sweep's candidates were recomputed on the current rung the next sweep moves one rung down: from there
+// on the recomputation costs more than the wider arithmetic saves.  Break-even with round 6's kernels at the headline size
+// (us per candidate: four planes 0.0735, five 0.1067, float64 0.2527): 0.0735 + 0.2527 f = 0.1067 at f = 13 %; the
+// threshold sits below it (rounds 4 / 5: 5 %, from 0.095 + 0.255 f = 0.125 with a margin of two).  tgp_set_hyper /
+// tgp_set_precision restart the ladder at four planes.  Whatever the rung, every result is inside the parity tolerance as
+// far as the 8-sigma bound of the error model goes (a statistical model of the dropped digit pairs, not a worst-case bound),
+// and the fused arg-max returns the float64 winner.
+constexpr double AUTO_DEMOTE = 0.10;
 constexpr int64_t I8_MAX_N = 16384;  // int32 accumulators: 5 pairs x 2^14 x N < 2^31
 int auto_rung_precision(tgp_handle h) {
   if (h->N > I8_MAX_N) return TGP_PREC_F64;
@@ -538,6 +540,8 @@ hipError_t launch_sweep_timed(tgp_handle h, const SweepArgs& a, bool joint) {
     if (ea != hipSuccess) return ea;
     am.kcache = h->s_kcache.as<double>();
     am.aslab = h->s_aslab.as<double>();
+    // (candidate blocks stay dealt, i, i + #WG, ...: drawn from a counter as in the int8 sweep the draw itself gains 0.5 % at
+    // C4's 10 000 blocks, but the kernel compiled with it runs 1.7 % slower in either mode -- profiles/r06_joint_dynblocks.txt)
     (void)hipEventRecord(h->ev0, h->stream);
     switch (h->kind) {
       case TGP_RBF: e = launch_joint_kind0(h->stream, a, wg); break;

@@ -154,11 +154,13 @@ class GaussianProcessRegression:
         # arithmetic of the fused candidate sweeps behind the acquisition functions (engine.set_precision): "f64" (the
         # parity path, default) or "auto" -- W K* on the int8 matrix cores with every candidate outside the parity
         # tolerance by its own error bound, and every candidate that could be the float64 arg-max, recomputed in float64
-        # inside the call (3.2x the float64 sweep at N = 4096; same winner; `predict` values inside the parity tolerance
+        # inside the call (3.4x the float64 sweep at N = 4096; same winner; `predict` values inside the parity tolerance
         # candidate by candidate -- to the 8-sigma model of the arithmetic's truncation error the bounds come from, which every
-        # sweep re-checks on a pseudo-random sample of its candidates in float64, leaving the int8 arithmetic when a sample
-        # fails: engine.get_auto_report()).  Float64 stays the arithmetic the parity claims are made on.  predict_joint,
-        # sample, gradients, `update` and `optimize` are float64 either way.
+        # sweep re-checks in float64 on a uniform sample of its candidates and on the candidates whose bounds sit closest to
+        # their tolerance, leaving the int8 arithmetic when a sample fails: engine.get_auto_report() / get_auto_strata(); the
+        # samples are compared, not written back, so values are a pure function of (model, rung, candidate)).  Float64 stays
+        # the arithmetic the parity claims are made on.  predict_joint, sample, gradients, `update` and `optimize` are float64
+        # either way.
         if sweep_precision not in ("f64", "auto", "i8x4", "i8x5"):
             raise ValueError(f"sweep_precision must be 'f64', 'auto', 'i8x4' or 'i8x5', got {sweep_precision!r}")
         self._sweep_precision = sweep_precision
