@@ -273,6 +273,13 @@ def secondary_line(name: str, precision: str, steps: int, device: int = 0, traff
     if precision == "auto" and kind == "ei":  # the int8 sweep with the a-posteriori float64 repair: price what it ran
         _, eff, frac = eng.get_precision()
         auto_info = {"arithmetic": eff, "recomputed_in_f64_fraction": frac}
+        try:  # the run-time check of the error model over the warm-up + timed sweeps: both strata of the canary, apart
+            strata = eng.get_auto_strata()
+            rep = eng.get_auto_report()
+            auto_info["canary"] = {"uniform_1_in_4096": strata["uniform"], "adversarial_worst_bound_per_64th": strata["adversarial"],
+                                   "slack_saved": strata["slack_saved"], "demotions": rep["demotions"], "rung": rep["level"]}
+        except Exception as e:  # (informational: never let it break the bench line)
+            auto_info["canary"] = f"failed: {type(e).__name__}: {e}"
         precision = eff
     emulated = precision != "f64" and kind == "ei"
     if emulated:
