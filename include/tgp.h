@@ -481,23 +481,28 @@ int tgp_set_update_concurrency(tgp_handle h, int n);
  * executes it on numpy blocks (any valid interleaving gives L and W) and checks that every pair of tasks touching the
  * same tile with a write among them is ordered by the flags.  Matrices: 0 = K + s I (tiles carry the partial sums),
  * 1 = L, 2 = W.  flags: bit 0 = B operand natural (else transposed), bit 1 = add the tile already at c_off, bit 2 =
- * negate the product.  dep[]: flag ids to wait for (0xffffffff = none); set: the task's own flag (= its position).
+ * negate the product, bit 3 = the task computes HALF of the tile's rows (bit 4: rows 64 .. 127, else 0 .. 63; the split plan
+ * of `flags` bit 1 below).  dep[], dep3: flag ids to wait for (0xffffffff = none); set: the task's own flag (= its position).
  * order[ntasks] (may be NULL): the DISPATCH order -- workers draw positions of it with one atomic and wait for the flags
  * of what they drew; it is a topological order (every flag a task waits for belongs to a chain step or to a task
  * earlier in it), which is what makes that dispatch deadlock-free whatever the residency.  tasks[0 .. *n_urgent) are the
  * tasks on the per-row critical paths (the last burst of a tile and the single-tile products).
  * Flag ids >= ntasks belong to the chain workgroup: ntasks + j = diagonal block j factored and inverted,
- * ntasks + nb + j = L(j+1, j) stored.  chain_dep[2 j], chain_dep[2 j + 1]: what the chain waits for before the leaf
- * of step j and before its L(j+1, j).  Returns TGP_OK, TGP_ERR_ARG, or TGP_ERR_SHAPE when cap < *ntasks (which is
- * always set). */
+ * ntasks + nb + j = L(j+1, j) stored.  chain_dep[3 nb]: chain_dep[2 j], chain_dep[2 j + 1]: what the chain waits for before
+ * the leaf of step j and before its L(j+1, j); chain_dep[2 nb + j]: a second flag before L(j+1, j) (the split plan finishes
+ * P(j+1, j) in two halves) or none.  Returns TGP_OK, TGP_ERR_ARG, or TGP_ERR_SHAPE when cap < *ntasks (which is always
+ * set). */
 typedef struct {
   uint32_t a_off, b_off, c_off, o_off, nk, flags;
   uint8_t a_mat, b_mat, c_mat, o_mat;
-  uint32_t dep[3], set, pad;
+  uint32_t dep[3], set, dep3;
 } tgp_dag_task;
 int tgp_dag_plan(int nb, int64_t ld, tgp_dag_task* tasks, int64_t cap, int64_t* ntasks, int64_t* n_urgent,
                  uint32_t* chain_dep, uint32_t* order,
-                 int flags /* bit 0: the factor only (tgp_nlml_trial's plan); bits 8-15: B > 0 -> `order` is the dispatch
+                 int flags /* bit 0: the factor only (tgp_nlml_trial's plan); bit 1: the SPLIT plan of the single update at the
+                              chain-bound sizes (round 6): T(i, i-2) and the last burst of tile (i, i-1) -- the two dependent
+                              single products between a leaf and the chain's next sub-diagonal product -- as two half-tile
+                              tasks each; bits 8-15: B > 0 -> `order` is the dispatch
                               list of a batched launch of B members (tgp_nlml_trial_batch): B * ntasks entries
                               (member << 24 | task), the members' orders interleaved */);
 /* Is `update` at N training points one persistent launch on this handle (size, variant bits)?  *yes = 0 / 1.  The host

@@ -19,14 +19,25 @@ from trieste_amd import _lib
 
 T = 128
 NONE = 0xFFFFFFFF
-NN, BETA, NEG = 1, 2, 4
+NN, BETA, NEG, HALF, HI = 1, 2, 4, 8, 16
+SPLIT = 2   # tgp_dag_plan flags bit 1: the split plan of the single full update (round 6)
 
 
 class Task(C.Structure):
     _fields_ = [("a_off", C.c_uint32), ("b_off", C.c_uint32), ("c_off", C.c_uint32), ("o_off", C.c_uint32),
                 ("nk", C.c_uint32), ("flags", C.c_uint32), ("a_mat", C.c_uint8), ("b_mat", C.c_uint8),
                 ("c_mat", C.c_uint8), ("o_mat", C.c_uint8), ("dep", C.c_uint32 * 3), ("set", C.c_uint32),
-                ("pad", C.c_uint32)]
+                ("dep3", C.c_uint32)]
+
+    @property
+    def deps(self):   # all four dependency slots
+        return list(self.dep) + [self.dep3]
+
+    @property
+    def rows(self):   # the rows of the output tile (and of the A operand) the task computes
+        if not self.flags & HALF:
+            return slice(0, T)
+        return slice(T // 2, T) if self.flags & HI else slice(0, T // 2)
 
 
 def plan(nb, ld=None, flags=0):
@@ -36,7 +47,7 @@ def plan(nb, ld=None, flags=0):
     rc = lib.tgp_dag_plan(nb, ld, None, 0, C.byref(n), C.byref(nu), None, None, flags)
     assert rc == _lib.TGP_ERR_SHAPE and n.value >= 0
     tasks = (Task * max(n.value, 1))()
-    chain = (C.c_uint32 * (2 * nb))()
+    chain = (C.c_uint32 * (3 * nb))()   # [2 j] diagonal step, [2 j + 1] sub-diagonal step, [2 nb + j] its second flag (split plan)
     order = (C.c_uint32 * max(n.value, 1))()
     assert lib.tgp_dag_plan(nb, ld, tasks, n.value, C.byref(n), C.byref(nu), chain, order, flags) == _lib.TGP_OK
     assert 0 <= nu.value <= n.value
@@ -53,17 +64,23 @@ def tile_of(off, ld):
     return r // T, c // T
 
 
+def both(mat, i, j):
+    """a whole tile as its two row halves (the unit a half-tile task of the split plan reads and writes)"""
+    return {(mat, i, j, 0), (mat, i, j, 1)}
+
+
 def accesses(t, ld):
-    """(reads, writes) of a bulk task as sets of (matrix, tile row, tile col)."""
+    """(reads, writes) of a bulk task as sets of (matrix, tile row, tile col, row half)."""
     reads, writes = set(), set()
     ai, ak = tile_of(t.a_off, ld)
     bi, bk = tile_of(t.b_off, ld)
+    mine = [1 if t.flags & HI else 0] if t.flags & HALF else [0, 1]   # the row halves of the A operand, of C and of the output
     for kt in range(t.nk):
-        reads.add((t.a_mat, ai, ak + kt))
-        reads.add((t.b_mat, bi + kt, bk) if t.flags & NN else (t.b_mat, bi, bk + kt))
+        reads |= {(t.a_mat, ai, ak + kt, h) for h in mine}
+        reads |= both(t.b_mat, bi + kt, bk) if t.flags & NN else both(t.b_mat, bi, bk + kt)
     if t.flags & BETA:
-        reads.add((t.c_mat,) + tile_of(t.c_off, ld))
-    writes.add((t.o_mat,) + tile_of(t.o_off, ld))
+        reads |= {(t.c_mat,) + tile_of(t.c_off, ld) + (h,) for h in mine}
+    writes |= {(t.o_mat,) + tile_of(t.o_off, ld) + (h,) for h in mine}
     return reads, writes
 
 
@@ -71,8 +88,8 @@ def chain_accesses(nb):
     """per chain node (A(j) = diagonal step, B(j) = sub-diagonal step): reads, writes, flag it sets (relative)"""
     out = []
     for j in range(nb):
-        out.append(({(0, j, j)}, {(1, j, j), (2, j, j)}))                      # P(j,j) -> L_jj, W_jj (Lsub stays in LDS)
-        out.append(({(0, j + 1, j), (2, j, j)} if j + 1 < nb else set(), {(1, j + 1, j)} if j + 1 < nb else set()))
+        out.append((both(0, j, j), both(1, j, j) | both(2, j, j)))              # P(j,j) -> L_jj, W_jj (Lsub stays in LDS)
+        out.append((both(0, j + 1, j) | both(2, j, j) if j + 1 < nb else set(), both(1, j + 1, j) if j + 1 < nb else set()))
     return out
 
 
@@ -93,28 +110,31 @@ class Machine:
         return self.m[mat][i * T:(i + 1) * T, j * T:(j + 1) * T]
 
     def ready(self, t):
-        return all(d == NONE or self.flags[d] for d in t.dep)
+        return all(d == NONE or self.flags[d] for d in t.deps)
 
     def run_bulk(self, idx):
         t, ld = self.tasks[idx], self.ld
         assert self.ready(t), f"task {idx} started before its flags"
         ai, ak = tile_of(t.a_off, ld)
         bi, bk = tile_of(t.b_off, ld)
-        acc = np.zeros((T, T))
+        rows = t.rows   # (a half-tile task: the same products restricted to its rows of A, C and the output)
+        acc = np.zeros((T, T))[rows]
         for kt in range(t.nk):
-            a = self.blk(t.a_mat, ai, ak + kt)
+            a = self.blk(t.a_mat, ai, ak + kt)[rows]
             acc += a @ self.blk(t.b_mat, bi + kt, bk) if t.flags & NN else a @ self.blk(t.b_mat, bi, bk + kt).T
-        cin = self.blk(t.c_mat, *tile_of(t.c_off, ld)).copy() if t.flags & BETA else 0.0
+        cin = self.blk(t.c_mat, *tile_of(t.c_off, ld))[rows].copy() if t.flags & BETA else 0.0
         oi, oj = tile_of(t.o_off, ld)
-        self.m[t.o_mat][oi * T:(oi + 1) * T, oj * T:(oj + 1) * T] = cin + (-acc if t.flags & NEG else acc)
+        self.m[t.o_mat][oi * T:(oi + 1) * T, oj * T:(oj + 1) * T][rows] = cin + (-acc if t.flags & NEG else acc)
         assert t.set == idx
         self.flags[idx] = True
 
     def chain_ready(self):
         if self.chain_pos >= 2 * self.nb:
             return False
-        d = self.chain[self.chain_pos]
-        return d == NONE or self.flags[d]
+        need = [self.chain[self.chain_pos]]
+        if self.chain_pos % 2 == 1:                       # the sub-diagonal step: a second flag in the split plan
+            need.append(self.chain[2 * self.nb + self.chain_pos // 2])
+        return all(d == NONE or self.flags[d] for d in need)
 
     def run_chain(self):
         j, part = divmod(self.chain_pos, 2)
@@ -166,9 +186,17 @@ def spd(n, seed):
     return np.exp(-0.5 * d2 / 0.3 ** 2) + 1e-2 * np.eye(n)
 
 
+@pytest.mark.parametrize("split", [0, SPLIT], ids=["whole-tiles", "split"])
 @pytest.mark.parametrize("nb", [1, 2, 4, 7, 49])  # (49: bursts of 8 k tiles)
-def test_plan_in_list_order_factors_and_inverts(nb):
-    tasks, chain, ld, nu = plan(nb)
+def test_plan_in_list_order_factors_and_inverts(nb, split):
+    tasks, chain, ld, nu = plan(nb, flags=split)
+    if split and nb >= 3:   # T(i, i-2) and the last burst of tile (i, i-1), i = 2 .. nb - 1, as two half-tile tasks each
+        halves = [t for t in tasks if t.flags & HALF]
+        assert len(halves) == 4 * (nb - 2) and sum(1 for t in halves if t.flags & HI) == 2 * (nb - 2)
+        assert all(t.nk == 1 for t in halves)
+        assert sum(1 for j in range(nb) if chain[2 * nb + j] != NONE) == nb - 2
+    else:
+        assert not any(t.flags & HALF for t in tasks) and all(c == NONE for c in chain[2 * nb:])
     n = nb * T
     A = spd(n, nb)
     mc = Machine(A, nb, tasks, chain, ld, nu)
@@ -222,12 +250,13 @@ def test_factor_only_plan_builds_the_factor_and_the_diagonal_inverses(nb):
     np.testing.assert_allclose(L @ z, r, atol=1e-9)
 
 
+@pytest.mark.parametrize("split", [0, SPLIT], ids=["whole-tiles", "split"])
 @pytest.mark.parametrize("seed", [0, 1, 2])
-def test_plan_in_random_valid_interleavings_gives_the_same_bits(seed):
+def test_plan_in_random_valid_interleavings_gives_the_same_bits(seed, split):
     """Three workers with a window: any ready task among the next few popped ones may run, in any order against the
     chain -- what different residencies / timings produce on the device.  Same L and W, bit for bit."""
     nb = 5
-    tasks, chain, ld, nu = plan(nb)
+    tasks, chain, ld, nu = plan(nb, flags=split)
     A = spd(nb * T, 11)
     ref = Machine(A, nb, tasks, chain, ld, nu)
     while not ref.done():
@@ -256,9 +285,9 @@ def test_plan_in_random_valid_interleavings_gives_the_same_bits(seed):
     np.testing.assert_array_equal(mc.m[2], ref.m[2])
 
 
-@pytest.mark.parametrize("nb", [3, 8, 32, 50, 90])  # (50, 90: bursts of 8 and 16 k tiles)
-def test_flags_order_every_conflicting_pair_and_point_backwards(nb):
-    tasks, chain, ld, nu = plan(nb, ld=max(nb * T, 4096) if nb == 32 else None)
+@pytest.mark.parametrize("nb,split", [(3, 0), (8, 0), (32, 0), (50, 0), (90, 0), (3, SPLIT), (8, SPLIT), (32, SPLIT), (40, SPLIT)])
+def test_flags_order_every_conflicting_pair_and_point_backwards(nb, split):   # (50, 90: bursts of 8 and 16 k tiles)
+    tasks, chain, ld, nu = plan(nb, ld=max(nb * T, 4096) if nb == 32 else None, flags=split)
     nt = len(tasks)
     # nodes: bulk tasks 0..nt-1, chain nodes nt + s (s = 2 j: diagonal step, 2 j + 1: sub-diagonal step)
     def chain_node_of_flag(f):  # flag ids >= nt: WD(j) = nt + j -> node nt + 2 j; LSUB(j) = nt + nb + j -> node nt + 2 j + 1
@@ -266,7 +295,7 @@ def test_flags_order_every_conflicting_pair_and_point_backwards(nb):
     preds = [[] for _ in range(nt + 2 * nb)]
     for i, t in enumerate(tasks):
         assert t.set == i
-        for d in t.dep:
+        for d in t.deps:
             if d == NONE:
                 continue
             assert d < nt + 2 * nb
@@ -277,15 +306,16 @@ def test_flags_order_every_conflicting_pair_and_point_backwards(nb):
     for s in range(2 * nb):
         if s > 0:
             preds[nt + s].append(nt + s - 1)
-        if chain[s] != NONE:
-            assert chain[s] < nt
-            preds[nt + s].append(chain[s])
+        for c in [chain[s]] + ([chain[2 * nb + s // 2]] if s % 2 == 1 else []):   # (+ the sub-diagonal step's second flag)
+            if c != NONE:
+                assert c < nt
+                preds[nt + s].append(c)
     # the dispatch order: a permutation in which every task dependency points backwards
     order = ORDER[(nb, ld)]
     assert sorted(order) == list(range(nt))
     where = {t: i for i, t in enumerate(order)}
     for i, t in enumerate(tasks):
-        for d in t.dep:
+        for d in t.deps:
             if d != NONE and d < nt:
                 assert where[d] < where[i], f"task {i} waits for task {d}, which is dispatched AFTER it: deadlock"
     # the dependency graph is acyclic: Kahn's algorithm places every node
@@ -337,9 +367,9 @@ def test_flags_order_every_conflicting_pair_and_point_backwards(nb):
     for t in tasks:
         oi, oj = tile_of(t.o_off, ld)
         ai, ak = tile_of(t.a_off, ld)
-        if t.a_mat == 1 and t.b_mat == 1:      # G
+        if t.a_mat == 1 and t.b_mat == 1:      # G (a half-tile task is half of its product)
             for kt in range(t.nk):
-                seen[("G", oi, oj, ak + kt)] = seen.get(("G", oi, oj, ak + kt), 0) + 1
+                seen[("G", oi, oj, ak + kt)] = seen.get(("G", oi, oj, ak + kt), 0) + (0.5 if t.flags & HALF else 1)
         elif t.a_mat == 1 and t.b_mat == 2:    # X
             for kt in range(t.nk):
                 seen[("X", oi, oj, ak + kt)] = seen.get(("X", oi, oj, ak + kt), 0) + 1
@@ -362,7 +392,7 @@ def plan_batch(nb, B):
     n, nu = C.c_int64(), C.c_int64()
     assert lib.tgp_dag_plan(nb, ld, None, 0, C.byref(n), C.byref(nu), None, None, flags) == _lib.TGP_ERR_SHAPE
     tasks = (Task * max(n.value, 1))()
-    chain = (C.c_uint32 * (2 * nb))()
+    chain = (C.c_uint32 * (3 * nb))()   # [2 j] diagonal step, [2 j + 1] sub-diagonal step, [2 nb + j] its second flag (split plan)
     order = (C.c_uint32 * max(B * n.value, 1))()
     assert lib.tgp_dag_plan(nb, ld, tasks, n.value, C.byref(n), C.byref(nu), chain, order, flags) == _lib.TGP_OK
     return [tasks[i] for i in range(n.value)], list(chain), ld, nu.value, [order[i] for i in range(B * n.value)]
@@ -387,7 +417,7 @@ def test_batched_plan_factors_every_member_from_one_list(nb, B):
     for e in order:
         b, i = e >> 24, e & 0xFFFFFF
         assert b < B and i < nt and not seen[b][i]
-        for dep in tasks[i].dep:
+        for dep in tasks[i].deps:
             assert dep == NONE or dep >= nt or seen[b][dep], "a member's entry precedes one of its producers"
         seen[b][i] = True
     assert all(all(s) for s in seen)
@@ -437,7 +467,7 @@ def test_batched_dispatch_list_is_topological_at_the_sizes_that_run(nb, B):
     for pos, e in enumerate(order):
         b, i = e >> 24, e & 0xFFFFFF
         assert b < B and i < nt and not seen[b, i]
-        for dep in tasks[i].dep:
+        for dep in tasks[i].deps:
             assert dep == NONE or dep >= nt or seen[b, dep]
         seen[b, i] = True
         first[b] = pos if first[b] is None else first[b]

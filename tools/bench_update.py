@@ -9,6 +9,7 @@ from trieste_amd.engine import GPEngine
 def run(kind, d, N, reps=5):
     X, Y = O.synthetic_problem(O.ackley, d, N)
     eng = GPEngine(d, kind)
+    eng.set_variant(int(os.environ.get('TGP_VARIANT', '0')))   # (e.g. 256: the persistent kernel's plan without round 6's split)
     eng.set_hyper(1.0, O.default_lengthscales(d), 1e-2, float(Y.mean()))
     eng.set_data(X, Y)
     ts, tn = [], []

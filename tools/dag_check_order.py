@@ -20,7 +20,7 @@ lib = _lib.load()
 class Task(C.Structure):
     _fields_ = [("a_off", C.c_uint32), ("b_off", C.c_uint32), ("c_off", C.c_uint32), ("o_off", C.c_uint32),
                 ("nk", C.c_uint32), ("flags", C.c_uint32), ("a_mat", C.c_uint8), ("b_mat", C.c_uint8),
-                ("c_mat", C.c_uint8), ("o_mat", C.c_uint8), ("dep", C.c_uint32 * 3), ("set", C.c_uint32), ("pad", C.c_uint32)]
+                ("c_mat", C.c_uint8), ("o_mat", C.c_uint8), ("dep", C.c_uint32 * 3), ("set", C.c_uint32), ("dep3", C.c_uint32)]
 for attempt in range(60):
     eng = GPEngine(d, "matern52"); eng.set_variant(32); eng.set_hyper(1.0, ls, 1e-2, float(Y.mean()))
     failed = False
@@ -38,10 +38,12 @@ for attempt in range(60):
     ch = raw[2:2 + 32 * NB].reshape(NB, 32).astype(np.int64)
     tk = raw[2 + 32 * NB:].reshape(nt, 4).astype(np.int64)
     ld = NB * 128
+    # the plan the engine used: the round-6 split plan at the chain-bound sizes unless tgp_set_variant bit 8 switched it off
+    PLAN_FLAGS = 2 if (3 <= NB < 48 and not (int(os.environ.get('TGP_VARIANT', '0')) & 256)) else 0
     n_, nu_ = C.c_int64(), C.c_int64()
-    lib.tgp_dag_plan(NB, ld, None, 0, C.byref(n_), C.byref(nu_), None, None, 0)
-    tarr = (Task * n_.value)(); carr = (C.c_uint32 * (2 * NB))()
-    lib.tgp_dag_plan(NB, ld, tarr, n_.value, C.byref(n_), C.byref(nu_), carr, None, 0)
+    lib.tgp_dag_plan(NB, ld, None, 0, C.byref(n_), C.byref(nu_), None, None, PLAN_FLAGS)
+    tarr = (Task * n_.value)(); carr = (C.c_uint32 * (3 * NB))()
+    lib.tgp_dag_plan(NB, ld, tarr, n_.value, C.byref(n_), C.byref(nu_), carr, None, PLAN_FLAGS)
     t0 = ch[0, 0]
     print(f"attempt {attempt} FAILED; NB={NB} tasks={nt}")
     bad = 0

@@ -15,7 +15,7 @@ def main():
     from trieste_amd import _lib
     X, Y = O.synthetic_problem(O.ackley, 8, N)
     eng = GPEngine(8, "matern52")
-    eng.set_variant(32)
+    eng.set_variant(32 | int(os.environ.get('TGP_VARIANT', '0')))   # (TGP_VARIANT=256: the plan without round 6's split)
     eng.set_hyper(1.0, O.default_lengthscales(8), 1e-2, float(Y.mean()))
     for _ in range(3):
         eng.set_data(X, Y)
@@ -46,14 +46,16 @@ def main():
         _fields_ = [("a_off", C.c_uint32), ("b_off", C.c_uint32), ("c_off", C.c_uint32), ("o_off", C.c_uint32),
                     ("nk", C.c_uint32), ("flags", C.c_uint32), ("a_mat", C.c_uint8), ("b_mat", C.c_uint8),
                     ("c_mat", C.c_uint8), ("o_mat", C.c_uint8), ("dep", C.c_uint32 * 3), ("set", C.c_uint32),
-                    ("pad", C.c_uint32)]
+                    ("dep3", C.c_uint32)]
 
     ld = NB * 128
+    # the plan the engine used: the round-6 split plan at the chain-bound sizes unless tgp_set_variant bit 8 switched it off
+    PLAN_FLAGS = 2 if (3 <= NB < 48 and not (int(os.environ.get('TGP_VARIANT', '0')) & 256)) else 0
     n_, nu_ = C.c_int64(), C.c_int64()
-    lib.tgp_dag_plan(NB, ld, None, 0, C.byref(n_), C.byref(nu_), None, None, 0)
+    lib.tgp_dag_plan(NB, ld, None, 0, C.byref(n_), C.byref(nu_), None, None, PLAN_FLAGS)
     tarr = (Task * n_.value)()
-    carr = (C.c_uint32 * (2 * NB))()
-    lib.tgp_dag_plan(NB, ld, tarr, n_.value, C.byref(n_), C.byref(nu_), carr, None, 0)
+    carr = (C.c_uint32 * (3 * NB))()
+    lib.tgp_dag_plan(NB, ld, tarr, n_.value, C.byref(n_), C.byref(nu_), carr, None, PLAN_FLAGS)
     tasks, chain, nu = [tarr[i] for i in range(n_.value)], list(carr), nu_.value
     kinds = []
     for t in tasks:

@@ -154,8 +154,9 @@ void apply_penalization(tgp_handle h, double* dvals, const double* dXq, int64_t 
 //   VARIANT_NO_REPAIR_PRODUCT (64): TGP_PREC_AUTO recomputes every flagged candidate through the SPLIT sweep (rounds 4 / 5)
 //                                   instead of the product path for short lists
 //   VARIANT_STATIC_BLOCKS (128): the int8 sweep's workgroups take candidate blocks i, i + #WG, ... instead of drawing them from a counter
+//   VARIANT_DAG_WHOLE_TILES (256): the persistent `update` kernel's plan without the round-6 split of its two critical single products
 constexpr int VARIANT_NO_SPLIT = 1, VARIANT_FORCE_SPLIT = 2, VARIANT_JOINT_V1 = 4, VARIANT_REG_STAGING = 8, VARIANT_NO_DAG = 16,
-              VARIANT_DAG_SMALL = 32, VARIANT_NO_REPAIR_PRODUCT = 64, VARIANT_STATIC_BLOCKS = 128;
+              VARIANT_DAG_SMALL = 32, VARIANT_NO_REPAIR_PRODUCT = 64, VARIANT_STATIC_BLOCKS = 128, VARIANT_DAG_WHOLE_TILES = 256;
 constexpr int64_t REPAIR_PCAP = 512;   // TGP_PREC_AUTO: lists up to this many candidates are recomputed as a product
 int gemm_tall(tgp_handle h, bool tb, int m, int n, int k, double alpha, const double* A, int64_t lda, const double* B,
               int64_t ldb, double beta, double* C, int64_t ldc, int tri);
@@ -685,13 +686,18 @@ struct SharedPlan {
   DevBuf tasks, chain, topo;
   int ntasks = 0;
 };
+// the split plan (dag_build split_critical): the single full update where its chain is the bound
+static bool dag_split(tgp_handle h, int slot, int NB) {
+  return slot == 0 && NB >= 3 && NB < 48 && !(h->variant & VARIANT_DAG_WHOLE_TILES);
+}
 int dag_plan_get(tgp_handle h, int slot, int NB, int64_t ld, int grid, int B) {
   tgp_handle_s::DagPlan& p = h->dag_plan[slot];
-  if (p.nb == NB && p.ld == ld && p.grid == grid && p.B == B) return TGP_OK;
+  const bool split = dag_split(h, slot, NB);
+  if (p.nb == NB && p.ld == ld && p.grid == grid && p.B == B && p.split == split) return TGP_OK;
   static std::mutex mu;
   static std::map<std::tuple<int, int, int, int64_t, int, int>, SharedPlan*> cache;  // (never freed: process lifetime)
   std::lock_guard<std::mutex> lk(mu);
-  const int kind = slot == 0 ? 0 : (slot == 1 ? 1 : 2);
+  const int kind = slot == 0 ? (split ? 3 : 0) : (slot == 1 ? 1 : 2);
   SharedPlan*& sp = cache[std::make_tuple(h->device, kind, NB, ld, grid, B)];
   if (!sp) {
     std::vector<DagTask> tasks;
@@ -699,7 +705,7 @@ int dag_plan_get(tgp_handle h, int slot, int NB, int64_t ld, int grid, int B) {
     int nu = 0;
     // the dispatch order is simulated for the workers there are: alone, or B members sharing grid - B of them
     dag_build(NB, ld, tasks, chain, nu, &topo, std::max(1, slot >= 2 ? (grid - B) / B : grid - 1), slot == 0, slot >= 2 ? B : 1,
-              grid - B, &merged);
+              grid - B, &merged, split);
     if (slot >= 2) {
       if (B == 1) dag_merge_order(topo, 1, merged);
       topo.swap(merged);
@@ -727,6 +733,7 @@ int dag_plan_get(tgp_handle h, int slot, int NB, int64_t ld, int grid, int B) {
   p.ld = ld;
   p.grid = grid;
   p.B = B;
+  p.split = split;
   p.ntasks = sp->ntasks;
   p.tasks = sp->tasks.p;
   p.chain = sp->chain.p;
@@ -1085,8 +1092,9 @@ int tgp_dag_plan(int nb, int64_t ld, tgp_dag_task* tasks, int64_t cap, int64_t* 
   std::vector<tgp::DagTask> t;
   std::vector<uint32_t> c, topo, merged;
   int nu = 0;
+  if ((flags & 2) && ((flags & 1) || B > 0)) return TGP_ERR_ARG;   // the split plan is the single full update's
   tgp::dag_build(nb, ld, t, c, nu, &topo, B > 0 ? std::max(1, (256 - B) / B) : 255, (flags & 1) == 0, std::max(1, B), 256 - B,
-                 &merged);
+                 &merged, (flags & 2) != 0);
   if (B > 0) {
     if (B == 1) tgp::dag_merge_order(topo, 1, merged);
     topo.swap(merged);

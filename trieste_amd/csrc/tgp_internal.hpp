@@ -189,6 +189,7 @@ void launch_traj_grad(hipStream_t s, const TrajDev& t, const double* Xq, int64_t
 // ---- `update` as one persistent launch (tgp_kernels_dag.hip) -----------------------------------------------------
 constexpr int DAG_MAT_A = 0, DAG_MAT_L = 1, DAG_MAT_W = 2;   // which matrix a tile offset refers to
 constexpr uint32_t DAG_NN = 1, DAG_BETA = 2, DAG_NEG = 4;     // B operand natural (else transposed); add Cin; negate
+constexpr uint32_t DAG_HALF = 8, DAG_HI = 16;                 // round 6: the task computes 64 of the tile's 128 rows (DAG_HI: rows 64 ..)
 constexpr int DAG_CTRL_WORDS = 64;
 struct DagTask {  // one 128 x 128 tile task: out = beta Cin + alpha sum_{kt < nk} A_kt B_kt(^T); 48 bytes
   uint32_t a_off, b_off, c_off, o_off;  // element offsets of the first tiles (k tiles of A follow at +128; of B at
@@ -197,14 +198,15 @@ struct DagTask {  // one 128 x 128 tile task: out = beta Cin + alpha sum_{kt < n
   uint8_t a_mat, b_mat, c_mat, o_mat;
   uint32_t dep[3];                      // flags to wait for (0xffffffff: none)
   uint32_t set;                         // flag to raise when the tile is stored
-  uint32_t pad;
+  uint32_t dep3;                        // a fourth flag to wait for (round 6: consumers of a tile produced in two halves)
 };
 struct DagArgs {
   double *Ap, *Lp, *Wp;        // K + s I (in; its tiles carry the partial sums P), L, W = L^-1; all ld x ld, row-major
   int64_t ld;
   int NB, ntasks;              // 128-blocks per side; tile tasks
   const DagTask* tasks;        // [ntasks]
-  const uint32_t* chain_dep;   // [2 NB] flag the chain workgroup waits for before step j's leaf / its L(j+1,j)
+  const uint32_t* chain_dep;   // [3 NB] flag the chain workgroup waits for before step j's leaf [2 j] / its L(j+1,j) [2 j + 1];
+                               // [2 NB + j]: a second flag before L(j+1,j) (P(j+1,j) finished in two halves), or none
   const uint32_t* topo;        // [ntasks] dispatch order: task indices in a topological order (dag_build)
   uint32_t* flags;             // [ntasks + 2 NB], zero at launch
   uint32_t* ctrl;              // [DAG_CTRL_WORDS] control words (arrival ticket, error, list head), then [ntasks]
@@ -221,7 +223,7 @@ struct DagArgs {
 void dag_merge_order(const std::vector<uint32_t>& member_order, int B, std::vector<uint32_t>& merged);
 void dag_build(int NB, int64_t ld, std::vector<DagTask>& tasks, std::vector<uint32_t>& chain_dep, int& n_urgent,
                std::vector<uint32_t>* topo_out = nullptr, int workers = 255, bool with_inverse = true, int batch = 1,
-               int batch_workers = 0, std::vector<uint32_t>* batch_out = nullptr);
+               int batch_workers = 0, std::vector<uint32_t>* batch_out = nullptr, bool split_critical = false);
 // z = L^-1 r over 128-blocks from L and the diagonal inverses in W; flags: [NB] words, zero at launch
 void launch_block_trsv(hipStream_t s, const double* L, const double* W, int64_t ld, int NB, const double* r, double* z,
                        uint32_t* flags, int B = 1, int64_t mat_stride = 0);

@@ -226,6 +226,10 @@ __device__ __forceinline__ DagArgs dag_uniform_copy(const DagArgs& m) {
 struct TaskU {  // a task descriptor with every field in scalar registers
   uint32_t a_off, b_off, c_off, o_off, nk, flags, a_mat, b_mat, c_mat, o_mat, set;
 };
+// HALF (round 6, the split plan's T(i,i-2) and last burst of (i,i-1)): the task computes 64 of the tile's 128 rows -- rows 64 hi ..
+// -- on 32 x 32 wave tiles (2 x 2 fragments instead of 4 x 2): half the A operand, half the MFMAs per wave, the same sum in the
+// same order for every element.
+template <bool HALF>
 __device__ __attribute__((noinline)) void run_task(const void* kernarg, uint32_t mb, uint32_t idx) {
   const DagArgs a0 = dag_args(kernarg);
   const DagArgs a = a0.B > 1 ? dag_member(a0, (uint32_t)__builtin_amdgcn_readfirstlane(mb)) : a0;
@@ -233,7 +237,8 @@ __device__ __attribute__((noinline)) void run_task(const void* kernarg, uint32_t
   char* const lds = dag_lds;
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = w >> 2, wc = w & 3;  // wave tile: rows 64 wr .., columns 32 wc ..
+  const int wr = w >> 2, wc = w & 3;  // wave tile: rows 64 wr .. (HALF: 32 wr ..), columns 32 wc ..
+  constexpr int RF = HALF ? 2 : 4;    // 16-row fragments per wave
   const DagTask* const tp = uniptr(a.tasks) + uni(idx);
   TaskU t;
   t.a_off = uni(tp->a_off); t.b_off = uni(tp->b_off); t.c_off = uni(tp->c_off); t.o_off = uni(tp->o_off);
@@ -246,7 +251,8 @@ __device__ __attribute__((noinline)) void run_task(const void* kernarg, uint32_t
   auto mat = [&](uint32_t m) { return m == DAG_MAT_A ? Ap : (m == DAG_MAT_L ? Lp : Wp); };
   const int64_t ld = (int64_t)uni((uint32_t)a.ld);
   const bool nn = (t.flags & DAG_NN) != 0;
-  const double* const Abase = mat(t.a_mat) + t.a_off;
+  const int64_t r0 = (HALF && (t.flags & DAG_HI)) ? (int64_t)(TILE / 2) * ld : 0;   // first row of the half, as an element offset
+  const double* const Abase = mat(t.a_mat) + t.a_off + r0;
   const double* const Bbase = mat(t.b_mat) + t.b_off;
   const int64_t bstep = nn ? (int64_t)TILE * ld : TILE;  // from one k tile of B to the next
   const uint32_t lds0 = (uint32_t)(size_t)(lds_char*)lds;
@@ -262,8 +268,8 @@ __device__ __attribute__((noinline)) void run_task(const void* kernarg, uint32_t
     const uint32_t sa = lds0 + (uint32_t)((c & 1) * STAGE), sb = sa + STAGE_A;
     const double* const At = Abase + (int64_t)kt * TILE + kk;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int g = 4 * w + u;
+    for (int u = 0; u < (HALF ? 2 : 4); ++u) {   // (HALF: 16 groups of four rows instead of 32)
+      const int g = (HALF ? 2 : 4) * w + u;
       glds16_sc1(At + (int64_t)(4 * g) * ld + a_lane, sa + (uint32_t)(g * GROUP_B));
     }
     if (nn) {
@@ -283,9 +289,9 @@ __device__ __attribute__((noinline)) void run_task(const void* kernarg, uint32_t
     }
   };
 
-  v4d acc[4][2];
+  v4d acc[RF][2];
 #pragma unroll
-  for (int bi = 0; bi < 4; ++bi)
+  for (int bi = 0; bi < RF; ++bi)
 #pragma unroll
     for (int bj = 0; bj < 2; ++bj) acc[bi][bj] = (v4d){0.0, 0.0, 0.0, 0.0};
 
@@ -308,11 +314,11 @@ __device__ __attribute__((noinline)) void run_task(const void* kernarg, uint32_t
     const char* const sb = sa + STAGE_A;
     // operands of k step k4 + 1 are fetched BEFORE the MFMAs of step k4 are issued (the scheduling barriers keep hipcc
     // from sinking the reads back below them): with two waves per SIMD an exposed LDS round trip per k step costs ~10 %
-    double av[2][4], bv[2][2];
-    auto fetch = [&](int k4, double (&fa)[4], double (&fb)[2]) {
+    double av[2][RF], bv[2][2];
+    auto fetch = [&](int k4, double (&fa)[RF], double (&fb)[2]) {
       const int rot = ((2 * k4 + c_lane) & 15) << 4;
 #pragma unroll
-      for (int bi = 0; bi < 4; ++bi) fa[bi] = *(const double*)(sa + (16 * wr + 4 * bi) * GROUP_B + lane_rows + rot);
+      for (int bi = 0; bi < RF; ++bi) fa[bi] = *(const double*)(sa + (4 * RF * wr + 4 * bi) * GROUP_B + lane_rows + rot);
       if (nn) {
 #pragma unroll
         for (int bj = 0; bj < 2; ++bj) fb[bj] = *(const double*)(sb + 4 * k4 * BN_ROW + bn_off + (32 * wc + 16 * bj) * 8);
@@ -328,7 +334,7 @@ __device__ __attribute__((noinline)) void run_task(const void* kernarg, uint32_t
       if (k4 + 1 < KC / 4) fetch(k4 + 1, av[(k4 + 1) & 1], bv[(k4 + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int bi = 0; bi < 4; ++bi)
+      for (int bi = 0; bi < RF; ++bi)
 #pragma unroll
         for (int bj = 0; bj < 2; ++bj) acc[bi][bj] = mfma_f64(av[k4 & 1][bi], bv[k4 & 1][bj], acc[bi][bj]);
       __builtin_amdgcn_sched_barrier(0);
@@ -339,26 +345,26 @@ __device__ __attribute__((noinline)) void run_task(const void* kernarg, uint32_t
   __syncthreads();  // the stages are dead: the tile goes through LDS once, so that global traffic is 16 B per lane
   double* const T = (double*)lds;
 #pragma unroll
-  for (int bi = 0; bi < 4; ++bi)
+  for (int bi = 0; bi < RF; ++bi)
 #pragma unroll
     for (int bj = 0; bj < 2; ++bj)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        T[(64 * wr + 16 * bi + lq + 4 * r) * OUT_LD + 32 * wc + 16 * bj + lr] = acc[bi][bj][r];
+        T[(16 * RF * wr + 16 * bi + lq + 4 * r) * OUT_LD + 32 * wc + 16 * bj + lr] = acc[bi][bj][r];
   __syncthreads();
   {
     const double alpha = (t.flags & DAG_NEG) ? -1.0 : 1.0;
     const bool beta = (t.flags & DAG_BETA) != 0;
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(mat(t.c_mat), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(mat(t.o_mat), 0, 0x7fffffff, 0x00020000);
-    constexpr int NIT = TILE * TILE / 1024;  // 16 passes of 512 threads x 2 doubles
+    constexpr int NIT = (HALF ? TILE / 2 : TILE) * TILE / 1024;  // 16 (HALF: 8) passes of 512 threads x 2 doubles
     v2d cin[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int e = tid + 512 * it, row = e >> 6, c2 = (e & 63) * 2;
       cin[it] = (v2d){0.0, 0.0};
       if (beta) {
-        const v4u raw = __builtin_amdgcn_raw_buffer_load_b128(rc, (int)(((int64_t)t.c_off + (int64_t)row * ld + c2) * 8), 0, 16);
+        const v4u raw = __builtin_amdgcn_raw_buffer_load_b128(rc, (int)(((int64_t)t.c_off + r0 + (int64_t)row * ld + c2) * 8), 0, 16);
         cin[it] = __builtin_bit_cast(v2d, raw);
       }
     }
@@ -370,7 +376,7 @@ __device__ __attribute__((noinline)) void run_task(const void* kernarg, uint32_t
       o.x = fma(alpha, v.x, cin[it].x);
       o.y = fma(alpha, v.y, cin[it].y);
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, o), ro,
-                                             (int)(((int64_t)t.o_off + (int64_t)row * ld + c2) * 8), 0, 16);
+                                             (int)(((int64_t)t.o_off + r0 + (int64_t)row * ld + c2) * 8), 0, 16);
     }
   }
   drain_vm();  // every storing wave drains its write-through stores, THEN the barrier, THEN one lane publishes
@@ -512,7 +518,7 @@ __device__ __forceinline__ void chain_diag(const DagArgs& a, int j, uint32_t pen
 // Step j, part 2: the 128-leaf on S (L_jj goes to global memory panel by panel, write-through), then W_jj = T.
 // `peek`: the flag the chain waits for next -- lane 0 looks at it before this part's closing barrier, which then also
 // hands the answer round (returned: the flag was up, the usual case; saves the two barriers of a wait of its own).
-__device__ __forceinline__ bool chain_leaf(const DagArgs& a, int j, uint32_t peek) {
+__device__ __forceinline__ bool chain_leaf(const DagArgs& a, int j, uint32_t peek, uint32_t peek2 = NONE) {
   DAG_LDS_DECL;
   double* const S = (double*)dag_lds;
   const WorkItem* const items = (const WorkItem*)(S + QN * QS);
@@ -526,7 +532,8 @@ __device__ __forceinline__ bool chain_leaf(const DagArgs& a, int j, uint32_t pee
                   Wp + off * ld + off);  // (stores W_jj as it goes)
   drain_vm();
   volatile uint32_t* const ctl = (volatile uint32_t*)(dag_lds + CTL_OFF);
-  if (tid == 0) ctl[1] = (peek == NONE || ld_flag(uniptr(a.flags) + peek) != 0) ? 1u : 0u;
+  if (tid == 0)
+    ctl[1] = ((peek == NONE || ld_flag(uniptr(a.flags) + peek) != 0) && (peek2 == NONE || ld_flag(uniptr(a.flags) + peek2) != 0)) ? 1u : 0u;
   __syncthreads();
   return ctl[1] != 0;
 }
@@ -630,11 +637,13 @@ __device__ __attribute__((noinline)) void run_chain(const DagArgs& a_mem) {
     pending = NONE;
     stamp(tr ? tr + 2 : nullptr);
     const bool last = j + 1 == a.NB;
-    const bool sub_up = chain_leaf(a, j, last ? NONE : a.chain_dep[2 * j + 1]);
+    // (the split plan finishes P(j+1,j) in two half-tile tasks: a second flag, chain_dep[2 NB + j])
+    const uint32_t sub_dep = last ? NONE : a.chain_dep[2 * j + 1], sub_dep2 = last ? NONE : a.chain_dep[2 * a.NB + j];
+    const bool sub_up = chain_leaf(a, j, sub_dep, sub_dep2);
     if (tid == 0) st_flag(a.flags + WD + j, 1u);
     stamp(tr ? tr + 3 : nullptr);
     if (last) break;
-    if (!sub_up && !wait_for(a.chain_dep[2 * j + 1])) return;
+    if (!sub_up && !(wait_for(sub_dep) && wait_for(sub_dep2))) return;
     stamp(tr ? tr + 4 : nullptr);
     diag_up = chain_sub(a, j, a.chain_dep[2 * j + 2]);
     pending = LSUB + (uint32_t)j;
@@ -682,6 +691,7 @@ __global__ __launch_bounds__(512) void dag_update_kernel(DagArgs a) {
         const uint32_t* const mflags = wa.flags + (size_t)mb * wa.flags_stride;
         bool ok = true;
         for (int d = 0; d < 3; ++d) ok = ok && wait_flag_at(mflags, wa.ctrl, wa.tasks[got].dep[d]);
+        ok = ok && wait_flag_at(mflags, wa.ctrl, wa.tasks[got].dep3);
         if (!ok) got = TASK_ERR;
       }
       ctl[0] = got;
@@ -701,15 +711,16 @@ __global__ __launch_bounds__(512) void dag_update_kernel(DagArgs a) {
       }
     }
     if (wa.trace && tid == 0) {  // development aid: a task must never start before its producers' flags are up
-      for (int d = 0; d < 3; ++d) {
-        const uint32_t dep = wa.tasks[idx].dep[d];
+      for (int d = 0; d < 4; ++d) {
+        const uint32_t dep = d < 3 ? wa.tasks[idx].dep[d] : wa.tasks[idx].dep3;
         if (dep != NONE && ld_flag(wa.flags + dep) == 0) {
           st_flag(wa.ctrl + C_ERR, 2u);
           st_flag(wa.ctrl + C_ERRINFO, idx);
         }
       }
     }
-    run_task(kernarg, mb, idx);
+    if (uni(wa.tasks[idx].flags) & DAG_HALF) run_task<true>(kernarg, mb, idx);
+    else run_task<false>(kernarg, mb, idx);
     stamp(tr ? tr + 2 : nullptr);
     if (tr) tr[3] = blockIdx.x;
   }
@@ -744,9 +755,16 @@ std::vector<std::pair<int, int>> bursts(int lo, int hi, int burst) {  // long bu
 // order of a simulated launch, see below), dependencies as flag ids.
 // flag ids: task n -> n;  chain: W_jj / L_jj ready -> ntasks + j;  L(j+1,j) ready -> ntasks + NB + j.
 // `with_inverse` false: the factor only (no X / E tasks: W keeps its diagonal tiles W_jj, which the T tasks need).
+// `split_critical` (round 6, the single full update at the chain-bound sizes): between the leaf of step j - 1 and the chain's
+// product L(j+1,j) = P(j+1,j) W_jj^T lie two DEPENDENT single products on the workers, T(j+1,j-1) = P(j+1,j-1) W^T and the
+// last burst of tile (j+1,j), P(j+1,j) -= L(j+1,j-1) L(j,j-1)^T -- 24 us each plus flag latencies, 53 us after the leaf's flag,
+// the second 54-us loop beside the chain (profiles/r05_update_breakdown.txt).  Both are split into two half-tile tasks (rows
+// 0 .. 63 / 64 .. 127 of the output: DAG_HALF, DAG_HI): a half of the second needs only ITS half of the first, every other consumer
+// of L(i,i-2) waits for both halves (a fourth dependency slot), the chain for both halves of P(j+1,j) (chain_dep[2 NB + j]).
+// Every element is still the same sum in the same order: bit-identical to the unsplit plan.
 void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<uint32_t>& chain_dep, int& n_urgent,
                std::vector<uint32_t>* topo_out, int workers, bool with_inverse, int batch, int batch_workers,
-               std::vector<uint32_t>* batch_out) {
+               std::vector<uint32_t>* batch_out, bool split_critical) {
   // k tiles per product: longer bursts amortise a task's fixed ~8 us (N = 8192 is throughput-bound: 8.0 -> 7.65 ms with
   // 8), shorter ones keep the scheduling fine where the chain is the bound (N = 4096: 1.91 ms with 4, 2.08 with 8)
   static const int burst_env = getenv("TGP_DAG_BURST") ? atoi(getenv("TGP_DAG_BURST")) : 0;  // development aid
@@ -757,14 +775,26 @@ void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<
   constexpr int CH_WD = -1000000, CH_LSUB = -2000000;  // chain producers: CH_WD - j, CH_LSUB - j
   std::vector<HostTask> ts;
   std::vector<int> lastG((size_t)NB * NB, -1), Tid((size_t)NB * NB, -1), Eid((size_t)NB * NB, -1);
+  std::vector<int> lastG2((size_t)NB * NB, -1), Tid2((size_t)NB * NB, -1);   // the second (upper) half where a task is split
   auto off = [&](int i, int j) { return (uint32_t)((int64_t)i * TILE * ld + (int64_t)j * TILE); };
-  auto Lprod = [&](int i, int k) {  // producer of tile L(i,k), i > k
-    return i == k + 1 ? CH_LSUB - k : Tid[(size_t)i * NB + k];
+  // producer(s) of tile L(i,k), i > k, onto a dependency list.  half < 0: the whole tile (both halves of a split T);
+  // half 0 / 1: only rows 0 .. 63 / 64 .. 127 (a half task reading its own rows of the A operand)
+  auto add_Lprod = [&](std::vector<int>& deps, int i, int k, int half) {
+    if (i == k + 1) {
+      deps.push_back(CH_LSUB - k);
+      return;
+    }
+    const int lo = Tid[(size_t)i * NB + k], hi = Tid2[(size_t)i * NB + k];
+    if (hi < 0) deps.push_back(lo);
+    else if (half < 0) {
+      deps.push_back(lo);
+      deps.push_back(hi);
+    } else deps.push_back(half == 0 ? lo : hi);
   };
   for (int j = 0; j < NB; ++j)
     for (int i = j; i < NB; ++i) {
       const int hi = i == j ? j - 1 : j;  // the chain adds column j - 1 to the diagonal tile itself
-      int prev = -1;
+      int prev = -1, prev2 = -1;
       for (auto [k0, k1] : bursts(0, std::max(hi, 0), BURST)) {
         HostTask h;
         h.t.a_mat = DAG_MAT_L; h.t.a_off = off(i, k0);
@@ -772,16 +802,27 @@ void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<
         h.t.c_mat = h.t.o_mat = DAG_MAT_A; h.t.c_off = h.t.o_off = off(i, j);
         h.t.nk = (uint32_t)(k1 - k0);
         h.t.flags = DAG_BETA | DAG_NEG;
-        h.deps.push_back(Lprod(i, k1 - 1));
-        if (i != j) h.deps.push_back(Lprod(j, k1 - 1));
-        if (prev >= 0) h.deps.push_back(prev);
         h.ready = k1 - 1;
         h.need = i == j ? j : (i == j + 1 ? j - 0.5 : j);
         h.urgent = k1 == hi;
-        prev = (int)ts.size();
-        ts.push_back(h);
+        // the last burst of tile (j+1, j): what the chain's next product waits for -- two half-tile tasks in the split plan
+        // (a single product: bursts() ends every tile on one)
+        const bool split = split_critical && i == j + 1 && k1 == hi && k1 - k0 == 1;
+        int id_lo = -1, id_hi = -1;
+        for (int half = 0; half < (split ? 2 : 1); ++half) {
+          HostTask g = h;
+          if (split) g.t.flags |= DAG_HALF | (half ? DAG_HI : 0);
+          add_Lprod(g.deps, i, k1 - 1, split ? half : -1);
+          if (i != j) add_Lprod(g.deps, j, k1 - 1, -1);
+          if (prev >= 0) g.deps.push_back(prev);   // (the burst before: a whole-tile task -- only a tile's LAST burst is split)
+          (half == 0 ? id_lo : id_hi) = (int)ts.size();
+          ts.push_back(g);
+        }
+        prev = id_lo;
+        prev2 = id_hi;
       }
       lastG[(size_t)i * NB + j] = prev;
+      lastG2[(size_t)i * NB + j] = prev2;
       if (i >= j + 2) {  // L(i,j) = P(i,j) W_jj^T
         HostTask h;
         h.t.a_mat = DAG_MAT_A; h.t.a_off = off(i, j);
@@ -794,8 +835,18 @@ void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<
         h.ready = j;
         h.need = j + 1;
         h.urgent = true;
+        const bool split = split_critical && i == j + 2;   // T(i, i-2): the first of the two dependent products
         Tid[(size_t)i * NB + j] = (int)ts.size();
-        ts.push_back(h);
+        if (split) {
+          HostTask lo = h, up = h;
+          lo.t.flags |= DAG_HALF;
+          up.t.flags |= DAG_HALF | DAG_HI;
+          ts.push_back(lo);
+          Tid2[(size_t)i * NB + j] = (int)ts.size();
+          ts.push_back(up);
+        } else {
+          ts.push_back(h);
+        }
       }
     }
   for (int i = 1; with_inverse && i < NB; ++i)
@@ -808,7 +859,7 @@ void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<
         h.t.c_mat = h.t.o_mat = DAG_MAT_W; h.t.c_off = h.t.o_off = off(i, c);
         h.t.nk = (uint32_t)(k1 - k0);
         h.t.flags = DAG_NN | (prev >= 0 ? DAG_BETA : 0);
-        h.deps.push_back(Lprod(i, k1 - 1));
+        add_Lprod(h.deps, i, k1 - 1, -1);
         h.deps.push_back(k1 - 1 == c ? CH_WD - c : Eid[(size_t)(k1 - 1) * NB + c]);
         if (prev >= 0) h.deps.push_back(prev);
         h.ready = k1 - 1 + 0.5;
@@ -840,8 +891,8 @@ void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<
   auto resolve = [&](int d) { return d <= CH_LSUB ? chainB(CH_LSUB - d) : (d <= CH_WD ? chainA(CH_WD - d) : d); };
   for (int n = 0; n < nb; ++n)
     for (int d : ts[n].deps) deps[n].push_back(resolve(d));
-  chain_dep.assign((size_t)2 * NB, NONE);
-  std::vector<int> chain_dep_host((size_t)2 * NB, -1);
+  chain_dep.assign((size_t)3 * NB, NONE);
+  std::vector<int> chain_dep_host((size_t)3 * NB, -1);
   for (int j = 0; j < NB; ++j) {
     if (j > 0) deps[chainA(j)].push_back(chainB(j - 1));
     if (lastG[(size_t)j * NB + j] >= 0) {
@@ -852,6 +903,10 @@ void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<
     if (j + 1 < NB && lastG[(size_t)(j + 1) * NB + j] >= 0) {
       deps[chainB(j)].push_back(lastG[(size_t)(j + 1) * NB + j]);
       chain_dep_host[2 * j + 1] = lastG[(size_t)(j + 1) * NB + j];
+      if (lastG2[(size_t)(j + 1) * NB + j] >= 0) {   // P(j+1,j) finished in two halves: the chain waits for both
+        deps[chainB(j)].push_back(lastG2[(size_t)(j + 1) * NB + j]);
+        chain_dep_host[2 * NB + j] = lastG2[(size_t)(j + 1) * NB + j];
+      }
     }
   }
   std::vector<int> indeg(total, 0);
@@ -870,7 +925,7 @@ void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<
   // of first bursts whose results are needed twenty steps later (the earlier order -- by the step a task becomes ready
   // at -- left the chain waiting 50 us every fourth step at N = 4096 and 70 us per step at N = 8192).
   std::vector<double> dur(total), tail(total, 0.0);
-  for (int n = 0; n < nb; ++n) dur[n] = 8.0 + 19.0 * ts[n].t.nk;
+  for (int n = 0; n < nb; ++n) dur[n] = 8.0 + ((ts[n].t.flags & DAG_HALF) ? 10.0 : 19.0) * ts[n].t.nk;
   for (int j = 0; j < NB; ++j) {
     dur[chainA(j)] = j == 0 ? 31.0 : 45.0;
     dur[chainB(j)] = j + 1 < NB ? 15.0 : 0.0;
@@ -1023,12 +1078,13 @@ void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<
   for (int p = 0; p < nb; ++p) {
     const HostTask& h = ts[order[p]];
     DagTask t = h.t;
-    t.dep[0] = t.dep[1] = t.dep[2] = NONE;
-    for (size_t d = 0; d < h.deps.size(); ++d) t.dep[d] = flag_of(h.deps[d]);
+    t.dep[0] = t.dep[1] = t.dep[2] = t.dep3 = NONE;
+    if (h.deps.size() > 4) abort();   // (the plan never needs more: see split_critical above)
+    for (size_t d = 0; d < h.deps.size(); ++d) (d < 3 ? t.dep[d] : t.dep3) = flag_of(h.deps[d]);
     t.set = (uint32_t)p;
     out_tasks[p] = t;
   }
-  for (int s = 0; s < 2 * NB; ++s)
+  for (int s = 0; s < 3 * NB; ++s)
     if (chain_dep_host[s] >= 0) chain_dep[s] = (uint32_t)place[chain_dep_host[s]];
 }
 
