@@ -43,10 +43,6 @@
 #ifndef TGP_DAG_LATE_K4
 #define TGP_DAG_LATE_K4 3   // the k4 step (of 8 per chunk) after which the late waves request the next chunk
 #endif
-#ifndef TGP_DAG_PIPE
-#define TGP_DAG_PIPE 1      // round 6: the chain's product L(j+1,j) = P(j+1,j) W_jj^T runs BEHIND the leaf's panels (SubPipe below); 0 = after
-                            // the leaf, as one product of all eight waves (rounds 3-5)
-#endif
 #ifndef TGP_DAG_SETPRIO
 #define TGP_DAG_SETPRIO 1   // s_setprio around a chunk's MFMAs: N = 8192 update 7.52 -> 7.42 ms (profiles/r04_dag_stagger_ab.txt)
 #endif
@@ -522,8 +518,7 @@ __device__ __forceinline__ void chain_diag(const DagArgs& a, int j, uint32_t pen
 // Step j, part 2: the 128-leaf on S (L_jj goes to global memory panel by panel, write-through), then W_jj = T.
 // `peek`: the flag the chain waits for next -- lane 0 looks at it before this part's closing barrier, which then also
 // hands the answer round (returned: the flag was up, the usual case; saves the two barriers of a wait of its own).
-template <class Hook>
-__device__ __forceinline__ bool chain_leaf(const DagArgs& a, int j, uint32_t peek, uint32_t peek2, Hook hook) {
+__device__ __forceinline__ bool chain_leaf(const DagArgs& a, int j, uint32_t peek, uint32_t peek2 = NONE) {
   DAG_LDS_DECL;
   double* const S = (double*)dag_lds;
   const WorkItem* const items = (const WorkItem*)(S + QN * QS);
@@ -534,151 +529,11 @@ __device__ __forceinline__ bool chain_leaf(const DagArgs& a, int j, uint32_t pee
   // (measured and rejected: a worker wave pulling P(j+1,j) into the L2 during the leaf with dummy LDS-DMA loads -- the
   // leaf slows down by 2.5 us and part 3's operand loads do not get faster: they are address-rate bound, not misses)
   leaf_core<true>(S, items, uniptr(a.Lp), ld, off, uniptr(a.info), (lds_sync_t*)(lds_char*)(dag_lds + CTL_OFF + 32),
-                  Wp + off * ld + off, hook);  // (stores W_jj as it goes)
+                  Wp + off * ld + off);  // (stores W_jj as it goes)
   drain_vm();
   volatile uint32_t* const ctl = (volatile uint32_t*)(dag_lds + CTL_OFF);
   if (tid == 0)
     ctl[1] = ((peek == NONE || ld_flag(uniptr(a.flags) + peek) != 0) && (peek2 == NONE || ld_flag(uniptr(a.flags) + peek2) != 0)) ? 1u : 0u;
-  __syncthreads();
-  return ctl[1] != 0;
-}
-
-// ---- Step j, part 3 BEHIND the leaf's panels (round 6) --------------------------------------------------------------------
-// Column block kb of L(j+1,j) = P(j+1,j) W_jj^T is  sum_{kc <= kb} P(:, kc) W(kb, kc)^T  and row block kb of W_jj = T is final
-// after panel kb of the leaf ([C kb] and its barrier).  So once P(j+1,j) is final -- with the split plan ~12 us before the leaf
-// ends -- the six worker waves of the leaf, which finish their items ahead of the panel waves, compute the column blocks of
-// THEIR 16 rows of L(j+1,j) panel by panel (LeafHook: called by every wave at the end of a panel iteration); what is left
-// after the leaf is the workers' last block(s) and the panel waves' two row blocks, which all eight waves share by column
-// block (sub_leftover).  Every block is the sum chain_sub forms, in its order: bit-identical.
-struct SubPipe {
-  double pb[QB][4];   // this wave's 16 rows of P(j+1,j): natural B operands, pb[kc][k4] = P[16 w + lr][16 kc + 4 lq + k4]
-  v4d o[QB];          // column blocks of this wave's rows of L(j+1,j)
-  int have;           // pb requested (the flags of P(j+1,j) were seen up)
-  int knext;          // column blocks [0, knext) are done
-  uint32_t look;      // the flag words requested at the end of the previous panel (consumed one panel later: a look must not
-                      // cost the worker a memory round trip -- its leaf items for the running panel wait behind it)
-  int looked;
-};
-__device__ __forceinline__ void sub_load_block(__amdgpu_buffer_rsrc_t rp, int row, int ld32, int kc, int lq, double (&b)[4]) {
-  const int voff = (row * ld32 + 16 * kc + 4 * lq) * 8;
-  const v4u lo = __builtin_amdgcn_raw_buffer_load_b128(rp, voff, 0, 16);
-  const v4u hi = __builtin_amdgcn_raw_buffer_load_b128(rp, voff + 16, 0, 16);
-  const v2d l2 = __builtin_bit_cast(v2d, lo), h2 = __builtin_bit_cast(v2d, hi);
-  b[0] = l2.x; b[1] = l2.y; b[2] = h2.x; b[3] = h2.y;
-}
-// o = sum_{kc <= KK} sum_k4 W(KK, kc)[., 4 lq + k4] * pb[kc][k4]   (A operand from S: W_jj's row block KK)
-template <int KK>
-__device__ __forceinline__ v4d sub_block(const char* S8, int lane_ap, const double (&pb)[QB][4]) {
-  v4d o = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int kc = 0; kc <= KK; ++kc)
-#pragma unroll
-    for (int k4 = 0; k4 < 4; ++k4) o = mfma_f64(ldsd(S8 + lane_ap + blk(KK, kc) + 8 * k4), pb[kc][k4], o);
-  return o;
-}
-template <int KK>
-struct SubBlocks {   // column blocks [from, to] of sp, compile-time block index per step
-  static __device__ __forceinline__ void run(const char* S8, int lane_ap, SubPipe& sp, int from, int to) {
-    if constexpr (KK < QB) {
-      if (KK >= from && KK <= to) sp.o[KK] = sub_block<KK>(S8, lane_ap, sp.pb);
-      SubBlocks<KK + 1>::run(S8, lane_ap, sp, from, to);
-    }
-  }
-};
-struct SubHook {
-  SubPipe& sp;
-  const uint32_t* flags;
-  uint32_t dep, dep2;          // the flag(s) of P(j+1,j); dep == NONE: no sub-diagonal tile (last step) or nothing to wait for
-  __amdgpu_buffer_rsrc_t rp;   // P(j+1,j)
-  int ld32, active;
-  __device__ __forceinline__ void operator()(int kb, int w) const {
-    if (!active || w < 2) return;   // the panel waves carry the pivot chain: nothing rides on them
-    DAG_LDS_DECL;
-    const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
-    if (!sp.have) {
-      // one look per panel, ASYNCHRONOUS: the flag words requested a panel ago are read now, the next look goes out; then the
-      // loads of P fly under the next panel's items and are consumed at its end
-      const bool up = sp.looked && __builtin_amdgcn_readfirstlane((int)sp.look) != 0;
-      if (up) {
-#pragma unroll
-        for (int kc = 0; kc < QB; ++kc) sub_load_block(rp, 16 * w + lr, ld32, kc, lq, sp.pb[kc]);
-        sp.have = 1;
-      } else {
-        const uint32_t f1 = dep == NONE ? 1u : ld_flag(flags + dep), f2 = dep2 == NONE ? 1u : ld_flag(flags + dep2);
-        sp.look = f1 & f2;   // (flags are 0 / 1; not waited for here)
-        sp.looked = 1;
-      }
-      return;
-    }
-    SubBlocks<0>::run((const char*)dag_lds, (lr * QS + 4 * lq) * 8, sp, sp.knext, kb);
-    sp.knext = kb + 1;
-  }
-};
-// the panel waves' rows 0 .. 31 after the leaf, shared by column block: wave W takes (row block 0, column block W) and
-// (row block 1, column block 7 - W) -- nine block products each
-template <int W>
-__device__ __forceinline__ void sub_leftover(const char* S8, int lane_ap, __amdgpu_buffer_rsrc_t rp, int ld32, int lr, int lq,
-                                             v4d& oa, v4d& ob) {
-  double pa[W + 1][4], pbb[QB - W][4];
-#pragma unroll
-  for (int kc = 0; kc <= W; ++kc) sub_load_block(rp, lr, ld32, kc, lq, pa[kc]);
-#pragma unroll
-  for (int kc = 0; kc <= QB - 1 - W; ++kc) sub_load_block(rp, 16 + lr, ld32, kc, lq, pbb[kc]);
-  oa = (v4d){0.0, 0.0, 0.0, 0.0};
-  ob = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int kc = 0; kc <= W; ++kc)
-#pragma unroll
-    for (int k4 = 0; k4 < 4; ++k4) oa = mfma_f64(ldsd(S8 + lane_ap + blk(W, kc) + 8 * k4), pa[kc][k4], oa);
-#pragma unroll
-  for (int kc = 0; kc <= QB - 1 - W; ++kc)
-#pragma unroll
-    for (int k4 = 0; k4 < 4; ++k4) ob = mfma_f64(ldsd(S8 + lane_ap + blk(QB - 1 - W, kc) + 8 * k4), pbb[kc][k4], ob);
-}
-// after the leaf (and after the flags of P(j+1,j) have been waited for): the workers finish their rows, everybody shares the
-// panel waves' rows, S becomes Lsub.  Returns like chain_sub (the next diagonal product's flag seen up).
-__device__ __forceinline__ bool chain_sub_finish(const DagArgs& a, int j, uint32_t peek, SubPipe& sp, __amdgpu_buffer_rsrc_t rp) {
-  DAG_LDS_DECL;
-  double* const S = (double*)dag_lds;
-  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const char* const S8 = (const char*)S;
-  const int ld32 = (int)uni((uint32_t)a.ld);
-  const int lane_ap = (lr * QS + 4 * lq) * 8;
-  j = __builtin_amdgcn_readfirstlane(j);
-  v4d oa, ob;
-  if (w >= 2 && !sp.have) {
-#pragma unroll
-    for (int kc = 0; kc < QB; ++kc) sub_load_block(rp, 16 * w + lr, ld32, kc, lq, sp.pb[kc]);
-    sp.have = 1;
-  }
-  switch (w) {   // (issued before the workers' remaining blocks: its loads fly under them)
-    case 0: sub_leftover<0>(S8, lane_ap, rp, ld32, lr, lq, oa, ob); break;
-    case 1: sub_leftover<1>(S8, lane_ap, rp, ld32, lr, lq, oa, ob); break;
-    case 2: sub_leftover<2>(S8, lane_ap, rp, ld32, lr, lq, oa, ob); break;
-    case 3: sub_leftover<3>(S8, lane_ap, rp, ld32, lr, lq, oa, ob); break;
-    case 4: sub_leftover<4>(S8, lane_ap, rp, ld32, lr, lq, oa, ob); break;
-    case 5: sub_leftover<5>(S8, lane_ap, rp, ld32, lr, lq, oa, ob); break;
-    case 6: sub_leftover<6>(S8, lane_ap, rp, ld32, lr, lq, oa, ob); break;
-    default: sub_leftover<7>(S8, lane_ap, rp, ld32, lr, lq, oa, ob); break;
-  }
-  if (w >= 2) SubBlocks<0>::run(S8, lane_ap, sp, sp.knext, QB - 1);
-  stamp((a.trace && tid == 0) ? a.trace + CT * j + 7 : nullptr);
-  stamp((a.trace && lane == 0) ? a.trace + CT * j + 8 + w : nullptr);
-  __syncthreads();  // W_jj has been read (and stored): S becomes Lsub, row-major
-  if (w >= 2) {
-#pragma unroll
-    for (int kb = 0; kb < QB; ++kb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) S[(16 * w + lr) * QS + 16 * kb + lq + 4 * r] = sp.o[kb][r];
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    S[lr * QS + 16 * w + lq + 4 * r] = oa[r];                    // (row block 0, column block w)
-    S[(16 + lr) * QS + 16 * (QB - 1 - w) + lq + 4 * r] = ob[r];  // (row block 1, column block 7 - w)
-  }
-  volatile uint32_t* const ctl = (volatile uint32_t*)(dag_lds + CTL_OFF);
-  if (tid == 0) ctl[1] = (peek == NONE || ld_flag(uniptr(a.flags) + peek) != 0) ? 1u : 0u;
   __syncthreads();
   return ctl[1] != 0;
 }
@@ -784,28 +639,13 @@ __device__ __attribute__((noinline)) void run_chain(const DagArgs& a_mem) {
     const bool last = j + 1 == a.NB;
     // (the split plan finishes P(j+1,j) in two half-tile tasks: a second flag, chain_dep[2 NB + j])
     const uint32_t sub_dep = last ? NONE : a.chain_dep[2 * j + 1], sub_dep2 = last ? NONE : a.chain_dep[2 * a.NB + j];
-#if TGP_DAG_PIPE
-    SubPipe sp;
-    sp.have = 0;
-    sp.knext = 0;
-    sp.looked = 0;
-    sp.look = 0u;
-    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
-        (double*)(a.Ap + ((int64_t)(j + 1) * TILE) * a.ld + (int64_t)j * TILE), 0, 0x7fffffff, 0x00020000);
-    const bool sub_up = chain_leaf(a, j, sub_dep, sub_dep2, SubHook{sp, a.flags, sub_dep, sub_dep2, rp, (int)a.ld, last ? 0 : 1});
-#else
-    const bool sub_up = chain_leaf(a, j, sub_dep, sub_dep2, NoLeafHook());
-#endif
+    const bool sub_up = chain_leaf(a, j, sub_dep, sub_dep2);
     if (tid == 0) st_flag(a.flags + WD + j, 1u);
     stamp(tr ? tr + 3 : nullptr);
     if (last) break;
     if (!sub_up && !(wait_for(sub_dep) && wait_for(sub_dep2))) return;
     stamp(tr ? tr + 4 : nullptr);
-#if TGP_DAG_PIPE
-    diag_up = chain_sub_finish(a, j, a.chain_dep[2 * j + 2], sp, rp);
-#else
     diag_up = chain_sub(a, j, a.chain_dep[2 * j + 2]);
-#endif
     pending = LSUB + (uint32_t)j;
     stamp(tr ? tr + 5 : nullptr);
   }
