@@ -463,9 +463,10 @@ int tgp_get_auto_strata(tgp_handle h, int64_t* checked2, int64_t* violations2, d
  * `update` through the recursion of dependent launches instead of the persistent task-DAG kernel, bit 5 = the persistent
  * kernel from Npad = 256 on (default: from 4096 on, where it is the faster one), bit 6 = TGP_PREC_AUTO recomputes every
  * flagged candidate through the row-group-split sweep instead of the product path it takes for lists of up to 512, bit 7 =
- * the int8 sweep's workgroups take candidate blocks i, i + #WG, ... instead of drawing them from a counter.  Bits 0-3, 7:
- * every setting computes the same arithmetic on every candidate; bits 4 - 6: the same values up to the rounding of another
- * summation order. */
+ * the int8 sweep's workgroups take candidate blocks i, i + #WG, ... instead of drawing them from a counter, bit 8 = the
+ * persistent `update` kernel's plan with whole tiles only (default since round 6 at 3 <= Npad / 128 < 48: its two critical
+ * single products as half-tile tasks, see tgp_dag_plan).  Bits 0-3, 7, 8: every setting computes the same arithmetic on
+ * every candidate / matrix entry, bit for bit; bits 4 - 6: the same values up to the rounding of another summation order. */
 int tgp_set_variant(tgp_handle h, int variant);
 /* `update` on SEVERAL handles at once (the prior draws of a hyper-parameter fit: reference models.py:294-321 evaluates
  * them one after the other): the persistent update kernel of a handle takes 1 / n of the compute units (n = 1 ... 16, default

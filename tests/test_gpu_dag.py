@@ -16,7 +16,7 @@ from tests.util import assert_close
 
 pytestmark = pytest.mark.gpu
 
-NO_DAG, DAG_SMALL = 16, 32
+NO_DAG, DAG_SMALL, DAG_WHOLE_TILES = 16, 32, 256
 
 
 def _problem(N, d=4, kind="matern52", noise=1e-2, seed_obj=O.ackley):
@@ -92,6 +92,24 @@ def test_dag_update_is_bit_identical_run_to_run_and_across_handles():
     st = O.gpr_update(kind, 1.0, ls, noise, c, X, Y)
     assert_close(La, st.L, rtol=1e-9, atol=1e-9 * np.abs(st.L).max(), what="L at N = 4096")
     assert np.abs(np.tril(Wa) @ np.tril(La) - np.eye(4096)).max() < 1e-8
+
+
+@pytest.mark.parametrize("N", [384, 640, 1100, 4096])
+def test_split_plan_gives_the_bits_of_the_whole_tile_plan(N):
+    """Round 6: at the chain-bound sizes (3 <= block rows < 48) the plan splits its two critical single products -- T(i,i-2)
+    and the last burst of tile (i,i-1) -- into half-tile tasks (32 x 32 wave tiles, a fourth dependency slot, a second flag for
+    the chain).  Every element is the same sum in the same order: L, W and alpha equal the whole-tile plan's (variant bit 8)
+    bit for bit, run to run -- and the recursion's factor up to rounding, as before."""
+    X, Y, ls, c, kind, noise = _problem(N, d=4 if N < 4096 else 8)
+    split = _engine(X, Y, ls, c, kind, noise, variant=DAG_SMALL)
+    whole = _engine(X, Y, ls, c, kind, noise, variant=DAG_SMALL | DAG_WHOLE_TILES)
+    Ls, Ws, als = split.get_factor()
+    Lw, Ww, alw = whole.get_factor()
+    assert np.array_equal(Ls, Lw) and np.array_equal(Ws, Ww) and np.array_equal(als, alw)
+    split.set_data(X, Y)
+    L2, W2, al2 = split.get_factor()
+    assert np.array_equal(L2, Ls) and np.array_equal(W2, Ws) and np.array_equal(al2, als)
+    assert np.abs(np.tril(Ws) @ np.tril(Ls) - np.eye(N)).max() < 1e-7
 
 
 def test_dag_update_at_n8200_ragged_padding():
