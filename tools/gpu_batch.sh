@@ -1,5 +1,4 @@
 #!/bin/bash
-# GPU batch (round 6): closing suite + the driver's command with the final library (split plan in)
-bash tools/gpu_suite.sh r06
-bash tools/gpu_evidence.sh r06 bench
-bash tools/gpu_evidence.sh r06 update
+# GPU batch (round 6): the -m gpu suite including its --runslow twins, with the final library
+set -u; OUT=$PWD/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
+timeout 3000 python -m pytest tests -q -m gpu --runslow --durations=8 2>&1 | grep -v "^$" | tail -16 > $OUT/r06_gpu_tests_runslow.txt; cat $OUT/r06_gpu_tests_runslow.txt
