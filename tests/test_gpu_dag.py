@@ -16,7 +16,7 @@ from tests.util import assert_close
 
 pytestmark = pytest.mark.gpu
 
-NO_DAG, DAG_SMALL, DAG_WHOLE_TILES = 16, 32, 256
+NO_DAG, DAG_SMALL, DAG_WHOLE_TILES, DAG_ONE_CHAIN = 16, 32, 256, 512
 
 
 def _problem(N, d=4, kind="matern52", noise=1e-2, seed_obj=O.ackley):
@@ -101,7 +101,7 @@ def test_split_plan_gives_the_bits_of_the_whole_tile_plan(N):
     the chain).  Every element is the same sum in the same order: L, W and alpha equal the whole-tile plan's (variant bit 8)
     bit for bit, run to run -- and the recursion's factor up to rounding, as before."""
     X, Y, ls, c, kind, noise = _problem(N, d=4 if N < 4096 else 8)
-    split = _engine(X, Y, ls, c, kind, noise, variant=DAG_SMALL)
+    split = _engine(X, Y, ls, c, kind, noise, variant=DAG_SMALL | DAG_ONE_CHAIN)
     whole = _engine(X, Y, ls, c, kind, noise, variant=DAG_SMALL | DAG_WHOLE_TILES)
     Ls, Ws, als = split.get_factor()
     Lw, Ww, alw = whole.get_factor()
@@ -216,6 +216,40 @@ def test_update_concurrency_shares_the_gpu_and_keeps_the_bits():
     for e in engs:
         L, W, _ = e.get_factor()
         assert np.array_equal(L, Lr) and np.array_equal(W, Wr)
+
+
+@pytest.mark.parametrize("N", [300, 384, 640, 1100, 2049, 4096])
+@pytest.mark.parametrize("noise", [1e-2, 1e-5])
+def test_two_workgroup_chain_against_the_one_workgroup_chain(N, noise):
+    """Round 6: the chain of the persistent kernel as TWO workgroups swapping roles (leaf / helper: csrc/tgp_kernels_dag.hip
+    run_duo) -- the default wherever the split plan applies.  L(j+1,j) is a blocked triangular solve against L_jj there and a
+    product with W_jj in the one-workgroup chain (variant bit 9): the same factor and inverse up to rounding, NOT the same bits;
+    bit-identical run to run and across handles like every other form; the residuals |W L - I| and |L L^T - K| at the level of the
+    one-workgroup chain's."""
+    X, Y, ls, c, kind, _ = _problem(N, d=4 if N < 4096 else 8, noise=noise)
+    duo = _engine(X, Y, ls, c, kind, noise, variant=DAG_SMALL)
+    one = _engine(X, Y, ls, c, kind, noise, variant=DAG_SMALL | DAG_ONE_CHAIN)
+    Ld, Wd, ad = duo.get_factor()
+    Lo, Wo, ao = one.get_factor()
+    cond = 1.0 + N / noise
+    tol = 64 * np.finfo(float).eps * cond
+    assert_close(Ld, Lo, rtol=1e-9, atol=tol * np.abs(Lo).max(), what="L: two workgroups vs one")
+    assert_close(Wd, Wo, rtol=1e-7, atol=tol * np.abs(Wo).max() * 64, what="W: two workgroups vs one")
+    assert np.array_equal(np.triu(Ld, 1), np.zeros_like(Ld)) and np.array_equal(np.triu(Wd, 1), np.zeros_like(Wd))
+    st = O.gpr_update(kind, 1.0, ls, noise, c, X, Y)
+    K = st.L @ st.L.T
+    rd, ro = np.abs(Ld @ Ld.T - K).max(), np.abs(Lo @ Lo.T - K).max()
+    assert rd <= 4 * ro + 64 * np.finfo(float).eps * np.abs(K).max(), (rd, ro)
+    wd, wo = np.abs(np.tril(Wd) @ np.tril(Ld) - np.eye(N)).max(), np.abs(np.tril(Wo) @ np.tril(Lo) - np.eye(N)).max()
+    assert wd <= 4 * wo + 1e-12, (wd, wo)
+    assert_close(ad, ao, rtol=1e-6, atol=1e-6 * np.abs(ao).max(), what="alpha")
+    for _ in range(2):
+        duo.set_data(X, Y)
+        L2, W2, a2 = duo.get_factor()
+        assert np.array_equal(L2, Ld) and np.array_equal(W2, Wd) and np.array_equal(a2, ad)
+    other = _engine(X, Y, ls, c, kind, noise, variant=DAG_SMALL)
+    L3, W3, a3 = other.get_factor()
+    assert np.array_equal(L3, Ld) and np.array_equal(W3, Wd) and np.array_equal(a3, ad)
 
 
 @pytest.mark.parametrize("N,variant", [(300, 0), (640, DAG_SMALL), (2049, DAG_SMALL), (4096, 0)])

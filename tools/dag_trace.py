@@ -5,6 +5,34 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
+def duo_summary(N, NB, nt, ch, tk):
+    """The two-workgroup chain (round 6): per step j the helper's stamps -- [0] entry, [1] P(j,j-1) / P(j,j) flags up, [8 + kc] column
+    block kc started, [16 + kc] finished -- and the leaf's: [2] start, [3] end (W_jj published)."""
+    t0 = ch[0, 2]
+    end = max(ch[-1, 3], tk[:, 2].max())
+    print(f"N={N} NB={NB} tasks={nt} (two-workgroup chain): launch span {end - t0:.1f} us; last leaf ends at {ch[-1, 3] - t0:.1f} us")
+    step = np.diff(ch[:, 2])
+    leaf = ch[:, 3] - ch[:, 2]
+    wait_bulk = ch[1:, 1] - ch[1:, 0]
+    gap = ch[1:, 2] - ch[:-1, 3]                      # leaf(j) starts this long after leaf(j-1) ended
+    idle = ch[2:, 0] - ch[:-2, 3]                     # the workgroup's own turn-round: leaf(j-2) end -> helper(j) entry
+    first = ch[1:, 8] - ch[1:, 1]                     # operands + panel 0 staged
+    work = ch[1:, 16:24] - ch[1:, 8:16]               # per column block: compute (incl. waiting for the next panel's flag)
+    between = ch[1:, 9:16] - ch[1:, 16:23]            # end barrier
+    print(f"step {step.mean():.1f} us (min {step.min():.1f} max {step.max():.1f});  leaf {leaf.mean():.1f};  leaf(j) starts {gap.mean():.1f} us after leaf(j-1) ends "
+          f"(min {gap.min():.1f} max {gap.max():.1f})")
+    print(f"helper: waits for the bulk's tiles {wait_bulk.mean():.1f} us (max {wait_bulk.max():.1f}); loads + panel 0 staged {first.mean():.1f}; "
+          f"column blocks {np.round(work.mean(0), 1)} (sum {work.sum(1).mean():.1f}); barriers between {between.mean():.2f}")
+    late = ch[1:, 1] - ch[:-1, 2]                    # when the helper has its tiles, relative to the start of the leaf it follows
+    print(f"  the helper has P(j,j-1) {late.mean():.1f} us after leaf(j-1) started (min {late.min():.1f} max {late.max():.1f}); "
+          f"its last column block ends {(ch[1:, 23] - ch[:-1, 3]).mean():.1f} us after that leaf ended")
+    print("  first steps (step, wait-bulk, gap):", " | ".join(f"{a:.0f} {b:.0f} {c:.0f}" for a, b, c in zip(step[:8], wait_bulk[:8], gap[:8])))
+    wait, run = tk[:, 1] - tk[:, 0], tk[:, 2] - tk[:, 1]
+    nwg = len(set(tk[:, 3].astype(int)))
+    print(f"bulk: {nwg} workgroups ran tasks; busy {run.sum():.0f} us = {run.sum() / (nwg * (end - t0)):.2f} of (workgroups x span); "
+          f"waiting on flags {wait.sum():.0f} us")
+
+
 def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     path = os.environ.get("TGP_DAG_TRACE", "/tmp/dag_trace.bin")
@@ -24,6 +52,11 @@ def main():
     ch = raw[2:2 + 32 * NB].reshape(NB, 32).astype(np.float64) * 1e-2      # us (100 MHz clock)
     tk = raw[2 + 32 * NB:].reshape(nt, 4).astype(np.float64)
     tk[:, :3] *= 1e-2
+    variant = int(os.environ.get('TGP_VARIANT', '0'))
+    split = 3 <= NB < 48 and not (variant & 256)
+    duo = split and not (variant & 512)
+    if duo:
+        return duo_summary(N, NB, nt, ch, tk)
     t0 = ch[0, 0]
     end = max(ch[-1, 3], tk[:, 2].max())
     print(f"N={N} NB={NB} tasks={nt}: launch span {end - t0:.1f} us; chain ends at {ch[-1, 3] - t0:.1f} us")
@@ -50,7 +83,7 @@ def main():
 
     ld = NB * 128
     # the plan the engine used: the round-6 split plan at the chain-bound sizes unless tgp_set_variant bit 8 switched it off
-    PLAN_FLAGS = 2 if (3 <= NB < 48 and not (int(os.environ.get('TGP_VARIANT', '0')) & 256)) else 0
+    PLAN_FLAGS = 2 if split else 0
     n_, nu_ = C.c_int64(), C.c_int64()
     lib.tgp_dag_plan(NB, ld, None, 0, C.byref(n_), C.byref(nu_), None, None, PLAN_FLAGS)
     tarr = (Task * n_.value)()

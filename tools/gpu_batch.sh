@@ -1,5 +1,14 @@
 #!/bin/bash
-# GPU batch (round 6): generation first on the light waves WITH the heavy waves holding priority 3 through their MFMA phase
+# GPU batch (round 6): the two-workgroup chain of the persistent update kernel -- tests, then update timing and traces (variant 512 = one chain)
 set -u; OUT=$PWD/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
-bash tools/gpu_ab.sh r06_i8_gfprio "python tools/bench_i8.py i8x4 i8x5" default tools/exp/libtgp_gfp.so default tools/exp/libtgp_gfp.so
-echo "== trace gfp"; TGP_LIB=$PWD/tools/exp/libtgp_gfptr.so timeout 300 python tools/i8_trace.py i8x4 2>&1 | grep -v amdgpu.ids | head -30 | tee $OUT/r06_i8_trace_gfprio.txt
+timeout 600 python -m pytest tests/test_gpu_dag.py -x -q -m gpu 2>&1 | tail -15 | tee $OUT/r06_dag_duo_tests.txt
+{
+for v in 512 0 512 0; do
+  echo "== TGP_VARIANT=$v (512 = one chain, 0 = two-workgroup chain)"
+  TGP_VARIANT=$v timeout 100 python tools/bench_update.py 4096 8192 2>&1 | grep -v amdgpu.ids
+done
+for v in 512 0; do
+  echo "== trace, TGP_VARIANT=$v"
+  TGP_VARIANT=$v TGP_DAG_TRACE=/tmp/dag_trace.bin timeout 100 python tools/dag_trace.py 4096 2>&1 | grep -v amdgpu.ids | head -40
+done
+} | tee $OUT/r06_dag_duo.txt

@@ -155,8 +155,10 @@ void apply_penalization(tgp_handle h, double* dvals, const double* dXq, int64_t 
 //                                   instead of the product path for short lists
 //   VARIANT_STATIC_BLOCKS (128): the int8 sweep's workgroups take candidate blocks i, i + #WG, ... instead of drawing them from a counter
 //   VARIANT_DAG_WHOLE_TILES (256): the persistent `update` kernel's plan without the round-6 split of its two critical single products
+//   VARIANT_DAG_ONE_CHAIN (512): the persistent `update` kernel's chain as ONE workgroup (rounds 3 - 5) instead of round 6's two
 constexpr int VARIANT_NO_SPLIT = 1, VARIANT_FORCE_SPLIT = 2, VARIANT_JOINT_V1 = 4, VARIANT_REG_STAGING = 8, VARIANT_NO_DAG = 16,
-              VARIANT_DAG_SMALL = 32, VARIANT_NO_REPAIR_PRODUCT = 64, VARIANT_STATIC_BLOCKS = 128, VARIANT_DAG_WHOLE_TILES = 256;
+              VARIANT_DAG_SMALL = 32, VARIANT_NO_REPAIR_PRODUCT = 64, VARIANT_STATIC_BLOCKS = 128, VARIANT_DAG_WHOLE_TILES = 256,
+              VARIANT_DAG_ONE_CHAIN = 512;
 constexpr int64_t REPAIR_PCAP = 512;   // TGP_PREC_AUTO: lists up to this many candidates are recomputed as a product
 int gemm_tall(tgp_handle h, bool tb, int m, int n, int k, double alpha, const double* A, int64_t lda, const double* B,
               int64_t ldb, double beta, double* C, int64_t ldc, int tri);
@@ -690,22 +692,26 @@ struct SharedPlan {
 static bool dag_split(tgp_handle h, int slot, int NB) {
   return slot == 0 && NB >= 3 && NB < 48 && !(h->variant & VARIANT_DAG_WHOLE_TILES);
 }
+// the two-workgroup chain (tgp_kernels_dag.hip run_duo): the single full update, wherever the split plan applies
+static bool dag_duo(tgp_handle h, int slot, int NB) {
+  return dag_split(h, slot, NB) && !(h->variant & VARIANT_DAG_ONE_CHAIN);
+}
 int dag_plan_get(tgp_handle h, int slot, int NB, int64_t ld, int grid, int B) {
   tgp_handle_s::DagPlan& p = h->dag_plan[slot];
-  const bool split = dag_split(h, slot, NB);
-  if (p.nb == NB && p.ld == ld && p.grid == grid && p.B == B && p.split == split) return TGP_OK;
+  const bool split = dag_split(h, slot, NB), duo = dag_duo(h, slot, NB);
+  if (p.nb == NB && p.ld == ld && p.grid == grid && p.B == B && p.split == split && p.duo == duo) return TGP_OK;
   static std::mutex mu;
   static std::map<std::tuple<int, int, int, int64_t, int, int>, SharedPlan*> cache;  // (never freed: process lifetime)
   std::lock_guard<std::mutex> lk(mu);
-  const int kind = slot == 0 ? (split ? 3 : 0) : (slot == 1 ? 1 : 2);
+  const int kind = slot == 0 ? (duo ? 4 : (split ? 3 : 0)) : (slot == 1 ? 1 : 2);
   SharedPlan*& sp = cache[std::make_tuple(h->device, kind, NB, ld, grid, B)];
   if (!sp) {
     std::vector<DagTask> tasks;
     std::vector<uint32_t> chain, topo, merged;
     int nu = 0;
     // the dispatch order is simulated for the workers there are: alone, or B members sharing grid - B of them
-    dag_build(NB, ld, tasks, chain, nu, &topo, std::max(1, slot >= 2 ? (grid - B) / B : grid - 1), slot == 0, slot >= 2 ? B : 1,
-              grid - B, &merged, split);
+    dag_build(NB, ld, tasks, chain, nu, &topo, std::max(1, slot >= 2 ? (grid - B) / B : grid - (duo ? 2 : 1)), slot == 0, slot >= 2 ? B : 1,
+              grid - B, &merged, split, duo);
     if (slot >= 2) {
       if (B == 1) dag_merge_order(topo, 1, merged);
       topo.swap(merged);
@@ -734,6 +740,7 @@ int dag_plan_get(tgp_handle h, int slot, int NB, int64_t ld, int grid, int B) {
   p.grid = grid;
   p.B = B;
   p.split = split;
+  p.duo = duo;
   p.ntasks = sp->ntasks;
   p.tasks = sp->tasks.p;
   p.chain = sp->chain.p;
@@ -751,7 +758,7 @@ int chol_inv_dag(tgp_handle h, bool factor_only = false) {
   if (int rc = dag_plan_get(h, slot, NB, Npad, grid, 1)) return rc;
   const tgp_handle_s::DagPlan& plan = h->dag_plan[slot];
   h->dag_last_slot = slot;
-  h->dag_state_words = (size_t)plan.ntasks + 2 * (size_t)NB + DAG_CTRL_WORDS + (size_t)plan.ntasks;
+  h->dag_state_words = (size_t)plan.ntasks + 2 * (size_t)NB + DAG_CTRL_WORDS + (size_t)plan.ntasks + (plan.duo ? (size_t)DAG_DUO_PF * (size_t)NB : 0);
   HIPCHK(h, h->d_dag_flags.reserve(h->dag_state_words * sizeof(uint32_t)));
   const size_t nflags = (size_t)plan.ntasks + 2 * (size_t)NB;
   // flags, control words and start counts all start from zero, before EVERY launch
@@ -770,6 +777,7 @@ int chol_inv_dag(tgp_handle h, bool factor_only = false) {
   a.ctrl = a.flags + nflags;
   a.info = h->d_info.as<int>();
   a.B = 1;
+  a.duo = plan.duo ? 1 : 0;
   a.flags_stride = (uint32_t)nflags;
   // development aid: TGP_DAG_TRACE=<file> -- time stamps of every chain phase and task of the LAST update, dumped as
   // uint64 [NB][32] + [ntasks][4] after the stream has drained (tools/dag_trace.py reads it)
@@ -1092,9 +1100,9 @@ int tgp_dag_plan(int nb, int64_t ld, tgp_dag_task* tasks, int64_t cap, int64_t* 
   std::vector<tgp::DagTask> t;
   std::vector<uint32_t> c, topo, merged;
   int nu = 0;
-  if ((flags & 2) && ((flags & 1) || B > 0)) return TGP_ERR_ARG;   // the split plan is the single full update's
-  tgp::dag_build(nb, ld, t, c, nu, &topo, B > 0 ? std::max(1, (256 - B) / B) : 255, (flags & 1) == 0, std::max(1, B), 256 - B,
-                 &merged, (flags & 2) != 0);
+  if ((flags & 6) && ((flags & 1) || B > 0)) return TGP_ERR_ARG;   // the split plan and the two-workgroup chain are the single full update's
+  tgp::dag_build(nb, ld, t, c, nu, &topo, B > 0 ? std::max(1, (256 - B) / B) : ((flags & 4) ? 254 : 255), (flags & 1) == 0, std::max(1, B),
+                 256 - B, &merged, (flags & 2) != 0, (flags & 4) != 0);
   if (B > 0) {
     if (B == 1) tgp::dag_merge_order(topo, 1, merged);
     topo.swap(merged);

@@ -137,6 +137,7 @@ struct tgp_handle_s {
   struct DagPlan {         // (a view: the device arrays belong to the process-wide plan cache of tgp_api.hip -- plans are
     int nb = 0, ntasks = 0, grid = 0, B = 0;   //  immutable once built, every handle of a device shares them)
     bool split = false;                         // the round-6 split plan (tgp_api.hip dag_split)
+    bool duo = false;                           // ... launched with the two-workgroup chain (dag_duo)
     int64_t ld = 0;
     const void *tasks = nullptr, *chain = nullptr, *topo = nullptr;
   } dag_plan[2 + 16];  // 0 full, 1 factor-only, 2 + (B - 1): batched factor-only with B = 1 .. 16 members

@@ -191,6 +191,7 @@ constexpr int DAG_MAT_A = 0, DAG_MAT_L = 1, DAG_MAT_W = 2;   // which matrix a t
 constexpr uint32_t DAG_NN = 1, DAG_BETA = 2, DAG_NEG = 4;     // B operand natural (else transposed); add Cin; negate
 constexpr uint32_t DAG_HALF = 8, DAG_HI = 16;                 // round 6: the task computes 64 of the tile's 128 rows (DAG_HI: rows 64 ..)
 constexpr int DAG_CTRL_WORDS = 64;
+constexpr int DAG_DUO_PF = 32;   // the two-workgroup chain: panel flag words per block row ([8 panels][panel wave 0, panel wave 1, W_d's wave, -])
 struct DagTask {  // one 128 x 128 tile task: out = beta Cin + alpha sum_{kt < nk} A_kt B_kt(^T); 48 bytes
   uint32_t a_off, b_off, c_off, o_off;  // element offsets of the first tiles (k tiles of A follow at +128; of B at
                                         // +128 (transposed form) or +128 ld (natural form))
@@ -210,20 +211,22 @@ struct DagArgs {
   const uint32_t* topo;        // [ntasks] dispatch order: task indices in a topological order (dag_build)
   uint32_t* flags;             // [ntasks + 2 NB], zero at launch
   uint32_t* ctrl;              // [DAG_CTRL_WORDS] control words (arrival ticket, error, list head), then [ntasks]
-                               // start counts; ALL ZERO at launch (memset before every launch)
+                               // start counts (then [DAG_DUO_PF NB] panel flags when `duo`); ALL ZERO at launch (memset before every launch)
   int* info;                   // Cholesky breakdown report (1 + index of the first bad pivot)
   unsigned long long* trace;   // development aid (TGP_DAG_TRACE): [NB][32] chain + [ntasks][4] task time stamps, or null
   // batched launch (tgp_nlml_trial_batch): B > 1 members share the plan; member b's matrices are Ap / Lp / Wp +
   // b mat_stride, its flags `flags + b flags_stride`, its breakdown report info[b]; topo then holds B ntasks entries
   // (member << 24 | task) and the start counts are [B][ntasks]
   int B;
+  int duo;                     // round 6: the chain is TWO workgroups (tgp_kernels_dag.hip run_duo; B <= 1 only); DAG_DUO_PF NB panel flag
+                               // words then follow the start counts (zero at launch like everything else)
   int64_t mat_stride;
   uint32_t flags_stride;
 };
 void dag_merge_order(const std::vector<uint32_t>& member_order, int B, std::vector<uint32_t>& merged);
 void dag_build(int NB, int64_t ld, std::vector<DagTask>& tasks, std::vector<uint32_t>& chain_dep, int& n_urgent,
                std::vector<uint32_t>* topo_out = nullptr, int workers = 255, bool with_inverse = true, int batch = 1,
-               int batch_workers = 0, std::vector<uint32_t>* batch_out = nullptr, bool split_critical = false);
+               int batch_workers = 0, std::vector<uint32_t>* batch_out = nullptr, bool split_critical = false, bool duo = false);
 // z = L^-1 r over 128-blocks from L and the diagonal inverses in W; flags: [NB] words, zero at launch
 void launch_block_trsv(hipStream_t s, const double* L, const double* W, int64_t ld, int NB, const double* r, double* z,
                        uint32_t* flags, int B = 1, int64_t mat_stride = 0);

@@ -137,6 +137,17 @@ __device__ __forceinline__ void glds16_sc1(const void* gsrc, uint32_t lds_dst_un
       : "v"(gsrc), "s"(lds_dst_uniform)
       : "memory");
 }
+// the same with the (wave-uniform) destination handed over in a VECTOR register: under scalar-register pressure hipcc keeps such
+// values in VGPRs and then fails to legalise an "s" asm operand (seen in duo_helper).  (s_nop first: the VALU instruction in front
+// of the statement may have just written that register, and nothing pads the inside of an asm string.)
+__device__ __forceinline__ void glds16_sc1_v(const void* gsrc, uint32_t lds_dst_uniform) {
+  unsigned keep, dst;
+  asm volatile(
+      "s_nop 1\n\tv_readfirstlane_b32 %1, %3\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off sc1\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep), "=&s"(dst)
+      : "v"(gsrc), "v"(lds_dst_uniform)
+      : "memory");
+}
 __device__ __forceinline__ void drain_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 __device__ __forceinline__ double ld8_sc1(const double* p) {  // compiler-tracked 8-byte load past the L1
@@ -187,6 +198,7 @@ __device__ __forceinline__ DagArgs dag_args(const void* kernarg) {
   a.info = (int*)q[10];
   a.trace = (unsigned long long*)q[11];
   a.B = (int)(uint32_t)q[12];
+  a.duo = (int)(uint32_t)(q[12] >> 32);
   a.mat_stride = (int64_t)q[13];
   a.flags_stride = (uint32_t)q[14];
   return a;
@@ -217,6 +229,7 @@ __device__ __forceinline__ DagArgs dag_uniform_copy(const DagArgs& m) {
   a.info = uniptr(m.info);
   a.trace = uniptr(m.trace);
   a.B = (int)uni((uint32_t)m.B);
+  a.duo = (int)uni((uint32_t)m.duo);
   a.mat_stride = uni64(m.mat_stride);
   a.flags_stride = uni(m.flags_stride);
   return a;
@@ -651,6 +664,288 @@ __device__ __attribute__((noinline)) void run_chain(const DagArgs& a_mem) {
   }
 }
 
+// ---- round 6: the chain as TWO workgroups ("duo") --------------------------------------------------------------------
+// run_chain's step is diag 13.4 + leaf 26.1 + sub 14.2 us on ONE compute unit, and during the leaf that unit's matrix pipes are
+// nearly idle.  Here the two products move to a SECOND workgroup that runs them UNDERNEATH the other one's leaf, panel by panel,
+// and the two workgroups swap roles every step, so that the diagonal block never crosses compute units:
+//   workgroup c = j & 1 runs leaf(j); meanwhile workgroup 1 - c is the HELPER of step j + 1: it holds P(j+1,j) in registers
+//   (wave w: rows 16 w .., as eight transposed 16 x 16 accumulator blocks) and -P(j+1,j+1) in 36 accumulator fragments, and for
+//   every panel kc of leaf(j) -- published by the leaf's panel waves through two flag words once their write-through stores of
+//   the L panel and of W_d(kc) = L_d(kc)^-1 have drained --
+//       L(j+1,j)[:, kc]   = X[:, kc] W_d(kc)^T                        (4 MFMAs per wave)
+//       X[:, kb]         -= L(j+1,j)[:, kc] L_jj(kb, kc)^T,  kb > kc   (right-looking: 4 (7 - kc) MFMAs)
+//       -S(j+1,j+1)      += L(j+1,j)[:, kc] L(j+1,j)[:, kc]^T          (the 36 lower fragments: 16 - 20 MFMAs)
+//   so that when the leaf's LAST panel is out only 4 + 20 MFMAs per wave stand between it and leaf(j+1), which the helper then
+//   runs itself on the S it has just finished -- while the other workgroup becomes the helper of step j + 2.
+// What crosses compute units per step is the stream of panels (<= 16 KiB each, through the L2 like every other tile) instead of
+// nothing -- and what it buys is that the step shrinks from diag + leaf + sub to the leaf + one panel's tail.
+// L(j+1,j) is formed as a blocked triangular solve against L_jj (inverted 16-blocks) rather than as the product with W_jj: the
+// same matrix to rounding, NOT the same bits as run_chain's (tests/test_gpu_dag.py compares the two to a tolerance); the
+// arithmetic is still fixed by the plan alone: bit-identical run to run, handle to handle, on any share of the GPU.
+// Inside a 16-block the contraction index and the accumulator row are permuted by sigma(i) = 4 (i & 3) + (i >> 2) so that
+// every lane's four operand values are 32 contiguous bytes (in global memory and in LDS alike).
+constexpr int DUO_PANEL_B = QN * 16 * 8;  // 16 KiB: a staged panel [W_d: 16 rows][L_jj rows below] or a column block of L(j+1,j): [128][16]
+constexpr int DUO_PF = DAG_DUO_PF;        // panel flag words per step: [panel][panel wave 0, panel wave 1, W_d's wave, -]
+// LDS of the helper (all inside what becomes the leaf's S): the eight staged panels back to back (panel kc: 128 - 16 kc rows of 128
+// bytes), then two column-block buffers
+__host__ __device__ constexpr int duo_poff(int kc) { return 128 * (128 * kc - 8 * kc * (kc - 1)); }
+constexpr int DUO_LP_OFF = duo_poff(QB);  // 73 728
+static_assert(DUO_LP_OFF + 2 * DUO_PANEL_B <= QN * QS * 8, "the helper's buffers live where the leaf's S will be");
+
+__device__ __forceinline__ uint32_t* duo_panel_flags(const DagArgs& a) { return a.ctrl + DAG_CTRL_WORDS + a.ntasks; }
+
+// The helper of step j >= 1: L(j,j-1) -> global memory (flag LSUB + j - 1), S(j,j) -> LDS, ready for leaf(j).  False: a wait
+// failed (every thread returns the same).
+__device__ __forceinline__ bool duo_helper(const DagArgs& a, int j) {
+  DAG_LDS_DECL;
+  char* const lds = dag_lds;
+  double* const S = (double*)lds;
+  volatile uint32_t* const ctl = (volatile uint32_t*)(lds + CTL_OFF);
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  j = __builtin_amdgcn_readfirstlane(j);
+  const int64_t ld = a.ld, off = (int64_t)j * TILE, offp = off - TILE;
+  const int ld32 = (int)ld;
+  unsigned long long* const tr = (a.trace && tid == 0) ? a.trace + CT * j : nullptr;
+  stamp(tr);
+  const uint32_t* const pf = duo_panel_flags(a) + DUO_PF * (j - 1);
+  // thread 0: how many panels of leaf(j-1) are out (all three words up), counted from the first
+  auto panels_out = [&]() -> uint32_t {
+    uint32_t f[DUO_PF], n = 0;
+#pragma unroll
+    for (int i = 0; i < DUO_PF; ++i) f[i] = (i & 3) == 3 ? 1u : ld_flag(pf + i);
+    bool run = true;
+#pragma unroll
+    for (int k = 0; k < QB; ++k) {
+      run = run && f[4 * k] != 0 && f[4 * k + 1] != 0 && f[4 * k + 2] != 0;
+      n += run ? 1u : 0u;
+    }
+    return n;
+  };
+  // thread 0, blocking: the bulk's three flags (first call) and panel kc -- everything polled TOGETHER, one round trip per look
+  // (one after the other these were seven dependent round trips of ~0.7 us at the head of every helper); -> the number of
+  // panels that are out, 0 on a timeout or when another workgroup has raised the error word
+  auto wait_inputs = [&](int kc, bool bulk) -> uint32_t {
+    const uint32_t d0 = bulk ? a.chain_dep[2 * j - 1] : NONE, d1 = bulk ? a.chain_dep[2 * a.NB + j - 1] : NONE, d2 = bulk ? a.chain_dep[2 * j] : NONE;
+    unsigned spins = 0;
+    for (;;) {
+      const uint32_t f0 = d0 == NONE ? 1u : ld_flag(a.flags + d0), f1 = d1 == NONE ? 1u : ld_flag(a.flags + d1);
+      const uint32_t f2 = d2 == NONE ? 1u : ld_flag(a.flags + d2);
+      const uint32_t n = panels_out();
+      if (f0 != 0 && f1 != 0 && f2 != 0 && n > (uint32_t)kc) return n;
+      __builtin_amdgcn_s_sleep(8);
+      if ((++spins & 255u) == 0) {
+        if (ld_flag(a.ctrl + 2) != 0) return 0u;
+        if (spins > SPIN_LIMIT) {
+          st_flag(a.ctrl + 2, DAG_ERR_TIMEOUT);
+          st_flag(a.ctrl + 3, 0x40000000u | ((uint32_t)j << 8) | (uint32_t)kc);
+          return 0u;
+        }
+      }
+    }
+  };
+  if (tid == 0) ctl[4] = wait_inputs(0, true);
+  __syncthreads();
+  if (ctl[4] == 0) return false;
+  uint32_t avail = ctl[4];  // panels 0 .. avail - 1 are out
+  stamp(tr ? tr + 1 : nullptr);
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((double*)a.Ap, 0, 0x7fffffff, 0x00020000);
+  const int tile_sub = (int)((off * ld + offp) * 8);  // byte offset of tile (j,j-1)
+  // Staging of the panels [k0, k1) of leaf(j-1) by LDS-DMA (no registers; the issuing wave drains before the barrier that hands
+  // them round): panel kc = [128 - 16 kc rows][16 doubles], rows 0 .. 15 W_d(kc) from W's diagonal tile, then L_jj's rows below;
+  // a wave's 64 lanes x 16 bytes are eight rows
+  const uint32_t lds0 = (uint32_t)(size_t)(lds_char*)lds;
+  const double* const Wt = a.Wp + offp * ld + offp;
+  const double* const Lt = a.Lp + offp * ld + offp;
+  auto stage_dma = [&](int k0, int k1) {
+#pragma unroll
+    for (int kc = 0; kc < QB; ++kc) {
+      if (kc < k0 || kc >= k1) continue;
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int row0 = 64 * it + 8 * w;  // (wave-uniform: inside the panel or not)
+        if (row0 < QN - 16 * kc) {
+          // (rows of 128 bytes one behind the other put every 16-lane group of a 16-byte operand read on TWO bank groups -- 8-way
+          // conflicts, measured as 25 us of column blocks against 15 of MFMA time; so LDS granule g of row R holds the row's
+          // granule g ^ ((R >> 1) & 7): the lanes lr = 0 .. 15 of such a read then cover all 64 banks once)
+          const int row = row0 + (lane >> 3), c2 = (((lane & 7) ^ (row >> 1)) & 7) * 2;
+          const double* const src = ((it == 0 && w < 2) ? Wt : Lt) + (int64_t)(16 * kc + row) * ld + 16 * kc + c2;
+          glds16_sc1_v(src, lds0 + (uint32_t)(duo_poff(kc) + row0 * 128));
+        }
+      }
+    }
+  };
+  // the panels that are out first (untracked asm loads: behind hipcc's own they would make every counted wait of its an over-wait),
+  // then X block by block -- block 0's products start while the rest of X streams in -- then the diagonal tile's fragments
+  stage_dma(0, (int)avail);
+  // X = P(j,j-1), rows 16 w ..: xt[kb][r] = X[16 w + lr][16 kb + 4 lq + r]
+  v4d xt[QB];
+#pragma unroll
+  for (int kb = 0; kb < QB; ++kb) {
+    const int voff = ((16 * w + lr) * ld32 + 16 * kb + 4 * lq) * 8;
+    const v2d l2 = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(rA, voff, tile_sub, 16));
+    const v2d h2 = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(rA, voff + 16, tile_sub, 16));
+    xt[kb] = (v4d){l2.x, l2.y, h2.x, h2.y};
+  }
+  // the 36 lower fragments of the diagonal tile, handed out as in chain_diag; sacc = -P(j,j) + sum of the column blocks' squares
+  constexpr int NF = 5;
+  const int p = w >> 1, h = (w ^ (w >> 2)) & 1;
+  v4d sacc[NF];
+  int fbi[NF], fbj[NF];
+  bool live[NF];
+  const double* const Pd = a.Ap + off * ld + off;
+#pragma unroll
+  for (int m = 0; m < NF; ++m) {
+    const int n = 2 * m + h;
+    live[m] = n < 9;
+    fbi[m] = n <= p ? p : 7 - p;
+    fbj[m] = n <= p ? n : (live[m] ? n - p - 1 : 0);
+    sacc[m] = (v4d){0.0, 0.0, 0.0, 0.0};
+    if (live[m]) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sacc[m][r] = -ld8_sc1(Pd + ((16 * fbi[m] + lq + 4 * r) * ld32 + 16 * fbj[m] + lr));
+    }
+  }
+  // (everything older than X's first block -- the panels' DMA -- has landed once that block is in registers: loads return in order)
+  asm volatile("" : "+v"(xt[0]));
+  uint32_t staged = avail;  // panels 0 .. staged - 1 are (being) staged; a wave's own DMA is drained before the next barrier it matters for
+  __syncthreads();
+  double* const Lg = a.Lp + off * ld + offp + (int64_t)(16 * w + lr) * ld + 4 * lq;  // this lane's 32 bytes of a column block
+  const int sg = 4 * (lr & 3) + (lr >> 2);                                            // sigma(lr)
+  // byte offsets of this lane's two 16-byte granules (columns 4 lq .. + 1, + 2 .. + 3) in a staged panel's row sigma(lr) and in a
+  // column-block buffer's row lr (the swizzle of stage_dma)
+  const int arow = sg * 128 + (((2 * lq) ^ (sg >> 1)) & 7) * 16, arow1 = sg * 128 + (((2 * lq + 1) ^ (sg >> 1)) & 7) * 16;
+  const int lrow = lr * 128 + (((2 * lq) ^ (lr >> 1)) & 7) * 16, lrow1 = lr * 128 + (((2 * lq + 1) ^ (lr >> 1)) & 7) * 16;
+#pragma unroll
+  for (int kc = 0; kc < QB; ++kc) {
+    const char* const st = lds + duo_poff(kc);
+    char* const lp = lds + DUO_LP_OFF + (kc & 1) * DUO_PANEL_B;
+    stamp(tr ? tr + 8 + kc : nullptr);
+    // column block kc of L(j,j-1): D[i][c] = L[16 w + c][16 kc + sigma(i)] = sum_k W_d[sigma(i)][sigma(k)] X[16 w + c][16 kc + sigma(k)]
+    // (two chains of two: a dependent float64 MFMA issues only every ~128 cycles)
+    v4d lt;
+    {
+      const v2d a01 = *(const v2d*)(st + arow), a23 = *(const v2d*)(st + arow1);
+      v4d l0 = mfma_f64(a01.x, xt[kc][0], (v4d){0.0, 0.0, 0.0, 0.0});
+      v4d l1 = mfma_f64(a01.y, xt[kc][1], (v4d){0.0, 0.0, 0.0, 0.0});
+      l0 = mfma_f64(a23.x, xt[kc][2], l0);
+      l1 = mfma_f64(a23.y, xt[kc][3], l1);
+      lt = l0 + l1;
+    }
+    {
+      const v2d o01 = (v2d){lt[0], lt[1]}, o23 = (v2d){lt[2], lt[3]};
+      *(v2d*)(lp + w * 2048 + lrow) = o01;
+      *(v2d*)(lp + w * 2048 + lrow1) = o23;
+      st16_sc1(Lg + 16 * kc, o01);
+      st16_sc1(Lg + 16 * kc + 2, o23);
+    }
+    if constexpr (true) {  // X[:, kb] -= L[:, kc] L_jj(kb, kc)^T, kb > kc: the k step outside, the independent blocks inside
+      const v4d nlt = -lt;
+      v2d b01[QB], b23[QB];
+#pragma unroll
+      for (int kb = kc + 1; kb < QB; ++kb) {
+        b01[kb] = *(const v2d*)(st + arow + (kb - kc) * 2048);
+        b23[kb] = *(const v2d*)(st + arow1 + (kb - kc) * 2048);
+      }
+#pragma unroll
+      for (int kb = kc + 1; kb < QB; ++kb) xt[kb] = mfma_f64(b01[kb].x, nlt[0], xt[kb]);
+#pragma unroll
+      for (int kb = kc + 1; kb < QB; ++kb) xt[kb] = mfma_f64(b01[kb].y, nlt[1], xt[kb]);
+#pragma unroll
+      for (int kb = kc + 1; kb < QB; ++kb) xt[kb] = mfma_f64(b23[kb].x, nlt[2], xt[kb]);
+#pragma unroll
+      for (int kb = kc + 1; kb < QB; ++kb) xt[kb] = mfma_f64(b23[kb].y, nlt[3], xt[kb]);
+    }
+    if (kc == 0) drain_vm();  // (block 0 has used all of X by now; the fragments of the diagonal tile are next)
+    __syncthreads();  // the column block is in LDS (the ONLY barrier of a block while the panels are ahead: the two column-block
+                      // buffers alternate, and a buffer's next writer has passed the barrier of the block in between)
+    {
+      const v2d lo01 = *(const v2d*)(lp + lrow + p * 2048), lo23 = *(const v2d*)(lp + lrow1 + p * 2048);
+      const v2d hi01 = *(const v2d*)(lp + lrow + (7 - p) * 2048), hi23 = *(const v2d*)(lp + lrow1 + (7 - p) * 2048);
+      v2d b01[NF], b23[NF];
+#pragma unroll
+      for (int m = 0; m < NF; ++m) {
+        b01[m] = *(const v2d*)(lp + lrow + fbj[m] * 2048);
+        b23[m] = *(const v2d*)(lp + lrow1 + fbj[m] * 2048);
+      }
+#pragma unroll
+      for (int m = 0; m < NF; ++m)
+        if (live[m]) sacc[m] = mfma_f64((2 * m + h) <= p ? lo01.x : hi01.x, b01[m].x, sacc[m]);
+#pragma unroll
+      for (int m = 0; m < NF; ++m)
+        if (live[m]) sacc[m] = mfma_f64((2 * m + h) <= p ? lo01.y : hi01.y, b01[m].y, sacc[m]);
+#pragma unroll
+      for (int m = 0; m < NF; ++m)
+        if (live[m]) sacc[m] = mfma_f64((2 * m + h) <= p ? lo23.x : hi23.x, b23[m].x, sacc[m]);
+#pragma unroll
+      for (int m = 0; m < NF; ++m)
+        if (live[m]) sacc[m] = mfma_f64((2 * m + h) <= p ? lo23.y : hi23.y, b23[m].y, sacc[m]);
+    }
+    stamp(tr ? tr + 16 + kc : nullptr);
+    if (kc + 1 < QB) {
+      if ((uint32_t)(kc + 1) >= staged) {  // the next panel was not out when this workgroup last looked: wait for it, stage what is out now
+        if (tid == 0) ctl[4] = wait_inputs(kc + 1, false);
+        __syncthreads();
+        avail = ctl[4];
+        if (avail == 0) return false;
+        stage_dma((int)staged, (int)avail);
+        staged = avail;
+        drain_vm();
+        __syncthreads();
+      }
+    } else {
+      drain_vm();  // (this wave's stores of L(j,j-1): the last ones went out before the fragment products)
+      __syncthreads();
+    }
+  }
+  if (tid == 0) st_flag(a.flags + (uint32_t)(a.ntasks + a.NB) + (uint32_t)(j - 1), 1u);  // L(j,j-1) is out
+#pragma unroll
+  for (int m = 0; m < NF; ++m) {
+    if (!live[m]) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * fbi[m] + lq + 4 * r, col = 16 * fbj[m] + lr;
+      S[row * QS + col] = (col <= row) ? -sacc[m][r] : 0.0;
+    }
+  }
+  drain_vm();
+  __syncthreads();
+  return true;
+}
+
+__device__ __attribute__((noinline)) void run_duo(const DagArgs& a_mem, uint32_t c) {
+  const DagArgs a = dag_uniform_copy(a_mem);
+  DAG_LDS_DECL;
+  char* const lds = dag_lds;
+  double* const S = (double*)lds;
+  WorkItem* const items = (WorkItem*)(S + QN * QS);
+  const int tid = threadIdx.x;
+  c = uni(c);
+  leaf_build_items(items, tid);
+  if (tid == 0) *(lds_sync_t*)(lds_char*)(dag_lds + CTL_OFF + 32) = 0;
+  __syncthreads();
+  const uint32_t WD = (uint32_t)a.ntasks;
+#pragma unroll 1
+  for (int j = (int)c; j < a.NB; j += 2) {
+    unsigned long long* const tr = (a.trace && tid == 0) ? a.trace + CT * j : nullptr;
+    if (j == 0) {
+      stamp(tr);
+      stamp(tr ? tr + 1 : nullptr);
+      chain_diag(a, 0, NONE);  // (tile (0,0) as the assembly kernel left it)
+    } else if (!duo_helper(a, j)) {
+      return;
+    }
+    stamp(tr ? tr + 2 : nullptr);
+    const int64_t off = (int64_t)j * TILE;
+    leaf_core<true, NoLeafHook, true>(S, items, a.Lp, a.ld, off, a.info, (lds_sync_t*)(lds_char*)(dag_lds + CTL_OFF + 32),
+                                      a.Wp + off * a.ld + off, NoLeafHook(), duo_panel_flags(a) + DUO_PF * j);
+    drain_vm();
+    __syncthreads();
+    if (tid == 0) st_flag(a.flags + WD + (uint32_t)j, 1u);
+    stamp(tr ? tr + 3 : nullptr);
+  }
+}
+
 // One launch, B >= 1 matrices (DagArgs::B; the factor-only plan of the hyper-parameter fit: tgp_nlml_trial_batch): the
 // first B workgroups to arrive are the chains of members 0 .. B - 1, everybody else draws from ONE list of
 // (member << 24 | task) entries -- the members' dispatch orders interleaved (dag_merge_order), a topological order of
@@ -666,6 +961,10 @@ __global__ __launch_bounds__(512) void dag_update_kernel(DagArgs a) {
   const uint32_t role = ctl[0];
   __syncthreads();
   const uint32_t nB = a.B > 1 ? (uint32_t)a.B : 1u;
+  if (a.duo && role < 2u) {
+    run_duo(a, role);
+    return;
+  }
   if (role < nB) {
     if (nB == 1) {
       run_chain(a);
@@ -764,7 +1063,7 @@ std::vector<std::pair<int, int>> bursts(int lo, int hi, int burst) {  // long bu
 // Every element is still the same sum in the same order: bit-identical to the unsplit plan.
 void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<uint32_t>& chain_dep, int& n_urgent,
                std::vector<uint32_t>* topo_out, int workers, bool with_inverse, int batch, int batch_workers,
-               std::vector<uint32_t>* batch_out, bool split_critical) {
+               std::vector<uint32_t>* batch_out, bool split_critical, bool duo) {
   // k tiles per product: longer bursts amortise a task's fixed ~8 us (N = 8192 is throughput-bound: 8.0 -> 7.65 ms with
   // 8), shorter ones keep the scheduling fine where the chain is the bound (N = 4096: 1.91 ms with 4, 2.08 with 8)
   static const int burst_env = getenv("TGP_DAG_BURST") ? atoi(getenv("TGP_DAG_BURST")) : 0;  // development aid
@@ -883,10 +1182,13 @@ void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<
       ts.push_back(h);
     }
   // chain steps as nodes of the same graph: A(j) = leaf (sets W_jj), B(j) = L(j+1,j)
+  // (`duo`, the two-workgroup chain: B(j) = the helper's tail after the leaf's last panel, and a third node C(j) = what the helper
+  // needs at least between the arrival of P(j+1,j) and the end of its eight column blocks; only the simulation sees it)
   const int nb = (int)ts.size();
   auto chainA = [&](int j) { return nb + 2 * j; };
   auto chainB = [&](int j) { return nb + 2 * j + 1; };
-  const int total = nb + 2 * NB;
+  auto chainC = [&](int j) { return nb + 2 * NB + j; };
+  const int total = nb + 3 * NB;
   std::vector<std::vector<int>> deps(total);
   auto resolve = [&](int d) { return d <= CH_LSUB ? chainB(CH_LSUB - d) : (d <= CH_WD ? chainA(CH_WD - d) : d); };
   for (int n = 0; n < nb; ++n)
@@ -900,14 +1202,17 @@ void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<
       chain_dep_host[2 * j] = lastG[(size_t)j * NB + j];
     }
     deps[chainB(j)].push_back(chainA(j));
+    if (duo) deps[chainB(j)].push_back(chainC(j));
+    const int bulk_in = duo ? chainC(j) : chainB(j);
     if (j + 1 < NB && lastG[(size_t)(j + 1) * NB + j] >= 0) {
-      deps[chainB(j)].push_back(lastG[(size_t)(j + 1) * NB + j]);
+      deps[bulk_in].push_back(lastG[(size_t)(j + 1) * NB + j]);
       chain_dep_host[2 * j + 1] = lastG[(size_t)(j + 1) * NB + j];
       if (lastG2[(size_t)(j + 1) * NB + j] >= 0) {   // P(j+1,j) finished in two halves: the chain waits for both
-        deps[chainB(j)].push_back(lastG2[(size_t)(j + 1) * NB + j]);
+        deps[bulk_in].push_back(lastG2[(size_t)(j + 1) * NB + j]);
         chain_dep_host[2 * NB + j] = lastG2[(size_t)(j + 1) * NB + j];
       }
     }
+    if (duo && j + 1 < NB && lastG[(size_t)(j + 1) * NB + j + 1] >= 0) deps[chainC(j)].push_back(lastG[(size_t)(j + 1) * NB + j + 1]);
   }
   std::vector<int> indeg(total, 0);
   std::vector<std::vector<int>> users(total);
@@ -927,8 +1232,9 @@ void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<
   std::vector<double> dur(total), tail(total, 0.0);
   for (int n = 0; n < nb; ++n) dur[n] = 8.0 + ((ts[n].t.flags & DAG_HALF) ? 10.0 : 19.0) * ts[n].t.nk;
   for (int j = 0; j < NB; ++j) {
-    dur[chainA(j)] = j == 0 ? 31.0 : 45.0;
-    dur[chainB(j)] = j + 1 < NB ? 15.0 : 0.0;
+    dur[chainA(j)] = duo ? 27.0 : (j == 0 ? 31.0 : 45.0);
+    dur[chainB(j)] = j + 1 < NB ? (duo ? 5.0 : 15.0) : 0.0;
+    dur[chainC(j)] = duo && j + 1 < NB ? 14.0 : 0.0;
   }
   std::vector<int> full;  // any topological order of all nodes
   {
