@@ -371,6 +371,9 @@ __device__ __attribute__((noinline)) void run_task(const void* kernarg, uint32_t
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(mat(t.c_mat), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(mat(t.o_mat), 0, 0x7fffffff, 0x00020000);
     constexpr int NIT = (HALF ? TILE / 2 : TILE) * TILE / 1024;  // 16 (HALF: 8) passes of 512 threads x 2 doubles
+    // (measured in round 6 and rejected: requesting the C tile two chunks before the end of the k loop instead of here -- 48
+    // callee-saved registers spilled at the task's entry and every task 1 - 1.5 us SLOWER, N = 8192 7.3 -> 7.65 ms: the epilogue
+    // is bound by its write-through stores, not by this round trip)
     v2d cin[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -816,74 +819,88 @@ __device__ __forceinline__ bool duo_helper(const DagArgs& a, int j) {
   // column-block buffer's row lr (the swizzle of stage_dma)
   const int arow = sg * 128 + (((2 * lq) ^ (sg >> 1)) & 7) * 16, arow1 = sg * 128 + (((2 * lq + 1) ^ (sg >> 1)) & 7) * 16;
   const int lrow = lr * 128 + (((2 * lq) ^ (lr >> 1)) & 7) * 16, lrow1 = lr * 128 + (((2 * lq + 1) ^ (lr >> 1)) & 7) * 16;
-#pragma unroll
-  for (int kc = 0; kc < QB; ++kc) {
+  // column block kc of L(j,j-1): D[i][c] = L[16 w + c][16 kc + sigma(i)] = sum_k W_d[sigma(i)][sigma(k)] X[16 w + c][16 kc + sigma(k)]
+  // (two chains of two: a dependent float64 MFMA issues only every ~128 cycles) -> LDS (for the fragment products) and global memory
+  auto col_block = [&](int kc) -> v4d {
     const char* const st = lds + duo_poff(kc);
     char* const lp = lds + DUO_LP_OFF + (kc & 1) * DUO_PANEL_B;
+    const v2d a01 = *(const v2d*)(st + arow), a23 = *(const v2d*)(st + arow1);
+    v4d l0 = mfma_f64(a01.x, xt[kc][0], (v4d){0.0, 0.0, 0.0, 0.0});
+    v4d l1 = mfma_f64(a01.y, xt[kc][1], (v4d){0.0, 0.0, 0.0, 0.0});
+    l0 = mfma_f64(a23.x, xt[kc][2], l0);
+    l1 = mfma_f64(a23.y, xt[kc][3], l1);
+    const v4d lt = l0 + l1;
+    const v2d o01 = (v2d){lt[0], lt[1]}, o23 = (v2d){lt[2], lt[3]};
+    *(v2d*)(lp + w * 2048 + lrow) = o01;
+    *(v2d*)(lp + w * 2048 + lrow1) = o23;
+    st16_sc1(Lg + 16 * kc, o01);
+    st16_sc1(Lg + 16 * kc + 2, o23);
+    return lt;
+  };
+  // X[:, kb] -= L[:, kc] L_jj(kb, kc)^T, kb > kc: the k step outside, the independent blocks inside
+  auto trailing = [&](int kc, v4d lt) {
+    const char* const st = lds + duo_poff(kc);
+    const v4d nlt = -lt;
+    v2d b01[QB], b23[QB];
+#pragma unroll
+    for (int kb = 0; kb < QB; ++kb) {
+      if (kb <= kc) continue;
+      b01[kb] = *(const v2d*)(st + arow + (kb - kc) * 2048);
+      b23[kb] = *(const v2d*)(st + arow1 + (kb - kc) * 2048);
+    }
+#pragma unroll
+    for (int kb = 0; kb < QB; ++kb)
+      if (kb > kc) xt[kb] = mfma_f64(b01[kb].x, nlt[0], xt[kb]);
+#pragma unroll
+    for (int kb = 0; kb < QB; ++kb)
+      if (kb > kc) xt[kb] = mfma_f64(b01[kb].y, nlt[1], xt[kb]);
+#pragma unroll
+    for (int kb = 0; kb < QB; ++kb)
+      if (kb > kc) xt[kb] = mfma_f64(b23[kb].x, nlt[2], xt[kb]);
+#pragma unroll
+    for (int kb = 0; kb < QB; ++kb)
+      if (kb > kc) xt[kb] = mfma_f64(b23[kb].y, nlt[3], xt[kb]);
+  };
+  // -S(j,j) += L[:, kc] L[:, kc]^T on this wave's fragments
+  auto fragments = [&](int kc) {
+    const char* const lp = lds + DUO_LP_OFF + (kc & 1) * DUO_PANEL_B;
+    const v2d lo01 = *(const v2d*)(lp + lrow + p * 2048), lo23 = *(const v2d*)(lp + lrow1 + p * 2048);
+    const v2d hi01 = *(const v2d*)(lp + lrow + (7 - p) * 2048), hi23 = *(const v2d*)(lp + lrow1 + (7 - p) * 2048);
+    v2d b01[NF], b23[NF];
+#pragma unroll
+    for (int m = 0; m < NF; ++m) {
+      b01[m] = *(const v2d*)(lp + lrow + fbj[m] * 2048);
+      b23[m] = *(const v2d*)(lp + lrow1 + fbj[m] * 2048);
+    }
+#pragma unroll
+    for (int m = 0; m < NF; ++m)
+      if (live[m]) sacc[m] = mfma_f64((2 * m + h) <= p ? lo01.x : hi01.x, b01[m].x, sacc[m]);
+#pragma unroll
+    for (int m = 0; m < NF; ++m)
+      if (live[m]) sacc[m] = mfma_f64((2 * m + h) <= p ? lo01.y : hi01.y, b01[m].y, sacc[m]);
+#pragma unroll
+    for (int m = 0; m < NF; ++m)
+      if (live[m]) sacc[m] = mfma_f64((2 * m + h) <= p ? lo23.x : hi23.x, b23[m].x, sacc[m]);
+#pragma unroll
+    for (int m = 0; m < NF; ++m)
+      if (live[m]) sacc[m] = mfma_f64((2 * m + h) <= p ? lo23.y : hi23.y, b23[m].y, sacc[m]);
+  };
+  // Software pipeline: column block kc + 1 (a dependent chain: operand read, two MFMA levels, an add, the LDS write) is formed
+  // BEFORE the fragment products of block kc, which fill the matrix pipe meanwhile.  One barrier per block while the panels are
+  // ahead: the two column-block buffers alternate, and a buffer's next writer has passed the barrier of the block in between.
+  v4d lt = col_block(0);
+  trailing(0, lt);
+  drain_vm();  // (all of X has been used; the fragments of the diagonal tile are next; the panels' DMA has landed)
+#pragma unroll
+  for (int kc = 0; kc < QB; ++kc) {
     stamp(tr ? tr + 8 + kc : nullptr);
-    // column block kc of L(j,j-1): D[i][c] = L[16 w + c][16 kc + sigma(i)] = sum_k W_d[sigma(i)][sigma(k)] X[16 w + c][16 kc + sigma(k)]
-    // (two chains of two: a dependent float64 MFMA issues only every ~128 cycles)
-    v4d lt;
-    {
-      const v2d a01 = *(const v2d*)(st + arow), a23 = *(const v2d*)(st + arow1);
-      v4d l0 = mfma_f64(a01.x, xt[kc][0], (v4d){0.0, 0.0, 0.0, 0.0});
-      v4d l1 = mfma_f64(a01.y, xt[kc][1], (v4d){0.0, 0.0, 0.0, 0.0});
-      l0 = mfma_f64(a23.x, xt[kc][2], l0);
-      l1 = mfma_f64(a23.y, xt[kc][3], l1);
-      lt = l0 + l1;
-    }
-    {
-      const v2d o01 = (v2d){lt[0], lt[1]}, o23 = (v2d){lt[2], lt[3]};
-      *(v2d*)(lp + w * 2048 + lrow) = o01;
-      *(v2d*)(lp + w * 2048 + lrow1) = o23;
-      st16_sc1(Lg + 16 * kc, o01);
-      st16_sc1(Lg + 16 * kc + 2, o23);
-    }
-    if constexpr (true) {  // X[:, kb] -= L[:, kc] L_jj(kb, kc)^T, kb > kc: the k step outside, the independent blocks inside
-      const v4d nlt = -lt;
-      v2d b01[QB], b23[QB];
-#pragma unroll
-      for (int kb = kc + 1; kb < QB; ++kb) {
-        b01[kb] = *(const v2d*)(st + arow + (kb - kc) * 2048);
-        b23[kb] = *(const v2d*)(st + arow1 + (kb - kc) * 2048);
-      }
-#pragma unroll
-      for (int kb = kc + 1; kb < QB; ++kb) xt[kb] = mfma_f64(b01[kb].x, nlt[0], xt[kb]);
-#pragma unroll
-      for (int kb = kc + 1; kb < QB; ++kb) xt[kb] = mfma_f64(b01[kb].y, nlt[1], xt[kb]);
-#pragma unroll
-      for (int kb = kc + 1; kb < QB; ++kb) xt[kb] = mfma_f64(b23[kb].x, nlt[2], xt[kb]);
-#pragma unroll
-      for (int kb = kc + 1; kb < QB; ++kb) xt[kb] = mfma_f64(b23[kb].y, nlt[3], xt[kb]);
-    }
-    if (kc == 0) drain_vm();  // (block 0 has used all of X by now; the fragments of the diagonal tile are next)
-    __syncthreads();  // the column block is in LDS (the ONLY barrier of a block while the panels are ahead: the two column-block
-                      // buffers alternate, and a buffer's next writer has passed the barrier of the block in between)
-    {
-      const v2d lo01 = *(const v2d*)(lp + lrow + p * 2048), lo23 = *(const v2d*)(lp + lrow1 + p * 2048);
-      const v2d hi01 = *(const v2d*)(lp + lrow + (7 - p) * 2048), hi23 = *(const v2d*)(lp + lrow1 + (7 - p) * 2048);
-      v2d b01[NF], b23[NF];
-#pragma unroll
-      for (int m = 0; m < NF; ++m) {
-        b01[m] = *(const v2d*)(lp + lrow + fbj[m] * 2048);
-        b23[m] = *(const v2d*)(lp + lrow1 + fbj[m] * 2048);
-      }
-#pragma unroll
-      for (int m = 0; m < NF; ++m)
-        if (live[m]) sacc[m] = mfma_f64((2 * m + h) <= p ? lo01.x : hi01.x, b01[m].x, sacc[m]);
-#pragma unroll
-      for (int m = 0; m < NF; ++m)
-        if (live[m]) sacc[m] = mfma_f64((2 * m + h) <= p ? lo01.y : hi01.y, b01[m].y, sacc[m]);
-#pragma unroll
-      for (int m = 0; m < NF; ++m)
-        if (live[m]) sacc[m] = mfma_f64((2 * m + h) <= p ? lo23.x : hi23.x, b23[m].x, sacc[m]);
-#pragma unroll
-      for (int m = 0; m < NF; ++m)
-        if (live[m]) sacc[m] = mfma_f64((2 * m + h) <= p ? lo23.y : hi23.y, b23[m].y, sacc[m]);
-    }
+    __syncthreads();  // column block kc is in LDS
+    const bool ahead = kc + 1 < QB && (uint32_t)(kc + 1) < staged;
+    if (ahead) lt = col_block(kc + 1);
+    fragments(kc);
     stamp(tr ? tr + 16 + kc : nullptr);
     if (kc + 1 < QB) {
-      if ((uint32_t)(kc + 1) >= staged) {  // the next panel was not out when this workgroup last looked: wait for it, stage what is out now
+      if (!ahead) {  // the next panel was not out when this workgroup last looked: wait for it, stage what is out now
         if (tid == 0) ctl[4] = wait_inputs(kc + 1, false);
         __syncthreads();
         avail = ctl[4];
@@ -892,12 +909,13 @@ __device__ __forceinline__ bool duo_helper(const DagArgs& a, int j) {
         staged = avail;
         drain_vm();
         __syncthreads();
+        lt = col_block(kc + 1);
       }
-    } else {
-      drain_vm();  // (this wave's stores of L(j,j-1): the last ones went out before the fragment products)
-      __syncthreads();
+      trailing(kc + 1, lt);
     }
   }
+  drain_vm();  // (this wave's stores of L(j,j-1))
+  __syncthreads();
   if (tid == 0) st_flag(a.flags + (uint32_t)(a.ntasks + a.NB) + (uint32_t)(j - 1), 1u);  // L(j,j-1) is out
 #pragma unroll
   for (int m = 0; m < NF; ++m) {
