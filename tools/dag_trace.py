@@ -27,6 +27,33 @@ def duo_summary(N, NB, nt, ch, tk):
     print(f"  the helper has P(j,j-1) {late.mean():.1f} us after leaf(j-1) started (min {late.min():.1f} max {late.max():.1f}); "
           f"its last column block ends {(ch[1:, 23] - ch[:-1, 3]).mean():.1f} us after that leaf ended")
     print("  first steps (step, wait-bulk, gap):", " | ".join(f"{a:.0f} {b:.0f} {c:.0f}" for a, b, c in zip(step[:8], wait_bulk[:8], gap[:8])))
+    # the tasks the helper waits for (plan flags 2 | 4: split + two-workgroup chain; chain_dep is [5 NB] then)
+    import ctypes as C
+    from trieste_amd import _lib
+    lib = _lib.load()
+
+    class Task(C.Structure):
+        _fields_ = [("a_off", C.c_uint32), ("b_off", C.c_uint32), ("c_off", C.c_uint32), ("o_off", C.c_uint32),
+                    ("nk", C.c_uint32), ("flags", C.c_uint32), ("a_mat", C.c_uint8), ("b_mat", C.c_uint8),
+                    ("c_mat", C.c_uint8), ("o_mat", C.c_uint8), ("dep", C.c_uint32 * 3), ("set", C.c_uint32),
+                    ("dep3", C.c_uint32)]
+    n_, nu_ = C.c_int64(), C.c_int64()
+    lib.tgp_dag_plan(NB, NB * 128, None, 0, C.byref(n_), C.byref(nu_), None, None, 6)
+    tarr = (Task * n_.value)()
+    carr = (C.c_uint32 * (3 * NB))()
+    lib.tgp_dag_plan(NB, NB * 128, tarr, n_.value, C.byref(n_), C.byref(nu_), carr, None, 6)
+    tid = {(t.o_off, t.flags & 16): i for i, t in enumerate(tarr) if t.a_mat == 0}   # T tasks by output tile (and half)
+    for j in (6, 7, 14, 15, 24):
+        z = ch[j - 1, 2]   # leaf(j-1) starts
+        line = [f"  step {j}: relative to the start of leaf({j - 1}): helper({j - 1}) block 5 at {ch[j - 1, 13] - z:.1f}, its end {ch[j - 1, 23] - z:.1f};"]
+        ld = NB * 128
+        o_t = j * 128 * ld + (j - 2) * 128
+        for name, t in (("G(j,j-1) lo", carr[2 * j - 1]), ("hi", carr[2 * NB + j - 1]), ("T(j,j-2) lo", tid.get((o_t, 0), 0xFFFFFFFF)),
+                        ("hi", tid.get((o_t, 16), 0xFFFFFFFF)), ("G(j,j)", carr[2 * j])):
+            if t == 0xFFFFFFFF: continue
+            line.append(f"{name}: drawn {tk[t, 0] - z:.1f} started {tk[t, 1] - z:.1f} ended {tk[t, 2] - z:.1f};")
+        line.append(f"helper({j}) has its tiles at {ch[j, 1] - z:.1f}, first block at {ch[j, 8] - z:.1f}, done {ch[j, 23] - z:.1f}; leaf({j - 1}) ends {ch[j - 1, 3] - z:.1f}")
+        print(" ".join(line))
     wait, run = tk[:, 1] - tk[:, 0], tk[:, 2] - tk[:, 1]
     nwg = len(set(tk[:, 3].astype(int)))
     print(f"bulk: {nwg} workgroups ran tasks; busy {run.sum():.0f} us = {run.sum() / (nwg * (end - t0)):.2f} of (workgroups x span); "

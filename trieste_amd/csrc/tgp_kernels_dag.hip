@@ -729,13 +729,14 @@ __device__ __forceinline__ bool duo_helper(const DagArgs& a, int j) {
   // (one after the other these were seven dependent round trips of ~0.7 us at the head of every helper); -> the number of
   // panels that are out, 0 on a timeout or when another workgroup has raised the error word
   auto wait_inputs = [&](int kc, bool bulk) -> uint32_t {
-    const uint32_t d0 = bulk ? a.chain_dep[2 * j - 1] : NONE, d1 = bulk ? a.chain_dep[2 * a.NB + j - 1] : NONE, d2 = bulk ? a.chain_dep[2 * j] : NONE;
+    // (the diagonal tile's own flag, chain_dep[2 j], is NOT waited for here: its last product -- a whole tile task that starts when
+    // L(j,j-2) is out -- ends ~18 us into the other workgroup's leaf, later than P(j,j-1); the tile is only needed at the very end)
+    const uint32_t d0 = bulk ? a.chain_dep[2 * j - 1] : NONE, d1 = bulk ? a.chain_dep[2 * a.NB + j - 1] : NONE;
     unsigned spins = 0;
     for (;;) {
       const uint32_t f0 = d0 == NONE ? 1u : ld_flag(a.flags + d0), f1 = d1 == NONE ? 1u : ld_flag(a.flags + d1);
-      const uint32_t f2 = d2 == NONE ? 1u : ld_flag(a.flags + d2);
       const uint32_t n = panels_out();
-      if (f0 != 0 && f1 != 0 && f2 != 0 && n > (uint32_t)kc) return n;
+      if (f0 != 0 && f1 != 0 && n > (uint32_t)kc) return n;
       __builtin_amdgcn_s_sleep(8);
       if ((++spins & 255u) == 0) {
         if (ld_flag(a.ctrl + 2) != 0) return 0u;
@@ -790,10 +791,12 @@ __device__ __forceinline__ bool duo_helper(const DagArgs& a, int j) {
     const v2d h2 = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(rA, voff + 16, tile_sub, 16));
     xt[kb] = (v4d){l2.x, l2.y, h2.x, h2.y};
   }
-  // the 36 lower fragments of the diagonal tile, handed out as in chain_diag; sacc = -P(j,j) + sum of the column blocks' squares
+  // the 36 lower fragments of the diagonal tile, handed out as in chain_diag; sacc = the sum of the column blocks' squares, and
+  // pin = P(j,j), requested two blocks before the end (S = pin - sacc)
   constexpr int NF = 5;
   const int p = w >> 1, h = (w ^ (w >> 2)) & 1;
   v4d sacc[NF];
+  double pin[NF][4];
   int fbi[NF], fbj[NF];
   bool live[NF];
   const double* const Pd = a.Ap + off * ld + off;
@@ -804,10 +807,8 @@ __device__ __forceinline__ bool duo_helper(const DagArgs& a, int j) {
     fbi[m] = n <= p ? p : 7 - p;
     fbj[m] = n <= p ? n : (live[m] ? n - p - 1 : 0);
     sacc[m] = (v4d){0.0, 0.0, 0.0, 0.0};
-    if (live[m]) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sacc[m][r] = -ld8_sc1(Pd + ((16 * fbi[m] + lq + 4 * r) * ld32 + 16 * fbj[m] + lr));
-    }
+    for (int r = 0; r < 4; ++r) pin[m][r] = 0.0;
   }
   // (everything older than X's first block -- the panels' DMA -- has landed once that block is in registers: loads return in order)
   asm volatile("" : "+v"(xt[0]));
@@ -894,7 +895,17 @@ __device__ __forceinline__ bool duo_helper(const DagArgs& a, int j) {
 #pragma unroll
   for (int kc = 0; kc < QB; ++kc) {
     stamp(tr ? tr + 8 + kc : nullptr);
+    if (kc == QB - 2 && tid == 0) ctl[5] = wait_flag(a, a.chain_dep[2 * j]) ? 1u : 0u;  // the diagonal tile (normally long up)
     __syncthreads();  // column block kc is in LDS
+    if (kc == QB - 2) {
+      if (ctl[5] == 0) return false;
+#pragma unroll
+      for (int m = 0; m < NF; ++m)
+        if (live[m]) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pin[m][r] = ld8_sc1(Pd + ((16 * fbi[m] + lq + 4 * r) * ld32 + 16 * fbj[m] + lr));
+        }
+    }
     const bool ahead = kc + 1 < QB && (uint32_t)(kc + 1) < staged;
     if (ahead) lt = col_block(kc + 1);
     fragments(kc);
@@ -923,7 +934,7 @@ __device__ __forceinline__ bool duo_helper(const DagArgs& a, int j) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = 16 * fbi[m] + lq + 4 * r, col = 16 * fbj[m] + lr;
-      S[row * QS + col] = (col <= row) ? -sacc[m][r] : 0.0;
+      S[row * QS + col] = (col <= row) ? pin[m][r] - sacc[m][r] : 0.0;
     }
   }
   drain_vm();
