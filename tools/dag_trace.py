@@ -43,7 +43,7 @@ def duo_summary(N, NB, nt, ch, tk):
     carr = (C.c_uint32 * (3 * NB))()
     lib.tgp_dag_plan(NB, NB * 128, tarr, n_.value, C.byref(n_), C.byref(nu_), carr, None, 6)
     tid = {(t.o_off, t.flags & 16): i for i, t in enumerate(tarr) if t.a_mat == 0}   # T tasks by output tile (and half)
-    for j in (6, 7, 14, 15, 24):
+    for j in (6, 7, 14, 15, 24, 25):
         z = ch[j - 1, 2]   # leaf(j-1) starts
         line = [f"  step {j}: relative to the start of leaf({j - 1}): helper({j - 1}) block 5 at {ch[j - 1, 13] - z:.1f}, its end {ch[j - 1, 23] - z:.1f};"]
         ld = NB * 128
@@ -52,6 +52,12 @@ def duo_summary(N, NB, nt, ch, tk):
                         ("hi", tid.get((o_t, 16), 0xFFFFFFFF)), ("G(j,j)", carr[2 * j])):
             if t == 0xFFFFFFFF: continue
             line.append(f"{name}: drawn {tk[t, 0] - z:.1f} started {tk[t, 1] - z:.1f} ended {tk[t, 2] - z:.1f};")
+        g = carr[2 * j - 1]
+        if g != 0xFFFFFFFF:
+            for d in list(tarr[g].dep) + [tarr[g].dep3]:
+                if d == 0xFFFFFFFF: continue
+                if d < nt: line.append(f"[dep task {d}: out=({tarr[d].o_off // (ld * 128)},{(tarr[d].o_off % ld) // 128}) nk={tarr[d].nk} drawn {tk[d, 0] - z:.1f} started {tk[d, 1] - z:.1f} ended {tk[d, 2] - z:.1f}]")
+                else: line.append(f"[dep chain flag {d - nt}]")
         line.append(f"helper({j}) has its tiles at {ch[j, 1] - z:.1f}, first block at {ch[j, 8] - z:.1f}, done {ch[j, 23] - z:.1f}; leaf({j - 1}) ends {ch[j - 1, 3] - z:.1f}")
         print(" ".join(line))
     wait, run = tk[:, 1] - tk[:, 0], tk[:, 2] - tk[:, 1]

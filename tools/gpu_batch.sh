@@ -7,8 +7,8 @@ for v in 512 0 512 0; do
   echo "== TGP_VARIANT=$v (512 = one chain, 0 = two-workgroup chain)"
   TGP_VARIANT=$v timeout 100 python tools/bench_update.py 4096 8192 2>&1 | grep -v amdgpu.ids
 done
-for v in 0; do
+for v in 512 0; do
   echo "== trace, TGP_VARIANT=$v"
-  TGP_VARIANT=$v TGP_DAG_TRACE=/tmp/dag_trace.bin timeout 100 python tools/dag_trace.py 4096 2>&1 | grep -v amdgpu.ids | head -40
+  TGP_VARIANT=$v TGP_DAG_TRACE=/tmp/dag_trace.bin timeout 100 python tools/dag_trace.py 4096 2>&1 | grep -v amdgpu.ids | cut -c1-400 | head -40
 done
 } | tee $OUT/r06_dag_duo.txt

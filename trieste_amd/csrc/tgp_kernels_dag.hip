@@ -1070,6 +1070,10 @@ std::vector<std::pair<int, int>> bursts(int lo, int hi, int burst) {  // long bu
     int n;
     if (left <= 2) n = 1;
     else if (left <= burst + 1) n = std::max(1, left - 2);
+    // (round 6: never burst, 1, 1 at the end of a tile with the short bursts of the chain-bound sizes -- the long burst cannot start
+    // before its last column is out, three steps before the tile is due, and 78 + 24 + 14 us of dependent tasks do not fit
+    // three steps of < 50 us: every fourth step of the chain waited 17 us for its tile (tools/dag_exec_sim.py))
+    else if (burst == 4 && left == burst + 2) n = burst - 1;
     else n = burst;
     out.emplace_back(k, k + n);
     k += n;
@@ -1261,9 +1265,11 @@ void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<
   std::vector<double> dur(total), tail(total, 0.0);
   for (int n = 0; n < nb; ++n) dur[n] = 8.0 + ((ts[n].t.flags & DAG_HALF) ? 10.0 : 19.0) * ts[n].t.nk;
   for (int j = 0; j < NB; ++j) {
+    // (duo, measured -- profiles/r06_dag_duo_v8.txt: leaf 27; the helper's loads 7 + eight column blocks 24 once P(j+1,j) is there,
+    // 2 more to hand S over)
     dur[chainA(j)] = duo ? 27.0 : (j == 0 ? 31.0 : 45.0);
-    dur[chainB(j)] = j + 1 < NB ? (duo ? 5.0 : 15.0) : 0.0;
-    dur[chainC(j)] = duo && j + 1 < NB ? 14.0 : 0.0;
+    dur[chainB(j)] = j + 1 < NB ? (duo ? 2.0 : 15.0) : 0.0;
+    dur[chainC(j)] = duo && j + 1 < NB ? 31.0 : 0.0;
   }
   std::vector<int> full;  // any topological order of all nodes
   {
