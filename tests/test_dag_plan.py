@@ -21,6 +21,7 @@ T = 128
 NONE = 0xFFFFFFFF
 NN, BETA, NEG, HALF, HI = 1, 2, 4, 8, 16
 SPLIT = 2   # tgp_dag_plan flags bit 1: the split plan of the single full update (round 6)
+DUO = 4     # bit 2: the order (and worker count) of the launch whose chain is two workgroups (the same tasks and flags)
 
 
 class Task(C.Structure):
@@ -186,7 +187,7 @@ def spd(n, seed):
     return np.exp(-0.5 * d2 / 0.3 ** 2) + 1e-2 * np.eye(n)
 
 
-@pytest.mark.parametrize("split", [0, SPLIT], ids=["whole-tiles", "split"])
+@pytest.mark.parametrize("split", [0, SPLIT, SPLIT | DUO], ids=["whole-tiles", "split", "split-two-workgroup-chain"])
 @pytest.mark.parametrize("nb", [1, 2, 4, 7, 49])  # (49: bursts of 8 k tiles)
 def test_plan_in_list_order_factors_and_inverts(nb, split):
     tasks, chain, ld, nu = plan(nb, flags=split)
@@ -250,7 +251,7 @@ def test_factor_only_plan_builds_the_factor_and_the_diagonal_inverses(nb):
     np.testing.assert_allclose(L @ z, r, atol=1e-9)
 
 
-@pytest.mark.parametrize("split", [0, SPLIT], ids=["whole-tiles", "split"])
+@pytest.mark.parametrize("split", [0, SPLIT, SPLIT | DUO], ids=["whole-tiles", "split", "split-two-workgroup-chain"])
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_plan_in_random_valid_interleavings_gives_the_same_bits(seed, split):
     """Three workers with a window: any ready task among the next few popped ones may run, in any order against the
@@ -285,7 +286,8 @@ def test_plan_in_random_valid_interleavings_gives_the_same_bits(seed, split):
     np.testing.assert_array_equal(mc.m[2], ref.m[2])
 
 
-@pytest.mark.parametrize("nb,split", [(3, 0), (8, 0), (32, 0), (50, 0), (90, 0), (3, SPLIT), (8, SPLIT), (32, SPLIT), (40, SPLIT)])
+@pytest.mark.parametrize("nb,split", [(3, 0), (8, 0), (32, 0), (50, 0), (90, 0), (3, SPLIT), (8, SPLIT), (32, SPLIT), (40, SPLIT),
+                                      (8, SPLIT | DUO), (32, SPLIT | DUO)])
 def test_flags_order_every_conflicting_pair_and_point_backwards(nb, split):   # (50, 90: bursts of 8 and 16 k tiles)
     tasks, chain, ld, nu = plan(nb, ld=max(nb * T, 4096) if nb == 32 else None, flags=split)
     nt = len(tasks)
