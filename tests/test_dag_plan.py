@@ -21,6 +21,7 @@ T = 128
 NONE = 0xFFFFFFFF
 NN, BETA, NEG, HALF, HI = 1, 2, 4, 8, 16
 SPLIT = 2   # tgp_dag_plan flags bit 1: the split plan of the single full update (round 6)
+SIB = 32    # DagTask flag: dep3 is the lower-half sibling (the two-workgroup chain's plan splits every T and every last product)
 DUO = 4     # bit 2: the order (and worker count) of the launch whose chain is two workgroups (the same tasks and flags)
 
 
@@ -31,8 +32,12 @@ class Task(C.Structure):
                 ("dep3", C.c_uint32)]
 
     @property
-    def deps(self):   # all four dependency slots
-        return list(self.dep) + [self.dep3]
+    def deps(self):   # the flags the task waits for before it STARTS: four slots, three for an upper half with a sibling (SIB)
+        return list(self.dep) + ([] if self.flags & SIB else [self.dep3])
+
+    @property
+    def sibling(self):   # SIB: the lower half whose flag this task waits for at its END, before its own flag goes up
+        return self.dep3 if self.flags & SIB else NONE
 
     @property
     def rows(self):   # the rows of the output tile (and of the A operand) the task computes
@@ -106,6 +111,7 @@ class Machine:
         self.pos = 0
         self.chain_pos = 0  # 2 j (diagonal step of j) or 2 j + 1
         self.lsub = None
+        self.parked = {}    # lower half -> an upper half that has finished and waits for it (SIB)
 
     def blk(self, mat, i, j):
         return self.m[mat][i * T:(i + 1) * T, j * T:(j + 1) * T]
@@ -127,7 +133,12 @@ class Machine:
         oi, oj = tile_of(t.o_off, ld)
         self.m[t.o_mat][oi * T:(oi + 1) * T, oj * T:(oj + 1) * T][rows] = cin + (-acc if t.flags & NEG else acc)
         assert t.set == idx
+        if t.sibling != NONE and not self.flags[t.sibling]:
+            self.parked[t.sibling] = idx      # the kernel's worker polls the sibling's flag here; its own flag stays down
+            return
         self.flags[idx] = True
+        if idx in self.parked:
+            self.flags[self.parked.pop(idx)] = True
 
     def chain_ready(self):
         if self.chain_pos >= 2 * self.nb:
@@ -193,7 +204,15 @@ def test_plan_in_list_order_factors_and_inverts(nb, split):
     tasks, chain, ld, nu = plan(nb, flags=split)
     if split and nb >= 3:   # T(i, i-2) and the last burst of tile (i, i-1), i = 2 .. nb - 1, as two half-tile tasks each
         halves = [t for t in tasks if t.flags & HALF]
-        assert len(halves) == 4 * (nb - 2) and sum(1 for t in halves if t.flags & HI) == 2 * (nb - 2)
+        if split & DUO:     # ... the two-workgroup chain's plan: EVERY T(i,j) and the last burst of EVERY tile below the diagonal,
+            #                 every upper half publishing for both (SIB: its dep3 is the lower half, an earlier task)
+            assert len(halves) == 2 * (nb - 1) * (nb - 2) and sum(1 for t in halves if t.flags & HI) == (nb - 1) * (nb - 2)
+            assert all(bool(t.flags & SIB) == bool(t.flags & HI) for t in halves)
+            assert all(tasks[t.dep3].flags & HALF and not tasks[t.dep3].flags & HI and tasks[t.dep3].o_off == t.o_off
+                       for t in halves if t.flags & SIB)
+        else:
+            assert len(halves) == 4 * (nb - 2) and sum(1 for t in halves if t.flags & HI) == 2 * (nb - 2)
+            assert not any(t.flags & SIB for t in tasks)
         assert all(t.nk == 1 for t in halves)
         assert sum(1 for j in range(nb) if chain[2 * nb + j] != NONE) == nb - 2
     else:
@@ -297,7 +316,8 @@ def test_flags_order_every_conflicting_pair_and_point_backwards(nb, split):   # 
     preds = [[] for _ in range(nt + 2 * nb)]
     for i, t in enumerate(tasks):
         assert t.set == i
-        for d in t.deps:
+        # (an upper half's flag goes up after its sibling's: whoever waits for it is ordered behind both halves)
+        for d in t.deps + ([t.sibling] if t.sibling != NONE else []):
             if d == NONE:
                 continue
             assert d < nt + 2 * nb
@@ -317,7 +337,7 @@ def test_flags_order_every_conflicting_pair_and_point_backwards(nb, split):   # 
     assert sorted(order) == list(range(nt))
     where = {t: i for i, t in enumerate(order)}
     for i, t in enumerate(tasks):
-        for d in t.deps:
+        for d in t.deps + [t.sibling]:   # (the sibling too: the upper half polls its flag, so somebody must have drawn it)
             if d != NONE and d < nt:
                 assert where[d] < where[i], f"task {i} waits for task {d}, which is dispatched AFTER it: deadlock"
     # the dependency graph is acyclic: Kahn's algorithm places every node

@@ -111,10 +111,11 @@ def run(NB, flags, workers, verbose=True):
         for item in list(waiting):
             i, w, td = item
             t = tasks[i]
-            deps = [d for d in list(t.dep) + [t.dep3] if d != NONE]
-            if all(np.isfinite(t_set[d]) for d in deps):
+            sib = bool(t.flags & 32)   # DAG_SIB: dep3 is the lower-half sibling, waited for at the END
+            deps = [d for d in list(t.dep) + ([] if sib else [t.dep3]) if d != NONE]
+            if all(np.isfinite(t_set[d]) for d in deps) and (not sib or np.isfinite(t_set[t.dep3])):
                 st = max([td] + [seen(d) for d in deps])
-                started[i] = st; ended[i] = st + dur(t); t_set[t.set] = ended[i]
+                started[i] = st; ended[i] = st + dur(t); t_set[t.set] = max(ended[i], seen(t.dep3)) if sib else ended[i]
                 heapq.heappush(free, (ended[i], w))
                 waiting.remove(item)
                 progressed = True

@@ -190,6 +190,9 @@ void launch_traj_grad(hipStream_t s, const TrajDev& t, const double* Xq, int64_t
 constexpr int DAG_MAT_A = 0, DAG_MAT_L = 1, DAG_MAT_W = 2;   // which matrix a tile offset refers to
 constexpr uint32_t DAG_NN = 1, DAG_BETA = 2, DAG_NEG = 4;     // B operand natural (else transposed); add Cin; negate
 constexpr uint32_t DAG_HALF = 8, DAG_HI = 16;                 // round 6: the task computes 64 of the tile's 128 rows (DAG_HI: rows 64 ..)
+constexpr uint32_t DAG_SIB = 32;   // (an upper half) dep3 is NOT a start dependency: it is the flag of the task's lower-half sibling, which the
+                                   // task waits for AT ITS END, before its own flag goes up -- that flag then says "both halves are done"
+                                   // and whoever needs the whole tile waits for this one flag (the sibling is earlier in the list)
 constexpr int DAG_CTRL_WORDS = 64;
 constexpr int DAG_DUO_PF = 32;   // the two-workgroup chain: panel flag words per block row ([8 panels][panel wave 0, panel wave 1, W_d's wave, -])
 struct DagTask {  // one 128 x 128 tile task: out = beta Cin + alpha sum_{kt < nk} A_kt B_kt(^T); 48 bytes

@@ -237,7 +237,7 @@ __device__ __forceinline__ DagArgs dag_uniform_copy(const DagArgs& m) {
 
 // ---- generic tile task ----------------------------------------------------------------------------------------------
 struct TaskU {  // a task descriptor with every field in scalar registers
-  uint32_t a_off, b_off, c_off, o_off, nk, flags, a_mat, b_mat, c_mat, o_mat, set;
+  uint32_t a_off, b_off, c_off, o_off, nk, flags, a_mat, b_mat, c_mat, o_mat, set, sib;
 };
 // HALF (round 6, the split plan's T(i,i-2) and last burst of (i,i-1)): the task computes 64 of the tile's 128 rows -- rows 64 hi ..
 // -- on 32 x 32 wave tiles (2 x 2 fragments instead of 4 x 2): half the A operand, half the MFMAs per wave, the same sum in the
@@ -258,6 +258,7 @@ __device__ __attribute__((noinline)) void run_task(const void* kernarg, uint32_t
   t.nk = uni(tp->nk); t.flags = uni(tp->flags);
   t.a_mat = uni(tp->a_mat); t.b_mat = uni(tp->b_mat); t.c_mat = uni(tp->c_mat); t.o_mat = uni(tp->o_mat);
   t.set = uni(tp->set);
+  t.sib = uni(tp->dep3);
   double* const Ap = uniptr(a.Ap);
   double* const Lp = uniptr(a.Lp);
   double* const Wp = uniptr(a.Wp);
@@ -397,7 +398,11 @@ __device__ __attribute__((noinline)) void run_task(const void* kernarg, uint32_t
   }
   drain_vm();  // every storing wave drains its write-through stores, THEN the barrier, THEN one lane publishes
   __syncthreads();
-  if (tid == 0) st_flag(uniptr(a.flags) + t.set, 1u);
+  if (tid == 0) {
+    // DAG_SIB: this flag also vouches for the lower half, a task earlier in the list (running, or done long ago)
+    if (HALF && (t.flags & DAG_SIB)) wait_flag_at(uniptr(a.flags), uniptr(a.ctrl), t.sib);
+    st_flag(uniptr(a.flags) + t.set, 1u);
+  }
 }
 
 // ---- the chain workgroup ------------------------------------------------------------------------------------------
@@ -1019,7 +1024,7 @@ __global__ __launch_bounds__(512) void dag_update_kernel(DagArgs a) {
         const uint32_t* const mflags = wa.flags + (size_t)mb * wa.flags_stride;
         bool ok = true;
         for (int d = 0; d < 3; ++d) ok = ok && wait_flag_at(mflags, wa.ctrl, wa.tasks[got].dep[d]);
-        ok = ok && wait_flag_at(mflags, wa.ctrl, wa.tasks[got].dep3);
+        if (!(wa.tasks[got].flags & DAG_SIB)) ok = ok && wait_flag_at(mflags, wa.ctrl, wa.tasks[got].dep3);
         if (!ok) got = TASK_ERR;
       }
       ctl[0] = got;
@@ -1039,7 +1044,7 @@ __global__ __launch_bounds__(512) void dag_update_kernel(DagArgs a) {
       }
     }
     if (wa.trace && tid == 0) {  // development aid: a task must never start before its producers' flags are up
-      for (int d = 0; d < 4; ++d) {
+      for (int d = 0; d < ((wa.tasks[idx].flags & DAG_SIB) ? 3 : 4); ++d) {
         const uint32_t dep = d < 3 ? wa.tasks[idx].dep[d] : wa.tasks[idx].dep3;
         if (dep != NONE && ld_flag(wa.flags + dep) == 0) {
           st_flag(wa.ctrl + C_ERR, 2u);
@@ -1058,6 +1063,7 @@ __global__ __launch_bounds__(512) void dag_update_kernel(DagArgs a) {
 struct HostTask {
   DagTask t{};
   std::vector<int> deps;   // producers (host task indices; chain steps are negative codes resolved below)
+  int sib = -1;            // DAG_SIB: the lower-half sibling (host index)
   double ready = 0, need = 0;
   bool urgent = false;     // the last burst of a tile, T, E: the per-row chains
 };
@@ -1109,6 +1115,11 @@ void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<
   std::vector<int> lastG((size_t)NB * NB, -1), Tid((size_t)NB * NB, -1), Eid((size_t)NB * NB, -1);
   std::vector<int> lastG2((size_t)NB * NB, -1), Tid2((size_t)NB * NB, -1);   // the second (upper) half where a task is split
   auto off = [&](int i, int j) { return (uint32_t)((int64_t)i * TILE * ld + (int64_t)j * TILE); };
+  // `duo` plans split EVERY T(i,j) and the last product of EVERY tile below the diagonal (not only the pair next to the chain): per
+  // column every row i runs T(i,k) -> last product of (i,k+1) -> T(i,k+1) ..., two dependent tasks that as whole tiles take 22 + 24 us
+  // + flags -- no chain step shorter than that can be kept up with (tools/dag_exec_sim.py); as halves they take 31.  The upper half
+  // waits for its sibling before it publishes (DAG_SIB), so that a whole-tile consumer still needs ONE flag per operand.
+  const bool split_all = split_critical && duo;
   // producer(s) of tile L(i,k), i > k, onto a dependency list.  half < 0: the whole tile (both halves of a split T);
   // half 0 / 1: only rows 0 .. 63 / 64 .. 127 (a half task reading its own rows of the A operand)
   auto add_Lprod = [&](std::vector<int>& deps, int i, int k, int half) {
@@ -1119,7 +1130,7 @@ void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<
     const int lo = Tid[(size_t)i * NB + k], hi = Tid2[(size_t)i * NB + k];
     if (hi < 0) deps.push_back(lo);
     else if (half < 0) {
-      deps.push_back(lo);
+      if (!split_all) deps.push_back(lo);   // (split_all: the upper half's flag stands for both, DAG_SIB)
       deps.push_back(hi);
     } else deps.push_back(half == 0 ? lo : hi);
   };
@@ -1139,7 +1150,7 @@ void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<
         h.urgent = k1 == hi;
         // the last burst of tile (j+1, j): what the chain's next product waits for -- two half-tile tasks in the split plan
         // (a single product: bursts() ends every tile on one)
-        const bool split = split_critical && i == j + 1 && k1 == hi && k1 - k0 == 1;
+        const bool split = split_critical && k1 == hi && k1 - k0 == 1 && (i == j + 1 || (split_all && i > j));
         int id_lo = -1, id_hi = -1;
         for (int half = 0; half < (split ? 2 : 1); ++half) {
           HostTask g = h;
@@ -1147,6 +1158,10 @@ void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<
           add_Lprod(g.deps, i, k1 - 1, split ? half : -1);
           if (i != j) add_Lprod(g.deps, j, k1 - 1, -1);
           if (prev >= 0) g.deps.push_back(prev);   // (the burst before: a whole-tile task -- only a tile's LAST burst is split)
+          if (split_all && half == 1) {
+            g.t.flags |= DAG_SIB;
+            g.sib = id_lo;
+          }
           (half == 0 ? id_lo : id_hi) = (int)ts.size();
           ts.push_back(g);
         }
@@ -1163,20 +1178,28 @@ void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<
         h.t.nk = 1;
         h.t.flags = 0;
         h.deps.push_back(CH_WD - j);
-        if (prev >= 0) h.deps.push_back(prev);
         h.ready = j;
         h.need = j + 1;
         h.urgent = true;
-        const bool split = split_critical && i == j + 2;   // T(i, i-2): the first of the two dependent products
+        const bool split = split_critical && (i == j + 2 || split_all);   // T(i, i-2): the first of the two dependent products
         Tid[(size_t)i * NB + j] = (int)ts.size();
         if (split) {
           HostTask lo = h, up = h;
           lo.t.flags |= DAG_HALF;
           up.t.flags |= DAG_HALF | DAG_HI;
+          if (prev >= 0) lo.deps.push_back(prev);
+          if (prev >= 0) up.deps.push_back(prev2 >= 0 ? prev2 : prev);   // (a half of a split last product: its own rows)
+          if (prev2 >= 0 && !split_all) up.deps.push_back(prev);
+          if (split_all) {
+            up.t.flags |= DAG_SIB;
+            up.sib = (int)ts.size();
+          }
           ts.push_back(lo);
           Tid2[(size_t)i * NB + j] = (int)ts.size();
           ts.push_back(up);
         } else {
+          if (prev >= 0) h.deps.push_back(prev);
+          if (prev2 >= 0) h.deps.push_back(prev2);
           ts.push_back(h);
         }
       }
@@ -1254,6 +1277,14 @@ void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<
       ++indeg[n];
       users[d].push_back(n);
     }
+  // DAG_SIB: an upper half is listed behind its sibling (it waits for the sibling's flag at its END: the sibling must have been
+  // drawn by then) -- in the simulation it may start as soon as the sibling has STARTED
+  std::vector<int> sib_user(total, -1);
+  for (int n = 0; n < nb; ++n)
+    if (ts[n].sib >= 0) {
+      sib_user[ts[n].sib] = n;
+      ++indeg[n];
+    }
   // Dispatch order = the start order of a LIST-SCHEDULING SIMULATION of the launch (highest level first): `workers`
   // workgroups draw, whenever one is free, the ready task with the longest remaining path to the end of the
   // factorisation; the chain steps run on their own workgroup.  Durations are the measured ones (tools/dag_trace.py,
@@ -1282,6 +1313,7 @@ void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<
       full.push_back(n);
       for (int u : users[n])
         if (--deg[u] == 0) stack.push_back(u);
+      if (sib_user[n] >= 0 && --deg[sib_user[n]] == 0) stack.push_back(sib_user[n]);
     }
   }
   for (auto it = full.rbegin(); it != full.rend(); ++it) {
@@ -1335,6 +1367,11 @@ void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<
         for (int u : users[n]) {
           const int uid = u * Bm + m;
           ready_at[uid] = std::max(ready_at[uid], f);
+          if (--pend[uid] == 0) known(uid);
+        }
+        if (sib_user[n] >= 0) {  // (the sibling: from this task's START)
+          const int uid = sib_user[n] * Bm + m;
+          ready_at[uid] = std::max(ready_at[uid], f - dur[n]);
           if (--pend[uid] == 0) known(uid);
         }
       }
@@ -1420,8 +1457,9 @@ void dag_build(int NB, int64_t ld, std::vector<DagTask>& out_tasks, std::vector<
     const HostTask& h = ts[order[p]];
     DagTask t = h.t;
     t.dep[0] = t.dep[1] = t.dep[2] = t.dep3 = NONE;
-    if (h.deps.size() > 4) abort();   // (the plan never needs more: see split_critical above)
+    if (h.deps.size() > (h.sib >= 0 ? 3u : 4u)) abort();   // (the plan never needs more: see split_critical above)
     for (size_t d = 0; d < h.deps.size(); ++d) (d < 3 ? t.dep[d] : t.dep3) = flag_of(h.deps[d]);
+    if (h.sib >= 0) t.dep3 = (uint32_t)place[h.sib];
     t.set = (uint32_t)p;
     out_tasks[p] = t;
   }
