@@ -760,6 +760,7 @@ __device__ __forceinline__ bool duo_helper(const DagArgs& a, int j) {
   stamp(tr ? tr + 1 : nullptr);
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((double*)a.Ap, 0, 0x7fffffff, 0x00020000);
   const int tile_sub = (int)((off * ld + offp) * 8);  // byte offset of tile (j,j-1)
+  const int tile_dd = (int)((off * ld + off) * 8);    // ... of tile (j,j)
   // Staging of the panels [k0, k1) of leaf(j-1) by LDS-DMA (no registers; the issuing wave drains before the barrier that hands
   // them round): panel kc = [128 - 16 kc rows][16 doubles], rows 0 .. 15 W_d(kc) from W's diagonal tile, then L_jj's rows below;
   // a wave's 64 lanes x 16 bytes are eight rows
@@ -908,7 +909,10 @@ __device__ __forceinline__ bool duo_helper(const DagArgs& a, int j) {
       for (int m = 0; m < NF; ++m)
         if (live[m]) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) pin[m][r] = ld8_sc1(Pd + ((16 * fbi[m] + lq + 4 * r) * ld32 + 16 * fbj[m] + lr));
+          for (int r = 0; r < 4; ++r) {   // (buffer loads: 32-bit offsets instead of a 64-bit address per load)
+            const int voff = ((16 * fbi[m] + lq + 4 * r) * ld32 + 16 * fbj[m] + lr) * 8;
+            pin[m][r] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rA, voff, tile_dd, 16));
+          }
         }
     }
     const bool ahead = kc + 1 < QB && (uint32_t)(kc + 1) < staged;
