@@ -465,8 +465,11 @@ int tgp_get_auto_strata(tgp_handle h, int64_t* checked2, int64_t* violations2, d
  * flagged candidate through the row-group-split sweep instead of the product path it takes for lists of up to 512, bit 7 =
  * the int8 sweep's workgroups take candidate blocks i, i + #WG, ... instead of drawing them from a counter, bit 8 = the
  * persistent `update` kernel's plan with whole tiles only (default since round 6 at 3 <= Npad / 128 < 48: its two critical
- * single products as half-tile tasks, see tgp_dag_plan).  Bits 0-3, 7, 8: every setting computes the same arithmetic on
- * every candidate / matrix entry, bit for bit; bits 4 - 6: the same values up to the rounding of another summation order. */
+ * single products as half-tile tasks, see tgp_dag_plan), bit 9 = the persistent `update` kernel's chain as ONE workgroup
+ * (rounds 3 - 5; default since round 6 at 3 <= Npad / 128 < 48: TWO workgroups swapping the roles of leaf and helper, which
+ * forms L(j+1,j) as a blocked triangular solve instead of a product with the inverted diagonal block).  Bits 0-3, 7, 8: every
+ * setting computes the same arithmetic on every candidate / matrix entry, bit for bit; bits 4 - 6, 9: the same values up to the
+ * rounding of another summation order. */
 int tgp_set_variant(tgp_handle h, int variant);
 /* `update` on SEVERAL handles at once (the prior draws of a hyper-parameter fit: reference models.py:294-321 evaluates
  * them one after the other): the persistent update kernel of a handle takes 1 / n of the compute units (n = 1 ... 16, default
@@ -483,7 +486,10 @@ int tgp_set_update_concurrency(tgp_handle h, int n);
  * same tile with a write among them is ordered by the flags.  Matrices: 0 = K + s I (tiles carry the partial sums),
  * 1 = L, 2 = W.  flags: bit 0 = B operand natural (else transposed), bit 1 = add the tile already at c_off, bit 2 =
  * negate the product, bit 3 = the task computes HALF of the tile's rows (bit 4: rows 64 .. 127, else 0 .. 63; the split plan
- * of `flags` bit 1 below).  dep[], dep3: flag ids to wait for (0xffffffff = none); set: the task's own flag (= its position).
+ * of `flags` bit 1 below), bit 5 (upper halves of the plan of `flags` bit 2) = dep3 is NOT waited for before the task starts:
+ * it is the flag of the task's lower-half sibling -- an earlier entry of `order` -- which the task waits for at its END,
+ * before its own flag goes up; that flag then stands for both halves and a consumer of the whole tile waits for it alone.
+ * dep[], dep3: flag ids to wait for (0xffffffff = none); set: the task's own flag (= its position).
  * order[ntasks] (may be NULL): the DISPATCH order -- workers draw positions of it with one atomic and wait for the flags
  * of what they drew; it is a topological order (every flag a task waits for belongs to a chain step or to a task
  * earlier in it), which is what makes that dispatch deadlock-free whatever the residency.  tasks[0 .. *n_urgent) are the
@@ -503,7 +509,10 @@ int tgp_dag_plan(int nb, int64_t ld, tgp_dag_task* tasks, int64_t cap, int64_t* 
                  int flags /* bit 0: the factor only (tgp_nlml_trial's plan); bit 1: the SPLIT plan of the single update at the
                               chain-bound sizes (round 6): T(i, i-2) and the last burst of tile (i, i-1) -- the two dependent
                               single products between a leaf and the chain's next sub-diagonal product -- as two half-tile
-                              tasks each; bits 8-15: B > 0 -> `order` is the dispatch
+                              tasks each; bit 2 (with bit 1): the plan of the launch whose chain is TWO workgroups
+                              (default at those sizes; tgp_set_variant bit 9 = one): EVERY T(i,j) and the last burst of EVERY
+                              tile below the diagonal as two halves (task flag bit 5), the order simulated for one worker
+                              less and for that chain's timing; bits 8-15: B > 0 -> `order` is the dispatch
                               list of a batched launch of B members (tgp_nlml_trial_batch): B * ntasks entries
                               (member << 24 | task), the members' orders interleaved */);
 /* Is `update` at N training points one persistent launch on this handle (size, variant bits)?  *yes = 0 / 1.  The host
