@@ -461,7 +461,7 @@ int tgp_get_auto_strata(tgp_handle h, int64_t* checked2, int64_t* violations2, d
  * small launches, bit 1 = always use it, bit 2 = joint mode on the first-generation kernel (64-column group slots;
  * dp = 32 always uses it), bit 3 = fused plain launches on the register-staged kernel instead of the LDS-DMA one, bit 4 =
  * `update` through the recursion of dependent launches instead of the persistent task-DAG kernel, bit 5 = the persistent
- * kernel from Npad = 256 on (default: from 4096 on, where it is the faster one), bit 6 = TGP_PREC_AUTO recomputes every
+ * kernel from Npad = 256 on (default: from 512 on since round 6, from 4096 on before), bit 6 = TGP_PREC_AUTO recomputes every
  * flagged candidate through the row-group-split sweep instead of the product path it takes for lists of up to 512, bit 7 =
  * the int8 sweep's workgroups take candidate blocks i, i + #WG, ... instead of drawing them from a counter, bit 8 = the
  * persistent `update` kernel's plan with whole tiles only (default since round 6 at 3 <= Npad / 128 < 48: its two critical

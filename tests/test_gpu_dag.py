@@ -1,5 +1,5 @@
-"""`update` as one persistent launch (csrc/tgp_kernels_dag.hip; tgp_set_data for 4096 <= Npad <= 16128, from Npad = 256 on
-with tgp_set_variant bit 5, which these tests set) on the GPU:
+"""`update` as one persistent launch (csrc/tgp_kernels_dag.hip; tgp_set_data for 512 <= Npad <= 16128 -- 4096 before round 6 --, from
+Npad = 256 on with tgp_set_variant bit 5, which these tests set) on the GPU:
 
 * L, W = L^-1 and alpha against numpy's Cholesky of the oracle's K + s I at the sizes where the task list changes
   shape (1 ... 5 block rows with and without padding, a mid size, the headline N = 4096), both noise levels;
@@ -252,7 +252,7 @@ def test_two_workgroup_chain_against_the_one_workgroup_chain(N, noise):
     assert np.array_equal(L3, Ld) and np.array_equal(W3, Wd) and np.array_equal(a3, ad)
 
 
-@pytest.mark.parametrize("N,variant", [(300, 0), (640, DAG_SMALL), (2049, DAG_SMALL), (4096, 0)])
+@pytest.mark.parametrize("N,variant", [(200, 0), (300, 0), (640, DAG_SMALL), (2049, DAG_SMALL), (4096, 0)])
 def test_trial_evaluation_matches_the_likelihood_of_a_full_update(N, variant):
     """tgp_nlml_trial (factor-only launch + block forward substitution where the persistent kernel applies, a full update
     below): the same value as set_data + nlml(value only) and as the oracle, at several hyper-parameter draws on the data
@@ -276,7 +276,7 @@ def test_trial_evaluation_matches_the_likelihood_of_a_full_update(N, variant):
         st = O.gpr_update(kind, var_t, ls_t, noise_t, c_t, X, Y)
         assert abs(got - O.nlml_and_grad(st)[0]) <= 1e-8 * abs(want) + 1e-8 * N
         assert eng.nlml_trial() == got                      # the same bits again
-    if variant == DAG_SMALL or N >= 4096:                  # factor only: nothing to query afterwards
+    if eng.update_is_persistent(N):                        # factor only: nothing to query afterwards (Npad >= 512 since round 6)
         with pytest.raises(RuntimeError):                   # TGP_ERR_STATE
             eng.predict(X[:3])
     eng.set_hyper(1.0, ls, noise, c)
@@ -384,9 +384,9 @@ def test_batched_trial_evaluations_equal_the_single_ones_bit_for_bit():
 
 
 def test_batched_trial_evaluations_below_the_persistent_size():
-    """Below N = 3841 the members run one after the other on the handle itself: tgp_nlml_trial's values, the handle's
-    hyper-parameters and posterior restored."""
-    X, Y, ls, c, kind, noise = _problem(300, d=4)
+    """Below N = 257 (Npad = 256: the recursion of dependent launches; round 5: below 3841) the members run one after the other on the
+    handle itself: tgp_nlml_trial's values, the handle's hyper-parameters and posterior restored."""
+    X, Y, ls, c, kind, noise = _problem(200, d=4)
     eng = _engine(X, Y, ls, c, kind, noise, variant=0)
     before = eng.predict(X[:20] + 0.01)
     rng = np.random.default_rng(3)

@@ -150,7 +150,7 @@ void apply_penalization(tgp_handle h, double* dvals, const double* dXq, int64_t 
 //   VARIANT_JOINT_V1 (4): joint mode on the first-generation kernel (64-column slots, Gram operands from L2)
 //   VARIANT_REG_STAGING (8): fused plain launches on the register-staged kernel instead of the LDS-DMA one
 //   VARIANT_NO_DAG (16): `update` through the recursion of dependent launches instead of the persistent task-DAG kernel
-//   VARIANT_DAG_SMALL (32): the persistent kernel from Npad = 256 on (default: from 4096 on, where it wins)
+//   VARIANT_DAG_SMALL (32): the persistent kernel from Npad = 256 on (default: from 512 on; rounds 3 - 5: 4096)
 //   VARIANT_NO_REPAIR_PRODUCT (64): TGP_PREC_AUTO recomputes every flagged candidate through the SPLIT sweep (rounds 4 / 5)
 //                                   instead of the product path for short lists
 //   VARIANT_STATIC_BLOCKS (128): the int8 sweep's workgroups take candidate blocks i, i + #WG, ... instead of drawing them from a counter
@@ -669,14 +669,20 @@ void chol_inv(tgp_handle h, int64_t lo, int64_t hi) {
                                h->d_info.as<int>()}, lo, hi);
 }
 
-// The whole factorisation + inverse as ONE persistent launch (tgp_kernels_dag.hip) for 4096 <= Npad <= 16128 (below:
-// 0.33 / 0.57 / 1.07 ms against the recursion's 0.24 / 0.45 / 0.98 ms at N = 512 / 1024 / 2048; tgp_set_variant bit 5
-// lowers the bound to 256 -- the tests use it; tile
+// The whole factorisation + inverse as ONE persistent launch (tgp_kernels_dag.hip) for 512 <= Npad <= 16128 (rounds 3 - 5: from
+// 4096 on -- 0.33 / 0.57 / 1.07 ms against the recursion's 0.24 / 0.45 / 0.98 ms at N = 512 / 1024 / 2048 THEN; tgp_set_variant
+// bit 5 lowers the bound to 256 -- the tests use it; tile
 // offsets in bytes fit 31 bits); the recursion above stays for everything else (small blocks, the append path, the
 // q x q / F x F factorisations of the samplers).  TGP_NO_DAG=1 forces the recursion (A/B aid, tests).
 bool dag_applies(tgp_handle h, int64_t Npad) {
   static const bool off = getenv("TGP_NO_DAG") != nullptr;
-  const int64_t min_n = (h->variant & VARIANT_DAG_SMALL) ? 256 : 4096;  // (measured: below 4096 the recursion wins)
+  // Npad >= 512 since round 6 (rounds 3 - 5: 4096).  Measured with the two-workgroup chain (profiles/r06_dag_small_sizes*.txt): `update`
+  // 0.84 against the recursion's 0.99 ms at N = 2048, 1.28 / 2.00 at 3072, 1.62 / 2.42 at 3840, equal at 900 - 1024, 0.28 / 0.24 at
+  // <= 512 -- and, what decides it, the hyper-parameter fit's prior draws go through tgp_nlml_trial_batch wherever this says yes:
+  // find_best_model_initialization(90) 12 -> 4 ms at N = 512, 30 -> 7 at 1024, 55 -> 16 at 2048, 102 -> 34 at 3072; a cold
+  // optimize() 21 -> 12, 35 -> 20, 67 -> 37, 128 -> 65 ms.  TGP_DAG_MIN_N overrides the bound (development aid).
+  static const int64_t min_env = getenv("TGP_DAG_MIN_N") ? atoll(getenv("TGP_DAG_MIN_N")) : 512;
+  const int64_t min_n = (h->variant & VARIANT_DAG_SMALL) ? 256 : min_env;
   return !off && !(h->variant & VARIANT_NO_DAG) && Npad >= min_n && Npad % 128 == 0 && Npad * Npad * 8 < (int64_t)0x7fffffff;
 }
 
