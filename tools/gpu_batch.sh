@@ -1,7 +1,12 @@
 #!/bin/bash
-# GPU batch (round 6, closing): the whole suite, the default bench line, the fit and update evidence with the final library (persistent update kernel from Npad = 512 on)
+# GPU batch (round 6): launch groups of up to 45 members for the batched prior draws below N = 4096 (TGP_TRIAL_BATCH_MAX=16: the old groups of 15)
 set -u; OUT=$PWD/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
-bash tools/gpu_suite.sh r06c 2>&1 | tail -6
-bash tools/gpu_evidence.sh r06c bench 2>&1 | tail -20
-bash tools/gpu_evidence.sh r06c fit 2>&1 | tail -12
-bash tools/gpu_evidence.sh r06c update 2>&1 | tail -4
+timeout 900 python -m pytest tests/test_gpu_dag.py -x -q -m gpu -k "batched or trial" 2>&1 | tail -4 | tee $OUT/r06_trial_groups_tests.txt
+{
+for N in 512 1024 2048 3072 3840; do
+  for m in 16 0 16 0; do
+    echo "== N = $N, TGP_TRIAL_BATCH_MAX=$m (0 = default: 45 below N = 4096)"
+    TGP_TRIAL_BATCH_MAX=$m timeout 300 python tools/fit_small_probe.py $N 2>&1 | grep -v amdgpu.ids | grep "find_best\|optimize" | tail -3
+  done
+done
+} | tee $OUT/r06_trial_groups.txt

@@ -1476,7 +1476,17 @@ int tgp_nlml_trial_batch(tgp_handle h, const double* hypers, int B, double* valu
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
   (void)hipGetLastError();
   const size_t budget = std::min<size_t>((size_t)12 << 30, bs.mats.cap + free_b - free_b / 5);  // (a fifth of what is free stays free)
-  int blimit = (int)std::min<size_t>(16, budget / per);
+  // Members per launch group.  From N = 2048 on a group of 15 is bound by tile-task throughput and a larger one buys nothing but
+  // scratch (measured, profiles/r06_trial_groups.txt: 12.5 ms for 90 draws at N = 2048 either way); up to N = 1024 a member's launch
+  // is its CHAIN (<= 8 steps of ~54 us) and its tile tasks fill a fraction of the workgroups: 90 draws as two launches of 45
+  // instead of six of 15 -- find_best_model_initialization(90) 3.55 -> 2.55 ms at N = 512, 5.6 -> 4.2 ms at N = 1024
+  constexpr int TRIAL_BATCH_MAX = 48;
+  static_assert(sizeof(((tgp_handle_s*)nullptr)->dag_plan) / sizeof(tgp_handle_s::DagPlan) == 2 + TRIAL_BATCH_MAX, "plan slots");
+  static const int bmax_env = getenv("TGP_TRIAL_BATCH_MAX") ? atoi(getenv("TGP_TRIAL_BATCH_MAX")) : 0;   // (development aid)
+  const bool chain_bound = NB <= 8;
+  const int bcap_size = bmax_env > 0 ? std::min(bmax_env, TRIAL_BATCH_MAX) : (chain_bound ? 45 : 16);
+  const size_t budget_size = chain_bound ? std::min<size_t>(budget, (size_t)6 << 30) : budget;
+  int blimit = (int)std::min<size_t>((size_t)bcap_size, budget_size / per);
   blimit = std::min(blimit, std::max(1, h->num_cu / 4));
   if (blimit < 1 || h->num_cu < 2 * blimit + 2) {
     scratch_lock.unlock();

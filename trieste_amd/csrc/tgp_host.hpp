@@ -140,7 +140,7 @@ struct tgp_handle_s {
     bool duo = false;                           // ... launched with the two-workgroup chain (dag_duo)
     int64_t ld = 0;
     const void *tasks = nullptr, *chain = nullptr, *topo = nullptr;
-  } dag_plan[2 + 16];  // 0 full, 1 factor-only, 2 + (B - 1): batched factor-only with B = 1 .. 16 members
+  } dag_plan[2 + 48];  // 0 full, 1 factor-only, 2 + (B - 1): batched factor-only with B = 1 .. TRIAL_BATCH_MAX members
   int dag_last_slot = 0;  // the slot of the most recent launch (its error words are read back after the stream drains)
   int update_share = 1;  // tgp_set_update_concurrency: the persistent update kernel takes num_cu / update_share workgroups
   DevBuf d_dag_flags, d_dag_trace;

@@ -544,7 +544,7 @@ class GaussianProcessRegression:
         persistent = self._engine.update_is_persistent(x.shape[0])  # (the library's own rule: size, variant bits, TGP_NO_DAG)
         if persistent and self.BATCHED_TRIALS:
             # from here on a factorisation is ONE persistent launch that leaves half of the compute units idle behind its
-            # chain: all draws go through tgp_nlml_trial_batch, up to sixteen members per launch sharing one task list
+            # chain: all draws go through tgp_nlml_trial_batch, fifteen members per launch (45 up to N = 1024) sharing one task list
             # (values equal the one-by-one trial evaluations bit for bit)
             hy = np.array([np.concatenate([[var], ls, [noise, c]]) for ls, var in draws])
             try:
