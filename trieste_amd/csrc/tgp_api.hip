@@ -696,7 +696,8 @@ struct SharedPlan {
 };
 // the split plan (dag_build split_critical): the single full update where its chain is the bound
 static bool dag_split(tgp_handle h, int slot, int NB) {
-  return slot == 0 && NB >= 3 && NB < 48 && !(h->variant & VARIANT_DAG_WHOLE_TILES);
+  static const int max_nb = getenv("TGP_DAG_SPLIT_MAX_NB") ? atoi(getenv("TGP_DAG_SPLIT_MAX_NB")) : 48;   // (development aid)
+  return slot == 0 && NB >= 3 && NB < max_nb && !(h->variant & VARIANT_DAG_WHOLE_TILES);
 }
 // the two-workgroup chain (tgp_kernels_dag.hip run_duo): the single full update, wherever the split plan applies
 static bool dag_duo(tgp_handle h, int slot, int NB) {
