@@ -442,10 +442,13 @@ def main():
         eng.set_hyper(1.0, ls, noise, float(Y.mean()))
         eng.set_data(X, Y)  # warm-up (allocations)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        eng.set_data(X, Y)  # every rank runs the same deterministic update (replicated model state)
-        torch.cuda.synchronize()
-        update_ms = (time.perf_counter() - t0) * 1e3
+        samples = []
+        for _ in range(5):  # every rank runs the same deterministic update (replicated model state); the median of five calls
+            t0 = time.perf_counter()
+            eng.set_data(X, Y)
+            torch.cuda.synchronize()
+            samples.append((time.perf_counter() - t0) * 1e3)
+        update_ms = sorted(samples)[2]
         eta = eng.eta()
         lo = min(rank * per, total_units)
         mine = max(0, min(lo + per, total_units) - lo)

@@ -218,8 +218,7 @@ def test_update_concurrency_shares_the_gpu_and_keeps_the_bits():
         assert np.array_equal(L, Lr) and np.array_equal(W, Wr)
 
 
-@pytest.mark.parametrize("N", [300, 384, 640, 1100, 2049, 4096])
-@pytest.mark.parametrize("noise", [1e-2, 1e-5])
+@pytest.mark.parametrize("N,noise", [(N, s2) for N in (300, 384, 640, 1100, 2049, 4096) for s2 in (1e-2, 1e-5)] + [(5000, 1e-2)])
 def test_two_workgroup_chain_against_the_one_workgroup_chain(N, noise):
     """Round 6: the chain of the persistent kernel as TWO workgroups swapping roles (leaf / helper: csrc/tgp_kernels_dag.hip
     run_duo) -- the default wherever the split plan applies.  L(j+1,j) is a blocked triangular solve against L_jj there and a
@@ -250,6 +249,19 @@ def test_two_workgroup_chain_against_the_one_workgroup_chain(N, noise):
     other = _engine(X, Y, ls, c, kind, noise, variant=DAG_SMALL)
     L3, W3, a3 = other.get_factor()
     assert np.array_equal(L3, Ld) and np.array_equal(W3, Wd) and np.array_equal(a3, ad)
+
+
+def test_default_policy_is_the_persistent_kernel_from_npad_512_on():
+    """Round 6: `update` is the persistent launch from Npad = 512 on (rounds 3 - 5: 4096) -- measured faster than the recursion from
+    N ~ 640 on and, above all, the size rule the batched prior draws of the fit hang on (profiles/r06_dag_small_sizes*.txt).  The
+    default policy gives the bits of the forced persistent kernel (variant bit 5) there, and the recursion's below."""
+    for N, persistent in ((200, False), (256, False), (300, True), (600, True), (1100, True)):
+        X, Y, ls, c, kind, noise = _problem(N, d=4)
+        default = _engine(X, Y, ls, c, kind, noise, variant=0)
+        assert default.update_is_persistent(N) == persistent, N
+        other = _engine(X, Y, ls, c, kind, noise, variant=DAG_SMALL if persistent else NO_DAG)
+        for a, b in zip(default.get_factor(), other.get_factor()):
+            assert np.array_equal(a, b), N
 
 
 @pytest.mark.parametrize("N,variant", [(200, 0), (300, 0), (640, DAG_SMALL), (2049, DAG_SMALL), (4096, 0)])

@@ -1,4 +1,5 @@
 #!/bin/bash
-# GPU batch (round 6): the two-workgroup chain (and its plan) beyond NB = 47 (TGP_DAG_SPLIT_MAX_NB)
+# GPU batch (round 6, closing): the whole suite and the default bench line with the final library
 set -u; OUT=$PWD/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
-for m in 48 127 48 127; do echo "== TGP_DAG_SPLIT_MAX_NB=$m (48 = default)"; TGP_DAG_SPLIT_MAX_NB=$m timeout 300 python tools/bench_update.py 5120 6144 7168 8192 2>&1 | grep -v amdgpu.ids | cut -c1-110; done | tee $OUT/r06_dag_duo_large.txt
+bash tools/gpu_suite.sh r06d 2>&1 | tail -6
+bash tools/gpu_evidence.sh r06d bench 2>&1 | tail -20
