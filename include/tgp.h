@@ -165,20 +165,21 @@ int tgp_nlml(tgp_handle h, double* value, double* grad);
 /* TRIAL evaluation: the value tgp_nlml(h, value, NULL) would return after tgp_set_hyper + tgp_set_data with the data
  * already on the device (tgp_set_data has run once on this handle) at the CURRENT hyper-parameters -- what
  * find_best_model_initialization does for every prior draw (reference models.py:294-321: assign the draw, evaluate
- * training_loss).  From N = 3841 on only the Cholesky factor is built (half the tile products of an update, so that more
+ * training_loss).  From N = 257 on (Npad >= 512: where `update` is the persistent kernel; rounds 3 - 5: from 3841 on) only the
+ * Cholesky factor is built (half the tile products of an update, so that more
  * trial handles run side by side: tgp_set_update_concurrency), err^T K^-1 err comes from a block forward substitution.
  * The handle is left WITHOUT a posterior: queries fail with TGP_ERR_STATE until the next tgp_set_data.  NOT_PD as for
  * tgp_set_data. */
 int tgp_nlml_trial(tgp_handle h, double* value);
 /* B trial evaluations at once: hypers [B][d + 3] (variance, lengthscales [d], noise_variance, mean_const per member),
  * values [B], status [B] (TGP_OK or TGP_ERR_NOT_PD per member; a member that breaks down gets a NaN value and does not
- * disturb the others).  From N = 3841 on up to 16 members share ONE persistent launch: B chain workgroups, one list of
+ * disturb the others).  From N = 257 on (rounds 4 - 5: 3841) up to 15 members -- 45 up to N = 1024 -- share ONE persistent launch: B chain workgroups, one list of
  * tile tasks over all members' factor-only plans (the start order of a list-scheduling simulation of the B graphs on the
  * workers they share) -- a single factorisation leaves half of the compute units idle behind its chain, and HIP runs at
  * most three such launches side by side.  Each value equals tgp_nlml_trial's at
  * the same hyper-parameters bit for bit.  The handle's own hyper-parameters and posterior are untouched (the members
  * live in scratch matrices, 3 N^2 doubles each: a process-wide scratch per device, allocated on first use and kept --
- * tgp_release_scratch frees it; concurrent calls on one device are serialised).  A launch takes at most 16 members, at
+ * tgp_release_scratch frees it; concurrent calls on one device are serialised).  A launch takes at most 16 (N <= 1024: 45) members, at
  * most a quarter of the compute units as chains, at most 12 GiB and at most four fifths of the device's free memory; a
  * failed allocation halves the group.  Below that size -- and when not even one member's matrices fit, or the device has
  * too few compute units for chains and workers -- the members are evaluated one after the other on the handle
