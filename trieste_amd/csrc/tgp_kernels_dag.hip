@@ -677,16 +677,20 @@ __device__ __attribute__((noinline)) void run_chain(const DagArgs& a_mem) {
 // nearly idle.  Here the two products move to a SECOND workgroup that runs them UNDERNEATH the other one's leaf, panel by panel,
 // and the two workgroups swap roles every step, so that the diagonal block never crosses compute units:
 //   workgroup c = j & 1 runs leaf(j); meanwhile workgroup 1 - c is the HELPER of step j + 1: it holds P(j+1,j) in registers
-//   (wave w: rows 16 w .., as eight transposed 16 x 16 accumulator blocks) and -P(j+1,j+1) in 36 accumulator fragments, and for
-//   every panel kc of leaf(j) -- published by the leaf's panel waves through two flag words once their write-through stores of
-//   the L panel and of W_d(kc) = L_d(kc)^-1 have drained --
+//   (wave w: rows 16 w .., as eight transposed 16 x 16 accumulator blocks) and the 36 lower fragments of L(j+1,j) L(j+1,j)^T in
+//   accumulators, and for every panel kc of leaf(j) -- published through three flag words: by the leaf's two panel waves once their
+//   write-through stores of the L panel have drained (a panel late, where the wait is free: tgp_leaf_dev.inc panel_factor), and by
+//   the wave that idles in [C kb] for W_d(kc) = L_d(kc)^-1, which it pushes --
 //       L(j+1,j)[:, kc]   = X[:, kc] W_d(kc)^T                        (4 MFMAs per wave)
 //       X[:, kb]         -= L(j+1,j)[:, kc] L_jj(kb, kc)^T,  kb > kc   (right-looking: 4 (7 - kc) MFMAs)
-//       -S(j+1,j+1)      += L(j+1,j)[:, kc] L(j+1,j)[:, kc]^T          (the 36 lower fragments: 16 - 20 MFMAs)
-//   so that when the leaf's LAST panel is out only 4 + 20 MFMAs per wave stand between it and leaf(j+1), which the helper then
-//   runs itself on the S it has just finished -- while the other workgroup becomes the helper of step j + 2.
-// What crosses compute units per step is the stream of panels (<= 16 KiB each, through the L2 like every other tile) instead of
-// nothing -- and what it buys is that the step shrinks from diag + leaf + sub to the leaf + one panel's tail.
+//       fragments        += L(j+1,j)[:, kc] L(j+1,j)[:, kc]^T          (the 36 lower fragments: 16 - 20 MFMAs)
+//   and at the end S(j+1,j+1) = P(j+1,j+1) - fragments (the diagonal tile is asked for two blocks before the end: its last product
+//   ends later than P(j+1,j)); it then runs leaf(j+1) itself on that S -- while the other workgroup becomes the helper of step j + 2.
+// What crosses compute units per step is the stream of panels (<= 16 KiB each, through the L2 like every other tile, LDS-DMA'd as
+// soon as they are out -- all of them up front when the helper starts behind the leaf, which is the usual case).  Measured
+// (profiles/r06_update_breakdown.txt): the helper has P(j+1,j) 16.7 us into the other workgroup's leaf, needs 6.8 us of loads and 25 us
+// for its eight column blocks (15.4 us of MFMA time), the step is 49.5 us against run_chain's 54 -- and tools/dag_exec_sim.py shows
+// why not less: below ~49 us the first half of the launch is bound by tile-task throughput.
 // L(j+1,j) is formed as a blocked triangular solve against L_jj (inverted 16-blocks) rather than as the product with W_jj: the
 // same matrix to rounding, NOT the same bits as run_chain's (tests/test_gpu_dag.py compares the two to a tolerance); the
 // arithmetic is still fixed by the plan alone: bit-identical run to run, handle to handle, on any share of the GPU.
