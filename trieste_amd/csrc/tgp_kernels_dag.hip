@@ -314,11 +314,30 @@ __device__ __attribute__((noinline)) void run_task(const void* kernarg, uint32_t
   const int c_lane = (lq >> 1) + 4 * (lr & 3);
   const int bn_off = lq * BN_ROW + lr * 8;
 
+#ifndef TGP_DAG_DEFER
+#define TGP_DAG_DEFER 1
+#endif
+  // Cross-barrier deferral (TGP_DAG_DEFER, round 6; the float64 sweep's form): the MFMAs of a chunk's LAST k step are issued
+  // behind the next chunk's barrier -- their operands are in registers, the stage they came from may be overwritten -- so that the
+  // matrix pipe has eight MFMAs per wave to run while the waves leave the barrier, request the next chunk and wait for the first
+  // operand reads of this one.  Every accumulator still sees the same products in the same order: the same bits.
+  double dav[RF], dbv[2];
+#pragma unroll
+  for (int bi = 0; bi < RF; ++bi) dav[bi] = 0.0;
+  dbv[0] = dbv[1] = 0.0;
+  auto deferred = [&]() {
+#pragma unroll
+    for (int bi = 0; bi < RF; ++bi)
+#pragma unroll
+      for (int bj = 0; bj < 2; ++bj) acc[bi][bj] = mfma_f64(dav[bi], dbv[bj], acc[bi][bj]);
+  };
+
   issue(0);
 #pragma unroll 1
   for (int c = 0; c < nchunks; ++c) {
     drain_vm();        // this wave's share of chunk c has landed ...
     __syncthreads();   // ... everyone's has, and everyone is done with the other stage (chunk c - 1)
+    if (TGP_DAG_DEFER && c > 0) deferred();
     // Waves w and w + 4 share a SIMD: the first four request chunk c + 1 now, their partners after half of this chunk's
     // MFMAs -- eight LDS-DMA instructions cost a wave several hundred issue cycles, during which its partner feeds the
     // matrix pipe (TGP_DAG_STAGGER = 0: everybody up front, round 3)
@@ -347,15 +366,23 @@ __device__ __attribute__((noinline)) void run_task(const void* kernarg, uint32_t
     for (int k4 = 0; k4 < KC / 4; ++k4) {
       if (k4 + 1 < KC / 4) fetch(k4 + 1, av[(k4 + 1) & 1], bv[(k4 + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
+      if (TGP_DAG_DEFER && k4 == KC / 4 - 1) {
 #pragma unroll
-      for (int bi = 0; bi < RF; ++bi)
+        for (int bi = 0; bi < RF; ++bi) dav[bi] = av[k4 & 1][bi];
+        dbv[0] = bv[k4 & 1][0];
+        dbv[1] = bv[k4 & 1][1];
+      } else {
 #pragma unroll
-        for (int bj = 0; bj < 2; ++bj) acc[bi][bj] = mfma_f64(av[k4 & 1][bi], bv[k4 & 1][bj], acc[bi][bj]);
+        for (int bi = 0; bi < RF; ++bi)
+#pragma unroll
+          for (int bj = 0; bj < 2; ++bj) acc[bi][bj] = mfma_f64(av[k4 & 1][bi], bv[k4 & 1][bj], acc[bi][bj]);
+      }
       __builtin_amdgcn_sched_barrier(0);
       if (k4 == TGP_DAG_LATE_K4 && !issue_early && c + 1 < nchunks) issue(c + 1);
     }
     if (TGP_DAG_SETPRIO) __builtin_amdgcn_s_setprio(0);
   }
+  if (TGP_DAG_DEFER) deferred();
   __syncthreads();  // the stages are dead: the tile goes through LDS once, so that global traffic is 16 B per lane
   double* const T = (double*)lds;
 #pragma unroll
