@@ -341,6 +341,66 @@ def test_continuous_optimizer_refines_the_sweep_winner():
         generate_continuous_optimizer(optimizer_args={"method": "BFGS"})(box, fn)
 
 
+def test_lockstep_lbfgsb_gives_what_scipy_minimize_gives_start_by_start():
+    """Round 6: the multi-start L-BFGS-B of the continuous optimizer is ONE driver loop around scipy's own core routine
+    (scipy.optimize._lbfgsb.setulb) instead of a scipy.optimize.minimize call and a greenlet per start (reference
+    optimizer.py:563-698 is the greenlet form).  Same iterates: successes, values, points and evaluation counts equal the
+    greenlet form's EXACTLY -- on a multimodal function with active bounds, batch-size-one and vectorized, with options --
+    and what the driver does not understand falls back to it."""
+    import trieste_amd.acquisition.optimizer as opt_mod
+
+    class Multimodal:
+        def __init__(self, shift):
+            self.shift = shift
+            self.calls = 0
+
+        def value_and_gradient(self, x):
+            self.calls += 1
+            x = np.asarray(x, dtype=np.float64)
+            w = 1.0 + np.arange(x.shape[-1])
+            c = np.linspace(-0.2, 0.9, x.shape[-1]) + self.shift     # (a maximiser partly OUTSIDE the box: active bounds)
+            v = -np.sum(w * (x - c) ** 2, axis=-1) + 0.1 * np.sin(9.0 * x).sum(-1)
+            g = -2.0 * w * (x - c) + 0.9 * np.cos(9.0 * x)
+            return v, g
+
+    class Vectorized:   # column v of [R, V, D] is function v
+        def __init__(self):
+            self.fs = [Multimodal(0.0), Multimodal(0.15), Multimodal(-0.1)]
+
+        def value_and_gradient(self, x):
+            out = [f.value_and_gradient(x[:, v, :]) for v, f in enumerate(self.fs)]
+            return np.stack([o[0] for o in out], axis=1), np.stack([o[1] for o in out], axis=1)
+
+    box = Box([0.0] * 5, [1.0] * 5)
+    rng = np.random.default_rng(11)
+    cases = [(Multimodal(0.0), rng.uniform(size=(24, 5)), {}),
+             (Multimodal(0.1), rng.uniform(size=(7, 5)), {"options": {"maxiter": 3}}),      # stops at the iteration limit: no success
+             (Multimodal(0.0), rng.uniform(size=(9, 5)), {"options": {"maxcor": 4, "gtol": 1e-8, "ftol": 1e-12, "maxls": 10}}),
+             (Vectorized(), rng.uniform(size=(6, 3, 5)), {})]
+    for fn, starts, args in cases:
+        assert opt_mod._lockstep_options(args) is not None
+        try:
+            opt_mod.LOCKSTEP_LBFGSB = True
+            fast = opt_mod._perform_parallel_continuous_optimization(fn, box, starts, args)
+            opt_mod.LOCKSTEP_LBFGSB = False
+            slow = opt_mod._perform_parallel_continuous_optimization(fn, box, starts, args)
+        finally:
+            opt_mod.LOCKSTEP_LBFGSB = True
+        for a, b, what in zip(fast, slow, ("success", "value", "point", "nfev")):
+            np.testing.assert_array_equal(a, b, err_msg=what)
+        assert fast[0].shape == starts.shape[:-1] and fast[2].shape == starts.shape
+        assert np.all(fast[2] >= 0.0) and np.all(fast[2] <= 1.0)
+    # limits are honoured the way scipy reports them
+    few = opt_mod._perform_parallel_continuous_optimization(Multimodal(0.1), box, rng.uniform(size=(4, 5)), {"options": {"maxiter": 1}})
+    assert not few[0].any()
+    # anything else goes through scipy.optimize.minimize itself
+    assert opt_mod._lockstep_options({"tol": 1e-3}) is None
+    assert opt_mod._lockstep_options({"options": {"disp": True}}) is None
+    assert opt_mod._lockstep_options({"callback": print}) is None
+    got = opt_mod._perform_parallel_continuous_optimization(Multimodal(0.0), box, rng.uniform(size=(3, 5)), {"tol": 1e-6})
+    assert got[0].all()
+
+
 # ---- rules (reference tests/unit/acquisition/test_rule.py) ---------------------------------------
 def test_ego_defaults_and_acquire():
     with pytest.raises(ValueError):

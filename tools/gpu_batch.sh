@@ -1,5 +1,10 @@
 #!/bin/bash
-# GPU batch (round 6, closing): smoke() with the final library
+# GPU batch (round 6): a default acquire with the lock-step L-BFGS-B driver against the scipy.optimize.minimize + greenlet form (TGP_LOCKSTEP=0)
 set -u; OUT=$PWD/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE OK')" > $OUT/r06_smoke.txt 2>&1; echo "rc=$?" >> $OUT/r06_smoke.txt
-grep -v "amdgpu.ids\|Hostname\|Librccl" $OUT/r06_smoke.txt | tail -8
+timeout 900 python -m pytest tests/test_gpu_host.py -x -q -m gpu 2>&1 | tail -3 | tee $OUT/r06_lockstep_tests.txt
+{
+for N in 1024 4096; do for m in 0 1 0 1; do
+  echo "== N = $N, lock-step driver: $m"
+  TGP_LOCKSTEP=$m timeout 300 python tools/prof_acquire.py $N 2>&1 | grep "acquire_single ms"
+done; done
+} | tee $OUT/r06_lockstep_acquire.txt

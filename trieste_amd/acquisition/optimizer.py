@@ -180,6 +180,91 @@ def sample_from_space(num_samples: int, batch_size: Optional[int] = None, seed: 
     return sampler
 
 
+# L-BFGS-B from many starts with ONE driver loop around scipy's own core routine (scipy.optimize._lbfgsb.setulb, the routine
+# scipy.optimize.minimize(method="L-BFGS-B") itself steps): the same iterates, values and evaluation counts as a
+# scipy.optimize.minimize call per start -- tests/test_host_logic.py holds the two against each other -- without the per-start
+# ScalarFunction / OptimizeResult / greenlet machinery, which is most of a default acquire's time (80 starts at d = 8: ~9 of
+# 12 ms at N = 4096, tools/prof_acquire.py).  Used when the optimizer arguments are the ones it understands and the private
+# routine has the signature of the scipy this was written against; the greenlet form below remains the fallback.
+LOCKSTEP_LBFGSB = True
+_LOCKSTEP_OPTIONS = {"maxcor": 10, "ftol": 2.2204460492503131e-09, "gtol": 1e-5, "maxfun": 15000, "maxiter": 15000, "maxls": 20}
+
+
+def _lockstep_options(args: Dict[str, Any]):
+    """The L-BFGS-B options of ``optimizer_args`` if the lock-step driver understands all of them, else None."""
+    if not LOCKSTEP_LBFGSB or set(args) - {"options"}:
+        return None
+    opts = dict(_LOCKSTEP_OPTIONS)
+    given = args.get("options") or {}
+    if set(given) - set(opts):
+        return None
+    opts.update(given)
+    if not opts["maxls"] > 0:
+        return None
+    try:
+        from scipy.optimize import _lbfgsb
+        if not hasattr(_lbfgsb, "setulb") or tuple(int(v) for v in __import__("scipy").__version__.split(".")[:2]) != (1, 15):
+            return None
+    except Exception:
+        return None
+    return opts
+
+
+def _lockstep_lbfgsb(evaluate, flat: np.ndarray, lower: np.ndarray, upper: np.ndarray, opts: Dict[str, Any]):
+    """Minimise from every row of ``flat`` [R, D]; ``evaluate(x [P, D], rows [P]) -> (f [P], g [P, D])`` is called with ALL
+    runs that are waiting for a value.  -> (success [R], f [R], x [R, D], nfev [R]) as scipy.optimize.minimize reports them
+    (scipy/optimize/_lbfgsb_py.py:_minimize_lbfgsb is the loop this restates, one run at a time there)."""
+    from scipy.optimize import _lbfgsb
+
+    R, n = flat.shape
+    m, maxls = int(opts["maxcor"]), int(opts["maxls"])
+    factr, pgtol = opts["ftol"] / np.finfo(float).eps, opts["gtol"]
+    nbd = np.zeros(n, np.int32)
+    low, up = np.zeros(n, np.float64), np.zeros(n, np.float64)
+    for i in range(n):  # (the bound codes of L-BFGS-B: 0 none, 1 lower, 2 both, 3 upper)
+        has_l, has_u = not np.isinf(lower[i]), not np.isinf(upper[i])
+        if has_l:
+            low[i] = lower[i]
+        if has_u:
+            up[i] = upper[i]
+        nbd[i] = (2 if has_u else 1) if has_l else (3 if has_u else 0)
+    x = np.clip(np.array(flat, dtype=np.float64), lower, upper)
+    f = [0.0] * R
+    g = np.zeros((R, n), np.float64)
+    wa = np.zeros((R, 2 * m * n + 5 * n + 11 * m * m + 8 * m), np.float64)
+    iwa = np.zeros((R, 3 * n), np.int32)
+    task, ln_task = np.zeros((R, 2), np.int32), np.zeros((R, 2), np.int32)
+    lsave, isave, dsave = np.zeros((R, 4), np.int32), np.zeros((R, 44), np.int32), np.zeros((R, 29), np.float64)
+    nit, nfev = np.zeros(R, np.int64), np.zeros(R, np.int64)
+    active = list(range(R))
+    while active:
+        need, still = [], []
+        for i in active:
+            while True:
+                _lbfgsb.setulb(m, x[i], low, up, nbd, f[i], g[i], factr, pgtol, wa[i], iwa[i], task[i], lsave[i], isave[i],
+                               dsave[i], maxls, ln_task[i])
+                if task[i, 0] == 3:     # value and gradient at x[i], please
+                    need.append(i)
+                    still.append(i)
+                    break
+                if task[i, 0] != 1:     # converged, stopped or failed
+                    break
+                nit[i] += 1             # a new iterate: the limits (an excess of evaluations is noticed here, as in scipy)
+                if nit[i] >= opts["maxiter"]:
+                    task[i] = (5, 504)
+                elif nfev[i] > opts["maxfun"]:
+                    task[i] = (5, 502)
+        active = still
+        if need:
+            rows = np.array(need)
+            vals, grads = evaluate(x[rows], rows)
+            for j, i in enumerate(need):
+                f[i] = float(vals[j])
+                g[i] = grads[j]
+                nfev[i] += 1
+    return task[:, 0] == 4, np.array(f, dtype=np.float64), x, nfev
+
+
 def _perform_parallel_continuous_optimization(fn, space: Box, starting_points: np.ndarray,
                                               optimizer_args: Dict[str, Any]):
     """L-BFGS-B from every start at once (optimizer.py:563-698): each run lives in a greenlet that
@@ -203,6 +288,22 @@ def _perform_parallel_continuous_optimization(fn, space: Box, starting_points: n
     for forbidden in ("method", "jac", "bounds"):
         if forbidden in args:
             raise ValueError(f"optimizer_args must not set {forbidden!r}")
+    opts = _lockstep_options(args)
+    if opts is not None:
+        scratch = flat.copy()   # (a vectorized function is evaluated on the full tensor, finished slots idle)
+
+        def evaluate(xs, rows):
+            if vectorized:
+                scratch[rows] = xs
+                vals, grads = fn.value_and_gradient(scratch.reshape(starts.shape))
+                vals, grads = -_to_host(vals).reshape(R)[rows], -_to_host(grads).reshape(R, D)[rows]
+            else:
+                vals, grads = fn.value_and_gradient(xs)
+                vals, grads = -_to_host(vals), -_to_host(grads)
+            return vals, grads
+
+        ok, fmin, xs, nfev = _lockstep_lbfgsb(evaluate, flat, lower, upper, opts)
+        return ok.reshape(lead), (-fmin).reshape(lead), xs.reshape(starts.shape), nfev.reshape(lead)
 
     class _Run(greenlet.greenlet):
         def run(self, start):
