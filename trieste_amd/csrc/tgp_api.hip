@@ -1928,10 +1928,11 @@ int tgp_acq_value_grad(tgp_handle h, int acq_kind, double param, const double* X
   if (int rc = stage_out_prepare(h, h->s_out1, val, P, where, &dval)) return rc;
   if (int rc = stage_out_prepare(h, h->s_out2, grad, (size_t)P * h->d, where, &dgrad)) return rc;
   const int64_t Nscratch = (acq_kind == TGP_ACQ_GIBBON && h->rep_twin) ? std::max(Npad, h->rep_twin->Npad) : Npad;
-  HIPCHK(h, h->s_grad.reserve((size_t)3 * Nscratch * Ppad * sizeof(double)));
+  HIPCHK(h, h->s_grad.reserve(((size_t)3 * Nscratch * Ppad + grad_tail_scratch_doubles(Ppad)) * sizeof(double)));
   double* B = h->s_grad.as<double>();
   double* C1 = B + (size_t)Npad * Ppad;
   double* Z = C1 + (size_t)Npad * Ppad;
+  double* const gpart = B + (size_t)3 * Nscratch * Ppad;   // the gradient tail's partial sums
   const ModelDev m = model_dev(h);
   launch_kstar_t(h->stream, m, dXq, P, Ppad, B);
   // C1 = W B (W = L^-1, lower triangular incl. explicit zeros), Z = W^T C1 = K^-1 k*
@@ -1942,7 +1943,7 @@ int tgp_acq_value_grad(tgp_handle h, int acq_kind, double param, const double* X
   if (acq_kind >= TGP_ACQ_MES && h->ent_S == 0)
     return fail(h, TGP_ERR_STATE, "entropy-search acquisition needs min-value samples: call tgp_set_min_value_samples");
   tgp_handle twin = acq_kind == TGP_ACQ_GIBBON ? h->rep_twin : nullptr;
-  launch_grad_tail(h->stream, m, dXq, P, Ppad, B, C1, Z, acq_kind, param, dval, dgrad, h->d_ent.as<double>(), h->ent_S,
+  launch_grad_tail(h->stream, m, dXq, P, Ppad, B, C1, Z, gpart, acq_kind, param, dval, dgrad, h->d_ent.as<double>(), h->ent_S,
                    twin ? h->rep_weight : 0.0, 0.0);
   if (twin) {  // + w/2 log(var_twin + noise): the same pipeline on the conditioned model, accumulated
     if (!twin->have_data) return fail(h, TGP_ERR_STATE, "the repulsion twin has no data");
@@ -1956,7 +1957,7 @@ int tgp_acq_value_grad(tgp_handle h, int acq_kind, double param, const double* X
                            Ppad, 3)) return rc;
     if (int rc = gemm_tall(h, false, (int)Nt, (int)Ppad, (int)Nt, 1.0, twin->d_A.as<double>(), Nt, C1t, Ppad, 0.0, Zt,
                            Ppad, 5)) return rc;
-    launch_grad_tail(h->stream, mt, dXq, P, Ppad, Bt, C1t, Zt, ACQ_LOGYVAR, 0.0, dval, dgrad, nullptr, 0, 0.0,
+    launch_grad_tail(h->stream, mt, dXq, P, Ppad, Bt, C1t, Zt, gpart, ACQ_LOGYVAR, 0.0, dval, dgrad, nullptr, 0, 0.0,
                      0.5 * h->rep_weight);
   }
   if (h->pen_kind != 0 && h->pen_P > 0) {

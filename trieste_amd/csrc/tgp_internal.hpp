@@ -148,8 +148,9 @@ void launch_qei_tail(hipStream_t s, const double* mean, const double* cov, int64
                      int* info);
 // gradients (tgp_kernels_grad.hip)
 void launch_kstar_t(hipStream_t s, const ModelDev& m, const double* Xq, int64_t P, int64_t Ppad, double* B);
+size_t grad_tail_scratch_doubles(int64_t Ppad);   // `part` of launch_grad_tail
 void launch_grad_tail(hipStream_t s, const ModelDev& m, const double* Xq, int64_t P, int64_t Ppad,
-                      const double* B, const double* C1, const double* Z, int acq, double param, double* val,
+                      const double* B, const double* C1, const double* Z, double* part, int acq, double param, double* val,
                       double* grad, const double* samples = nullptr, int S = 0, double rep_w = 0.0,
                       double accum = 0.0);
 void launch_entropy_tail(hipStream_t s, const double* mean, const double* var, const double* var_twin, int64_t M,

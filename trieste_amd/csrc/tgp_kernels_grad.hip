@@ -147,60 +147,113 @@ void launch_theta_tail(hipStream_t s, const double* mean, int64_t ldm, const dou
                      ldr, F, B, scale, theta, ws);
 }
 
-constexpr int GT_THREADS = 256;
+constexpr int GT_THREADS = 256, GT_KS = 16, GT_J = 2 + 2 * MAX_D;
+size_t grad_tail_scratch_doubles(int64_t Ppad) { return (size_t)GT_KS * (size_t)Ppad * GT_J; }
 
-// one workgroup per query point
-__global__ __launch_bounds__(GT_THREADS) void grad_tail_kernel(ModelDev m, const double* __restrict__ Xq,
-                                                               int64_t P, int64_t Ppad,
-                                                               const double* __restrict__ B,
-                                                               const double* __restrict__ C1,
-                                                               const double* __restrict__ Z, int acq,
-                                                               double param, const double* __restrict__ samples,
-                                                               int S, double rep_w, double accum,
-                                                               double* __restrict__ val,
-                                                               double* __restrict__ grad) {
-  __shared__ double red[4][2 + 2 * MAX_D];
-  const int64_t p = blockIdx.x;
-  const int d = m.d, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  double xs[MAX_D];
-  for (int c = 0; c < d; ++c) xs[c] = Xq[p * d + c] / m.ls[c];
+// Value and gradient of the acquisition function at P points from B = K*^T [N][Ppad], C1 = W K*, Z = K^-1 k* (same layout):
+//   mean = sum_k B alpha,  var = s_f^2 - sum_k C1^2,  d mean / dx = sum_k alpha dk/dx,  d var / dx = -2 sum_k Z dk/dx.
+// Two passes since round 6 (one workgroup per point before: its lanes walked k, i.e. a column of the three row-major arrays --
+// 3 N cache lines of 8 useful bytes per point, 113 us at N = 4096, P = 80 on 80 of the 256 compute units):
+//   (1) grad_partial_kernel, grid (Ppad / 16, GT_KS): a workgroup takes 16 points x 1/16 of the rows; lane = (point, row
+//       phase), so a wave's loads are four rows of 128 contiguous bytes; partial sums -> part[ks][p][j], every sum in a fixed order;
+//   (2) grad_finish_kernel: one thread per point adds the GT_KS partials in order and evaluates the acquisition's tail.
+// (DP = the padded input dimension: the per-lane arrays are indexed by unrolled loops only -- with the run-time d of round 5's kernel
+// they lived in scratch)
+template <int DP>
+__global__ __launch_bounds__(GT_THREADS) void grad_partial_kernel(ModelDev m, const double* __restrict__ Xq, int64_t P,
+                                                                  int64_t Ppad, const double* __restrict__ B,
+                                                                  const double* __restrict__ C1,
+                                                                  const double* __restrict__ Z,
+                                                                  double* __restrict__ part) {
+  __shared__ double red[4][16][GT_J + 1];
+  const int d = m.d, tid = threadIdx.x, pl = tid & 15, kl = tid >> 4, w = tid >> 6, lane = tid & 63;
+  const int64_t p = 16 * (int64_t)blockIdx.x + pl, pc = p < P ? p : P - 1;   // (padded columns repeat the last point: never stored)
+  const int ks = blockIdx.y;
+  const int64_t chunk = (m.Npad + GT_KS - 1) / GT_KS;
+  const int64_t k0 = ks * chunk, k1 = (k0 + chunk < m.N) ? k0 + chunk : m.N;
+  // (x / ls by DIVISION, as Xs was formed: a query point that IS a training point must give t = 0 exactly -- the kernels with a kink
+  // at r = 0 divide by r)
+  double xs[DP], ls[DP];
+#pragma unroll
+  for (int c = 0; c < DP; ++c) {
+    ls[c] = m.ls[c];                               // (padded with 1.0)
+    xs[c] = c < d ? Xq[pc * d + c] / ls[c] : 0.0;  // (Xs is zero padded)
+  }
   double mean = 0.0, ssq = 0.0;
-  double gm[MAX_D], gv[MAX_D];
-  for (int c = 0; c < d; ++c) gm[c] = gv[c] = 0.0;
-  for (int64_t k = tid; k < m.N; k += GT_THREADS) {
+  double gm[DP], gv[DP];
+#pragma unroll
+  for (int c = 0; c < DP; ++c) gm[c] = gv[c] = 0.0;
+  for (int64_t k = k0 + kl; k < k1; k += 16) {
     const double kv = B[k * Ppad + p], ck = C1[k * Ppad + p], zk = Z[k * Ppad + p];
     const double al = m.alpha[k];
     mean = fma(kv, al, mean);
     ssq = fma(ck, ck, ssq);
-    double r2 = 0.0;
-    for (int c = 0; c < d; ++c) {
-      const double t = xs[c] - m.Xs[k * m.dp + c];
-      r2 = fma(t, t, r2);
+    double t[DP], r2 = 0.0;
+#pragma unroll
+    for (int c = 0; c < DP; ++c) {
+      t[c] = xs[c] - m.Xs[k * DP + c];
+      r2 = fma(t[c], t[c], r2);
     }
     const double f1 = 2.0 * kernel_dr2(m.kind, r2, m.variance);
-    for (int c = 0; c < d; ++c) {
-      const double dk = f1 * (xs[c] - m.Xs[k * m.dp + c]) / m.ls[c];
+#pragma unroll
+    for (int c = 0; c < DP; ++c) {
+      const double dk = f1 * t[c] / ls[c];
       gm[c] = fma(al, dk, gm[c]);
       gv[c] = fma(zk, dk, gv[c]);
     }
   }
-  mean = wave_sum(mean);
-  ssq = wave_sum(ssq);
-  for (int c = 0; c < d; ++c) {
-    gm[c] = wave_sum(gm[c]);
-    gv[c] = wave_sum(gv[c]);
+  // the four row phases of a wave (lanes pl, pl + 16, pl + 32, pl + 48), then the four waves through LDS: a fixed order
+  auto fold = [&](double v) {
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+  };
+  mean = fold(mean);
+  ssq = fold(ssq);
+#pragma unroll
+  for (int c = 0; c < DP; ++c) {
+    gm[c] = fold(gm[c]);
+    gv[c] = fold(gv[c]);
   }
-  if (lane == 0) {
-    red[w][0] = mean;
-    red[w][1] = ssq;
-    for (int c = 0; c < d; ++c) {
-      red[w][2 + c] = gm[c];
-      red[w][2 + MAX_D + c] = gv[c];
+  if (lane < 16) {
+    red[w][pl][0] = mean;
+    red[w][pl][1] = ssq;
+#pragma unroll
+    for (int c = 0; c < DP; ++c) {
+      red[w][pl][2 + c] = gm[c];
+      red[w][pl][2 + MAX_D + c] = gv[c];
     }
   }
   __syncthreads();
-  if (tid == 0) {
-    auto tot = [&](int j) { return (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]); };
+  if (tid < 16) {
+    double* const out = part + ((size_t)ks * Ppad + p) * GT_J;
+    auto tot = [&](int j) { return (red[0][pl][j] + red[1][pl][j]) + (red[2][pl][j] + red[3][pl][j]); };
+    out[0] = tot(0);
+    out[1] = tot(1);
+    for (int c = 0; c < d; ++c) {
+      out[2 + c] = tot(2 + c);
+      out[2 + MAX_D + c] = tot(2 + MAX_D + c);
+    }
+  }
+}
+
+// one workgroup per point: thread j adds the GT_KS partials of sum j in order (coalesced over j), thread 0 evaluates the tail
+__global__ __launch_bounds__(128) void grad_finish_kernel(ModelDev m, int64_t P, int64_t Ppad,
+                                                          const double* __restrict__ part, int acq, double param,
+                                                          const double* __restrict__ samples, int S, double rep_w,
+                                                          double accum, double* __restrict__ val,
+                                                          double* __restrict__ grad) {
+  __shared__ double sums[GT_J];
+  const int64_t p = blockIdx.x;
+  const int d = m.d, j = threadIdx.x;
+  if (j < GT_J) {
+    double s = 0.0;
+    for (int ks = 0; ks < GT_KS; ++ks) s += part[((size_t)ks * Ppad + p) * GT_J + j];
+    sums[j] = s;
+  }
+  __syncthreads();
+  auto tot = [&](int jj) { return sums[jj]; };
+  if (j == 0) {
     const double mu = tot(0) + m.mean_const;
     const double var_raw = m.variance - tot(1);
     const bool clipped = !(var_raw > VAR_FLOOR);
@@ -254,10 +307,17 @@ void launch_kstar_t(hipStream_t s, const ModelDev& m, const double* Xq, int64_t 
 }
 
 void launch_grad_tail(hipStream_t s, const ModelDev& m, const double* Xq, int64_t P, int64_t Ppad,
-                      const double* B, const double* C1, const double* Z, int acq, double param, double* val,
+                      const double* B, const double* C1, const double* Z, double* part, int acq, double param, double* val,
                       double* grad, const double* samples, int S, double rep_w, double accum) {
-  hipLaunchKernelGGL(grad_tail_kernel, dim3((unsigned)P), dim3(GT_THREADS), 0, s, m, Xq, P, Ppad, B, C1, Z, acq,
-                     param, samples, S, rep_w, accum, val, grad);
+  const dim3 grid((unsigned)(Ppad / 16), (unsigned)GT_KS);
+  if (m.dp == 2) hipLaunchKernelGGL(grad_partial_kernel<2>, grid, dim3(GT_THREADS), 0, s, m, Xq, P, Ppad, B, C1, Z, part);
+  else if (m.dp == 4) hipLaunchKernelGGL(grad_partial_kernel<4>, grid, dim3(GT_THREADS), 0, s, m, Xq, P, Ppad, B, C1, Z, part);
+  else if (m.dp == 6) hipLaunchKernelGGL(grad_partial_kernel<6>, grid, dim3(GT_THREADS), 0, s, m, Xq, P, Ppad, B, C1, Z, part);
+  else if (m.dp == 8) hipLaunchKernelGGL(grad_partial_kernel<8>, grid, dim3(GT_THREADS), 0, s, m, Xq, P, Ppad, B, C1, Z, part);
+  else if (m.dp == 16) hipLaunchKernelGGL(grad_partial_kernel<16>, grid, dim3(GT_THREADS), 0, s, m, Xq, P, Ppad, B, C1, Z, part);
+  else hipLaunchKernelGGL(grad_partial_kernel<32>, grid, dim3(GT_THREADS), 0, s, m, Xq, P, Ppad, B, C1, Z, part);
+  hipLaunchKernelGGL(grad_finish_kernel, dim3((unsigned)P), dim3(128), 0, s, m, P, Ppad, part, acq, param,
+                     samples, S, rep_w, accum, val, grad);
 }
 
 }  // namespace tgp
