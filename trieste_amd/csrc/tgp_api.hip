@@ -566,8 +566,12 @@ hipError_t launch_sweep_timed(tgp_handle h, const SweepArgs& a, bool joint) {
     const int nb = (int)(a.m.Npad / 256);
     int g = (int)std::min<int64_t>(std::min(8, nb), (8 * (int64_t)h->num_cu + grid - 1) / grid);
     if (h->variant & VARIANT_FORCE_SPLIT) g = std::min(8, nb);
+    // (round 6: with as many groups as row blocks the equal-work boundaries leave a group empty -- nb = 4 and nb = 8, i.e.
+    // N <= 1024 and N <= 2048, never split at all and EGO's 8000-candidate sweep ran on 125 of 256 compute units: 2.2 ms at
+    // N = 2048 for 0.5 ms of arithmetic; take the largest group count that works)
+    while (g > 1 && !plan_split(am, nb, g)) --g;
     if (g > 1) {
-      const bool ok = plan_split(am, nb, g);
+      const bool ok = true;
       if (ok) {
         am.split_g = g;
         hipError_t ep = h->s_part.reserve((size_t)grid * g * 256 * sizeof(double));
