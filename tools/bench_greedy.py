@@ -6,6 +6,7 @@ import numpy as np
 from trieste_amd import objectives as OBJ  # seeded synthetic problems (product side)
 import trieste_amd.models as M
 import trieste_amd.acquisition as A
+import trieste_amd.extras as E   # (the entropy builders: out of SURVEY 8's rows, frozen under extras)
 from trieste_amd.data import Dataset
 from trieste_amd.space import Box
 
@@ -48,13 +49,13 @@ eng.set_repulsion(twin, 0.01)
 ms3, _ = timed(lambda: eng.acq_argmax("gibbon", 0.0, cand), 2)
 eng.set_repulsion(None)
 print(f"MES arg-max over 2^20 candidates {ms2:.1f} ms; GIBBON with a 10-point repulsion twin (rank-10 variance update) {ms3:.1f} ms", flush=True)
-for name, builder in (("MinValueEntropySearch", lambda: A.MinValueEntropySearch(space)),):
+for name, builder in (("MinValueEntropySearch", lambda: E.MinValueEntropySearch(space)),):
     rule = A.EfficientGlobalOptimization(builder())
     rule.acquire_single(space, model, data)
     t0 = time.perf_counter()
     rule.acquire_single(space, model, data)
     print(f"EGO {name}: acquire {(time.perf_counter() - t0) * 1e3:.0f} ms", flush=True)
-for name, builder in (("GIBBON", lambda: A.GIBBON(space)),
+for name, builder in (("GIBBON", lambda: E.GIBBON(space)),
                       ("LocalPenalization(soft)", lambda: A.LocalPenalization(space)),
                       ("LocalPenalization(hard)", lambda: A.LocalPenalization(space, penalizer=A.hard_local_penalizer)),
                       ("Fantasizer(KB)", lambda: A.Fantasizer()),
