@@ -468,9 +468,11 @@ int tgp_get_auto_strata(tgp_handle h, int64_t* checked2, int64_t* violations2, d
  * persistent `update` kernel's plan with whole tiles only (default since round 6 at 3 <= Npad / 128 < 48: its two critical
  * single products as half-tile tasks, see tgp_dag_plan), bit 9 = the persistent `update` kernel's chain as ONE workgroup
  * (rounds 3 - 5; default since round 6 at 3 <= Npad / 128 < 48: TWO workgroups swapping the roles of leaf and helper, which
- * forms L(j+1,j) as a blocked triangular solve instead of a product with the inverted diagonal block).  Bits 0-3, 7, 8: every
+ * forms L(j+1,j) as a blocked triangular solve instead of a product with the inverted diagonal block), bit 10 = tgp_predict at
+ * <= 2048 points through a sweep launch (rounds 1 - 5) instead of one skinny triangular product (round 6: the default when no sweep
+ * policy bit and no arithmetic other than float64 is set).  Bits 0-3, 7, 8: every
  * setting computes the same arithmetic on every candidate / matrix entry, bit for bit; bits 4 - 6, 9: the same values up to the
- * rounding of another summation order. */
+ * rounding of another summation order (bit 10 as well). */
 int tgp_set_variant(tgp_handle h, int variant);
 /* `update` on SEVERAL handles at once (the prior draws of a hyper-parameter fit: reference models.py:294-321 evaluates
  * them one after the other): the persistent update kernel of a handle takes 1 / n of the compute units (n = 1 ... 16, default

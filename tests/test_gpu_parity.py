@@ -130,6 +130,33 @@ def test_sweep_matches_oracle(cfg, variant):
     np.testing.assert_array_equal(tv, ov_)
 
 
+@pytest.mark.parametrize("M", [1, 7, 64, 65, 128, 1000, 2048])
+@pytest.mark.parametrize("cfg", CONFIGS, ids=[c[0] for c in CONFIGS])
+def test_predict_at_a_handful_of_points_matches_the_oracle_and_the_sweep(cfg, M):
+    """Round 6: tgp_predict at <= 2048 points is K*^T, one skinny triangular product W K* and a two-pass tail (the arrays of the
+    value-and-gradient call) instead of a sweep launch -- mean and variance against the oracle at the sweep's tolerances, against
+    the sweep itself (tgp_set_variant bit 10) to rounding, mean-only and variance-only calls, training inputs, duplicates and the
+    far field among the points; 2049 points go through the sweep again (the same values as with bit 10: bit for bit)."""
+    _, obj, d, kind, N, noise = cfg
+    X, Y, ls, c, st, Xq_all = _problem(obj, d, kind, N, noise, M=2100)
+    Xq = np.ascontiguousarray(np.concatenate([Xq_all[:M - 3], Xq_all[-3:]]) if M >= 7 else Xq_all[:M])
+    floor = cancellation_floor(N, 1.0, noise)
+    eng = _engine(kind, d, 1.0, ls, noise, c, X, Y, 0)
+    sweep = _engine(kind, d, 1.0, ls, noise, c, X, Y, 1024)
+    mean, var = eng.predict(Xq)
+    om, ov = O.predict(st, Xq)
+    assert_close(mean, om, atol=floor * 10, what="mean at a handful of points")
+    assert_close(var, ov, atol=floor, what="var at a handful of points")
+    ms, vs = sweep.predict(Xq)
+    assert_close(mean, ms, atol=floor * 10, what="mean: skinny product vs sweep")
+    assert_close(var, vs, atol=floor, what="var: skinny product vs sweep")
+    assert np.all(var >= 1e-12)
+    np.testing.assert_array_equal(eng.predict_mean(Xq), sweep.predict_mean(Xq))   # (its own kernel either way)
+    big = np.ascontiguousarray(Xq_all[:2049])
+    for a, b in zip(eng.predict(big), sweep.predict(big)):
+        np.testing.assert_array_equal(a, b)
+
+
 @pytest.mark.parametrize("cfg", [CONFIGS[2], CONFIGS[3], CONFIGS[1]], ids=lambda c: c[0])
 def test_launch_policies_agree_to_rounding(cfg):
     """Fused and row-group-split launches form the same products; only the order in which the row blocks' partial

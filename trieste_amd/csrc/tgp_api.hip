@@ -158,7 +158,8 @@ void apply_penalization(tgp_handle h, double* dvals, const double* dXq, int64_t 
 //   VARIANT_DAG_ONE_CHAIN (512): the persistent `update` kernel's chain as ONE workgroup (rounds 3 - 5) instead of round 6's two
 constexpr int VARIANT_NO_SPLIT = 1, VARIANT_FORCE_SPLIT = 2, VARIANT_JOINT_V1 = 4, VARIANT_REG_STAGING = 8, VARIANT_NO_DAG = 16,
               VARIANT_DAG_SMALL = 32, VARIANT_NO_REPAIR_PRODUCT = 64, VARIANT_STATIC_BLOCKS = 128, VARIANT_DAG_WHOLE_TILES = 256,
-              VARIANT_DAG_ONE_CHAIN = 512;
+              VARIANT_DAG_ONE_CHAIN = 512, VARIANT_SWEEP_SMALL_PREDICT = 1024;
+//   VARIANT_SWEEP_SMALL_PREDICT (1024): tgp_predict at <= 2048 points through a sweep launch (rounds 1 - 5) instead of the skinny product
 constexpr int64_t REPAIR_PCAP = 512;   // TGP_PREC_AUTO: lists up to this many candidates are recomputed as a product
 int gemm_tall(tgp_handle h, bool tb, int m, int n, int k, double alpha, const double* A, int64_t lda, const double* B,
               int64_t ldb, double beta, double* C, int64_t ldc, int tri);
@@ -1820,6 +1821,31 @@ int tgp_get_factor(tgp_handle h, double* L, double* Winv, double* alpha, int whe
   return sync(h);
 }
 
+// predict (mean, variance) at a handful of points: K*^T, ONE skinny triangular product W K* and a two-pass tail -- the arrays and
+// kernels of tgp_acq_value_grad -- instead of a sweep launch whose workgroup walks all of W for its 64 candidates (round 6:
+// 1.64 -> 0.15 ms for 128 points at N = 4096, 1.68 -> 0.93 ms for 2048; the greedy batch builders predict at their pending points once per element).
+// Exact float64 whatever tgp_set_precision says.  tgp_set_variant bit 10 keeps the sweep (A/B, tests).
+// (measured, profiles/r06_predict_small_threshold.txt: the product wins up to ~4096 points at every N -- 0.15 / 0.42 / 0.93 ms at
+// 128 / 1024 / 2048 points against the sweep launch's 1.64 / 1.65 / 1.68 ms at N = 4096, 0.34 against 5.12 ms for 128 points at
+// N = 8192 -- and costs 2 Npad Mpad doubles of scratch: 2048 points it is)
+static const int64_t SMALL_PREDICT_M = getenv("TGP_SMALL_PREDICT_M") ? atoll(getenv("TGP_SMALL_PREDICT_M")) : 2048;   // (env: development aid)
+static int predict_small(tgp_handle h, const double* dXq, int64_t M, double* dmean, double* dvar) {
+  const int64_t Ppad = ((M + 63) / 64) * 64, Npad = h->Npad;
+  HIPCHK(h, h->s_grad.reserve(((size_t)2 * Npad * Ppad + predict_small_scratch_doubles(Ppad)) * sizeof(double)));
+  double* B = h->s_grad.as<double>();
+  double* C1 = B + (size_t)Npad * Ppad;
+  double* part = C1 + (size_t)Npad * Ppad;
+  const ModelDev m = model_dev(h);
+  launch_kstar_t(h->stream, m, dXq, M, Ppad, B);
+  if (dvar)
+    if (int rc = gemm_tall(h, false, (int)Npad, (int)Ppad, (int)Npad, 1.0, h->d_W.as<double>(), Npad, B, Ppad, 0.0, C1, Ppad, 3))
+      return rc;
+  launch_predict_small_tail(h->stream, m, M, Ppad, B, C1, part, dmean, dvar);
+  h->last_launches = 0;
+  h->last_ms = -1.0;
+  return TGP_OK;
+}
+
 static int sweep_common(tgp_handle h, const double* Xq, int64_t M, double* mean, double* var, double* acq,
                         int acq_kind, double param, int where) {
   if (!h) return TGP_ERR_ARG;
@@ -1841,6 +1867,17 @@ static int sweep_common(tgp_handle h, const double* Xq, int64_t M, double* mean,
   if (int rc = stage_out_prepare(h, h->s_out3, acq, M, where, &a.acq_out)) return rc;
   a.acq_kind = acq_kind;
   a.acq_param = param;
+  // (not when a sweep policy was asked for by hand -- variant bits 0, 1, 3 -- or another arithmetic than float64 was set: those
+  // calls mean the sweep)
+  if (acq_kind < 0 && !acq && M <= SMALL_PREDICT_M && h->precision_req == TGP_PREC_F64 &&
+      !(h->variant & (VARIANT_SWEEP_SMALL_PREDICT | VARIANT_NO_SPLIT | VARIANT_FORCE_SPLIT | VARIANT_REG_STAGING))) {
+    if (int rc = predict_small(h, dXq, M, a.mean_out, a.var_out)) return rc;
+    if (int rc = stage_out_finish(h, a.mean_out, mean, M, where)) return rc;
+    if (int rc = stage_out_finish(h, a.var_out, var, M, where)) return rc;
+    if (int rc = sync(h)) return rc;
+    HIPCHK(h, hipGetLastError());
+    return TGP_OK;
+  }
   for (int attempt = 0;; ++attempt) {
     HIPCHK(h, launch_sweep_timed(h, a, false));
     if (acq_kind >= 0) apply_penalization(h, a.acq_out, dXq, M);

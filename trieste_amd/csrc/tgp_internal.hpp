@@ -148,6 +148,9 @@ void launch_qei_tail(hipStream_t s, const double* mean, const double* cov, int64
                      int* info);
 // gradients (tgp_kernels_grad.hip)
 void launch_kstar_t(hipStream_t s, const ModelDev& m, const double* Xq, int64_t P, int64_t Ppad, double* B);
+size_t predict_small_scratch_doubles(int64_t Ppad);   // `part` of launch_predict_small_tail
+void launch_predict_small_tail(hipStream_t s, const ModelDev& m, int64_t P, int64_t Ppad, const double* B, const double* C1,
+                               double* part, double* mean_out, double* var_out);
 size_t grad_tail_scratch_doubles(int64_t Ppad);   // `part` of launch_grad_tail
 void launch_grad_tail(hipStream_t s, const ModelDev& m, const double* Xq, int64_t P, int64_t Ppad,
                       const double* B, const double* C1, const double* Z, double* part, int acq, double param, double* val,

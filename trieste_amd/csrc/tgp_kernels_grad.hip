@@ -301,6 +301,69 @@ __global__ __launch_bounds__(128) void grad_finish_kernel(ModelDev m, int64_t P,
   }
 }
 
+// ---- predict at a handful of points (round 6) --------------------------------------------------------------------------------
+// mean = sum_k K*[k][p] alpha_k + c,  var = max(s_f^2 - sum_k (W K*)[k][p]^2, floor)  from B = K*^T and C1 = W K* ([N][Ppad], the
+// arrays of the value-and-gradient call): the same two passes as the gradient tail, two sums per point.  The sweep kernels are
+// built for 10^4 .. 10^7 candidates; a workgroup of theirs walks all of W for its 64 candidates -- 1.7 ms at N = 4096 for ONE point.
+__global__ __launch_bounds__(GT_THREADS) void predict_small_partial_kernel(const double* __restrict__ B,
+                                                                           const double* __restrict__ C1,
+                                                                           const double* __restrict__ alpha, int64_t N,
+                                                                           int64_t Npad, int64_t Ppad, int with_var,
+                                                                           double* __restrict__ part) {
+  __shared__ double red[4][16][2];
+  const int tid = threadIdx.x, pl = tid & 15, kl = tid >> 4, w = tid >> 6, lane = tid & 63;
+  const int64_t p = 16 * (int64_t)blockIdx.x + pl;
+  const int ks = blockIdx.y;
+  const int64_t chunk = (Npad + GT_KS - 1) / GT_KS;
+  const int64_t k0 = ks * chunk, k1 = (k0 + chunk < N) ? k0 + chunk : N;
+  double mean = 0.0, ssq = 0.0;
+  for (int64_t k = k0 + kl; k < k1; k += 16) {
+    mean = fma(B[k * Ppad + p], alpha[k], mean);
+    if (with_var) {
+      const double ck = C1[k * Ppad + p];
+      ssq = fma(ck, ck, ssq);
+    }
+  }
+  mean += __shfl_xor(mean, 16);
+  mean += __shfl_xor(mean, 32);
+  ssq += __shfl_xor(ssq, 16);
+  ssq += __shfl_xor(ssq, 32);
+  if (lane < 16) {
+    red[w][pl][0] = mean;
+    red[w][pl][1] = ssq;
+  }
+  __syncthreads();
+  if (tid < 16) {
+    double* const out = part + ((size_t)ks * Ppad + p) * 2;
+    out[0] = (red[0][pl][0] + red[1][pl][0]) + (red[2][pl][0] + red[3][pl][0]);
+    out[1] = (red[0][pl][1] + red[1][pl][1]) + (red[2][pl][1] + red[3][pl][1]);
+  }
+}
+
+__global__ __launch_bounds__(64) void predict_small_finish_kernel(const double* __restrict__ part, int64_t P, int64_t Ppad,
+                                                                  double variance, double mean_const,
+                                                                  double* __restrict__ mean_out,
+                                                                  double* __restrict__ var_out) {
+  const int64_t p = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (p >= P) return;
+  double mu = 0.0, s = 0.0;
+  for (int ks = 0; ks < GT_KS; ++ks) {
+    mu += part[((size_t)ks * Ppad + p) * 2];
+    s += part[((size_t)ks * Ppad + p) * 2 + 1];
+  }
+  if (mean_out) mean_out[p] = mu + mean_const;
+  if (var_out) var_out[p] = fmax(variance - s, VAR_FLOOR);   // reference interface.py:123
+}
+
+size_t predict_small_scratch_doubles(int64_t Ppad) { return (size_t)GT_KS * (size_t)Ppad * 2; }
+void launch_predict_small_tail(hipStream_t s, const ModelDev& m, int64_t P, int64_t Ppad, const double* B, const double* C1,
+                               double* part, double* mean_out, double* var_out) {
+  hipLaunchKernelGGL(predict_small_partial_kernel, dim3((unsigned)(Ppad / 16), (unsigned)GT_KS), dim3(GT_THREADS), 0, s, B, C1,
+                     m.alpha, m.N, m.Npad, Ppad, var_out ? 1 : 0, part);
+  hipLaunchKernelGGL(predict_small_finish_kernel, dim3((unsigned)((P + 63) / 64)), dim3(64), 0, s, part, P, Ppad, m.variance,
+                     m.mean_const, mean_out, var_out);
+}
+
 void launch_kstar_t(hipStream_t s, const ModelDev& m, const double* Xq, int64_t P, int64_t Ppad, double* B) {
   dim3 grid((unsigned)(Ppad / 64), (unsigned)(m.Npad / 4));
   hipLaunchKernelGGL(kstar_t_kernel, grid, dim3(256), 0, s, m, Xq, P, Ppad, B);
