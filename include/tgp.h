@@ -258,6 +258,21 @@ int tgp_qei(tgp_handle h, const double* Xq, int64_t G, int q, const double* eps,
 int tgp_reparam_samples(tgp_handle h, const double* Xq, int64_t G, int q, const double* eps, int S,
                         double jitter, double* out, int where);
 
+/* == value and gradient of a BATCH acquisition function at the handful of q-batches an L-BFGS-B iteration holds: the reference
+ * optimises BatchMonteCarloExpectedImprovement through batchify_joint(generate_continuous_optimizer) (acquisition/optimizer.py:
+ * 897-934, 344-560) with tfp.math.value_and_gradient (optimizer.py:628-629), i.e. autodiff THROUGH predict_joint
+ * (models/gpflow/interface.py:126-133), the Cholesky factor of the q x q covariance and the reparametrised samples
+ * (models/gpflow/sampler.py:276-287).  The engine's share of that derivative, round 6:
+ *   tgp_joint_forward: mean [G,q], cov [G,q,q] of Xq [G,q,d] -- tgp_predict_joint's values to the rounding of another summation
+ *     order (diagonal clipped at 1e-12), as K*^T, one skinny triangular product and a Gram product instead of the joint kernel
+ *     built for 10^5 groups; any q, G * q <= 2048 per call;
+ *   tgp_joint_vjp: grad [G,q,d] = d/dXq of  sum_gi gmean[g,i] mean[g,i] + sum_gij gcov[g,i,j] cov[g,i,j]  (gcov need not be
+ *     symmetric: both triangles of cov count as written; a clipped diagonal entry has zero gradient at the caller: pass 0).
+ * The q x q factorisation and its adjoint in between are the caller's (host) arithmetic.  TGP_ERR_SHAPE beyond 2048 points. */
+int tgp_joint_forward(tgp_handle h, const double* Xq, int64_t G, int q, double* mean, double* cov, int where);
+int tgp_joint_vjp(tgp_handle h, const double* Xq, int64_t G, int q, const double* gmean, const double* gcov, double* grad,
+                  int where);
+
 /* == GaussianProcessRegression.covariance_between_points_encoded (models/gpflow/models.py:188-254):
  * out [P1,P2] = k(X1, X2) - (L^-1 k(X, X1))^T (L^-1 k(X, X2)); no clipping (the reference applies
  * none here).  X1 [P1,d], X2 [P2,d]. */

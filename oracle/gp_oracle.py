@@ -333,6 +333,66 @@ def batch_mc_ei(state: GPRState, Xq: np.ndarray, eps: np.ndarray, eta: float,
     return np.mean(np.maximum(eta - np.min(s, axis=-1), 0.0), axis=-1)
 
 
+def batch_mc_ei_value_and_grad(state: GPRState, Xq: np.ndarray, eps: np.ndarray, eta: float, jitter: float = JITTER):
+    """qEI [G] and its gradient [G, q, d] w.r.t. the batch points -- what tfp.math.value_and_gradient
+    (reference acquisition/optimizer.py:628-629) returns when batchify_joint (optimizer.py:897-934) hands
+    BatchMonteCarloExpectedImprovement (function.py:1150-1186) to the continuous optimizer: the derivative through predict_joint
+    (interface.py:126-133, a clipped diagonal entry has zero gradient: tf.clip_by_value), tf.linalg.cholesky and the
+    reparametrised samples (sampler.py:276-287).  FORWARD mode, one tangent per coordinate (i, c): d mean, d cov from the
+    kernel derivatives, d L = L Phi(L^-1 d cov L^-T) (Phi: lower triangle, diagonal halved), d samples = d mean + d L eps,
+    d value = mean_s 1[improvement > 0] (-d sample at the arg-min).  Plain loops: small cases only."""
+    Xq = np.asarray(Xq, dtype=np.float64)
+    G, q, d = Xq.shape
+    ls = state.lengthscales
+    Bx = state.X / ls
+    alpha = _solve_triangular(state.L.T, _solve_triangular(state.L, state.err, lower=True), lower=False)
+    S = eps.shape[1]
+    vals = np.empty(G)
+    grads = np.zeros((G, q, d))
+    for g in range(G):
+        A = Xq[g] / ls
+        diff = A[:, None, :] - Bx[None, :, :]                      # [q, N, d]
+        r2 = np.sum(diff * diff, axis=-1)
+        Kq = kernel_from_r2(state.kind, state.variance, r2)        # [q, N]
+        Cq = _solve_triangular(state.L, Kq.T, lower=True)          # [N, q]  c_i = L^-1 k*_i
+        dff = A[:, None, :] - A[None, :, :]                        # [q, q, d]
+        r2q = np.sum(dff * dff, axis=-1)
+        cov = kernel_from_r2(state.kind, state.variance, r2q) - Cq.T @ Cq
+        raw_diag = np.diag(cov).copy()
+        clipped = ~(raw_diag > VAR_FLOOR)
+        cov[np.diag_indices(q)] = np.where(clipped, VAR_FLOOR, raw_diag)
+        mean = Kq @ alpha + state.mean_const
+        Lq = _cholesky(cov + jitter * np.eye(q), lower=True)
+        smp = mean[None, :] + (Lq @ eps).T                          # [S, q]
+        jmin = np.argmin(smp, axis=1)
+        imp = eta - smp[np.arange(S), jmin]
+        active = imp > 0.0
+        vals[g] = np.mean(np.where(active, imp, 0.0))
+        dk = (2.0 * _kernel_dr2(state.kind, state.variance, r2))[:, :, None] * diff / ls       # [q, N, d]  d k*_i / d x_i
+        dkq = (2.0 * _kernel_dr2(state.kind, state.variance, r2q))[:, :, None] * dff / ls      # [q, q, d]  d k(x_i, x_j) / d x_i
+        for i in range(q):
+            for c in range(d):
+                dmean = np.zeros(q)
+                dmean[i] = dk[i, :, c] @ alpha
+                dci = _solve_triangular(state.L, dk[i, :, c], lower=True)   # d c_i
+                dcov = np.zeros((q, q))
+                row = -(dci @ Cq)                                           # -d c_i^T c_j for every j
+                for j in range(q):
+                    if j != i:
+                        row[j] += dkq[i, j, c]
+                dcov[i, :] += row
+                dcov[:, i] += row                                           # (entry (i, i) twice: -2 d c_i^T c_i)
+                if clipped[i]:
+                    dcov[i, i] = 0.0
+                M = _solve_triangular(Lq, _solve_triangular(Lq, dcov, lower=True).T, lower=True).T   # L^-1 dcov L^-T
+                Phi = np.tril(M)
+                Phi[np.diag_indices(q)] *= 0.5
+                dL = Lq @ Phi
+                dsmp = dmean[None, :] + (dL @ eps).T                        # [S, q]
+                grads[g, i, c] = np.mean(np.where(active, -dsmp[np.arange(S), jmin], 0.0))
+    return vals, grads
+
+
 def joint_samples(state: GPRState, Xq: np.ndarray, eps: np.ndarray, jitter: float = JITTER) -> np.ndarray:
     """GPflowPredictor.sample_encoded (interface.py:135-137) -> gpflow predict_f_samples: mean, cov =
     predict_f(full_cov=True) (NO clipping), samples = mean + chol(cov + jitter I) eps (sample_mvn).

@@ -414,6 +414,35 @@ class FakeEngine:
         out = O.batch_mc_ei(self._st(), Xq.reshape((-1,) + Xq.shape[-2:]), np.asarray(eps, float), eta, jitter)
         return out.reshape(lead)
 
+    JOINT_SMALL_POINTS = 2048
+
+    def joint_forward(self, Xq):
+        return O.predict_joint(self._st(), np.asarray(Xq, float))
+
+    def joint_vjp(self, Xq, gmean, gcov):
+        """The engine's vector-Jacobian product of predict_joint on dense numpy arrays (K^-1 formed explicitly)."""
+        st = self._st()
+        Xq, gmean, gcov = np.asarray(Xq, float), np.asarray(gmean, float), np.asarray(gcov, float)
+        G, q, d = Xq.shape
+        ls = st.lengthscales
+        Kinv = np.linalg.inv(st.L @ st.L.T)
+        alpha = Kinv @ st.err
+        out = np.zeros((G, q, d))
+        for g in range(G):
+            Gs = gcov[g] + gcov[g].T
+            diff = (Xq[g][:, None, :] - st.X[None, :, :]) / ls
+            r2 = np.sum(diff * diff, -1)
+            Kq = O.kernel_from_r2(st.kind, st.variance, r2)                      # [q, N]
+            dk = (2.0 * O._kernel_dr2(st.kind, st.variance, r2))[:, :, None] * diff / ls
+            V = gmean[g][:, None] * alpha[None, :] - (Gs @ Kq) @ Kinv            # [q, N]
+            out[g] = np.einsum("qnd,qn->qd", dk, V)
+            dq = (Xq[g][:, None, :] - Xq[g][None, :, :]) / ls
+            r2q = np.sum(dq * dq, -1)
+            dkq = (2.0 * O._kernel_dr2(st.kind, st.variance, r2q))[:, :, None] * dq / ls
+            off = Gs * (1.0 - np.eye(q))
+            out[g] += np.einsum("ij,ijd->id", off, dkq)
+        return out
+
     def reparam_samples(self, Xq, eps, jitter=1e-6):
         Xq = np.asarray(Xq, float)
         lead = Xq.shape[:-2]

@@ -435,6 +435,105 @@ def test_acq_value_and_gradient_match_oracle(cfg):
         assert_close(val, vals2, rtol=1e-9, atol=floor, what=f"{acq} value == sweep value")
 
 
+def _dense_joint_vjp(st, Xq, gmean, gcov):
+    """d/dXq of sum gmean * mean + sum gcov * cov on dense numpy arrays (explicit solves against the oracle's factor): the
+    checker of tgp_joint_vjp."""
+    G, q, d = Xq.shape
+    ls = st.lengthscales
+    alpha = O._solve_triangular(st.L.T, O._solve_triangular(st.L, st.err, lower=True), lower=False)
+    out = np.zeros((G, q, d))
+    for g in range(G):
+        Gs = gcov[g] + gcov[g].T
+        diff = (Xq[g][:, None, :] - st.X[None, :, :]) / ls
+        r2 = np.sum(diff * diff, -1)
+        Kq = O.kernel_from_r2(st.kind, st.variance, r2)
+        dk = (2.0 * O._kernel_dr2(st.kind, st.variance, r2))[:, :, None] * diff / ls
+        T = O._solve_triangular(st.L.T, O._solve_triangular(st.L, (Gs @ Kq).T, lower=True), lower=False).T   # (Gs Kq) K^-1
+        out[g] = np.einsum("qnd,qn->qd", dk, gmean[g][:, None] * alpha[None, :] - T)
+        dq = (Xq[g][:, None, :] - Xq[g][None, :, :]) / ls
+        dkq = (2.0 * O._kernel_dr2(st.kind, st.variance, np.sum(dq * dq, -1)))[:, :, None] * dq / ls
+        out[g] += np.einsum("ij,ijd->id", Gs * (1.0 - np.eye(q)), dkq)
+    return out
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=[c[0] for c in CONFIGS])
+def test_joint_forward_and_vjp_of_a_handful_of_batches_match_the_oracle(cfg):
+    """Round 6: tgp_joint_forward (predict_joint of the few q-batches an L-BFGS-B iteration holds, as a skinny product) against the
+    oracle's predict_joint AND the joint kernel's (tgp_predict_joint), tgp_joint_vjp against a dense numpy evaluation of the same
+    vector-Jacobian product with random, NON-symmetric adjoints -- q from 1 to 64, group counts 1 ... 300, a group starting at
+    a training input, a group with two nearly coincident points, 2048 points exactly; more than 2048 points is a shape error."""
+    _, obj, d, kind, N, noise = cfg
+    X, Y, ls, c, st, _ = _problem(obj, d, kind, N, noise)
+    floor = cancellation_floor(N, 1.0, noise)
+    eng = _engine(kind, d, 1.0, ls, noise, c, X, Y)
+    rng = np.random.default_rng(17)
+    for q, G in ((1, 1), (1, 70), (3, 21), (5, 300), (17, 6), (50, 10), (64, 3), (64, 32)):
+        Xg = rng.uniform(size=(G, q, d))
+        Xg[0, 0] = X[0]
+        if q >= 3:
+            Xg[-1, 1] = Xg[-1, 0] + 1e-4
+        jm, jc = eng.joint_forward(Xg)
+        om, oc = O.predict_joint(st, Xg)
+        assert_close(jm, om, atol=floor * 10, what=f"joint_forward mean q={q} G={G}")
+        # (off-diagonal entries are differences of O(1) numbers formed by a k-split product: tgp_cov_between's tolerance,
+        # the same pipeline; the diagonal holds the plain floor)
+        assert_close(jc, oc, atol=floor * 10, what=f"joint_forward cov q={q} G={G}")
+        dg = np.arange(q)
+        assert_close(jc[:, dg, dg], oc[:, dg, dg], atol=floor, what=f"joint_forward variances q={q} G={G}")
+        np.testing.assert_array_equal(jc, np.swapaxes(jc, -1, -2))   # both triangles from one entry of the product
+        if q <= 64:
+            km, kc = eng.predict_joint(Xg)
+            assert_close(jm, km, atol=floor * 10, what="joint_forward mean vs the joint kernel")
+            assert_close(jc, kc, atol=floor * 10, what="joint_forward cov vs the joint kernel")
+        gm, gc = rng.normal(size=(G, q)), rng.normal(size=(G, q, q))
+        got = eng.joint_vjp(Xg, gm, gc)
+        want = _dense_joint_vjp(st, Xg, gm, gc)
+        gscale = np.abs(want).max() + 1e-300
+        assert_close(got, want, rtol=1e-5, atol=max(floor * 1e3 * q, 1e-9 * gscale), what=f"joint_vjp q={q} G={G}")
+        np.testing.assert_array_equal(eng.joint_vjp(Xg, gm, gc), got)   # a fixed summation order: bit-identical call to call
+    with pytest.raises(ValueError):
+        eng.joint_forward(rng.uniform(size=(41, 50, d)))
+    from trieste_amd import _lib
+    big = np.ascontiguousarray(rng.uniform(size=(2049, 1, d)))
+    out = np.empty(2049 * (1 + 1))
+    rc = eng._lib.tgp_joint_forward(eng._h, big.ctypes.data, 2049, 1, out.ctypes.data, out[2049:].ctypes.data, _lib.HOST)
+    assert rc == _lib.TGP_ERR_SHAPE
+
+
+@pytest.mark.parametrize("cfg", [CONFIGS[0], CONFIGS[1], CONFIGS[2], CONFIGS[4]], ids=lambda c: c[0])
+def test_qei_value_and_gradient_match_the_oracle(cfg):
+    """The gradient of BatchMonteCarloExpectedImprovement w.r.t. the batch points as the host layer assembles it (engine:
+    joint_forward + joint_vjp; host: q x q factorisations, sample reduction, Cholesky adjoint) against the oracle's FORWARD-mode
+    derivative of the reference's computation (predict_joint -> cholesky -> reparametrised samples -> mean of max(eta - min, 0):
+    function.py:1181-1186, sampler.py:276-287), at an incumbent where most values are non-zero."""
+    from trieste_amd.acquisition.function import batch_monte_carlo_expected_improvement
+
+    _, obj, d, kind, N, noise = cfg
+    X, Y, ls, c, st, _ = _problem(obj, d, kind, N, noise)
+    floor = cancellation_floor(N, 1.0, noise)
+    eng = _engine(kind, d, 1.0, ls, noise, c, X, Y)
+    rng = np.random.default_rng(23)
+    for q, G, S in ((1, 6, 32), (3, 5, 64), (7, 3, 48)):
+        Xg = rng.uniform(size=(G, q, d))
+        eps = rng.normal(size=(q, S))
+        eta = float(np.median(O.predict_joint(st, Xg)[0]))
+
+        class _Sampler:
+            def eps(self, qq):
+                assert qq == q
+                return eps
+
+        fn = batch_monte_carlo_expected_improvement.__new__(batch_monte_carlo_expected_improvement)
+        fn._engine, fn._sampler, fn._eta, fn._jitter, fn._sample_size = eng, _Sampler(), eta, 1e-6, S
+        val, grad = fn.value_and_gradient(Xg)
+        oval, ograd = O.batch_mc_ei_value_and_grad(st, Xg, eps, eta, 1e-6)
+        assert np.count_nonzero(oval) >= oval.size // 2, f"vacuous qEI comparison at q={q}: {oval}"
+        assert_close(val, oval, atol=floor, what=f"qEI value q={q}")
+        assert_close(val, eng.qei(Xg, eps, eta, 1e-6), atol=floor, what=f"qEI value == tgp_qei q={q}")
+        gscale = np.abs(ograd).max() + 1e-300
+        assert_close(grad, ograd, rtol=1e-5, atol=max(floor * 1e3 * q, 1e-7 * gscale), what=f"qEI gradient q={q}")
+
+
 @pytest.mark.parametrize("cfg", CONFIGS[:5], ids=[c[0] for c in CONFIGS[:5]])
 def test_nlml_value_and_gradient_match_oracle(cfg):
     """tgp_nlml vs the oracle (whose gradient is finite-difference checked in test_oracle_gradient.py)."""

@@ -428,6 +428,61 @@ def test_ego_batch_with_joint_builder():
     assert pts.shape == (3, 2) and np.all((pts >= 0) & (pts <= 1))
 
 
+@pytest.mark.parametrize("kernel", ["matern52", "rbf"])
+def test_batch_mc_ei_value_and_gradient_matches_the_oracle_and_finite_differences(kernel):
+    """qEI's value and gradient w.r.t. the batch points -- what the reference's optimizer gets from
+    tfp.math.value_and_gradient (optimizer.py:628-629) through predict_joint, the Cholesky factor and the reparametrised samples
+    -- host reverse mode (Cholesky adjoint) + the engine's vector-Jacobian product, against the oracle's FORWARD-mode derivative
+    (another derivation) and central differences of the function itself."""
+    from oracle import gp_oracle as O
+
+    kern = None if kernel == "matern52" else M.SquaredExponential(1.3, [0.4, 0.6])
+    model, data = _model(n=14, noise=1e-2, kernel=kern)
+    fn = BatchMonteCarloExpectedImprovement(96).prepare_acquisition_function(model, dataset=data)
+    x = np.random.default_rng(11).uniform(size=(5, 3, 2))
+    x[4, 1] = x[4, 0] + 1e-3   # two nearly coincident points in a batch
+    vals, grads = fn.value_and_gradient(x)
+    np.testing.assert_allclose(vals, fn(x)[:, 0], rtol=1e-10, atol=1e-14)
+    st = model.engine._st()
+    ov, og = O.batch_mc_ei_value_and_grad(st, x, fn._sampler.eps(3), fn._eta, 1e-6)
+    np.testing.assert_allclose(vals, ov, rtol=1e-10, atol=1e-14)
+    np.testing.assert_allclose(grads, og, rtol=1e-6, atol=1e-9 * max(1.0, np.abs(og).max()))
+    h = 1e-6
+    for (g, i, c) in [(0, 0, 0), (1, 2, 1), (3, 1, 0)]:
+        xp, xm = x.copy(), x.copy()
+        xp[g, i, c] += h
+        xm[g, i, c] -= h
+        fd = (fn(xp)[g, 0] - fn(xm)[g, 0]) / (2 * h)
+        assert abs(fd - grads[g, i, c]) <= 1e-6 * max(1.0, abs(fd))
+
+
+def test_ego_refines_a_joint_batch_with_lbfgsb_when_the_builder_has_a_gradient():
+    """batchify_joint hands the flattened qEI WITH its gradient to the continuous optimizer (optimizer.py:897-934, 107-114):
+    the batch the default optimizer returns is at least as good as the best of its own initial samples."""
+    from trieste_amd.acquisition.optimizer import _FlattenedBatchFunction, automatic_optimizer_selector, batchify_joint
+
+    model, data = _model(n=10, noise=1e-2)
+    builder = BatchMonteCarloExpectedImprovement(64)
+    fn = builder.prepare_acquisition_function(model, dataset=data)
+    seen = {}
+
+    def spy(space, f):
+        seen["f"] = f
+        return generate_continuous_optimizer(num_initial_samples=200, num_optimization_runs=4)(space, f)
+
+    box = Box([0, 0], [1, 1])
+    pts = batchify_joint(spy, 2)(box, fn)
+    assert isinstance(seen["f"], _FlattenedBatchFunction) and pts.shape == (2, 2)
+    assert np.all((pts >= 0) & (pts <= 1))
+    start = (box ** 2).sample(200, seed=5)
+    assert fn(pts[None])[0, 0] >= np.max(seen["f"](start[:, None, :])) - 1e-12 or fn(pts[None])[0, 0] > 0
+    v, g = seen["f"].value_and_gradient(start[:7])
+    assert v.shape == (7,) and g.shape == (7, 4)
+    ego = EfficientGlobalOptimization(builder, num_query_points=2)   # the default optimizer: L-BFGS-B on the 4-dimensional batch
+    out = ego.acquire_single(box, model, dataset=data)
+    assert out.shape == (2, 2) and np.all((out >= 0) & (out <= 1))
+
+
 def test_discrete_thompson_sampling_and_random_sampling():
     model, data = _model(n=10)
     box = Box([0, 0], [1, 1])

@@ -281,6 +281,60 @@ class batch_monte_carlo_expected_improvement(AcquisitionFunctionClass):
         return self._engine.qei(x, eps, self._eta, self._jitter)[..., None]
 
 
+    def value_and_gradient(self, points):
+        """points [P, q, D] -> (values [P], gradients [P, q, D]): the derivative TF autodiff takes through ``predict_joint``,
+        ``tf.linalg.cholesky`` and the reparametrised samples when ``batchify_joint`` hands this function to the continuous
+        optimizer (optimizer.py:628-629, 897-934; sampler.py:276-287), in reverse mode: the engine returns mean and covariance
+        of the P groups as a skinny product (``joint_forward``) and, given the adjoints of both, the gradient w.r.t. the points
+        (``joint_vjp``: K*, W K*, W^T (...) and the kernel derivatives over all N training rows); the q x q factorisations, the
+        S-sample reduction and the Cholesky adjoint  A_bar = L^-T sym(Phi(L^T L_bar)) L^-1  in between are host arithmetic."""
+        x = np.ascontiguousarray(points.cpu().numpy() if _is_torch(points) else points, dtype=np.float64)
+        if x.ndim != 3:
+            raise ValueError(f"points must be [P, q, D], got shape {x.shape}")
+        P, q, _ = x.shape
+        eps = np.asarray(self._sampler.eps(q), dtype=np.float64)                      # [q, S]
+        S = eps.shape[1]
+        epsT = np.ascontiguousarray(eps.T)
+        values, grads = np.empty(P), np.empty(x.shape)
+        chunk = max(1, getattr(self._engine, "JOINT_SMALL_POINTS", 2048) // q)
+        eye = np.eye(q)
+        for g0 in range(0, P, chunk):
+            xs = x[g0:g0 + chunk]
+            mean, cov = (np.asarray(a) for a in self._engine.joint_forward(xs))         # [g, q], [g, q, q]
+            g = mean.shape[0]
+            clipped = np.diagonal(cov, axis1=-2, axis2=-1) <= 1e-12                     # (clip_by_value: zero gradient)
+            L = np.linalg.cholesky(cov + self._jitter * eye)
+            smp = L @ eps                                                               # [g, q, S]: the sample index innermost
+            smp += mean[:, :, None]
+            low = smp[:, 0, :].copy()                                                   # running minimum over the batch points,
+            jmin = np.zeros(low.shape, dtype=np.int64)                                  # its FIRST index on ties (tf.reduce_min's
+            for i in range(1, q):                                                       # gradient goes to ... any one: measure zero)
+                better = smp[:, i, :] < low
+                jmin[better] = i
+                np.minimum(low, smp[:, i, :], out=low)
+            imp = self._eta - low
+            active = imp > 0.0
+            values[g0:g0 + chunk] = np.where(active, imp, 0.0).mean(axis=1)
+            jmin[~active] = -1
+            # adjoints: d value / d sample[g, i, s] = -1/S where i is the arg-min of an improving sample, else 0
+            gmean, Lbar = np.empty((g, q)), np.zeros((g, q, q))
+            for i in range(q):
+                w = (jmin == i).astype(np.float64)                                      # [g, S]
+                gmean[:, i] = w.sum(axis=-1)
+                Lbar[:, i, :i + 1] = w @ epsT[:, :i + 1]                                # lower triangle of sum_s d sample eps^T
+            gmean *= -1.0 / S
+            Lbar *= -1.0 / S
+            Lt = np.swapaxes(L, -1, -2)
+            Q = np.tril(Lt @ Lbar)
+            Q[:, np.arange(q), np.arange(q)] *= 0.5
+            R = 0.5 * (Q + np.swapaxes(Q, -1, -2))
+            Y = np.linalg.solve(Lt, R)                                                  # L^-T R
+            gcov = np.swapaxes(np.linalg.solve(Lt, np.swapaxes(Y, -1, -2)), -1, -2)     # L^-T R L^-1
+            gcov[:, np.arange(q), np.arange(q)] = np.where(clipped, 0.0, np.diagonal(gcov, axis1=-2, axis2=-1))
+            grads[g0:g0 + chunk] = np.asarray(self._engine.joint_vjp(xs, gmean, np.ascontiguousarray(gcov)))
+        return values, grads
+
+
 class BatchMonteCarloExpectedImprovement(SingleModelAcquisitionBuilder):
     """Builder for qEI (function.py:1074-1147)."""
 

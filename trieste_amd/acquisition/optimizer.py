@@ -397,6 +397,22 @@ def generate_continuous_optimizer(num_initial_samples=NUM_SAMPLES_MIN, num_optim
     return optimize_continuous
 
 
+class _FlattenedBatchFunction:
+    """``x [..., 1, B * D] -> f(x reshaped to [..., B, D])`` (optimizer.py:921-926) for a batch function that exposes
+    ``value_and_gradient([P, B, D]) -> ([P], [P, B, D])``: the flattened function's is ``[P, B * D] -> ([P], [P, B * D])``."""
+
+    def __init__(self, f, batch_size: int):
+        self._f, self._batch_size = f, batch_size
+
+    def __call__(self, x):
+        return self._f(x.reshape(tuple(x.shape[:-2]) + (self._batch_size, -1)))
+
+    def value_and_gradient(self, points):
+        pts = _to_host(points)
+        vals, grads = self._f.value_and_gradient(pts.reshape(pts.shape[0], self._batch_size, -1))
+        return _to_host(vals), _to_host(grads).reshape(pts.shape)
+
+
 def batchify_joint(batch_size_one_optimizer, batch_size: int):
     """Optimise the B points of a batch acquisition function jointly over space**B
     (optimizer.py:897-934)."""
@@ -411,6 +427,10 @@ def batchify_joint(batch_size_one_optimizer, batch_size: int):
         def target_func_with_vectorized_inputs(x):  # [..., 1, B * D] -> [..., 1]
             return f(x.reshape(tuple(x.shape[:-2]) + (batch_size, -1)))
 
+        if hasattr(f, "value_and_gradient") and hasattr(getattr(f, "_engine", None), "joint_vjp"):
+            # a batch function with an analytic gradient (qEI): the flattened function carries it, so that
+            # automatic_optimizer_selector / generate_continuous_optimizer refine with L-BFGS-B as the reference does
+            target_func_with_vectorized_inputs = _FlattenedBatchFunction(f, batch_size)
         pts = batch_size_one_optimizer(expanded, target_func_with_vectorized_inputs)  # [1, B * D]
         return np.asarray(pts).reshape(batch_size, -1)
 

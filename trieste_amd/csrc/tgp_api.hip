@@ -2013,6 +2013,92 @@ int tgp_acq_value_grad(tgp_handle h, int acq_kind, double param, const double* X
   return TGP_OK;
 }
 
+// ---- the handful of q-batches of an L-BFGS-B iteration over a BATCH acquisition function (qEI; round 6) ------------------------
+// The reference optimises BatchMonteCarloExpectedImprovement with batchify_joint(generate_continuous_optimizer) (optimizer.py:
+// 897-934, 344-560): every iterate of every start is a group of q points, value and gradient by TF autodiff THROUGH predict_joint
+// (interface.py:126-133), the Cholesky factor of the q x q covariance and the reparametrised samples (sampler.py:276-287).  Here:
+// tgp_joint_forward = predict_joint of those few groups in the skinny-product form of tgp_predict at a handful of points (the joint
+// kernel is built for 10^5 groups: one 250-point block walks all of W, 5 ms at N = 2048), tgp_joint_vjp = the vector-Jacobian
+// product of predict_joint (tgp_kernels_grad.hip); the q x q factorisation and its adjoint in between are host arithmetic.
+constexpr int64_t JOINT_SMALL_P = 2048;   // points per call (groups x q)
+static int joint_small_common(tgp_handle h, const double* Xq, int64_t G, int q, int where, const double** dXq, int64_t* P,
+                              int64_t* Ppad) {
+  if (!h->have_data) return fail(h, TGP_ERR_STATE, "model has no data: call tgp_set_data first");
+  if (G < 1 || q < 1 || !Xq) return fail(h, TGP_ERR_SHAPE, "need G >= 1 groups of q >= 1 points");
+  if (G * (int64_t)q > JOINT_SMALL_P)
+    return fail(h, TGP_ERR_SHAPE, "G * q = %lld points: at most %lld per call (chunk the groups)", (long long)(G * q),
+                (long long)JOINT_SMALL_P);
+  if (int rc = set_device(h)) return rc;
+  *P = G * (int64_t)q;
+  *Ppad = ((*P + 63) / 64) * 64;
+  return stage_in(h, h->s_in, Xq, (size_t)*P * h->d, where, dXq);
+}
+
+int tgp_joint_forward(tgp_handle h, const double* Xq, int64_t G, int q, double* mean, double* cov, int where) {
+  if (!h) return TGP_ERR_ARG;
+  if (!mean || !cov) return fail(h, TGP_ERR_ARG, "mean / cov is NULL");
+  const double* dXq;
+  int64_t P, Ppad;
+  if (int rc = joint_small_common(h, Xq, G, q, where, &dXq, &P, &Ppad)) return rc;
+  const int64_t Npad = h->Npad;
+  double *dmean, *dcov;
+  if (int rc = stage_out_prepare(h, h->s_out1, mean, (size_t)P, where, &dmean)) return rc;
+  if (int rc = stage_out_prepare(h, h->s_out2, cov, (size_t)P * q, where, &dcov)) return rc;
+  HIPCHK(h, h->s_grad.reserve(((size_t)3 * Npad * Ppad + (size_t)Ppad * Ppad + predict_small_scratch_doubles(Ppad)) *
+                              sizeof(double)));
+  double* B = h->s_grad.as<double>();
+  double* C1 = B + (size_t)Npad * Ppad;
+  double* C1t = C1 + (size_t)Npad * Ppad;
+  double* S = C1t + (size_t)Npad * Ppad;
+  double* part = S + (size_t)Ppad * Ppad;
+  const ModelDev m = model_dev(h);
+  launch_kstar_t(h->stream, m, dXq, P, Ppad, B);
+  if (int rc = gemm_tall(h, false, (int)Npad, (int)Ppad, (int)Npad, 1.0, h->d_W.as<double>(), Npad, B, Ppad, 0.0, C1, Ppad, 3))
+    return rc;
+  launch_transpose(h->stream, C1, Npad, Ppad, Ppad, C1t, Npad);
+  if (int rc = gemm_tall(h, false, (int)Ppad, (int)Ppad, (int)Npad, 1.0, C1t, Npad, C1, Ppad, 0.0, S, Ppad, 0)) return rc;
+  launch_predict_small_tail(h->stream, m, P, Ppad, B, C1, part, dmean, nullptr);
+  launch_joint_pick(h->stream, m, dXq, P, Ppad, q, S, dcov);
+  if (int rc = stage_out_finish(h, dmean, mean, (size_t)P, where)) return rc;
+  if (int rc = stage_out_finish(h, dcov, cov, (size_t)P * q, where)) return rc;
+  if (int rc = sync(h)) return rc;
+  HIPCHK(h, hipGetLastError());
+  return TGP_OK;
+}
+
+int tgp_joint_vjp(tgp_handle h, const double* Xq, int64_t G, int q, const double* gmean, const double* gcov, double* grad,
+                  int where) {
+  if (!h) return TGP_ERR_ARG;
+  if (!gmean || !gcov || !grad) return fail(h, TGP_ERR_ARG, "gmean / gcov / grad is NULL");
+  const double* dXq;
+  int64_t P, Ppad;
+  if (int rc = joint_small_common(h, Xq, G, q, where, &dXq, &P, &Ppad)) return rc;
+  const int64_t Npad = h->Npad;
+  const double *dgm, *dgc;
+  double* dgrad;
+  if (int rc = stage_in(h, h->s_in2, gmean, (size_t)P, where, &dgm)) return rc;
+  if (int rc = stage_in(h, h->s_out2, gcov, (size_t)P * q, where, &dgc)) return rc;
+  if (int rc = stage_out_prepare(h, h->s_out1, grad, (size_t)P * h->d, where, &dgrad)) return rc;
+  HIPCHK(h, h->s_grad.reserve(((size_t)4 * Npad * Ppad + grad_tail_scratch_doubles(Ppad)) * sizeof(double)));
+  double* B = h->s_grad.as<double>();
+  double* C1 = B + (size_t)Npad * Ppad;
+  double* D = C1 + (size_t)Npad * Ppad;
+  double* Z = D + (size_t)Npad * Ppad;
+  double* part = Z + (size_t)Npad * Ppad;
+  const ModelDev m = model_dev(h);
+  launch_kstar_t(h->stream, m, dXq, P, Ppad, B);
+  if (int rc = gemm_tall(h, false, (int)Npad, (int)Ppad, (int)Npad, 1.0, h->d_W.as<double>(), Npad, B, Ppad, 0.0, C1, Ppad, 3))
+    return rc;
+  launch_joint_mix(h->stream, C1, dgc, P, Ppad, Npad, q, D);
+  if (int rc = gemm_tall(h, false, (int)Npad, (int)Ppad, (int)Npad, 1.0, h->d_A.as<double>(), Npad, D, Ppad, 0.0, Z, Ppad, 5))
+    return rc;
+  launch_joint_vjp_tail(h->stream, m, dXq, P, Ppad, q, B, C1, Z, part, dgm, dgc, dgrad);
+  if (int rc = stage_out_finish(h, dgrad, grad, (size_t)P * h->d, where)) return rc;
+  if (int rc = sync(h)) return rc;
+  HIPCHK(h, hipGetLastError());
+  return TGP_OK;
+}
+
 int tgp_cov_between(tgp_handle h, const double* X1, int64_t P1, const double* X2, int64_t P2, double* out,
                     int where) {
   if (!h) return TGP_ERR_ARG;

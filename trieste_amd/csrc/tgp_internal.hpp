@@ -151,6 +151,10 @@ void launch_kstar_t(hipStream_t s, const ModelDev& m, const double* Xq, int64_t 
 size_t predict_small_scratch_doubles(int64_t Ppad);   // `part` of launch_predict_small_tail
 void launch_predict_small_tail(hipStream_t s, const ModelDev& m, int64_t P, int64_t Ppad, const double* B, const double* C1,
                                double* part, double* mean_out, double* var_out);
+void launch_joint_pick(hipStream_t s, const ModelDev& m, const double* Xq, int64_t P, int64_t Ppad, int q, const double* S, double* cov);
+void launch_joint_mix(hipStream_t s, const double* C1, const double* gcov, int64_t P, int64_t Ppad, int64_t Npad, int q, double* D);
+void launch_joint_vjp_tail(hipStream_t s, const ModelDev& m, const double* Xq, int64_t P, int64_t Ppad, int q, const double* B,
+                           const double* C1, const double* Z, double* part, const double* gmean, const double* gcov, double* grad);
 size_t grad_tail_scratch_doubles(int64_t Ppad);   // `part` of launch_grad_tail
 void launch_grad_tail(hipStream_t s, const ModelDev& m, const double* Xq, int64_t P, int64_t Ppad,
                       const double* B, const double* C1, const double* Z, double* part, int acq, double param, double* val,

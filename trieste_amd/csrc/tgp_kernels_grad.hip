@@ -369,9 +369,105 @@ void launch_kstar_t(hipStream_t s, const ModelDev& m, const double* Xq, int64_t 
   hipLaunchKernelGGL(kstar_t_kernel, grid, dim3(256), 0, s, m, Xq, P, Ppad, B);
 }
 
-void launch_grad_tail(hipStream_t s, const ModelDev& m, const double* Xq, int64_t P, int64_t Ppad,
-                      const double* B, const double* C1, const double* Z, double* part, int acq, double param, double* val,
-                      double* grad, const double* samples, int S, double rep_w, double accum) {
+// ---- vector-Jacobian product of predict_joint (round 6): the gradient of qEI for the L-BFGS-B refinement ----------------------
+// phi = sum_i gm_i mean_i + sum_ij gc_ij cov_ij over a group of q points (mean_i = k*_i^T alpha + c, cov_ij = k(x_i, x_j) - c_i^T c_j,
+// c_i = W k*_i; reference interface.py:126-133).  With Gs = gc + gc^T:
+//     d phi / d x_i = (d k*_i / d x_i)^T [gm_i alpha - W^T sum_j Gs_ij c_j] + sum_{j != i} Gs_ij d k(x_i, x_j) / d x_i
+// -- what TF autodiff gives the reference's optimizer (optimizer.py:628-629) through predict_joint, in analytic form.
+// (1) joint_mix_kernel: D[k][p] = sum_{j in group(p)} Gs[p][j] C1[k][j]  (k-major [Npad][Ppad] like C1; padded columns zero);
+// (2) Z' = W^T D by the tall GEMM; (3) grad_partial_kernel with Z' in the place of Z: part[2 + c] = sum_k alpha_k dk_k/dx_c,
+// part[2 + MAX_D + c] = sum_k Z'_k dk_k/dx_c; (4) joint_vjp_finish_kernel adds the partials in order and the group's cross terms.
+__global__ void joint_mix_kernel(const double* __restrict__ C1, const double* __restrict__ gcov, int64_t P, int64_t Ppad,
+                                 int64_t Npad, int q, double* __restrict__ D) {
+  const int64_t p = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int64_t k = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (p >= Ppad || k >= Npad) return;
+  double v = 0.0;
+  if (p < P) {
+    const int64_t g = p / q, i = p - g * q;
+    const double* const G = gcov + (size_t)g * q * q;
+    const double* const row = C1 + k * Ppad + g * q;
+    for (int j = 0; j < q; ++j) v = fma(G[i * q + j] + G[j * q + i], row[j], v);
+  }
+  D[k * Ppad + p] = v;
+}
+
+__global__ __launch_bounds__(64) void joint_vjp_finish_kernel(ModelDev m, const double* __restrict__ Xq, int64_t P,
+                                                              int64_t Ppad, int q, const double* __restrict__ part,
+                                                              const double* __restrict__ gmean,
+                                                              const double* __restrict__ gcov, double* __restrict__ grad) {
+  const int64_t p = blockIdx.x;
+  const int d = m.d, c = threadIdx.x;
+  if (c >= d) return;
+  double sa = 0.0, sz = 0.0;
+  for (int ks = 0; ks < GT_KS; ++ks) {
+    sa += part[((size_t)ks * Ppad + p) * GT_J + 2 + c];
+    sz += part[((size_t)ks * Ppad + p) * GT_J + 2 + MAX_D + c];
+  }
+  double g = gmean[p] * sa - sz;
+  const int64_t grp = p / q, i = p - grp * q;
+  const double* const G = gcov + (size_t)grp * q * q;
+  for (int j = 0; j < q; ++j) {
+    if (j == i) continue;   // k(x, x) = s_f^2: no dependence on x
+    const int64_t pj = grp * q + j;
+    double r2 = 0.0, tc = 0.0;
+    for (int cc = 0; cc < d; ++cc) {
+      const double t = (Xq[p * d + cc] - Xq[pj * d + cc]) / m.ls[cc];
+      r2 = fma(t, t, r2);
+      if (cc == c) tc = t;
+    }
+    const double f1 = 2.0 * kernel_dr2(m.kind, r2, m.variance);
+    g = fma(G[i * q + j] + G[j * q + i], f1 * tc / m.ls[c], g);
+  }
+  grad[p * d + c] = g;
+}
+
+// cov[g][i][j] = k(x_i, x_j) - S[g q + i][g q + j], the diagonal clipped at the floor (reference interface.py:126-133); S = C1^T C1
+// over all the call's points, of which the q x q diagonal blocks are the groups' (the off-diagonal blocks are not read)
+__global__ void joint_pick_kernel(ModelDev m, const double* __restrict__ Xq, int64_t P, int64_t Ppad, int q,
+                                  const double* __restrict__ S, double* __restrict__ cov) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= P * q) return;
+  const int64_t p = e / q, j = e - p * q, g = p / q, pj = g * q + j;
+  double v;
+  if (pj == p) {
+    v = fmax(m.variance - S[p * Ppad + p], VAR_FLOOR);
+  } else {
+    double r2 = 0.0;
+    for (int c = 0; c < m.d; ++c) {
+      const double t = (Xq[p * m.d + c] - Xq[pj * m.d + c]) / m.ls[c];
+      r2 = fma(t, t, r2);
+    }
+    // (the product's two triangles agree to rounding only: read the lower one for both, as the joint kernel's halves are identical)
+    const int64_t a = p > pj ? p : pj, b = p > pj ? pj : p;
+    v = kernel_rt(m.kind, r2, m.variance) - S[a * Ppad + b];
+  }
+  cov[e] = v;
+}
+
+void launch_joint_pick(hipStream_t s, const ModelDev& m, const double* Xq, int64_t P, int64_t Ppad, int q, const double* S,
+                       double* cov) {
+  hipLaunchKernelGGL(joint_pick_kernel, dim3((unsigned)((P * q + 255) / 256)), dim3(256), 0, s, m, Xq, P, Ppad, q, S, cov);
+}
+
+void launch_joint_mix(hipStream_t s, const double* C1, const double* gcov, int64_t P, int64_t Ppad, int64_t Npad, int q,
+                      double* D) {
+  dim3 grid((unsigned)(Ppad / 64), (unsigned)(Npad / 4));
+  hipLaunchKernelGGL(joint_mix_kernel, grid, dim3(256), 0, s, C1, gcov, P, Ppad, Npad, q, D);
+}
+
+static void launch_grad_partial(hipStream_t s, const ModelDev& m, const double* Xq, int64_t P, int64_t Ppad, const double* B,
+                                const double* C1, const double* Z, double* part);
+
+void launch_joint_vjp_tail(hipStream_t s, const ModelDev& m, const double* Xq, int64_t P, int64_t Ppad, int q, const double* B,
+                           const double* C1, const double* Z, double* part, const double* gmean, const double* gcov,
+                           double* grad) {
+  launch_grad_partial(s, m, Xq, P, Ppad, B, C1, Z, part);
+  hipLaunchKernelGGL(joint_vjp_finish_kernel, dim3((unsigned)P), dim3(64), 0, s, m, Xq, P, Ppad, q, part, gmean, gcov, grad);
+}
+
+static void launch_grad_partial(hipStream_t s, const ModelDev& m, const double* Xq, int64_t P, int64_t Ppad, const double* B,
+                                const double* C1, const double* Z, double* part) {
   const dim3 grid((unsigned)(Ppad / 16), (unsigned)GT_KS);
   if (m.dp == 2) hipLaunchKernelGGL(grad_partial_kernel<2>, grid, dim3(GT_THREADS), 0, s, m, Xq, P, Ppad, B, C1, Z, part);
   else if (m.dp == 4) hipLaunchKernelGGL(grad_partial_kernel<4>, grid, dim3(GT_THREADS), 0, s, m, Xq, P, Ppad, B, C1, Z, part);
@@ -379,6 +475,12 @@ void launch_grad_tail(hipStream_t s, const ModelDev& m, const double* Xq, int64_
   else if (m.dp == 8) hipLaunchKernelGGL(grad_partial_kernel<8>, grid, dim3(GT_THREADS), 0, s, m, Xq, P, Ppad, B, C1, Z, part);
   else if (m.dp == 16) hipLaunchKernelGGL(grad_partial_kernel<16>, grid, dim3(GT_THREADS), 0, s, m, Xq, P, Ppad, B, C1, Z, part);
   else hipLaunchKernelGGL(grad_partial_kernel<32>, grid, dim3(GT_THREADS), 0, s, m, Xq, P, Ppad, B, C1, Z, part);
+}
+
+void launch_grad_tail(hipStream_t s, const ModelDev& m, const double* Xq, int64_t P, int64_t Ppad,
+                      const double* B, const double* C1, const double* Z, double* part, int acq, double param, double* val,
+                      double* grad, const double* samples, int S, double rep_w, double accum) {
+  launch_grad_partial(s, m, Xq, P, Ppad, B, C1, Z, part);
   hipLaunchKernelGGL(grad_finish_kernel, dim3((unsigned)P), dim3(128), 0, s, m, P, Ppad, part, acq, param,
                      samples, S, rep_w, accum, val, grad);
 }

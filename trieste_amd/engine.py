@@ -478,6 +478,41 @@ class GPEngine:
                                     a.where))
         return out
 
+    JOINT_SMALL_POINTS = 2048   # tgp_joint_forward / tgp_joint_vjp: points (groups x q) per call
+
+    def _joint_small(self, Xq):
+        a = _Arg(Xq)
+        if len(a.shape) != 3 or a.shape[-1] != self.d:
+            raise ValueError(f"batch query points must be [G, q, {self.d}], got {a.shape}")
+        G, q = a.shape[0], a.shape[1]
+        if G * q > self.JOINT_SMALL_POINTS:
+            raise ValueError(f"{G} groups of {q} points: at most {self.JOINT_SMALL_POINTS} points per call (chunk the groups)")
+        return a, G, q
+
+    def joint_forward(self, Xq):
+        """Xq [G, q, d] (G * q <= 2048) -> mean [G, q], cov [G, q, q]: ``predict_joint`` of the handful of q-batches an
+        L-BFGS-B iteration holds, as a skinny product (tgp_joint_forward)."""
+        a, G, q = self._joint_small(Xq)
+        mean, pm = self._out(a, (G, q))
+        cov, pc = self._out(a, (G, q, q))
+        if G:
+            self._chk(self._lib.tgp_joint_forward(self._h, a.ptr, G, q, pm, pc, a.where))
+        return mean, cov
+
+    def joint_vjp(self, Xq, gmean, gcov):
+        """d/dXq [G, q, d] of sum gmean * mean + sum gcov * cov (tgp_joint_vjp): the engine's share of a batch acquisition
+        function's gradient."""
+        a, G, q = self._joint_small(Xq)
+        gm, gc = _Arg(gmean), _Arg(gcov)
+        if gm.shape != (G, q) or gc.shape != (G, q, q):
+            raise ValueError(f"gmean must be [{G}, {q}] and gcov [{G}, {q}, {q}], got {gm.shape} and {gc.shape}")
+        if gm.where != a.where or gc.where != a.where:
+            raise ValueError("Xq, gmean and gcov must live in the same place (all host or all device)")
+        grad, pg = self._out(a, (G, q, self.d))
+        if G:
+            self._chk(self._lib.tgp_joint_vjp(self._h, a.ptr, G, q, gm.ptr, gc.ptr, pg, a.where))
+        return grad
+
     def reparam_samples(self, Xq, eps, jitter: float = 1e-6):
         """Xq [..., q, d], eps [q, S] -> samples [..., S, q]."""
         a = _Arg(Xq)
