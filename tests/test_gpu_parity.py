@@ -491,6 +491,15 @@ def test_joint_forward_and_vjp_of_a_handful_of_batches_match_the_oracle(cfg):
         gscale = np.abs(want).max() + 1e-300
         assert_close(got, want, rtol=1e-5, atol=max(floor * 1e3 * q, 1e-9 * gscale), what=f"joint_vjp q={q} G={G}")
         np.testing.assert_array_equal(eng.joint_vjp(Xg, gm, gc), got)   # a fixed summation order: bit-identical call to call
+    # device-resident arguments (torch tensors on the GPU): the same bits as the host-buffer call
+    import torch
+    Xd, gmd, gcd = (torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (Xg, gm, gc))
+    jmd, jcd = eng.joint_forward(Xd)
+    np.testing.assert_array_equal(jmd.cpu().numpy(), jm)
+    np.testing.assert_array_equal(jcd.cpu().numpy(), jc)
+    np.testing.assert_array_equal(eng.joint_vjp(Xd, gmd, gcd).cpu().numpy(), got)
+    with pytest.raises(ValueError):
+        eng.joint_vjp(Xd, gm, gc)   # mixed residency
     with pytest.raises(ValueError):
         eng.joint_forward(rng.uniform(size=(41, 50, d)))
     from trieste_amd import _lib
