@@ -268,10 +268,18 @@ int tgp_reparam_samples(tgp_handle h, const double* Xq, int64_t G, int q, const 
  *     built for 10^5 groups; any q, G * q <= 2048 per call;
  *   tgp_joint_vjp: grad [G,q,d] = d/dXq of  sum_gi gmean[g,i] mean[g,i] + sum_gij gcov[g,i,j] cov[g,i,j]  (gcov need not be
  *     symmetric: both triangles of cov count as written; a clipped diagonal entry has zero gradient at the caller: pass 0).
- * The q x q factorisation and its adjoint in between are the caller's (host) arithmetic.  TGP_ERR_SHAPE beyond 2048 points. */
+ *     With these two the q x q factorisation and its adjoint in between are the caller's (host) arithmetic.  TGP_ERR_SHAPE
+ *     beyond 2048 points.
+ *   tgp_qei_value_grad: both of them with the q x q arithmetic in between ON THE DEVICE -- val [G] = qEI (tgp_qei's value), grad
+ *     [G,q,d] = its gradient w.r.t. Xq for eps [q,S], eta, jitter: one wave per group factorises cov + jitter I, draws the samples,
+ *     accumulates the adjoints of mean and factor and applies the Cholesky adjoint; one call, one synchronisation.  q <= 64,
+ *     G * q <= 2048, 8 (2 q (q|1) + 128) + 4 S bytes of LDS <= 160 KiB (S <= ~23 000 at q = 64), else TGP_ERR_SHAPE: the pair
+ *     above takes any q and S.  TGP_ERR_NOT_PD as tgp_qei. */
 int tgp_joint_forward(tgp_handle h, const double* Xq, int64_t G, int q, double* mean, double* cov, int where);
 int tgp_joint_vjp(tgp_handle h, const double* Xq, int64_t G, int q, const double* gmean, const double* gcov, double* grad,
                   int where);
+int tgp_qei_value_grad(tgp_handle h, const double* Xq, int64_t G, int q, const double* eps, int S, double eta, double jitter,
+                       double* val, double* grad, int where);
 
 /* == GaussianProcessRegression.covariance_between_points_encoded (models/gpflow/models.py:188-254):
  * out [P1,P2] = k(X1, X2) - (L^-1 k(X, X1))^T (L^-1 k(X, X2)); no clipping (the reference applies

@@ -419,6 +419,13 @@ class FakeEngine:
     def joint_forward(self, Xq):
         return O.predict_joint(self._st(), np.asarray(Xq, float))
 
+    @staticmethod
+    def qei_value_grad_fits(q, S):
+        return False   # the CPU tests exercise the host adjoint (joint_forward + joint_vjp), not a second oracle call
+
+    def qei_value_grad(self, Xq, eps, eta, jitter=1e-6):
+        return O.batch_mc_ei_value_and_grad(self._st(), np.asarray(Xq, float), np.asarray(eps, float), eta, jitter)
+
     def joint_vjp(self, Xq, gmean, gcov):
         """The engine's vector-Jacobian product of predict_joint on dense numpy arrays (K^-1 formed explicitly)."""
         st = self._st()

@@ -510,7 +510,7 @@ def test_joint_forward_and_vjp_of_a_handful_of_batches_match_the_oracle(cfg):
 
 
 @pytest.mark.parametrize("cfg", [CONFIGS[0], CONFIGS[1], CONFIGS[2], CONFIGS[4]], ids=lambda c: c[0])
-def test_qei_value_and_gradient_match_the_oracle(cfg):
+def test_qei_value_and_gradient_match_the_oracle(cfg, monkeypatch):
     """The gradient of BatchMonteCarloExpectedImprovement w.r.t. the batch points as the host layer assembles it (engine:
     joint_forward + joint_vjp; host: q x q factorisations, sample reduction, Cholesky adjoint) against the oracle's FORWARD-mode
     derivative of the reference's computation (predict_joint -> cholesky -> reparametrised samples -> mean of max(eta - min, 0):
@@ -522,7 +522,7 @@ def test_qei_value_and_gradient_match_the_oracle(cfg):
     floor = cancellation_floor(N, 1.0, noise)
     eng = _engine(kind, d, 1.0, ls, noise, c, X, Y)
     rng = np.random.default_rng(23)
-    for q, G, S in ((1, 6, 32), (3, 5, 64), (7, 3, 48)):
+    for q, G, S in ((1, 6, 32), (3, 5, 64), (7, 3, 48), (9, 40, 70), (17, 4, 130), (33, 2, 64), (50, 2, 96), (64, 2, 33)):
         Xg = rng.uniform(size=(G, q, d))
         eps = rng.normal(size=(q, S))
         eta = float(np.median(O.predict_joint(st, Xg)[0]))
@@ -534,13 +534,24 @@ def test_qei_value_and_gradient_match_the_oracle(cfg):
 
         fn = batch_monte_carlo_expected_improvement.__new__(batch_monte_carlo_expected_improvement)
         fn._engine, fn._sampler, fn._eta, fn._jitter, fn._sample_size = eng, _Sampler(), eta, 1e-6, S
-        val, grad = fn.value_and_gradient(Xg)
+        val, grad = fn.value_and_gradient(Xg)                      # tgp_qei_value_grad: the q x q arithmetic on the device too
+        assert eng.qei_value_grad_fits(q, S)
+        np.testing.assert_array_equal(fn.value_and_gradient(Xg)[1], grad)   # no atomics: bit-identical call to call
+        monkeypatch.setattr(type(eng), "qei_value_grad_fits", staticmethod(lambda q_, S_: False))
+        hval, hgrad = fn.value_and_gradient(Xg)                    # tgp_joint_forward + the HOST's adjoint + tgp_joint_vjp
+        monkeypatch.undo()
         oval, ograd = O.batch_mc_ei_value_and_grad(st, Xg, eps, eta, 1e-6)
+        assert_close(hval, oval, atol=floor, what=f"qEI value (host adjoint) q={q}")
+        assert_close(hgrad, ograd, rtol=1e-5, atol=max(floor * 1e3 * q, 1e-7 * (np.abs(ograd).max() + 1e-300)),
+                     what=f"qEI gradient (host adjoint) q={q}")
         assert np.count_nonzero(oval) >= oval.size // 2, f"vacuous qEI comparison at q={q}: {oval}"
         assert_close(val, oval, atol=floor, what=f"qEI value q={q}")
         assert_close(val, eng.qei(Xg, eps, eta, 1e-6), atol=floor, what=f"qEI value == tgp_qei q={q}")
         gscale = np.abs(ograd).max() + 1e-300
         assert_close(grad, ograd, rtol=1e-5, atol=max(floor * 1e3 * q, 1e-7 * gscale), what=f"qEI gradient q={q}")
+    assert not eng.qei_value_grad_fits(64, 30000) and not eng.qei_value_grad_fits(65, 8)
+    with pytest.raises(ValueError):   # the tail's LDS holds 8 (2 q (q|1) + 128) + 4 S bytes: the shape error of the C-ABI, not a fault
+        eng.qei_value_grad(rng.uniform(size=(2, 64, d)), rng.normal(size=(64, 30000)), 0.0, 1e-6)
 
 
 @pytest.mark.parametrize("cfg", CONFIGS[:5], ids=[c[0] for c in CONFIGS[:5]])

@@ -70,6 +70,7 @@ SIGNATURES = {
     "tgp_cov_between": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int]),
     "tgp_joint_forward": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, C.c_int]),
     "tgp_joint_vjp": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp, C.c_int]),
+    "tgp_qei_value_grad": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, C.c_int, C.c_double, C.c_double, _vp, _vp, C.c_int]),
     "tgp_traj_argmin": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, _vp, _vp, C.c_int]),
     "tgp_acq_argmax_async": (C.c_int, [_vp, C.c_int, C.c_double, _vp, C.c_int64, C.c_int64, _vp]),
     "tgp_traj_argmin_async": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, _vp]),

@@ -298,8 +298,13 @@ class batch_monte_carlo_expected_improvement(AcquisitionFunctionClass):
         values, grads = np.empty(P), np.empty(x.shape)
         chunk = max(1, getattr(self._engine, "JOINT_SMALL_POINTS", 2048) // q)
         eye = np.eye(q)
+        on_device = hasattr(self._engine, "qei_value_grad") and self._engine.qei_value_grad_fits(q, S)
         for g0 in range(0, P, chunk):
             xs = x[g0:g0 + chunk]
+            if on_device:   # the q x q arithmetic below on the device as well (one wave per group): one call per chunk
+                v, g_ = self._engine.qei_value_grad(xs, eps, self._eta, self._jitter)
+                values[g0:g0 + chunk], grads[g0:g0 + chunk] = np.asarray(v), np.asarray(g_)
+                continue
             mean, cov = (np.asarray(a) for a in self._engine.joint_forward(xs))         # [g, q], [g, q, q]
             g = mean.shape[0]
             clipped = np.diagonal(cov, axis1=-2, axis2=-1) <= 1e-12                     # (clip_by_value: zero gradient)

@@ -2099,6 +2099,65 @@ int tgp_joint_vjp(tgp_handle h, const double* Xq, int64_t G, int q, const double
   return TGP_OK;
 }
 
+// qEI value and gradient of a handful of q-batches in ONE call, everything on the device: tgp_joint_forward's arrays -> the
+// one-wave-per-group tail (factorisation, samples, value, the adjoints of mean and covariance: qei_grad_tail_kernel) -> tgp_joint_vjp's
+// second half on the SAME K*^T and W K*.  One host synchronisation.  q <= 64, G * q <= 2048, the tail's LDS holds S sample slots.
+int tgp_qei_value_grad(tgp_handle h, const double* Xq, int64_t G, int q, const double* eps, int S, double eta, double jitter,
+                       double* val, double* grad, int where) {
+  if (!h) return TGP_ERR_ARG;
+  if (!(jitter >= 0.0)) return fail(h, TGP_ERR_ARG, "jitter must be >= 0");
+  if (S < 1 || !eps) return fail(h, TGP_ERR_ARG, "need S >= 1 draws");
+  if (!val || !grad) return fail(h, TGP_ERR_ARG, "val / grad is NULL");
+  if (q > MAX_Q) return fail(h, TGP_ERR_SHAPE, "q must be in 1..%d, got %d", MAX_Q, q);
+  if (q >= 1 && qei_grad_tail_lds_bytes(q, S) > (size_t)160 * 1024)
+    return fail(h, TGP_ERR_SHAPE, "q = %d with S = %d draws does not fit the tail's LDS (tgp_joint_forward / tgp_joint_vjp take any S)", q, S);
+  const double* dXq;
+  int64_t P, Ppad;
+  if (int rc = joint_small_common(h, Xq, G, q, where, &dXq, &P, &Ppad)) return rc;
+  const int64_t Npad = h->Npad;
+  const double* deps;
+  double *dval, *dgrad;
+  if (int rc = stage_in(h, h->s_in2, eps, (size_t)q * S, where, &deps)) return rc;
+  if (int rc = stage_out_prepare(h, h->s_out1, val, (size_t)G, where, &dval)) return rc;
+  if (int rc = stage_out_prepare(h, h->s_out2, grad, (size_t)P * h->d, where, &dgrad)) return rc;
+  const size_t part_doubles = std::max(predict_small_scratch_doubles(Ppad), grad_tail_scratch_doubles(Ppad));
+  HIPCHK(h, h->s_grad.reserve(((size_t)4 * Npad * Ppad + (size_t)Ppad * Ppad + part_doubles + (size_t)2 * P * (1 + q)) * sizeof(double)));
+  double* B = h->s_grad.as<double>();
+  double* C1 = B + (size_t)Npad * Ppad;
+  double* T1 = C1 + (size_t)Npad * Ppad;   // C1^T, then D
+  double* Z = T1 + (size_t)Npad * Ppad;
+  double* Spp = Z + (size_t)Npad * Ppad;
+  double* part = Spp + (size_t)Ppad * Ppad;
+  double* dmean = part + part_doubles;
+  double* dcov = dmean + P;
+  double* dgm = dcov + (size_t)P * q;
+  double* dgc = dgm + P;
+  const ModelDev m = model_dev(h);
+  HIPCHK(h, h->d_info.reserve(sizeof(int)));
+  HIPCHK(h, hipMemsetAsync(h->d_info.p, 0, sizeof(int), h->stream));
+  launch_kstar_t(h->stream, m, dXq, P, Ppad, B);
+  if (int rc = gemm_tall(h, false, (int)Npad, (int)Ppad, (int)Npad, 1.0, h->d_W.as<double>(), Npad, B, Ppad, 0.0, C1, Ppad, 3))
+    return rc;
+  launch_transpose(h->stream, C1, Npad, Ppad, Ppad, T1, Npad);
+  if (int rc = gemm_tall(h, false, (int)Ppad, (int)Ppad, (int)Npad, 1.0, T1, Npad, C1, Ppad, 0.0, Spp, Ppad, 0)) return rc;
+  launch_predict_small_tail(h->stream, m, P, Ppad, B, C1, part, dmean, nullptr);
+  launch_joint_pick(h->stream, m, dXq, P, Ppad, q, Spp, dcov);
+  launch_qei_grad_tail(h->stream, dmean, dcov, G, q, deps, S, eta, jitter, dval, dgm, dgc, h->d_info.as<int>());
+  launch_joint_mix(h->stream, C1, dgc, P, Ppad, Npad, q, T1);
+  if (int rc = gemm_tall(h, false, (int)Npad, (int)Ppad, (int)Npad, 1.0, h->d_A.as<double>(), Npad, T1, Ppad, 0.0, Z, Ppad, 5))
+    return rc;
+  launch_joint_vjp_tail(h->stream, m, dXq, P, Ppad, q, B, C1, Z, part, dgm, dgc, dgrad);
+  if (int rc = stage_out_finish(h, dval, val, (size_t)G, where)) return rc;
+  if (int rc = stage_out_finish(h, dgrad, grad, (size_t)P * h->d, where)) return rc;
+  if (int rc = sync(h)) return rc;
+  int info = 0;
+  HIPCHK(h, hipMemcpy(&info, h->d_info.p, sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(h, hipGetLastError());
+  if (info != 0)
+    return fail(h, TGP_ERR_NOT_PD, "qEI: cov + jitter*I not positive definite for group %d", info - 1);
+  return TGP_OK;
+}
+
 int tgp_cov_between(tgp_handle h, const double* X1, int64_t P1, const double* X2, int64_t P2, double* out,
                     int where) {
   if (!h) return TGP_ERR_ARG;

@@ -146,6 +146,9 @@ void launch_sample_box(hipStream_t s, uint64_t seed, int64_t first, int64_t M, i
 void launch_qei_tail(hipStream_t s, const double* mean, const double* cov, int64_t G, int q,
                      const double* eps, int S, double eta, double jitter, double* out, double* samples_out,
                      int* info);
+size_t qei_grad_tail_lds_bytes(int q, int S);
+void launch_qei_grad_tail(hipStream_t s, const double* mean, const double* cov, int64_t G, int q, const double* eps, int S,
+                          double eta, double jitter, double* val, double* gmean, double* gcov, int* info);
 // gradients (tgp_kernels_grad.hip)
 void launch_kstar_t(hipStream_t s, const ModelDev& m, const double* Xq, int64_t P, int64_t Ppad, double* B);
 size_t predict_small_scratch_doubles(int64_t Ppad);   // `part` of launch_predict_small_tail

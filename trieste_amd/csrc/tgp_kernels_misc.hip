@@ -626,6 +626,169 @@ void launch_qei_tail(hipStream_t s, const double* mean, const double* cov, int64
   else launch_qei_tail_qp<MAX_Q>(s, mean, cov, G, q, eps, S, eta, jitter, out, samples_out, info);
 }
 
+// ---------------------------------------------------------------------------------------------
+// qEI AND its adjoints w.r.t. (mean, cov), ONE WAVE per group (round 6; the gradient of BatchMonteCarloExpectedImprovement for the
+// L-BFGS-B refinement of a joint batch: reference optimizer.py:628-629 through sampler.py:276-287 and function.py:1183-1186):
+//   L = chol(cov + jitter I);  f_s = mean + L eps[:, s];  value = mean_s max(eta - min_i f_s,i, 0)
+//   d value / d f_s,i = -1/S  where i is the (first) arg-min of an improving sample  ->  gmean_i = sum_s ...,  Lbar = tril(sum_s df_s eps_s^T)
+//   gcov = L^-T sym(Phi(L^T Lbar)) L^-1   (the Cholesky adjoint; Phi: lower triangle, diagonal halved), a clipped diagonal entry of
+//   cov (interface.py:129-131: tf.clip_by_value) gets zero.
+// Factorisation and samples as in qei_tail_kernel (same arithmetic, operation for operation: the value is tgp_qei's); every later
+// phase gives lane c column c (or row r) of the q x q work matrix in LDS -- fixed summation orders, no atomics: bit-identical
+// run to run.  q x q arithmetic per group, 10 ... 300 groups per call: none of it is a roofline item.
+template <int QP>
+__global__ __launch_bounds__(64) void qei_grad_tail_kernel(const double* __restrict__ mean, const double* __restrict__ cov,
+                                                           int64_t G, int q, const double* __restrict__ eps, int S, double eta,
+                                                           double jitter, double* __restrict__ val,
+                                                           double* __restrict__ gmean, double* __restrict__ gcov,
+                                                           int* __restrict__ info) {
+  extern __shared__ double qei_lds[];
+  const int64_t g = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int ldq = q | 1;  // odd row stride
+  double* const Ls = qei_lds;                    // [q][ldq] (+ QP of slack, as in qei_tail_kernel)
+  double* const Ms = Ls + q * ldq + QP;          // [q][ldq]: Lbar -> Q -> R -> L^-T R -> gcov, in place
+  double* const mu = Ms + q * ldq;               // [QP]
+  int* const jm = (int*)(mu + QP);               // [S]: arg-min row of an improving sample, -1 otherwise
+  auto bcast = [](double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+  };
+  const bool live = lane < q;
+  double* const Lrow = Ls + (live ? lane : 0) * ldq;
+  bool clipped = false;
+  if (live) {
+    const double* const crow = cov + (g * q + lane) * q;
+    for (int k = 0; k < q; ++k) Lrow[k] = crow[k] + (k == lane ? jitter : 0.0);
+    clipped = !(crow[lane] > VAR_FLOOR);
+    mu[lane] = mean[g * q + lane];
+    for (int i = 0; i < q; ++i) Ms[i * ldq + lane] = 0.0;
+  }
+  for (int j = 0; j < q; ++j) {
+    const double x = Lrow[j];
+    double dj = bcast(x, j);
+    if (!(dj > 0.0)) {
+      if (lane == 0) atomicCAS(info, 0, (int)(g % 2000000000) + 1);
+      dj = 1.0;
+    }
+    const double sd = sqrt(dj);
+    const double lij = lane == j ? sd : x / sd;
+    const bool below = live && lane > j;
+    if (live && lane >= j) Lrow[j] = lij;
+    const double nl = -lij;
+    for (int k = j + 1; k < q; ++k) {
+      const double lkj = bcast(lij, k);
+      if (below) Lrow[k] = fma(nl, lkj, Lrow[k]);
+    }
+  }
+  __syncthreads();
+  constexpr int RG = 2;
+  double acc = 0.0;
+  for (int s0 = 0; s0 < S; s0 += 64) {
+    const int s = s0 + lane;
+    const bool valid = s < S;
+    double er[QP];
+#pragma unroll
+    for (int k = 0; k < QP; ++k) er[k] = (k < q && valid) ? eps[(int64_t)k * S + s] : 0.0;
+    double mn = INFINITY;
+    int jmin = 0;
+#pragma unroll
+    for (int j0 = 0; j0 < QP; j0 += RG) {
+      if (j0 < q) {  // (wave-uniform)
+        double v[RG];
+        const double* Lj[RG];
+#pragma unroll
+        for (int r = 0; r < RG; ++r) {
+          const int j = j0 + r < q ? j0 + r : q - 1;
+          Lj[r] = Ls + j * ldq;
+          v[r] = mu[j];
+        }
+#pragma unroll
+        for (int k = 0; k < j0 + RG; ++k)
+#pragma unroll
+          for (int r = 0; r < RG; ++r)
+            if (k <= j0 + r) v[r] = fma(Lj[r][k], er[k], v[r]);
+#pragma unroll
+        for (int r = 0; r < RG; ++r)
+          if (j0 + r < q && v[r] < mn) {  // strict: the first index on ties
+            mn = v[r];
+            jmin = j0 + r;
+          }
+      }
+    }
+    const double imp = eta - mn;
+    if (valid) {
+      acc += fmax(imp, 0.0);
+      jm[s] = imp > 0.0 ? jmin : -1;
+    }
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) val[g] = acc / (double)S;
+  __syncthreads();
+  // Lbar (lower triangle) and gmean: lane c owns column c; the samples in order
+  const double ninv = -1.0 / (double)S;
+  if (live) {
+    int cnt = 0;
+    const double* const ec = eps + (int64_t)lane * S;
+    for (int s = 0; s < S; ++s) {
+      const int i = jm[s];  // (wave-uniform)
+      if (i < 0) continue;
+      if (i == lane) ++cnt;
+      if (i >= lane) Ms[i * ldq + lane] += ec[s];
+    }
+    gmean[g * q + lane] = ninv * (double)cnt;
+    // Q = tril(L^T Lbar) in place, column c: Q[a][c] = sum_{k >= a} L[k][a] Lbar[k][c]  (rows ascending: row a is read before it
+    // is written and never again), then R's lower triangle = Q / 2 (Phi halves the diagonal, sym the rest)
+    for (int a = lane; a < q; ++a) {
+      double t = 0.0;
+      for (int k = a; k < q; ++k) t = fma(Ls[k * ldq + a], ninv * Ms[k * ldq + lane], t);
+      Ms[a * ldq + lane] = 0.5 * t;
+    }
+  }
+  __syncthreads();
+  if (live)
+    for (int a = 0; a < lane; ++a) Ms[a * ldq + lane] = Ms[lane * ldq + a];  // R = R^T
+  __syncthreads();
+  if (live)  // Y = L^-T R: back substitution down column c
+    for (int a = q - 1; a >= 0; --a) {
+      double t = Ms[a * ldq + lane];
+      for (int k = a + 1; k < q; ++k) t = fma(-Ls[k * ldq + a], Ms[k * ldq + lane], t);
+      Ms[a * ldq + lane] = t / Ls[a * ldq + a];
+    }
+  __syncthreads();
+  if (live) {  // gcov = Y L^-1: back substitution along row r
+    double* const row = Ms + lane * ldq;
+    for (int a = q - 1; a >= 0; --a) {
+      double t = row[a];
+      for (int k = a + 1; k < q; ++k) t = fma(-Ls[k * ldq + a], row[k], t);
+      row[a] = t / Ls[a * ldq + a];
+    }
+    if (clipped) row[lane] = 0.0;
+  }
+  __syncthreads();
+  if (live)
+    for (int r = 0; r < q; ++r) gcov[(g * q + r) * q + lane] = Ms[r * ldq + lane];
+}
+template <int QP>
+static void launch_qei_grad_tail_qp(hipStream_t s, const double* mean, const double* cov, int64_t G, int q, const double* eps,
+                                    int S, double eta, double jitter, double* val, double* gmean, double* gcov, int* info) {
+  const size_t lds = (size_t)(2 * q * (q | 1) + 2 * QP) * sizeof(double) + (size_t)((S + 1) & ~1) * sizeof(int);
+  (void)hipFuncSetAttribute((const void*)qei_grad_tail_kernel<QP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL(qei_grad_tail_kernel<QP>, dim3((unsigned)G), dim3(64), lds, s, mean, cov, G, q, eps, S, eta, jitter, val,
+                     gmean, gcov, info);
+}
+size_t qei_grad_tail_lds_bytes(int q, int S) {
+  return (size_t)(2 * q * (q | 1) + 2 * MAX_Q) * sizeof(double) + (size_t)((S + 1) & ~1) * sizeof(int);
+}
+void launch_qei_grad_tail(hipStream_t s, const double* mean, const double* cov, int64_t G, int q, const double* eps, int S,
+                          double eta, double jitter, double* val, double* gmean, double* gcov, int* info) {
+  if (q <= 8) launch_qei_grad_tail_qp<8>(s, mean, cov, G, q, eps, S, eta, jitter, val, gmean, gcov, info);
+  else if (q <= 16) launch_qei_grad_tail_qp<16>(s, mean, cov, G, q, eps, S, eta, jitter, val, gmean, gcov, info);
+  else if (q <= 32) launch_qei_grad_tail_qp<32>(s, mean, cov, G, q, eps, S, eta, jitter, val, gmean, gcov, info);
+  else launch_qei_grad_tail_qp<MAX_Q>(s, mean, cov, G, q, eps, S, eta, jitter, val, gmean, gcov, info);
+}
+
 // final arg-min over per-workgroup partials for B trajectories: one workgroup per trajectory.
 __global__ __launch_bounds__(256) void argmin_final_multi_kernel(const double* __restrict__ bv,
                                                                  const int64_t* __restrict__ bi,

@@ -513,6 +513,27 @@ class GPEngine:
             self._chk(self._lib.tgp_joint_vjp(self._h, a.ptr, G, q, gm.ptr, gc.ptr, pg, a.where))
         return grad
 
+    @staticmethod
+    def qei_value_grad_fits(q: int, S: int) -> bool:
+        """Does tgp_qei_value_grad take groups of q points with S draws (one wave per group, everything in LDS)?"""
+        return 1 <= q <= 64 and 8 * (2 * q * (q | 1) + 128) + 4 * ((S + 1) & ~1) <= 160 * 1024
+
+    def qei_value_grad(self, Xq, eps, eta: float, jitter: float = 1e-6):
+        """Xq [G, q, d] (G * q <= 2048, q <= 64), eps [q, S] -> (qEI [G], gradient [G, q, d]) in one device call
+        (tgp_qei_value_grad)."""
+        a, G, q = self._joint_small(Xq)
+        e = _Arg(eps)
+        if len(e.shape) != 2 or e.shape[0] != q:
+            raise ValueError(f"eps must be [q={q}, S], got {e.shape}")
+        if e.where != a.where:
+            raise ValueError("Xq and eps must live in the same place (both host or both device)")
+        val, pv = self._out(a, (G,))
+        grad, pg = self._out(a, (G, q, self.d))
+        if G:
+            self._chk(self._lib.tgp_qei_value_grad(self._h, a.ptr, G, q, e.ptr, e.shape[1], float(eta), float(jitter), pv, pg,
+                                                   a.where))
+        return val, grad
+
     def reparam_samples(self, Xq, eps, jitter: float = 1e-6):
         """Xq [..., q, d], eps [q, S] -> samples [..., S, q]."""
         a = _Arg(Xq)
