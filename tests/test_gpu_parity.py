@@ -274,7 +274,7 @@ _sample_atol = reparam_sample_atol
 WIDE = load_wide_qei_goldens()
 
 
-@pytest.mark.parametrize("variant", [0, 4], ids=["packed-128x256", "slots-256x128"])
+@pytest.mark.parametrize("variant", [0, 1024, 4], ids=["skinny-product", "packed-128x256", "slots-256x128"])
 @pytest.mark.parametrize("c", WIDE, ids=[c["name"] for c in WIDE])
 def test_engine_wide_qei_matches_mpmath_goldens(c, variant):
     """The engine against 50-digit arithmetic at q = 9, 17, 33, 50 -- every instantiation of the one-wave qEI tail
@@ -295,10 +295,11 @@ def test_engine_wide_qei_matches_mpmath_goldens(c, variant):
     assert_close(eng.qei(Xg, eps, c["eta"], c["jitter"]), want, atol=atol, what=f"golden qEI q={c['q']}")
 
 
-@pytest.mark.parametrize("variant", [0, 4], ids=["packed-128x256", "slots-256x128"])
+@pytest.mark.parametrize("variant", [0, 1024, 4], ids=["skinny-product", "packed-128x256", "slots-256x128"])
 @pytest.mark.parametrize("cfg", [CONFIGS[1], CONFIGS[2], CONFIGS[4]], ids=lambda c: c[0])
 def test_joint_and_qei_match_oracle(cfg, variant):
-    """Joint mode on both kernels: contiguously packed groups in 128 x 256 tiles with the LDS Gram phase (default,
+    """(Round 6: a call of <= 2048 points takes the skinny-product form of tgp_joint_forward by default; variant bit 10 keeps the
+    joint kernel for it, so that every case below still runs on all three.)  Joint mode on both kernels: contiguously packed groups in 128 x 256 tiles with the LDS Gram phase (default,
     dp <= 16) and the first-generation 64-column slots (variant bit 2).  Group counts around the block capacity
     (floor(256 / q) groups per block), q from 1 to 64, a group starting at a training input."""
     _, obj, d, kind, N, noise = cfg
@@ -482,7 +483,9 @@ def test_joint_forward_and_vjp_of_a_handful_of_batches_match_the_oracle(cfg):
         assert_close(jc[:, dg, dg], oc[:, dg, dg], atol=floor, what=f"joint_forward variances q={q} G={G}")
         np.testing.assert_array_equal(jc, np.swapaxes(jc, -1, -2))   # both triangles from one entry of the product
         if q <= 64:
+            eng.set_variant(1024)   # the joint kernel itself (a call this small takes the skinny product by default)
             km, kc = eng.predict_joint(Xg)
+            eng.set_variant(0)
             assert_close(jm, km, atol=floor * 10, what="joint_forward mean vs the joint kernel")
             assert_close(jc, kc, atol=floor * 10, what="joint_forward cov vs the joint kernel")
         gm, gc = rng.normal(size=(G, q)), rng.normal(size=(G, q, q))

@@ -32,8 +32,11 @@ for G in (10, 60, 300):
     G = min(G, 2048 // q)
     xs = rng.uniform(size=(G, q, d))
     gm, gc = rng.normal(size=(G, q)), rng.normal(size=(G, q, q))
-    print(f"N={N} q={q} G={G}: joint_forward {t(lambda: eng.joint_forward(xs)):.2f} ms, predict_joint (joint kernel) "
-          f"{t(lambda: eng.predict_joint(xs)):.2f} ms, joint_vjp {t(lambda: eng.joint_vjp(xs, gm, gc)):.2f} ms, "
+    eng.set_variant(1024)   # bit 10: small calls through the joint kernel (rounds 1 - 5)
+    kern_pj, kern_qei = t(lambda: eng.predict_joint(xs)), t(lambda: fn(xs))
+    eng.set_variant(0)
+    print(f"N={N} q={q} G={G}: joint_forward {t(lambda: eng.joint_forward(xs)):.2f} ms, predict_joint {t(lambda: eng.predict_joint(xs)):.2f} ms "
+          f"(through the joint kernel: {kern_pj:.2f} ms; tgp_qei {kern_qei:.2f} ms), joint_vjp {t(lambda: eng.joint_vjp(xs, gm, gc)):.2f} ms, "
           f"qEI value_and_gradient {t(lambda: fn.value_and_gradient(xs)):.2f} ms, qEI value (tgp_qei) {t(lambda: fn(xs)):.2f} ms")
 for name, opt in (("default (L-BFGS-B on the flattened batch)", None),
                   ("random search, 10^5 batches", A.generate_random_search_optimizer(100000))):

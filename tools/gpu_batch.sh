@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU batch (round 6): qEI value-and-gradient on the device -- parity tests, timings
+# GPU batch (round 6): small joint calls through the skinny product -- the whole suite, timings
 set -u; OUT=$PWD/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
-timeout 1200 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "joint_forward or qei_value_and" 2>&1 | grep -v amdgpu.ids | tail -25 | tee $OUT/r06_qei_grad_tests2.txt
-for a in "2048 5" "4096 5" "1024 10"; do timeout 600 python tools/bench_qei_grad.py $a 2>&1 | grep -v amdgpu.ids | cut -c1-260; done | tee $OUT/r06_qei_grad2.txt
+bash tools/gpu_suite.sh r06j 2>&1 | tail -30
+for a in "2048 5" "4096 5"; do timeout 600 python tools/bench_qei_grad.py $a 2>&1 | grep -v amdgpu.ids | cut -c1-260; done | tee $OUT/r06_joint_small.txt
