@@ -1,5 +1,6 @@
 #!/bin/bash
-# GPU batch (round 6): small joint calls through the skinny product -- the whole suite, timings
+# GPU batch (round 6, closing): the --runslow twins and the driver's command with the final library
 set -u; OUT=$PWD/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
-bash tools/gpu_suite.sh r06j 2>&1 | tail -30
-for a in "2048 5" "4096 5"; do timeout 600 python tools/bench_qei_grad.py $a 2>&1 | grep -v amdgpu.ids | cut -c1-260; done | tee $OUT/r06_joint_small.txt
+timeout 1500 python -m pytest tests -x -q -m gpu --runslow only 2>&1 | grep -v amdgpu.ids | tail -6 | tee $OUT/r06_gpu_tests_runslow.txt
+bash tools/gpu_evidence.sh r06h bench 2>&1 | tail -20
+for a in "2048 5"; do timeout 600 python tools/bench_qei_grad.py $a 2>&1 | grep -v amdgpu.ids | cut -c1-300; done | tee $OUT/r06_joint_small2.txt
