@@ -87,6 +87,47 @@ def test_ask_tell_loop_on_gpu_finds_scaled_branin_minimum():
     np.testing.assert_allclose(np.min(opt.dataset.observations), -1.047393, rtol=0.005)
 
 
+def test_ego_refines_a_joint_qei_batch_with_lbfgsb_on_the_engine():
+    """Round 6: EGO + BatchMonteCarloExpectedImprovement with the DEFAULT optimizer -- batchify_joint over
+    automatic_optimizer_selector, which (as in the reference, optimizer.py:107-114, 897-934) is L-BFGS-B on the flattened batch
+    now that the function has a gradient (tgp_qei_value_grad).  The device gradient against central differences of tgp_qei itself
+    (no oracle involved), the refined batch against the best of a random search over the same function, and a short Ask-Tell
+    loop of 3-point batches on the scaled Branin function at the reference's bar (test_bayesian_optimization.py:103-300:
+    12 steps, rtol 0.005... here of the minimum found)."""
+    from trieste_amd import objectives as OBJ
+    from trieste_amd.acquisition import (BatchMonteCarloExpectedImprovement, EfficientGlobalOptimization,
+                                         generate_random_search_optimizer)
+    from trieste_amd.ask_tell_optimization import AskTellOptimizer
+    from trieste_amd.data import Dataset
+
+    space, data, model, st = _setup(n=30, noise=1e-2)
+    builder = BatchMonteCarloExpectedImprovement(256)
+    fn = builder.prepare_acquisition_function(model, dataset=data)
+    x = np.random.default_rng(5).uniform(size=(4, 3, 2))
+    val, grad = fn.value_and_gradient(x)
+    assert_close(val, np.asarray(fn(x))[:, 0], atol=1e-12, what="value_and_gradient's value == __call__")
+    h = 1e-6
+    for g, i, c in ((0, 0, 0), (1, 2, 1), (3, 1, 0)):
+        xp, xm = x.copy(), x.copy()
+        xp[g, i, c] += h
+        xm[g, i, c] -= h
+        fd = (float(np.asarray(fn(xp))[g, 0]) - float(np.asarray(fn(xm))[g, 0])) / (2 * h)
+        assert abs(fd - grad[g, i, c]) <= 2e-6 * max(1.0, abs(fd)), (fd, grad[g, i, c])
+    refined = EfficientGlobalOptimization(builder, num_query_points=3).acquire_single(space, model, dataset=data)
+    assert refined.shape == (3, 2) and np.all((refined >= 0) & (refined <= 1))
+    rs = EfficientGlobalOptimization(builder, num_query_points=3, optimizer=generate_random_search_optimizer(5000, seed=4))
+    swept = rs.acquire_single(space, model, dataset=data)
+    f2 = rs.acquisition_function     # one function (one set of draws) for both batches
+    assert float(np.asarray(f2(refined[None]))[0, 0]) >= 0.98 * float(np.asarray(f2(swept[None]))[0, 0])
+    space, data, model, _ = _setup(n=6, noise=1e-5, seed=0)
+    opt = AskTellOptimizer(space, data, model, EfficientGlobalOptimization(BatchMonteCarloExpectedImprovement(500), num_query_points=3))
+    for _ in range(12):
+        q = opt.ask()
+        assert q.shape == (3, 2)
+        opt.tell(Dataset(q, OBJ.scaled_branin(q)))
+    np.testing.assert_allclose(np.min(opt.dataset.observations), -1.047393, rtol=0.005)
+
+
 def test_ask_tell_loop_under_auto_precision_matches_the_float64_loop():
     """The same Ask-Tell loop with sweep_precision="auto": every step's fused sweep runs the int8 kernel with the float64
     repair on a model that is re-factorised every step (N = 6 ... 17: as ill-conditioned for digit planes as it gets) --
