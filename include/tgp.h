@@ -496,8 +496,8 @@ int tgp_get_auto_strata(tgp_handle h, int64_t* checked2, int64_t* violations2, d
  * (rounds 3 - 5; default since round 6 at 3 <= Npad / 128 < 48: TWO workgroups swapping the roles of leaf and helper, which
  * forms L(j+1,j) as a blocked triangular solve instead of a product with the inverted diagonal block), bit 10 = tgp_predict at
  * <= 2048 points through a sweep launch and tgp_predict_joint / tgp_qei / tgp_reparam_samples of <= 2048 points (groups x q) through
- * the joint kernel (rounds 1 - 5) instead of skinny triangular products (round 6: the default when no sweep / joint policy bit and
- * no arithmetic other than float64 is set).  Bits 0-3, 7, 8: every
+ * the joint kernel (rounds 1 - 5) instead of skinny triangular products (round 6: the default when no sweep / joint policy bit is
+ * set -- and, for tgp_predict, no arithmetic other than float64; joint mode is float64 on every path).  Bits 0-3, 7, 8: every
  * setting computes the same arithmetic on every candidate / matrix entry, bit for bit; bits 4 - 6, 9: the same values up to the
  * rounding of another summation order (bit 10 as well). */
 int tgp_set_variant(tgp_handle h, int variant);

@@ -494,6 +494,14 @@ def test_joint_forward_and_vjp_of_a_handful_of_batches_match_the_oracle(cfg):
         gscale = np.abs(want).max() + 1e-300
         assert_close(got, want, rtol=1e-5, atol=max(floor * 1e3 * q, 1e-9 * gscale), what=f"joint_vjp q={q} G={G}")
         np.testing.assert_array_equal(eng.joint_vjp(Xg, gm, gc), got)   # a fixed summation order: bit-identical call to call
+    # joint mode is float64 whatever the sweep precision: a small call takes the same skinny product under "auto"
+    eng.set_precision("auto")
+    am, ac = eng.predict_joint(Xg)
+    eng.set_precision("f64")
+    fm, fc = eng.predict_joint(Xg)
+    np.testing.assert_array_equal(am, fm)
+    np.testing.assert_array_equal(ac, fc)
+    np.testing.assert_array_equal(fc, jc)   # ... which is tgp_joint_forward's arithmetic
     # device-resident arguments (torch tensors on the GPU): the same bits as the host-buffer call
     import torch
     Xd, gmd, gcd = (torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (Xg, gm, gc))

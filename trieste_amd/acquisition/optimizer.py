@@ -112,7 +112,8 @@ def generate_random_search_optimizer(num_samples: int = NUM_SAMPLES_MIN, seed: O
 def automatic_optimizer_selector(space: SearchSpace, target_func) -> np.ndarray:
     """Pick an optimizer for the space (optimizer.py:90-121): exhaustive for discrete spaces; for a
     Box the continuous optimizer with max(5000, 1000 * D) initial samples and 10 * D L-BFGS-B runs.
-    Functions that expose no gradient (foreign callables, qEI) are swept by random search only."""
+    Functions that expose no gradient (foreign callables) are swept by random search only; a batch function with
+    ``value_and_gradient`` (qEI since round 6) reaches this selector flattened by ``batchify_joint`` and is refined too."""
     if isinstance(space, DiscreteSearchSpace):
         return optimize_discrete(space, target_func)
     if isinstance(space, Box):

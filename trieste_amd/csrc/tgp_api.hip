@@ -2428,8 +2428,8 @@ static int joint_common(tgp_handle h, const double* Xq, int64_t G, int q, int wh
   // a handful of groups (round 6): the skinny-product form of tgp_joint_forward -- the joint kernel is built for 10^5 groups, ONE
   // of its 250-point blocks walks all of W (4.9 ms at N = 2048, 18 ms at N = 4096 whatever the count); variant bit 10 or a joint
   // policy bit keep the kernel
-  if (G * (int64_t)q <= JOINT_SMALL_P && h->precision_req == TGP_PREC_F64 &&
-      !(h->variant & (VARIANT_SWEEP_SMALL_PREDICT | VARIANT_JOINT_V1))) {
+  // (whatever tgp_set_precision says: joint mode is float64 on every path)
+  if (G * (int64_t)q <= JOINT_SMALL_P && !(h->variant & (VARIANT_SWEEP_SMALL_PREDICT | VARIANT_JOINT_V1))) {
     const int64_t P = G * (int64_t)q, Ppad = ((P + 63) / 64) * 64;
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));   // (the callers read the elapsed time between the two events)
     if (int rc = joint_small_device(h, *dXq, P, Ppad, q, *dmean, *dcov)) return rc;
