@@ -833,7 +833,9 @@ int gemm_tall(tgp_handle h, bool tb, int m, int n, int k, double alpha, const do
               const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int tri) {
   const int64_t tiles = (int64_t)(m / 64) * (n / 64);
   int nz = 1;
-  if (tiles < 256 && k >= 1024) nz = (int)std::min<int64_t>(8, std::max<int64_t>(1, 512 / tiles));
+  static const int64_t nz_max = getenv("TGP_KSPLIT_MAX") ? atoll(getenv("TGP_KSPLIT_MAX")) : 8;            // (env: development aids)
+  static const int64_t nz_target = getenv("TGP_KSPLIT_TARGET") ? atoll(getenv("TGP_KSPLIT_TARGET")) : 512;
+  if (tiles < 256 && k >= 1024) nz = (int)std::min<int64_t>(nz_max, std::max<int64_t>(1, nz_target / tiles));
   if (nz > 1) {
     HIPCHK(h, h->s_ks.reserve((size_t)nz * m * n * sizeof(double)));
     launch_gemm_ksplit(h->stream, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, nz, h->s_ks.as<double>());
