@@ -204,6 +204,41 @@ def end_to_end_acquire_ms(X, Y, w):
         return f"failed: {type(e).__name__}: {e}"
 
 
+def small_call_ms(X, Y, w):
+    """Informational (outside the timed region): the calls a BO step makes on a HANDFUL of points at this model -- since the last
+    session of round 6 skinny products instead of launches of the sweep / joint kernels: predict at 128 points,
+    predict_joint of 60 groups of 5, and qEI value + gradient of 300 groups of 5 (one L-BFGS-B iteration of a joint batch) --
+    median of 10 host-timed calls each, ms."""
+    try:
+        from trieste_amd import objectives as O
+        from trieste_amd.engine import GPEngine
+
+        d = w["d"]
+        eng = GPEngine(d, w["kernel"])
+        eng.set_hyper(1.0, O.default_lengthscales(d), w["noise"], float(Y.mean()))
+        eng.set_data(X, Y)
+        rng = np.random.default_rng(3)
+        xp, xg, xq = rng.uniform(size=(128, d)), rng.uniform(size=(60, 5, d)), rng.uniform(size=(300, 5, d))
+        eps = rng.standard_normal((5, 512))
+        eta = float(np.median(np.asarray(eng.predict(xp)[0])))
+
+        def med(f):
+            f()
+            ts = []
+            for _ in range(10):
+                t0 = time.perf_counter()
+                f()
+                ts.append((time.perf_counter() - t0) * 1e3)
+            return sorted(ts)[5]
+
+        out = {"predict_128": med(lambda: eng.predict(xp)), "predict_joint_60x5": med(lambda: eng.predict_joint(xg)),
+               "qei_value_grad_300x5_S512": med(lambda: eng.qei_value_grad(xq, eps, eta, 1e-6))}
+        eng.close()
+        return out
+    except Exception as e:  # never let the informational figure break the bench line
+        return f"failed: {type(e).__name__}: {e}"
+
+
 def qei_eta(eng, Xq) -> float:
     """The incumbent of the qEI workload: the MEDIAN posterior mean over the first 8192 candidate points.  At the
     reference's eta = min_i mean(X_i) (function.py:1135-1147) every uniformly random q-batch of this synthetic problem
@@ -583,6 +618,7 @@ def main():
         if nshards == 1 and not args.no_acquire and kind == "ei":
             out["config"]["acquire_ms"] = end_to_end_acquire_ms(X, Y, w)
             out["config"]["fit"] = end_to_end_fit_ms(X, Y, w)
+            out["config"]["small_calls_ms"] = small_call_ms(X, Y, w)
         if (nshards == 1 and not args.no_secondary and args.workload == "headline" and args.precision == "f64"
                 and not args.m_per_gpu and not group_mode):
             # every other workload of BASELINE.json's configs in the same driver-timed run: few steps each, same pricing
