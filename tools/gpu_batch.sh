@@ -1,11 +1,8 @@
 #!/bin/bash
-# GPU batch (round 6, closing): the driver's command with the small-call timings in config
+# GPU batch (round 6): the tall products' k-split on 128 x 128 tiles
 set -u; OUT=$PWD/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
-timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/r06_bench_default_final_3.json 2> $OUT/r06_bench_default_final_3.err; echo "rc=$?"
-python - <<'PY'
-import json
-j = json.load(open('gpurun_out/r06_bench_default_final_3.json'))
-print(j['value'], j['roofline']['frac'], j['config']['update_ms'], j['config']['acquire_ms'], j['config']['fit'], j['config']['small_calls_ms'])
-print({k: v.get('value') for k, v in j['secondary'].items()})
-PY
-timeout 300 python -m pytest tests/test_gpu_multi.py -x -q -m gpu 2>&1 | tail -3
+for N in 4096 8192 2048 1024; do
+for cfg in "0 0 0" "1 0 0" "1 32 4096" "1 8 512"; do set -- $cfg
+  echo -n "big=$1 "; TGP_KSPLIT_BIG=$1 TGP_KSPLIT_MAX=$2 TGP_KSPLIT_TARGET=$3 timeout 200 python tools/bench_ksplit.py $N 2>&1 | grep -v amdgpu.ids | cut -c1-400
+done; done | tee $OUT/r06_ksplit_big.txt
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_host.py -x -q -m gpu -k "handful or gradient or joint or covariance or qei or greedy or fantas or penal" 2>&1 | tail -4
