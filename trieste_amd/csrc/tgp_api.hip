@@ -833,11 +833,13 @@ int gemm_tall(tgp_handle h, bool tb, int m, int n, int k, double alpha, const do
               const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int tri) {
   const int64_t tiles = (int64_t)(m / 64) * (n / 64);
   int nz = 1;
-  // up to 8 slices towards 512 workgroups; from k = 4096 on up to 16 towards 2048 (profiles/r06_ksplit.txt: the value-and-gradient
-  // call at 80 points 0.252 -> 0.225 ms at N = 4096, tgp_predict 0.153 -> 0.137; at N <= 2048 the finer split is neutral or slower)
+  // up to 16 slices towards 2048 workgroups (rounds 1 - 5: 8 towards 512).  profiles/r06_ksplit.txt: with a slice of each tile's own
+  // pruned range the finer split paid from k = 4096 on only (the value-and-gradient call at 80 points 0.252 -> 0.225 ms, neutral at
+  // 2048, slower at 1024); with slices of FIXED depth (gemm8_body: empty slices write nothing, ksplit_reduce_kernel sums the live ones)
+  // it pays at every size -- 0.132 -> 0.118 ms at N = 2048, 0.104 -> 0.093 at N = 1024 (profiles/r06_ksplit_fixed.txt)
   static const int64_t nz_max_env = getenv("TGP_KSPLIT_MAX") ? atoll(getenv("TGP_KSPLIT_MAX")) : 0;          // (env: development aids)
   static const int64_t nz_target_env = getenv("TGP_KSPLIT_TARGET") ? atoll(getenv("TGP_KSPLIT_TARGET")) : 0;
-  const int64_t nz_max = nz_max_env ? nz_max_env : (k >= 4096 ? 16 : 8), nz_target = nz_target_env ? nz_target_env : (k >= 4096 ? 2048 : 512);
+  const int64_t nz_max = nz_max_env ? nz_max_env : 16, nz_target = nz_target_env ? nz_target_env : 2048;
   if (tiles < 256 && k >= 1024) nz = (int)std::min<int64_t>(nz_max, std::max<int64_t>(1, nz_target / tiles));
   if (nz > 1) {
     HIPCHK(h, h->s_ks.reserve((size_t)nz * m * n * sizeof(double)));

@@ -359,6 +359,8 @@ __device__ __forceinline__ void tile_of_block(int lower_only, int tri, int nt_m,
 //
 // gridDim.y > 1: k-split -- slice blockIdx.y of the (pruned) k range, partial result to C + slice * m * ldc.
 constexpr int GKT = 32;
+// depth of a k-split slice: the k range in nz equal parts, rounded up to whole 32-deep steps
+__host__ __device__ __forceinline__ int ksplit_depth(int k, int nz) { return ((k / GKT + nz - 1) / nz) * GKT; }
 template <bool TB>
 __device__ __forceinline__ void gemm8_body(int m, int n, int k, double alpha, const double* __restrict__ A,
                                            int64_t lda, const double* __restrict__ B, int64_t ldb, double beta,
@@ -378,10 +380,15 @@ __device__ __forceinline__ void gemm8_body(int m, int n, int k, double alpha, co
   else if (tri == 4) klo = min(k, max(tm, tn) * GB);
   else if (tri == 5) klo = min(k, tm * GB);
   if (gridDim.y > 1) {
-    const int steps = (khi - klo + GKT - 1) / GKT, per = (steps + (int)gridDim.y - 1) / (int)gridDim.y;
-    const int lo2 = klo + (int)blockIdx.y * per * GKT;
-    khi = min(khi, lo2 + per * GKT);
-    klo = min(lo2, khi);
+    // slices of FIXED depth over the absolute k range (round 6, last session: a slice of the tile's own pruned range before -- every
+    // tile wrote gridDim.y partial tiles however short its range, 67 MB of partials for a 4096 x 128 product at 16 slices, and the
+    // workgroups of the last tile rows walked 16 times the depth of the first); a slice that misses the tile's range writes nothing,
+    // ksplit_reduce_kernel sums the live ones (ksplit_live below is the one rule both use)
+    const int per = ksplit_depth(k, (int)gridDim.y);
+    const int lo2 = (int)blockIdx.y * per, hi2 = lo2 + per;
+    if (hi2 <= klo || lo2 >= khi) return;
+    klo = max(klo, lo2);
+    khi = min(khi, hi2);
     C += (int64_t)blockIdx.y * m * ldc;
   }
   const double* Ab = A + (int64_t)tm * GB * lda;
@@ -677,12 +684,21 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(int m, int n, int k, d
 
 // C = beta C + alpha sum_z P[z]  (fixed order: deterministic) for the k-split launches below.
 __global__ void ksplit_reduce_kernel(const double* __restrict__ P, int nz, int64_t m, int64_t n, int64_t ldp,
-                                     double alpha, double beta, double* __restrict__ C, int64_t ldc) {
+                                     double alpha, double beta, double* __restrict__ C, int64_t ldc, int k, int tri) {
   const int64_t j = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
   const int64_t i = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6);
   if (i >= m || j >= n) return;
+  // the slices that met this element's 64 x 64 tile (gemm8_body's pruning, the same expressions)
+  const int tm = (int)(i / GB), tn = (int)(j / GB);
+  int klo = 0, khi = k;
+  if (tri == 1) khi = min(k, (tn + 1) * GB);
+  else if (tri == 2) klo = min(k, tn * GB);
+  else if (tri == 3) khi = min(k, (tm + 1) * GB);
+  else if (tri == 4) klo = min(k, max(tm, tn) * GB);
+  else if (tri == 5) klo = min(k, tm * GB);
+  const int per = ksplit_depth(k, nz);
   double acc = 0.0;
-  for (int z = 0; z < nz; ++z) acc += P[((int64_t)z * m + i) * ldp + j];
+  for (int z = klo / per; z < nz && z * per < khi; ++z) acc += P[((int64_t)z * m + i) * ldp + j];
   double* dst = C + i * ldc + j;
   *dst = (beta == 0.0) ? alpha * acc : fma(beta, *dst, alpha * acc);
 }
@@ -697,7 +713,7 @@ void launch_gemm_ksplit(hipStream_t s, bool tb, int m, int n, int k, double alph
   if (tb) hipLaunchKernelGGL(gemm_kernel8<true>, grid, dim3(512), 0, s, m, n, k, 1.0, A, lda, B, ldb, 0.0, scratch, (int64_t)n, 0, tri);
   else hipLaunchKernelGGL(gemm_kernel8<false>, grid, dim3(512), 0, s, m, n, k, 1.0, A, lda, B, ldb, 0.0, scratch, (int64_t)n, 0, tri);
   dim3 rg((unsigned)((n + 63) / 64), (unsigned)((m + 3) / 4));
-  hipLaunchKernelGGL(ksplit_reduce_kernel, rg, dim3(256), 0, s, scratch, nz, (int64_t)m, (int64_t)n, (int64_t)n, alpha, beta, C, ldc);
+  hipLaunchKernelGGL(ksplit_reduce_kernel, rg, dim3(256), 0, s, scratch, nz, (int64_t)m, (int64_t)n, (int64_t)n, alpha, beta, C, ldc, k, tri);
 }
 
 // k must be a multiple of 32 (all call sites pass multiples of 64).
