@@ -19,4 +19,4 @@ for P in (16, 80, 128, 500, 1024, 2048):
         for _ in range(30):
             t0 = time.perf_counter(); f(); ts.append((time.perf_counter() - t0) * 1e3)
         out.append(f"{name} P={P}: {sorted(ts)[15]:.3f}")
-print(f"N={N} max={os.environ.get('TGP_KSPLIT_MAX', '8')} target={os.environ.get('TGP_KSPLIT_TARGET', '512')} ms: " + "  ".join(out))
+print(f"N={N} max={os.environ.get('TGP_KSPLIT_MAX', 'library rule')} target={os.environ.get('TGP_KSPLIT_TARGET', 'library rule')} ms: " + "  ".join(out))
